@@ -1,0 +1,90 @@
+"""Seeded parity cases shared by tests/golden/make_golden.py and the test-suite.
+
+Each case is generated from seeds by localhgt_amd.synth (inputs are not committed, their
+sha256 is, so a drift of the generator is detected rather than silently accepted) and run
+through the 12-argument `extract_ref` contract
+(/root/reference/src/extract_ref_normal_peak.cpp:1352-1364).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+from localhgt_amd import synth
+
+
+@dataclass
+class Case:
+    name: str
+    k: int = 24
+    e: int = 3
+    seed: int = 1
+    sample: float = 1
+    hit_ratio: float = 0.1
+    match_ratio: float = 0.08
+    max_peak: int = 1000000
+    # generator knobs
+    ref_seed: int = 11
+    n_contigs: int = 8
+    min_len: int = 20000
+    max_len: int = 40000
+    short_contig_at: Optional[int] = 8          # index in the contig list (None = no short contig)
+    n_run_at: Optional[Tuple[int, int, int]] = None
+    reads_seed: int = 12
+    depth: float = 12
+    snp_rate: float = 0.0
+    n_read_frac: float = 0.02
+    fq2_header_pad: int = 0
+    lowercase_every: int = 0
+    preexisting_index: bool = False             # run twice, keep outputs of the 2nd run (quirk Q3)
+    bed_defined: bool = True                    # False when a short contig sits mid-file (quirk Q7)
+    notes: str = ""
+
+
+CASES: Dict[str, Case] = {c.name: c for c in [
+    Case("k24_base", notes="short contig last; every read kept"),
+    Case("k32_base", k=32, notes="default k; 2^32 tables"),
+    Case("k21_e3", k=21, ref_seed=21, reads_seed=22, snp_rate=0.01, notes="config-5 k; 1% SNPs"),
+    Case("k24_sample_half_fresh", sample=0.5, notes="sampling active, index built in-run (Q3)"),
+    Case("k24_sample_half_cached", sample=0.5, preexisting_index=True, notes="sampling active, index cached (Q3)"),
+    Case("k24_sample_bases", sample=700000.0, notes="--sample > 1: cal_sam_ratio path"),
+    Case("k24_fq2_longer", fq2_header_pad=20, notes="fq2 bigger than fq1: mate-2 counting truncated (Q4)"),
+    Case("k24_short_mid", short_contig_at=2, bed_defined=False, notes="short contig mid-file (Q7): interval only"),
+    Case("k20_e2", k=20, e=2, ref_seed=31, reads_seed=32, notes="two hashes"),
+    Case("k22_e5", k=22, e=5, ref_seed=41, reads_seed=42, match_ratio=0.04, notes="five hashes: two rand() rows per position"),
+    Case("k24_nrun_lower", n_run_at=(1, 9000, 40), lowercase_every=7, snp_rate=0.005, ref_seed=51, reads_seed=52,
+         notes="N run in the reference (Q6), lower-case read bases, SNPs"),
+    Case("k24_seed7", seed=7, ref_seed=61, reads_seed=62, n_contigs=5, min_len=12000, max_len=20000,
+         short_contig_at=None, depth=10, notes="tiny; inputs also committed gz-compressed"),
+]}
+
+
+def sha256_file(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def materialise(case: Case, outdir: str):
+    """Write ref.fa / s.1.fq / s.2.fq for the case into outdir; returns the three paths."""
+    ref = synth.make_reference(case.ref_seed, case.n_contigs, case.min_len, case.max_len,
+                               short_contig_at=case.short_contig_at, n_run_at=case.n_run_at)
+    reads = synth.make_sample(ref, case.reads_seed, depth=case.depth, snp_rate=case.snp_rate,
+                              n_read_frac=case.n_read_frac)
+    return synth.write_case(outdir, ref, reads, fq2_header_pad=case.fq2_header_pad,
+                            lowercase_every=case.lowercase_every)
+
+
+def extract_ref_argv(case: Case, fq1: str, fq2: str, fa: str, interval: str):
+    """argv[1:] of extract_ref for the case, threads fixed at 1 (parity contract = -t 1)."""
+    def num(x):
+        return str(int(x)) if float(x) == int(x) else repr(float(x))
+    return [fq1, fq2, fa, interval, repr(case.hit_ratio), repr(case.match_ratio), "1", str(case.k),
+            str(case.max_peak), str(case.e), str(case.seed), num(case.sample)]
+
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

@@ -1,0 +1,119 @@
+/* localhgt_hip.h -- C-ABI of the MI355X k-mer sketch->peak engine (liblocalhgt_hip.so).
+ *
+ * The reference has no in-process FFI for this path: its boundary is the `extract_ref`
+ * process (scripts/pipeline.sh:35; argv at src/extract_ref_normal_peak.cpp:1352-1364).
+ * This header is the boundary a replacement binds instead; each entry point names the
+ * reference code it replaces ("E" = /root/reference/src/extract_ref_normal_peak.cpp).
+ * Plain C types only, opaque context, every call returns an int status (0 = ok) and never
+ * aborts; lhgt_last_error() gives the text of the last failure on the calling thread.
+ * One context per process and GPU; calls on one context must not overlap.
+ */
+#ifndef LOCALHGT_HIP_H
+#define LOCALHGT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LHGT_ABI_VERSION 1
+#define LHGT_CODER_SLOTS 300      /* E:21,1186: choose_coder[300] */
+#define LHGT_MAX_READ_LEN 500     /* E:1004-1005: int reads_int[500] */
+#define LHGT_MAX_RANDOM 50000000L /* E:40 */
+
+enum {
+    LHGT_OK = 0,
+    LHGT_E_ARG = 1,        /* bad argument */
+    LHGT_E_IO = 2,         /* file open/read/write */
+    LHGT_E_HIP = 3,        /* HIP runtime error (message has the HIP string) */
+    LHGT_E_FORMAT = 4,     /* malformed FASTA/FASTQ/index */
+    LHGT_E_STATE = 5,      /* call order violated (e.g. ref_scan before index_load) */
+    LHGT_E_TOO_MANY_PEAKS = 6, /* E:272-274 "Too many peaks!" (the reference overruns its arrays) */
+    LHGT_E_NOMEM = 7,
+    LHGT_E_NO_DEVICE = 8
+};
+
+typedef struct lhgt_ctx lhgt_ctx;
+
+int lhgt_abi_version(void);
+const char* lhgt_last_error(void);
+int lhgt_device_count(int* n);
+
+/* ---- context: k-mer length k (<= 32), e hash functions (1..9).  Allocates the 2-bit count
+ * table of 2^k slots in HBM (replaces `new char[2^k]` + memset, E:1375-1376,1416). */
+int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out);
+int lhgt_ctx_destroy(lhgt_ctx* ctx);
+
+/* ---- R: glibc rand() stream and the position coder (host side, private random_r state) */
+int lhgt_rng_seed(lhgt_ctx* ctx, unsigned seed);                       /* srand(seed), E:1386 */
+int lhgt_coder_generate(lhgt_ctx* ctx);                                /* random_coder, E:1182-1222 */
+int lhgt_coder_set(lhgt_ctx* ctx, const int16_t* cc /*[300]*/);        /* saved_random_coder, E:1224-1242 */
+int lhgt_coder_get(lhgt_ctx* ctx, int16_t* cc /*[300]*/);
+int lhgt_sampling_init(lhgt_ctx* ctx, double ratio_percent);           /* get_random, E:1332-1340; no draw when ratio >= 100 */
+int lhgt_sampling_get(lhgt_ctx* ctx, float* out, long n);              /* first n values of random_array (tests) */
+
+/* ---- H: hash of every k-mer of one sequence (parity probe for E:1052-1081 / 786-811).
+ * out_hash[(j*e)+i], out_valid[j]; runs the same device code as every phase. */
+int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* out_hash, uint8_t* out_valid);
+
+/* ---- I: index build / load (read_ref E:727-886, read side E:888-945).  File formats are the
+ * reference's: <ref>.k<k>.h<e>.index.dat and <ref>.genome.len.txt. */
+int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_path, const char* genome_len_path,
+                     long* n_contigs, long* n_bases);
+int lhgt_index_load(lhgt_ctx* ctx, const char* index_path, long* n_contigs, long* n_bases);
+/* resident index straight from sequences already in host memory (bench / tests): contig c is
+ * ascii[off[c] .. off[c+1]) */
+int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* off, long n_contigs);
+
+/* ---- reads: sampling ratio (cal_sam_ratio E:1244-1270) and the resident pair store */
+int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, long* n_records);
+/* Parse both FASTQs in lock-step (E:350-359), keep pair n iff random_array[n % 5e7] < ratio
+ * (E:413-419, 1037-1044), mark mate 2 as not-counted once its byte cursor passed size(fq1)
+ * (E:1419-1445), keep pairs of block (n / shard_block) % shard_world == shard_rank, upload
+ * and 2-bit pack them.  The store stays resident for phases A and C. */
+int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent,
+                          int shard_rank, int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept);
+/* Append pairs from host memory: mate m of pair p is seq_m[off_m[p] .. off_m[p+1]).
+ * count_mate2 (optional, one byte per pair) = 0 excludes mate 2 from phase A only. */
+int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
+                      const uint64_t* off2, long n_pairs, const uint8_t* count_mate2);
+int lhgt_pairs_clear(lhgt_ctx* ctx);
+int lhgt_pairs_count(lhgt_ctx* ctx, long* n_pairs);
+
+/* ---- A: saturating k-mer count of every resident read into the 2-bit table (read_fastq E:981-1107).
+ * Result per slot = min(3, occurrences): order independent, equal to the -t 1 reference. */
+int lhgt_count_kmers(lhgt_ctx* ctx);
+int lhgt_counts_clear(lhgt_ctx* ctx);
+
+/* ---- multi-GPU plumbing (no reference counterpart).  Device pointers are handed
+ * to the host layer (torch.distributed/RCCL); merge = per-slot saturating add of 2-bit fields. */
+int lhgt_counts_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes);
+int lhgt_counts_merge(lhgt_ctx* ctx, const void* dev_other, size_t byte_offset, size_t bytes);
+int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes); /* u32 votes per peak */
+
+/* ---- B: reference scan + peak registry (read_index E:888-979, slide_window E:550-725,
+ * add_peak/merge_peak E:239-301).  hit_ratio/match_ratio are the float32 values of E:1368-1369. */
+int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks);
+
+/* ---- C: read re-scan + split-read vote (slide_reads E:313-506, Split_reads E:91-202) */
+int lhgt_vote(lhgt_ctx* ctx);
+
+/* ---- D: interval file (count_filtered_peak E:515-548) */
+int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered);
+
+/* ---- introspection for parity tests (device -> host copies) */
+int lhgt_counts_export_u8(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint8_t* out);
+int lhgt_counts_histogram(lhgt_ctx* ctx, uint64_t out[4]);            /* cal_tab_empty_rate, count_diff_kmer.cpp:26-50 */
+int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t* out);
+int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci /*[2*n]*/, uint8_t* filter /*[n]*/, long n);
+int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint32_t* out);
+
+/* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */
+int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C*/, float* ms);
+int lhgt_stream(lhgt_ctx* ctx, void** hip_stream);
+int lhgt_synchronize(lhgt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

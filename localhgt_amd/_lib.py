@@ -1,0 +1,98 @@
+"""ctypes binding of liblocalhgt_hip.so (include/localhgt_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible the product
+path raises.  `load(require_gpu=False)` is only for symbol checks on a CPU-only box."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblocalhgt_hip.so")
+
+CODER_SLOTS = 300
+MAX_RANDOM = 50_000_000
+
+ERRORS = {0: "OK", 1: "E_ARG", 2: "E_IO", 3: "E_HIP", 4: "E_FORMAT", 5: "E_STATE", 6: "E_TOO_MANY_PEAKS",
+          7: "E_NOMEM", 8: "E_NO_DEVICE"}
+
+_vp, _i, _l, _d, _f = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
+_u8p, _u16p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_i32p, _lp, _fp, _dp = C.POINTER(C.c_int32), C.POINTER(C.c_long), C.POINTER(C.c_float), C.POINTER(C.c_double)
+_cs = C.c_char_p
+
+# name -> argtypes; every entry point of include/localhgt_hip.h (restype int unless noted)
+SIGNATURES = {
+    "lhgt_abi_version": [],
+    "lhgt_last_error": [],
+    "lhgt_device_count": [C.POINTER(C.c_int)],
+    "lhgt_ctx_create": [_i, _i, _i, C.POINTER(_vp)],
+    "lhgt_ctx_destroy": [_vp],
+    "lhgt_rng_seed": [_vp, C.c_uint],
+    "lhgt_coder_generate": [_vp],
+    "lhgt_coder_set": [_vp, _u16p],
+    "lhgt_coder_get": [_vp, _u16p],
+    "lhgt_sampling_init": [_vp, _d],
+    "lhgt_sampling_get": [_vp, _fp, _l],
+    "lhgt_hash_sequence": [_vp, _cs, _l, _u32p, _u8p],
+    "lhgt_index_build": [_vp, _cs, _cs, _cs, _lp, _lp],
+    "lhgt_index_load": [_vp, _cs, _lp, _lp],
+    "lhgt_index_from_memory": [_vp, _u8p, _u64p, _l],
+    "lhgt_fastq_sam_ratio": [_cs, _d, _dp, _lp],
+    "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
+    "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
+    "lhgt_pairs_clear": [_vp],
+    "lhgt_pairs_count": [_vp, _lp],
+    "lhgt_count_kmers": [_vp],
+    "lhgt_counts_clear": [_vp],
+    "lhgt_counts_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
+    "lhgt_counts_merge": [_vp, _vp, C.c_size_t, C.c_size_t],
+    "lhgt_filter_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
+    "lhgt_ref_scan": [_vp, _f, _f, _l, _lp],
+    "lhgt_vote": [_vp],
+    "lhgt_write_intervals": [_vp, _cs, _lp],
+    "lhgt_counts_export_u8": [_vp, C.c_uint64, C.c_uint64, _u8p],
+    "lhgt_counts_histogram": [_vp, _u64p],
+    "lhgt_flags_export": [_vp, C.c_uint64, C.c_uint64, _u8p],
+    "lhgt_peaks_export": [_vp, _i32p, _u8p, _l],
+    "lhgt_peak_kmer_export": [_vp, C.c_uint64, C.c_uint64, _u32p],
+    "lhgt_phase_ms": [_vp, _i, _fp],
+    "lhgt_stream": [_vp, C.POINTER(_vp)],
+    "lhgt_synchronize": [_vp],
+}
+
+
+class LocalHGTError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"liblocalhgt_hip: {ERRORS.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load(require_gpu: bool = True):
+    """Load the shared library and bind every declared symbol. Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). localhgt_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+            fn.argtypes = argtypes
+            fn.restype = C.c_char_p if name == "lhgt_last_error" else C.c_int
+        _lib = lib
+    if require_gpu:
+        n = C.c_int(0)
+        _lib.lhgt_device_count(C.byref(n))
+        if n.value < 1:
+            raise RuntimeError("liblocalhgt_hip: no HIP device visible; localhgt_amd has no CPU fallback")
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise LocalHGTError(rc, (_lib.lhgt_last_error() or b"").decode(errors="replace"))

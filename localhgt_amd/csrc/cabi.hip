@@ -1,0 +1,96 @@
+// cabi.hip -- context life cycle and the small accessors of the C-ABI (include/localhgt_hip.h).
+#include <cstring>
+#include "lhgt_common.hpp"
+
+using namespace lhgt;
+
+extern "C" {
+
+int lhgt_device_count(int* n) {
+    if (!n) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = e == hipSuccess ? c : 0;
+    return LHGT_OK;
+}
+
+int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
+    if (!out) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    *out = nullptr;
+    if (k < 8 || k > 32) LHGT_FAIL(LHGT_E_ARG, "k = %d outside [8, 32] (hashes are 32-bit, E:1012)", k);
+    if (e < 1 || e > 9) LHGT_FAIL(LHGT_E_ARG, "e = %d outside [1, 9]", e);
+    if (k * e > LHGT_CODER_SLOTS) LHGT_FAIL(LHGT_E_ARG, "k*e = %d exceeds the %d coder slots (E:1186)", k * e, LHGT_CODER_SLOTS);
+    if (device == -1) {  // host-only context: the RNG/coder rows only; every device call fails with E_NO_DEVICE
+        lhgt_ctx* c = new lhgt_ctx();
+        c->device = -1;
+        c->k = k;
+        c->e = e;
+        memset(c->cc, 0, sizeof c->cc);
+        *out = c;
+        return LHGT_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
+    if (device < 0 || device >= n) LHGT_FAIL(LHGT_E_ARG, "device %d not in [0, %d)", device, n);
+    LHGT_HIP(hipSetDevice(device));
+    lhgt_ctx* c = new lhgt_ctx();
+    c->device = device;
+    c->k = k;
+    c->e = e;
+    memset(c->cc, 0, sizeof c->cc);
+    memset(c->rng_state, 0, sizeof c->rng_state);
+    c->counts_words = ((size_t)1 << k) / 16;
+    hipError_t he = hipStreamCreate(&c->stream);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev0);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev1);
+    if (he == hipSuccess) he = hipMalloc(&c->d_counts, c->counts_words * 4);
+    if (he == hipSuccess) he = hipMemsetAsync(c->d_counts, 0, c->counts_words * 4, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) {
+        set_error("context setup failed: %s", hipGetErrorString(he));
+        lhgt_ctx_destroy(c);
+        return LHGT_E_HIP;
+    }
+    *out = c;
+    return LHGT_OK;
+}
+
+int lhgt_ctx_destroy(lhgt_ctx* c) {
+    if (!c) return LHGT_OK;
+    if (c->device < 0) { free(c->rng); delete c; return LHGT_OK; }
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    lhgt_pairs_clear(c);
+    for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags,
+                    (void*)c->d_peak_kmer, (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
+                    (void*)c->d_ws_ascii, (void*)c->d_ws_words})
+        if (p) hipFree(p);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    free(c->rng);
+    delete c;
+    return LHGT_OK;
+}
+
+int lhgt_phase_ms(lhgt_ctx* ctx, int phase, float* ms) {
+    if (!ctx || !ms || phase < 0 || phase > 2) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    *ms = ctx->phase_ms[phase];
+    return LHGT_OK;
+}
+
+int lhgt_stream(lhgt_ctx* ctx, void** hip_stream) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !hip_stream) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    *hip_stream = (void*)ctx->stream;
+    return LHGT_OK;
+}
+
+int lhgt_synchronize(lhgt_ctx* ctx) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    return LHGT_OK;
+}
+
+}  // extern "C"

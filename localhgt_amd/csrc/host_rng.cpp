@@ -1,0 +1,121 @@
+// host_rng.cpp -- the glibc rand() stream and the position coder.
+//
+// srand/rand are part of the reference's contract (E:1386, 1199, 1336): the TYPE_3 additive
+// feedback generator of glibc.  random_r on a private 128-byte state is that same generator
+// (rand() is random() on glibc's default 128-byte table), without touching the process-wide
+// stream of whoever loaded this library.
+#include <cstdarg>
+#include <cstring>
+#include "lhgt_common.hpp"
+
+namespace lhgt {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+int rng_next(lhgt_ctx* ctx) {
+    int32_t r = 0;
+    random_r((struct random_data*)ctx->rng, &r);
+    return (int)r;
+}
+
+int build_hash_params(const int16_t* cc, int k, int e, HashParams* hp) {
+    memset(hp, 0, sizeof *hp);
+    hp->k = k;
+    hp->e = e;
+    for (int z = 0; z < k; z++)
+        for (int i = 0; i < e; i++) {
+            int m = cc[z * e + i];
+            if (m < 0 || m > 2) {
+                set_error("coder entry [%d][%d] = %d is not one of 0,1,2 (corrupt index header?)", z, i, m);
+                return LHGT_E_FORMAT;
+            }
+            hp->mask[i][m] |= 1u << (k - 1 - z);
+        }
+    return LHGT_OK;
+}
+
+}  // namespace lhgt
+
+using namespace lhgt;
+
+extern "C" {
+
+const char* lhgt_last_error(void) { return lhgt::last_error(); }
+int lhgt_abi_version(void) { return LHGT_ABI_VERSION; }
+
+int lhgt_rng_seed(lhgt_ctx* ctx, unsigned seed) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (!ctx->rng) ctx->rng = calloc(1, sizeof(struct random_data));
+    memset(ctx->rng, 0, sizeof(struct random_data));
+    memset(ctx->rng_state, 0, sizeof ctx->rng_state);
+    if (initstate_r(seed, ctx->rng_state, sizeof ctx->rng_state, (struct random_data*)ctx->rng))
+        LHGT_FAIL(LHGT_E_ARG, "initstate_r failed");
+    ctx->seeded = true;
+    return LHGT_OK;
+}
+
+// random_coder (E:1182-1222): per k-mer offset, t = e/3+1 draws of rand()%6, each a row of the
+// six permutations of (0,1,2); the first e entries of the concatenated rows are kept.
+int lhgt_coder_generate(lhgt_ctx* ctx) {
+    if (!ctx || !ctx->seeded) LHGT_FAIL(LHGT_E_STATE, "lhgt_rng_seed must be called before lhgt_coder_generate");
+    static const int16_t permu[18] = {0, 1, 2, 0, 2, 1, 1, 2, 0, 1, 0, 2, 2, 0, 1, 2, 1, 0};
+    int16_t cc[LHGT_CODER_SLOTS];
+    for (int i = 0; i < LHGT_CODER_SLOTS; i++) cc[i] = 100;  // E:1189
+    int t = ctx->e / 3 + 1;
+    int16_t row[16];
+    for (int j = 0; j < ctx->k; j++) {
+        for (int z = 0; z < t; z++) {
+            int r = rng_next(ctx) % 6;
+            for (int w = 0; w < 3; w++) row[3 * z + w] = permu[r * 3 + w];
+        }
+        for (int i = 0; i < ctx->e; i++) cc[j * ctx->e + i] = row[i];
+    }
+    return lhgt_coder_set(ctx, cc);
+}
+
+int lhgt_coder_set(lhgt_ctx* ctx, const int16_t* cc) {
+    if (!ctx || !cc) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    HashParams hp;
+    LHGT_TRY(build_hash_params(cc, ctx->k, ctx->e, &hp));
+    memcpy(ctx->cc, cc, sizeof ctx->cc);
+    ctx->hp = hp;
+    ctx->have_coder = true;
+    return LHGT_OK;
+}
+
+int lhgt_coder_get(lhgt_ctx* ctx, int16_t* cc) {
+    if (!ctx || !cc) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
+    memcpy(cc, ctx->cc, sizeof ctx->cc);
+    return LHGT_OK;
+}
+
+// get_random (E:1332-1340): 50 M values float((rand() % 100000) / 1000.0).  Every value is
+// < 100, so with ratio >= 100 every read passes `r < ratio` (E:1044) and the array is not needed;
+// nothing draws from the stream afterwards, so skipping the fill is unobservable.
+int lhgt_sampling_init(lhgt_ctx* ctx, double ratio_percent) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    ctx->ratio = ratio_percent;
+    ctx->random_array.clear();
+    if (ratio_percent >= 100.0) return LHGT_OK;
+    if (!ctx->seeded) LHGT_FAIL(LHGT_E_STATE, "lhgt_rng_seed must be called before lhgt_sampling_init");
+    ctx->random_array.resize(LHGT_MAX_RANDOM);
+    for (long i = 0; i < LHGT_MAX_RANDOM; i++) ctx->random_array[i] = (float)((rng_next(ctx) % 100000) / 1000.0);
+    return LHGT_OK;
+}
+
+int lhgt_sampling_get(lhgt_ctx* ctx, float* out, long n) {
+    if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if ((long)ctx->random_array.size() < n) LHGT_FAIL(LHGT_E_STATE, "sampling array not filled (ratio >= 100?)");
+    memcpy(out, ctx->random_array.data(), sizeof(float) * (size_t)n);
+    return LHGT_OK;
+}
+
+}  // extern "C"

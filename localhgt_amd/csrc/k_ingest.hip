@@ -1,0 +1,306 @@
+// k_ingest.hip -- 2-bit packing of bases, the resident pair store, the index builder/loader.
+#include <cstring>
+#include "lhgt_hash.hpp"
+
+namespace lhgt {
+
+// ---------------------------------------------------------------- pack kernel
+// Thread (r, w) turns bases [32w, 32w+32) of sequence r into one word of each plane.
+// Sequence r is ascii[byte_off[r] .. byte_off[r+1]); its record starts at words[word_off[r]]
+// and is [hi | lo | not-a-base], wpr = ceil(len/32)+1 words each (last word = zero pad).
+__global__ void __launch_bounds__(256) pack_bases(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ byte_off,
+                                                  const uint64_t* __restrict__ word_off, long n_seq, int max_wpr,
+                                                  uint32_t* __restrict__ words) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long r = t / max_wpr;
+    int w = (int)(t % max_wpr);
+    if (r >= n_seq) return;
+    uint64_t b0 = byte_off[r];
+    long len = (long)(byte_off[r + 1] - b0);
+    int wpr = (int)((len + 31) / 32) + 1;
+    if (w >= wpr) return;
+    uint32_t hi = 0, lo = 0, nb = 0;
+    long base = 32L * w;
+    const uint8_t* s = ascii + b0 + base;
+    int n = (int)(len - base < 32 ? (len - base < 0 ? 0 : len - base) : 32);
+    for (int b = 0; b < n; b++) {
+        uint32_t c = base_code(s[b]);
+        uint32_t bit = 0x80000000u >> b;
+        if (c == 4) nb |= bit;
+        else {
+            if (c & 2) hi |= bit;
+            if (c & 1) lo |= bit;
+        }
+    }
+    uint32_t* rec = words + word_off[r];
+    rec[w] = hi;
+    rec[wpr + w] = lo;
+    rec[2 * wpr + w] = nb;
+}
+
+// ---------------------------------------------------------------- hash every position of one packed sequence
+__global__ void __launch_bounds__(256) hash_positions(const uint32_t* __restrict__ rec, long len, HashParams hp,
+                                                      uint32_t* __restrict__ out, uint8_t* __restrict__ out_valid) {
+    long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long nk = len - hp.k + 1;
+    if (j >= nk) return;
+    int wpr = (int)((len + 31) / 32) + 1;
+    // windows are cut relative to a word-aligned base so the 32-bit in-word offset stays small
+    const uint32_t* hi = rec + (j >> 5);
+    int jj = (int)(j & 31);
+    uint32_t whi = plane_window(hi, jj, hp.k);
+    uint32_t wlo = plane_window(hi + wpr, jj, hp.k);
+    uint32_t wnb = plane_window(hi + 2 * wpr, jj, hp.k);
+    uint32_t rhi = brev_k(whi, hp.k), rlo = brev_k(wlo, hp.k);
+    bool valid = wnb == 0;
+    for (int i = 0; i < hp.e; i++) {
+        uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+        out[j * hp.e + i] = valid ? h : 0u;  // invalid k-mers are stored as hash 0 (E:808-810, quirk Q6)
+    }
+    if (out_valid) out_valid[j] = valid;
+}
+
+int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words) {
+    if (ascii_bytes > ctx->ws_ascii_cap) {
+        if (ctx->d_ws_ascii) hipFree(ctx->d_ws_ascii);
+        ctx->ws_ascii_cap = ascii_bytes + ascii_bytes / 4 + 4096;
+        LHGT_HIP(hipMalloc(&ctx->d_ws_ascii, ctx->ws_ascii_cap));
+    }
+    if (plane_words > ctx->ws_words_cap) {
+        if (ctx->d_ws_words) hipFree(ctx->d_ws_words);
+        ctx->ws_words_cap = plane_words + plane_words / 4 + 1024;
+        LHGT_HIP(hipMalloc(&ctx->d_ws_words, ctx->ws_words_cap * 4));
+    }
+    return LHGT_OK;
+}
+
+// pack one host sequence into the workspace planes and hash all its positions into d_out
+int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid) {
+    if (len < ctx->k) return LHGT_OK;
+    int wpr = (int)((len + 31) / 32) + 1;
+    LHGT_TRY(ws_reserve(ctx, (size_t)len + 32, (size_t)3 * wpr + 8));
+    uint64_t offs[3] = {0, (uint64_t)len, 0};  // byte_off[0..1], word_off[0]
+    uint64_t* d_meta = (uint64_t*)(ctx->d_ws_words + (size_t)3 * wpr + 2 - ((size_t)3 * wpr) % 2);
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_meta, offs, sizeof offs, hipMemcpyHostToDevice, ctx->stream));
+    long threads = wpr;
+    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_ascii,
+                       d_meta, d_meta + 2, 1L, wpr, ctx->d_ws_words);
+    long nk = len - ctx->k + 1;
+    hipLaunchKernelGGL(hash_positions, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_words, len,
+                       ctx->hp, d_out, d_valid);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));  // the host buffers above are stack/pageable
+    return LHGT_OK;
+}
+
+// ---------------------------------------------------------------- resident pairs
+static void free_batch(ReadBatch& b) {
+    for (void*& p : b.alloc) if (p) { hipFree(p); p = nullptr; }
+}
+
+int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
+                 long n, const uint8_t* count_mate2) {
+    if (n <= 0) return LHGT_OK;
+    const int k = ctx->k;
+    size_t bytes1 = off1[n] - off1[0], bytes2 = off2[n] - off2[0];
+    std::vector<uint64_t> byte_off(2 * n + 1), word_off(2 * n);
+    std::vector<uint16_t> lens(2 * n);
+    uint64_t words = 0, nkm = 0;
+    int max_len = 0;
+    for (long r = 0; r < 2 * n; r++) {
+        bool m2 = r >= n;
+        const uint64_t* off = m2 ? off2 : off1;
+        long p = m2 ? r - n : r;
+        uint64_t len = off[p + 1] - off[p];
+        if (len > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read longer than %d bases", LHGT_MAX_READ_LEN);
+        byte_off[r] = (m2 ? bytes1 : 0) + (off[p] - off[0]);
+        word_off[r] = words;
+        lens[r] = (uint16_t)len;
+        words += 3 * ((len + 31) / 32 + 1);
+        if ((int)len > max_len) max_len = (int)len;
+        if ((long)len >= k) nkm += len - k + 1;
+    }
+    byte_off[2 * n] = bytes1 + bytes2;
+    if (words >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "batch too large: %llu plane words (split the append)", (unsigned long long)words);
+    ReadBatch b;
+    b.n_words = words;
+    b.max_len = max_len;
+    b.n_kmers = nkm;
+    uint32_t *d_words, *d_off32;
+    uint16_t* d_len;
+    uint8_t* d_cnt = nullptr;
+    uint64_t *d_byte_off, *d_word_off;
+    LHGT_HIP(hipMalloc(&d_words, words * 4 + 16));
+    b.alloc[0] = d_words;
+    LHGT_HIP(hipMalloc(&d_off32, (size_t)2 * n * 4));
+    b.alloc[1] = d_off32;
+    LHGT_HIP(hipMalloc(&d_len, (size_t)2 * n * 2));
+    b.alloc[2] = d_len;
+    if (count_mate2) {
+        LHGT_HIP(hipMalloc(&d_cnt, (size_t)n));
+        b.alloc[3] = d_cnt;
+        LHGT_HIP(hipMemcpyAsync(d_cnt, count_mate2, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    LHGT_HIP(hipMalloc(&d_byte_off, (size_t)(2 * n + 1) * 8));
+    b.alloc[4] = d_byte_off;
+    LHGT_HIP(hipMalloc(&d_word_off, (size_t)2 * n * 8));
+    b.alloc[5] = d_word_off;
+    LHGT_TRY(ws_reserve(ctx, bytes1 + bytes2 + 32, 0));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, seq1 + off1[0], bytes1, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + bytes1, seq2 + off2[0], bytes2, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_byte_off, byte_off.data(), byte_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_word_off, word_off.data(), word_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint32_t> off32(word_off.begin(), word_off.end());
+    LHGT_HIP(hipMemcpyAsync(d_off32, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_len, lens.data(), lens.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    int max_wpr = (max_len + 31) / 32 + 1;
+    long threads = 2 * n * max_wpr;
+    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_ascii,
+                       d_byte_off, d_word_off, 2 * n, max_wpr, d_words);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(d_byte_off);
+    hipFree(d_word_off);
+    b.alloc[4] = b.alloc[5] = nullptr;
+    b.d.words = d_words;
+    b.d.off[0] = d_off32;
+    b.d.off[1] = d_off32 + n;
+    b.d.len[0] = d_len;
+    b.d.len[1] = d_len + n;
+    b.d.count2 = d_cnt;
+    b.d.n_pairs = n;
+    ctx->batches.push_back(b);
+    ctx->n_pairs += n;
+    return LHGT_OK;
+}
+
+// ---------------------------------------------------------------- index layout / install
+int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens) {
+    const int k = ctx->k, e = ctx->e;
+    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_tile_count})
+        if (p) hipFree(p);
+    ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_tile_count = nullptr;
+    ctx->contigs.clear();
+    std::vector<TileDev> tiles;
+    uint64_t word = 0, flat = 0;
+    uint32_t ref_index = 1;
+    for (uint32_t len : lens) {
+        if ((long)len <= k) LHGT_FAIL(LHGT_E_FORMAT, "contig of length %u <= k in the index", len);
+        ContigDev c;
+        c.hash_word = word + 1;
+        c.flat_base = flat;
+        c.len = len;
+        c.ref_index = ref_index++;
+        ctx->contigs.push_back(c);
+        for (uint32_t j0 = 0; j0 < len; j0 += TILE) tiles.push_back(TileDev{(uint32_t)(ctx->contigs.size() - 1), j0});
+        word += 1 + (uint64_t)(len - k + 1) * e;
+        flat += len;
+    }
+    ctx->index_words = word;
+    ctx->n_pos = flat;
+    ctx->n_tiles = (long)tiles.size();
+    if (ctx->contigs.empty()) return LHGT_OK;
+    LHGT_HIP(hipMalloc(&ctx->d_index, word * 4));
+    LHGT_HIP(hipMalloc(&ctx->d_contigs, ctx->contigs.size() * sizeof(ContigDev)));
+    LHGT_HIP(hipMalloc(&ctx->d_tiles, tiles.size() * sizeof(TileDev)));
+    LHGT_HIP(hipMalloc(&ctx->d_flags, flat));
+    LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 1) * 4));
+    LHGT_HIP(hipMemcpy(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice));
+    LHGT_HIP(hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    return LHGT_OK;
+}
+
+int index_install(lhgt_ctx* ctx, const uint32_t* w, size_t n_words, bool /*words_on_device*/) {
+    const int k = ctx->k, e = ctx->e;
+    std::vector<uint32_t> lens;
+    size_t pos = 0;
+    while (pos < n_words) {
+        uint32_t len = w[pos];
+        if ((long)len <= k) LHGT_FAIL(LHGT_E_FORMAT, "index: contig length %u <= k at word %zu", len, pos);
+        size_t step = 1 + (size_t)(len - k + 1) * e;
+        if (pos + step > n_words) LHGT_FAIL(LHGT_E_FORMAT, "index: truncated contig record at word %zu", pos);
+        lens.push_back(len);
+        pos += step;
+    }
+    LHGT_TRY(index_layout(ctx, lens));
+    const size_t CH = 64u << 20;  // words per copy
+    for (size_t o = 0; o < n_words; o += CH) {
+        size_t n = n_words - o < CH ? n_words - o : CH;
+        LHGT_HIP(hipMemcpy(ctx->d_index + o, w + o, n * 4, hipMemcpyHostToDevice));
+    }
+    return LHGT_OK;
+}
+
+}  // namespace lhgt
+
+using namespace lhgt;
+
+extern "C" {
+
+int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
+                      const uint64_t* off2, long n_pairs, const uint8_t* count_mate2) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !seq1 || !off1 || !seq2 || !off2 || n_pairs < 0) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    const long CH = 4L << 20;  // pairs per device batch (keeps 32-bit word offsets inside a batch)
+    for (long p = 0; p < n_pairs; p += CH) {
+        long n = n_pairs - p < CH ? n_pairs - p : CH;
+        LHGT_TRY(upload_pairs(ctx, seq1, off1 + p, seq2, off2 + p, n, count_mate2 ? count_mate2 + p : nullptr));
+    }
+    return LHGT_OK;
+}
+
+int lhgt_pairs_clear(lhgt_ctx* ctx) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    for (auto& b : ctx->batches) free_batch(b);
+    ctx->batches.clear();
+    ctx->n_pairs = 0;
+    return LHGT_OK;
+}
+
+int lhgt_pairs_count(lhgt_ctx* ctx, long* n_pairs) {
+    if (!ctx || !n_pairs) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    *n_pairs = ctx->n_pairs;
+    return LHGT_OK;
+}
+
+int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* out_hash, uint8_t* out_valid) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !ascii || !out_hash) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
+    long nk = len - ctx->k + 1;
+    if (nk <= 0) return LHGT_OK;
+    uint32_t* d_out;
+    uint8_t* d_valid;
+    LHGT_HIP(hipMalloc(&d_out, (size_t)nk * ctx->e * 4));
+    LHGT_HIP(hipMalloc(&d_valid, (size_t)nk));
+    int rc = hash_contig_to_device(ctx, ascii, len, d_out, d_valid);
+    if (rc == LHGT_OK) {
+        hipMemcpy(out_hash, d_out, (size_t)nk * ctx->e * 4, hipMemcpyDeviceToHost);
+        if (out_valid) hipMemcpy(out_valid, d_valid, (size_t)nk, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_out);
+    hipFree(d_valid);
+    return rc;
+}
+
+int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* off, long n_contigs) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !ascii || !off || n_contigs < 0) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
+    std::vector<uint32_t> lens;
+    std::vector<long> src;
+    for (long c = 0; c < n_contigs; c++) {
+        uint64_t len = off[c + 1] - off[c];
+        if ((long)len > ctx->k) { lens.push_back((uint32_t)len); src.push_back(c); }  // E:772: shorter contigs are not indexed
+    }
+    LHGT_TRY(index_layout(ctx, lens));
+    for (size_t i = 0; i < lens.size(); i++) {
+        const ContigDev& c = ctx->contigs[i];
+        LHGT_HIP(hipMemcpyAsync(ctx->d_index + c.hash_word - 1, &lens[i], 4, hipMemcpyHostToDevice, ctx->stream));
+        LHGT_TRY(hash_contig_to_device(ctx, ascii + off[src[i]], (long)lens[i], ctx->d_index + c.hash_word, nullptr));
+    }
+    return LHGT_OK;
+}
+
+}  // extern "C"

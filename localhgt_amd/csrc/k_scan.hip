@@ -1,0 +1,311 @@
+// k_scan.hip -- phase B: reference scan, window/peak stencil and the peak registry
+// (read_index E:888-979, slide_window E:550-725, add_peak/merge_peak E:239-301).
+//
+// The reference walks every contig sequentially; here each step is restated as an
+// order-independent per-position rule over tiles of TILE positions (TILE % 50 == 0):
+//   B1 ref_flags      single/trio from the e gathered counts                     (E:573-595, 933-945)
+//   B2 window_peak    500-wide window sums -> good-window bit; 5-wide contrast   (E:597-615, 644-671)
+//   B3 interval_mask  "inside a merged good interval" from the nearest good       (E:617-638, 675-686)
+//                     window on each side; first-peak-of-its-50bp-bucket flags     (E:288-301)
+//   B4 tile_scan      exclusive scan of new-peak counts = sequential peak ids     (E:232-235, 275)
+//   B5 register       peak_loci + peak_kmer[h] = max id (ids grow in write order) (E:247-267)
+// flags byte per reference position: bit0 single, bit1 trio, bit2 good window, bit3 peak,
+// bit4 inside a good interval, bit5 selected (peak & interval), bit6 new peak.
+#include "lhgt_hash.hpp"
+
+namespace lhgt {
+
+constexpr int BT = 256;        // threads per scan block
+constexpr int WINDOW = 500;    // E:556
+constexpr int HL2 = 512, HR2 = 80;          // halo of B2: 499 back for the window, 2k+5 forward for the contrast test
+constexpr int N2 = TILE + HL2 + HR2;
+constexpr int HALO3 = 2500;    // B3: 2*window on each side plus the 500 merge gap (E:618, 625, 629)
+constexpr int N3 = TILE + 2 * HALO3;
+
+__device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uint32_t h) {
+    return (T[h >> 4] >> ((h & 15u) * 2u)) & 3u;
+}
+
+// ---- B1
+__global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                int k, int e, uint8_t* __restrict__ flags) {
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= c.len) break;
+        uint8_t f = 0;
+        if (j < nk) {  // the last k-1 positions have no k-mer: zero (quirk Q1 contract)
+            const uint32_t* hp = index + c.hash_word + j * e;
+            int hc = 0;
+            for (int i = 0; i < e; i++) {
+                uint32_t h = hp[i];
+                if (h != 0 && count_of(counts, h) == 3u) hc++;  // hash 0 = invalid (E:936-941); least_depth 3 (E:580)
+            }
+            f = (uint8_t)((hc > 0) | ((hc == e) << 1));
+        }
+        flags[c.flat_base + j] = f;
+    }
+}
+
+// exclusive prefix over the block's per-thread values (simple: every thread sums its predecessors)
+__device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    int s = 0;
+    for (int i = 0; i < (int)threadIdx.x; i++) s += sh[i];
+    __syncthreads();
+    return s;
+}
+
+// ---- B2
+__global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                  int k, int one_min, int three_min, uint8_t* __restrict__ flags) {
+    __shared__ int P1[N2], P3[N2], part[BT];
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long len = c.len, lo = (long)t.j0 - HL2;
+    uint8_t* F = flags + c.flat_base;
+    constexpr int CH = (N2 + BT - 1) / BT;
+    const int b = threadIdx.x * CH, en = b + CH < N2 ? b + CH : N2;
+    int s1 = 0, s3 = 0;
+    for (int i = b; i < en; i++) {
+        long pos = lo + i;
+        int f = (pos >= 0 && pos < len) ? F[pos] : 0;
+        s1 += f & 1;
+        s3 += (f >> 1) & 1;
+        P1[i] = s1;
+        P3[i] = s3;
+    }
+    int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
+    for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
+    __syncthreads();
+#define W5(t_) (P1[(t_)] - P1[(t_) - 5])  /* singles over positions t-4..t */
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= len) break;
+        const int i = jj + HL2;
+        int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
+        int good = one >= one_min && three >= three_min;
+        int peak = 0;
+        // the test run AT j: right = W5[j]; left_m = W5[j-5] + W5[j-m-5] - W5[j-k-5]  (E:647-660, literal update rule)
+        if (j > 2 * k + 10) {
+            int right = W5(i), base = W5(i - 5) - W5(i - k - 5);
+            for (int m = k; m < 2 * k; m++)
+                if (base + W5(i - m - 5) - right <= -2) { peak = 1; break; }
+        }
+        // tests run at j' = j+m+5 that mark THIS position (peak_hit[j'-m-w], E:662-664)
+        if (!peak) {
+            int me = W5(i);
+            for (int m = k; m < 2 * k; m++) {
+                long jp = j + m + 5;
+                if (jp > 2 * k + 10 && jp < len && W5(i + m) + me - W5(i + m - k) - W5(i + m + 5) >= 2) { peak = 1; break; }
+            }
+        }
+        F[j] = (uint8_t)((F[j] & 3) | (good << 2) | (peak << 3));
+    }
+#undef W5
+}
+
+// ---- B3
+__global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count) {
+    __shared__ int prevg[N3], nextg[N3], part[BT];
+    __shared__ uint8_t sel[TILE];
+    __shared__ int n_new;
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long len = c.len, lo = (long)t.j0 - HALO3;
+    uint8_t* F = flags + c.flat_base;
+    constexpr int CH = (N3 + BT - 1) / BT;
+    constexpr int NONE_LO = -(1 << 28), NONE_HI = 1 << 28;
+    const int b = threadIdx.x * CH, en = b + CH < N3 ? b + CH : N3;
+    if (threadIdx.x == 0) n_new = 0;
+    // index (relative to lo) of the nearest good window at or before / at or after each position
+    int last = NONE_LO;
+    for (int i = b; i < en; i++) {
+        long pos = lo + i;
+        int g = (pos >= 0 && pos < len) ? (F[pos] >> 2) & 1 : 0;
+        if (g) last = i;
+        prevg[i] = last;
+        nextg[i] = g;  // staged: turned into the next-index below
+    }
+    part[threadIdx.x] = last;
+    __syncthreads();
+    int carry = NONE_LO;
+    for (int q = 0; q < (int)threadIdx.x; q++) carry = part[q] > carry ? part[q] : carry;
+    __syncthreads();
+    int nxt = NONE_HI;
+    for (int i = en - 1; i >= b; i--) {
+        if (prevg[i] < carry) prevg[i] = carry;
+        if (nextg[i]) nxt = i;
+        nextg[i] = nxt;
+    }
+    part[threadIdx.x] = nxt;
+    __syncthreads();
+    carry = NONE_HI;
+    for (int q = BT - 1; q > (int)threadIdx.x; q--) carry = part[q] < carry ? part[q] : carry;
+    for (int i = b; i < en; i++) if (nextg[i] > carry) nextg[i] = carry;
+    __syncthreads();
+    // inside a merged interval: within 2*window of a good window (E:618, 625), or in a gap the
+    // merge rule closes: start_next - end_prev < window  <=>  next - prev <= 4*window + window (E:629)
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        uint8_t s = 0;
+        if (j < len) {
+            int i = jj + HALO3;
+            int dp = i - prevg[i], dn = nextg[i] - i;  // huge when absent
+            int inside = j >= 1 && (dp <= 2 * WINDOW || dn <= 2 * WINDOW || dp + dn <= 5 * WINDOW);
+            uint8_t f = F[j];
+            s = inside && ((f >> 3) & 1);
+            F[j] = (uint8_t)((f & 15) | (inside << 4) | (s << 5));
+        }
+        sel[jj] = s;
+    }
+    __syncthreads();
+    // a selected position opens a new peak iff it is the first selected one of its 50-bp bucket (E:296)
+    for (int bk = threadIdx.x; bk < TILE / 50; bk += BT) {
+        for (int q = 0; q < 50; q++) {
+            int jj = bk * 50 + q;
+            if (sel[jj]) {
+                F[(long)t.j0 + jj] |= 1 << 6;
+                atomicAdd(&n_new, 1);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = (uint32_t)n_new;
+}
+
+// ---- B4: in-place exclusive scan of tile_count[0..n); total lands in tile_count[n]
+__global__ void __launch_bounds__(1024) tile_scan(uint32_t* __restrict__ v, long n) {
+    __shared__ unsigned long long part[1024];
+    long ch = (n + 1023) / 1024;
+    long b = threadIdx.x * ch, en = b + ch < n ? b + ch : n;
+    unsigned long long s = 0;
+    for (long i = b; i < en; i++) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    unsigned long long off = 0;
+    for (int q = 0; q < (int)threadIdx.x; q++) off += part[q];
+    for (long i = b; i < en; i++) {
+        uint32_t x = v[i];
+        v[i] = (uint32_t)(off > 0xffffffffull ? 0xffffffffull : off);
+        off += x;
+    }
+    if (threadIdx.x == 1023) v[n] = (uint32_t)(off > 0xffffffffull ? 0xffffffffull : off);
+}
+
+// ---- B5
+__global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                     const uint8_t* __restrict__ flags, const uint32_t* __restrict__ tile_base,
+                                                     int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer) {
+    __shared__ int incl[TILE], part[BT];
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long len = c.len, nk = len - k + 1;
+    const uint8_t* F = flags + c.flat_base;
+    const uint32_t base = tile_base[blockIdx.x];
+    if (tile_base[blockIdx.x + 1] == base) return;  // no peak in this tile (uniform exit)
+    constexpr int CH = (TILE + BT - 1) / BT;
+    const int b = threadIdx.x * CH, en = b + CH < TILE ? b + CH : TILE;
+    int s = 0;
+    for (int jj = b; jj < en; jj++) {
+        long j = (long)t.j0 + jj;
+        s += (j < len) ? (F[j] >> 6) & 1 : 0;
+        incl[jj] = s;
+    }
+    int off = block_excl_sum(s, part);
+    for (int jj = b; jj < en; jj++) incl[jj] += off;
+    __syncthreads();
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= len) break;
+        uint8_t f = F[j];
+        if (!((f >> 5) & 1)) continue;
+        uint32_t id = base + (uint32_t)incl[jj] - 1u;  // merged peaks take the id of their bucket's first peak
+        if ((f >> 6) & 1) {
+            loci[2 * (long)id] = (int32_t)c.ref_index;
+            loci[2 * (long)id + 1] = (int32_t)j;
+        }
+        if (j < nk) {  // E:247,262; beyond nk the hit array is zero anyway
+            const uint32_t* hp = index + c.hash_word + j * e;
+            for (int i = 0; i < e; i++) {
+                uint32_t h = hp[i];
+                if (h != 0 && count_of(counts, h) > 0) atomicMax(&peak_kmer[h], id);  // later (larger) id wins
+            }
+        }
+    }
+}
+
+}  // namespace lhgt
+
+using namespace lhgt;
+
+extern "C" {
+
+int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (!ctx->d_index || ctx->n_tiles == 0) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load first");
+    if (max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "max_peak must be positive");
+    const int k = ctx->k, e = ctx->e;
+    int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
+    int three_min = (int)(WINDOW * match_ratio);
+    size_t slots = (size_t)1 << k;
+    if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
+    LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    LHGT_HIP(hipMemsetAsync(ctx->d_peak_kmer, 0, slots * 4, ctx->stream));  // E:1458
+    dim3 grid((unsigned)ctx->n_tiles), blk(BT);
+    hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags);
+    hipLaunchKernelGGL(window_peak, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, one_min, three_min, ctx->d_flags);
+    hipLaunchKernelGGL(interval_mask, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_flags, ctx->d_tile_count);
+    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
+    LHGT_HIP(hipGetLastError());
+    uint32_t total = 0;
+    LHGT_HIP(hipMemcpyAsync(&total, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_peaks = -1;
+    if ((long)total > max_peak)
+        LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
+    if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
+    if (ctx->d_filter) { hipFree(ctx->d_filter); ctx->d_filter = nullptr; }
+    LHGT_HIP(hipMalloc(&ctx->d_loci, ((size_t)total + 1) * 8));
+    LHGT_HIP(hipMalloc(&ctx->d_filter, ((size_t)total + 1) * 4));
+    LHGT_HIP(hipMemsetAsync(ctx->d_filter, 0, ((size_t)total + 1) * 4, ctx->stream));  // E:1457
+    LHGT_HIP(hipMemsetAsync(ctx->d_loci, 0, ((size_t)total + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(register_peaks, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts,
+                       ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    LHGT_HIP(hipEventSynchronize(ctx->ev1));
+    LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[1], ctx->ev0, ctx->ev1));
+    ctx->n_peaks = total;
+    ctx->max_peak = max_peak;
+    ctx->voted = false;
+    if (n_peaks) *n_peaks = total;
+    return LHGT_OK;
+}
+
+int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t* out) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (first_pos + n_pos > ctx->n_pos) LHGT_FAIL(LHGT_E_ARG, "position range outside the reference");
+    LHGT_HIP(hipMemcpy(out, ctx->d_flags + first_pos, n_pos, hipMemcpyDeviceToHost));
+    return LHGT_OK;
+}
+
+int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint32_t* out) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (!ctx->d_peak_kmer) LHGT_FAIL(LHGT_E_STATE, "no scan done");
+    if (first_slot + n_slots > (1ull << ctx->k)) LHGT_FAIL(LHGT_E_ARG, "slot range outside the table");
+    LHGT_HIP(hipMemcpy(out, ctx->d_peak_kmer + first_slot, n_slots * 4, hipMemcpyDeviceToHost));
+    return LHGT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// k_vote.hip -- phase C: re-scan of the resident pairs against peak_kmer and the split-read
+// vote (Peaks::slide_reads E:313-506, Split_reads::judge_base E:118-159, check_split E:161-202).
+//
+// One wave per pair.  The e probes of every k-mer offset (mate 1 then mate 2, E:430-495) are
+// done by all lanes; offsets where some probe hits a peak are compacted, in offset order, into
+// an LDS event list.  Only pairs with >= 6 such offsets (MIN_BASE_NUM, E:29,496) run the
+// order-dependent judge_base logic, sequentially on lane 0 over the few events.
+#include "lhgt_hash.hpp"
+
+namespace lhgt {
+
+struct ChrEntry { int chr, count, first_id; };
+
+// Per-wave LDS: events[max_ev][e] peak ids, then the contig table (<= max_ev entries).
+__global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
+                                                   const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
+                                                   int max_ev, int waves_per_block) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    if (wib >= waves_per_block) return;
+    const int e = hp.e, k = hp.k;
+    const size_t per_wave = (size_t)max_ev * e + (size_t)max_ev * 3;
+    uint32_t* ev = lds + (size_t)wib * per_wave;
+    ChrEntry* tab = (ChrEntry*)(ev + (size_t)max_ev * e);
+    const long wave = (long)blockIdx.x * waves_per_block + wib;
+    const long n_waves = (long)gridDim.x * waves_per_block;
+    for (long p = wave; p < b.n_pairs; p += n_waves) {
+        int n_ev = 0;
+        for (int m = 0; m < 2; m++) {
+            const int len = b.len[m][p];
+            const int nk = len - k + 1;
+            if (nk <= 0) continue;
+            const int wpr = ((len + 31) >> 5) + 1;
+            const uint32_t* rec = b.words + b.off[m][p];
+            for (int j0 = 0; j0 < nk; j0 += 64) {
+                const int j = j0 + lane;
+                uint32_t ids[9];
+                bool hit = false;
+                if (j < nk && plane_window(rec + 2 * wpr, j, k) == 0) {
+                    uint32_t whi = plane_window(rec, j, k), wlo = plane_window(rec + wpr, j, k);
+                    uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+#pragma unroll
+                    for (int i = 0; i < 9; i++)
+                        if (i < e) {
+                            ids[i] = peak_kmer[hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i])];  // 0 = no peak (E:454)
+                            hit |= ids[i] != 0;
+                        }
+                }
+                unsigned long long bal = __ballot(hit);
+                if (bal) {
+                    if (hit) {
+                        int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                        for (int i = 0; i < 9; i++)
+                            if (i < e) ev[(size_t)slot * e + i] = ids[i];
+                    }
+                    n_ev += __popcll(bal);
+                }
+            }
+        }
+        if (n_ev < 6) continue;  // base_hits = offsets with any hit (E:149-157, 496)
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            int n_tab = 0;
+            for (int q = 0; q < n_ev; q++) {
+                // judge_base: among the hashes that hit, prefer the contig with the largest running
+                // count (ties: later hash, `>=` at E:131); an unseen contig is taken only if nothing is selected yet
+                int sel_chr = 0, sel_id = 0, sel_num = 0, sel_slot = -1;
+                for (int i = 0; i < e; i++) {
+                    uint32_t id = ev[(size_t)q * e + i];
+                    if (!id) continue;
+                    int chr = loci[2 * (long)id];
+                    int s = -1;
+                    for (int u = 0; u < n_tab; u++) if (tab[u].chr == chr) { s = u; break; }
+                    if (s >= 0) {
+                        if (tab[s].count >= sel_num) { sel_id = (int)id; sel_chr = chr; sel_num = tab[s].count; sel_slot = s; }
+                    } else if (sel_id == 0) { sel_id = (int)id; sel_chr = chr; sel_num = 0; sel_slot = -1; }
+                }
+                if (sel_slot >= 0) tab[sel_slot].count++;
+                else { tab[n_tab].chr = sel_chr; tab[n_tab].count = 1; tab[n_tab].first_id = sel_id; n_tab++; }
+            }
+            // check_split: contigs with >= 6 offsets; the two largest counts (with multiplicity) vote
+            int largest = 0, second = 0, n_f = 0;
+            for (int u = 0; u < n_tab; u++) {
+                int c = tab[u].count;
+                if (c < 6) continue;
+                n_f++;
+                if (c >= largest) { second = largest; largest = c; }
+                else if (c >= second) second = c;
+            }
+            if (n_f > 1)
+                for (int u = 0; u < n_tab; u++) {
+                    int c = tab[u].count;
+                    if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[tab[u].first_id], 1u);  // clamped to 254 at export (E:194)
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace lhgt
+
+using namespace lhgt;
+
+extern "C" {
+
+int lhgt_vote(lhgt_ctx* ctx) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan must precede lhgt_vote");
+    LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (const ReadBatch& b : ctx->batches) {
+        int nk = b.max_len - ctx->k + 1;
+        if (nk <= 0) continue;
+        int max_ev = 2 * nk;
+        size_t per_wave = ((size_t)max_ev * ctx->e + (size_t)max_ev * 3) * 4;
+        int wpb = (int)(65536 / per_wave);
+        if (wpb > 4) wpb = 4;
+        if (wpb < 1) wpb = 1;
+        long blocks = (b.d.n_pairs + wpb - 1) / wpb;
+        if (blocks > 256L * 16) blocks = 256L * 16;
+        hipLaunchKernelGGL(vote_kernel, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp,
+                           ctx->d_peak_kmer, ctx->d_loci, ctx->d_filter, max_ev, wpb);
+    }
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    LHGT_HIP(hipEventSynchronize(ctx->ev1));
+    LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[2], ctx->ev0, ctx->ev1));
+    ctx->voted = true;
+    return LHGT_OK;
+}
+
+int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !dev_ptr || !bytes) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
+    *dev_ptr = ctx->d_filter;
+    *bytes = (size_t)ctx->n_peaks * 4;
+    return LHGT_OK;
+}
+
+int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
+    if (n > ctx->n_peaks) LHGT_FAIL(LHGT_E_ARG, "asked for %ld peaks, have %ld", n, ctx->n_peaks);
+    if (n == 0) return LHGT_OK;
+    if (loci) LHGT_HIP(hipMemcpy(loci, ctx->d_loci, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (filter) {
+        std::vector<uint32_t> v((size_t)n);
+        LHGT_HIP(hipMemcpy(v.data(), ctx->d_filter, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; i++) filter[i] = (uint8_t)(v[i] > 254 ? 254 : v[i]);  // `if (< 254) ++` saturates at 254
+    }
+    return LHGT_OK;
+}
+
+// count_filtered_peak (E:515-548), single thread range: leading sentinel "1 1 1", merge while the
+// contig is the same and the gap to the running end is < 500.
+int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !path) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
+    long n = ctx->n_peaks;
+    std::vector<int32_t> loci((size_t)2 * n + 2);
+    std::vector<uint8_t> filt((size_t)n + 1);
+    LHGT_TRY(lhgt_peaks_export(ctx, loci.data(), filt.data(), n));
+    FILE* f = fopen(path, "w");
+    if (!f) LHGT_FAIL(LHGT_E_IO, "cannot write %s", path);
+    int start = 1, end = 1, chr = 1;
+    long nf = 0;
+    for (long i = 0; i < n; i++) {
+        if (filt[i] < 1) continue;  // MIN_READS (E:37)
+        nf++;
+        int c = loci[2 * i], pos = loci[2 * i + 1];
+        if (chr == c && pos - 500 - end < 500) end = pos + 500;
+        else {
+            fprintf(f, "%d\t%d\t%d\n", chr, start, end);
+            chr = c; start = pos - 500; end = pos + 500;
+        }
+    }
+    fprintf(f, "%d\t%d\t%d\n", chr, start, end);
+    fclose(f);
+    if (n_filtered) *n_filtered = nf;
+    return LHGT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// lhgt_common.hpp -- context, error plumbing and device-side data layout shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "../../include/localhgt_hip.h"
+
+namespace lhgt {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+#define LHGT_HIP(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            lhgt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return LHGT_E_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+#define LHGT_TRY(expr)            \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != LHGT_OK) return rc_; \
+    } while (0)
+#define LHGT_FAIL(code, ...)      \
+    do {                          \
+        lhgt::set_error(__VA_ARGS__); \
+        return (code);            \
+    } while (0)
+
+// ---------------------------------------------------------------- hash parameters (by value to kernels)
+// mask[i][m] has bit (k-1-z) set iff choose_coder[z*e+i] == m  
+struct HashParams {
+    uint32_t mask[9][3];
+    int k, e;
+};
+
+// ---------------------------------------------------------------- resident read store
+// One batch = n_pairs pairs.  Read (m, p) owns 3*wpr words at words[off[m][p]]: the hi-bit
+// plane, the lo-bit plane and the not-a-base plane of its 2-bit codes (A=0 C=1 G=2 T=3),
+// 32 bases per word, first base at the MSB, wpr = ceil(len/32)+1 (one zero pad word so a
+// k-bit window can always be cut from two consecutive words).
+struct ReadBatchDev {
+    const uint32_t* words;
+    const uint32_t* off[2];
+    const uint16_t* len[2];
+    const uint8_t* count2;  // nullable: 0 = mate 2 not counted in phase A (quirk Q4)
+    long n_pairs;
+};
+struct ReadBatch {
+    ReadBatchDev d{};
+    void* alloc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t n_words = 0;
+    int max_len = 0;
+    uint64_t n_kmers = 0;  // valid-or-not k-mer positions of both mates (for rates)
+};
+
+// ---------------------------------------------------------------- resident index
+// d_index = the index file minus its 1200-byte header: per contig [u32 len][(len-k+1)*e u32].
+struct ContigDev {
+    uint64_t hash_word;  // word offset of the contig's first hash in d_index
+    uint64_t flat_base;  // position of base 0 in the flat per-position arrays
+    uint32_t len;
+    uint32_t ref_index;  // 1,2,3.. in index order (E:905,963; quirk Q7)
+};
+constexpr int TILE = 2000;  // positions per scan tile; multiple of 50 so peak buckets never straddle tiles
+struct TileDev {
+    uint32_t contig;
+    uint32_t j0;
+};
+
+}  // namespace lhgt
+
+struct lhgt_ctx {
+    int device = 0, k = 0, e = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float phase_ms[3] = {0, 0, 0};
+    // R
+    char rng_state[128];
+    void* rng = nullptr;  // struct random_data*
+    bool seeded = false;
+    int16_t cc[LHGT_CODER_SLOTS];
+    bool have_coder = false;
+    lhgt::HashParams hp{};
+    std::vector<float> random_array;
+    double ratio = 100.0;
+    // A
+    uint32_t* d_counts = nullptr;  // 2-bit saturating counters, 16 per word
+    size_t counts_words = 0;
+    // I
+    uint32_t* d_index = nullptr;
+    size_t index_words = 0;
+    std::vector<lhgt::ContigDev> contigs;
+    lhgt::ContigDev* d_contigs = nullptr;
+    lhgt::TileDev* d_tiles = nullptr;
+    long n_tiles = 0;
+    uint64_t n_pos = 0;
+    uint8_t* d_flags = nullptr;
+    // reads
+    std::vector<lhgt::ReadBatch> batches;
+    long n_pairs = 0;
+    // B/C
+    uint32_t* d_peak_kmer = nullptr;
+    int32_t* d_loci = nullptr;
+    uint32_t* d_filter = nullptr;
+    uint32_t* d_tile_count = nullptr;
+    long n_peaks = -1, max_peak = 0;
+    bool voted = false;
+    // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)
+    uint8_t* d_ws_ascii = nullptr;
+    size_t ws_ascii_cap = 0;
+    uint32_t* d_ws_words = nullptr;
+    size_t ws_words_cap = 0;
+};
+
+namespace lhgt {
+// host helpers implemented across the .cpp/.hip files
+int build_hash_params(const int16_t* cc, int k, int e, HashParams* hp);
+int rng_next(lhgt_ctx* ctx);  // one rand() draw from the private glibc stream
+int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
+                 long n_pairs, const uint8_t* count_mate2);
+int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens);  // allocates d_index, tiles, flags
+int index_install(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, bool words_on_device);
+int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words);
+int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid);
+}  // namespace lhgt

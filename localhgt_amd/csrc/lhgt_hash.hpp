@@ -1,0 +1,43 @@
+// lhgt_hash.hpp -- the e position-dependent 1-bit-per-base hashes, O(1) per k-mer.
+//
+// Reference: for hash i the k-mer s hashes to min(fwd, rc) with
+//   fwd = sum_z proj[cc[z][i]](s[z]) << (k-1-z),   rc = sum_z proj[cc[k-1-z][i]](comp(s[z])) << z
+// (/root/reference/src/extract_ref_normal_peak.cpp:1058-1081, maps :1109-1180).  The three
+// projections are bit-planes of the 2-bit code (A=0 C=1 G=2 T=3, hi/lo bits):
+//   map0 (A,T->1) = ~(hi^lo), map1 (A,C->1) = ~hi, map2 (A,G->1) = ~lo,
+// and the complemented base has both bits flipped, so the rc word is the same formula on the
+// bit-reversed window with hi/lo un-negated.  mask[i][m] selects the positions where hash i
+// uses map m (verified there against index bytes).
+#pragma once
+#include "lhgt_common.hpp"
+
+namespace lhgt {
+
+// k-bit window starting at base j of a plane (32 bases per word, first base at the MSB).
+__device__ __forceinline__ uint32_t plane_window(const uint32_t* __restrict__ w, int j, int k) {
+    int q = j >> 5, r = j & 31;
+    uint64_t v = ((uint64_t)w[q] << 32) | w[q + 1];
+    return (uint32_t)((v << r) >> 32) >> (32 - k);
+}
+
+__device__ __forceinline__ uint32_t brev_k(uint32_t x, int k) { return __brev(x) >> (32 - k); }
+
+__device__ __forceinline__ uint32_t hash_from_windows(uint32_t whi, uint32_t wlo, uint32_t rhi, uint32_t rlo,
+                                                      const uint32_t* __restrict__ m) {
+    uint32_t fwd = (~(whi ^ wlo) & m[0]) | (~whi & m[1]) | (~wlo & m[2]);
+    uint32_t rc = (~(rhi ^ rlo) & m[0]) | (rhi & m[1]) | (rlo & m[2]);
+    return fwd < rc ? fwd : rc;
+}
+
+// ASCII -> 2-bit code, 4 = not a base (E:1112-1151: upper and lower case ACGT only)
+__host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
+    switch (c | 0x20) {
+        case 'a': return 0;
+        case 'c': return 1;
+        case 'g': return 2;
+        case 't': return 3;
+        default: return 4;
+    }
+}
+
+}  // namespace lhgt

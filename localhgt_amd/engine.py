@@ -1,0 +1,197 @@
+"""Python face of the C-ABI: one `Engine` = one `lhgt_ctx` on one GPU.
+
+Method names follow the phases of the reference binary
+(/root/reference/src/extract_ref_normal_peak.cpp: main at :1342-1519)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Engine:
+    def __init__(self, k: int, e: int, device: int = 0):
+        self.lib = _lib.load(require_gpu=(device >= 0))  # device -1 = host-only context (RNG/coder rows)
+        self.k, self.e, self.device = int(k), int(e), int(device)
+        h = C.c_void_p()
+        _lib.check(self.lib.lhgt_ctx_create(self.device, self.k, self.e, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lhgt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- R
+    def rng_seed(self, seed: int):
+        _lib.check(self.lib.lhgt_rng_seed(self.h, C.c_uint(seed & 0xFFFFFFFF)))
+
+    def coder_generate(self):
+        _lib.check(self.lib.lhgt_coder_generate(self.h))
+
+    def coder_set(self, cc: np.ndarray):
+        cc = np.ascontiguousarray(cc, dtype=np.int16)
+        assert cc.size == _lib.CODER_SLOTS
+        _lib.check(self.lib.lhgt_coder_set(self.h, _ptr(cc, C.c_int16)))
+
+    def coder_get(self) -> np.ndarray:
+        cc = np.zeros(_lib.CODER_SLOTS, dtype=np.int16)
+        _lib.check(self.lib.lhgt_coder_get(self.h, _ptr(cc, C.c_int16)))
+        return cc
+
+    def sampling_init(self, ratio_percent: float):
+        _lib.check(self.lib.lhgt_sampling_init(self.h, float(ratio_percent)))
+
+    def sampling_get(self, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.float32)
+        _lib.check(self.lib.lhgt_sampling_get(self.h, _ptr(out, C.c_float), n))
+        return out
+
+    # ---- H
+    def hash_sequence(self, seq: bytes) -> Tuple[np.ndarray, np.ndarray]:
+        nk = max(0, len(seq) - self.k + 1)
+        out = np.zeros((nk, self.e), dtype=np.uint32)
+        valid = np.zeros(nk, dtype=np.uint8)
+        _lib.check(self.lib.lhgt_hash_sequence(self.h, seq, len(seq), _ptr(out, C.c_uint32), _ptr(valid, C.c_uint8)))
+        return out, valid.astype(bool)
+
+    # ---- I
+    def index_build(self, fasta: str, index_path: str, genome_len_path: str) -> Tuple[int, int]:
+        nc, nb = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_index_build(self.h, fasta.encode(), index_path.encode(), genome_len_path.encode(),
+                                             C.byref(nc), C.byref(nb)))
+        return nc.value, nb.value
+
+    def index_load(self, index_path: str) -> Tuple[int, int]:
+        nc, nb = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_index_load(self.h, index_path.encode(), C.byref(nc), C.byref(nb)))
+        return nc.value, nb.value
+
+    def index_from_memory(self, ascii_bases: np.ndarray, offsets: np.ndarray):
+        a = np.ascontiguousarray(ascii_bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _lib.check(self.lib.lhgt_index_from_memory(self.h, _ptr(a, C.c_uint8), _ptr(o, C.c_uint64), o.size - 1))
+
+    # ---- reads
+    def sam_ratio(self, fq1: str, sample: float) -> float:
+        r, n = C.c_double(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_fastq_sam_ratio(fq1.encode(), float(sample), C.byref(r), C.byref(n)))
+        return r.value
+
+    def pairs_load_fastq(self, fq1: str, fq2: str, ratio_percent: float, rank: int = 0, world: int = 1,
+                         block: int = 4096) -> Tuple[int, int]:
+        seen, kept = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_pairs_load_fastq(self.h, fq1.encode(), fq2.encode(), float(ratio_percent), rank, world,
+                                                  block, C.byref(seen), C.byref(kept)))
+        return seen.value, kept.value
+
+    def pairs_append(self, seq1: np.ndarray, off1: np.ndarray, seq2: np.ndarray, off2: np.ndarray,
+                     count_mate2: Optional[np.ndarray] = None):
+        s1 = np.ascontiguousarray(seq1, dtype=np.uint8)
+        s2 = np.ascontiguousarray(seq2, dtype=np.uint8)
+        o1 = np.ascontiguousarray(off1, dtype=np.uint64)
+        o2 = np.ascontiguousarray(off2, dtype=np.uint64)
+        assert o1.size == o2.size
+        c2 = None if count_mate2 is None else np.ascontiguousarray(count_mate2, dtype=np.uint8)
+        _lib.check(self.lib.lhgt_pairs_append(self.h, _ptr(s1, C.c_uint8), _ptr(o1, C.c_uint64), _ptr(s2, C.c_uint8),
+                                              _ptr(o2, C.c_uint64), o1.size - 1,
+                                              None if c2 is None else _ptr(c2, C.c_uint8)))
+
+    def pairs_clear(self):
+        _lib.check(self.lib.lhgt_pairs_clear(self.h))
+
+    def pairs_count(self) -> int:
+        n = C.c_long(0)
+        _lib.check(self.lib.lhgt_pairs_count(self.h, C.byref(n)))
+        return n.value
+
+    # ---- phases
+    def count_kmers(self):
+        _lib.check(self.lib.lhgt_count_kmers(self.h))
+
+    def counts_clear(self):
+        _lib.check(self.lib.lhgt_counts_clear(self.h))
+
+    def ref_scan(self, hit_ratio: float, match_ratio: float, max_peak: int) -> int:
+        n = C.c_long(0)
+        _lib.check(self.lib.lhgt_ref_scan(self.h, C.c_float(np.float32(hit_ratio)), C.c_float(np.float32(match_ratio)),
+                                          int(max_peak), C.byref(n)))
+        return n.value
+
+    def vote(self):
+        _lib.check(self.lib.lhgt_vote(self.h))
+
+    def write_intervals(self, path: str) -> int:
+        n = C.c_long(0)
+        _lib.check(self.lib.lhgt_write_intervals(self.h, path.encode(), C.byref(n)))
+        return n.value
+
+    def phase_ms(self, phase: int) -> float:
+        ms = C.c_float(0)
+        _lib.check(self.lib.lhgt_phase_ms(self.h, phase, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        _lib.check(self.lib.lhgt_synchronize(self.h))
+
+    # ---- device buffers for the multi-GPU exchange
+    def counts_buffer(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_size_t(0)
+        _lib.check(self.lib.lhgt_counts_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def counts_merge(self, dev_ptr: int, byte_offset: int, nbytes: int):
+        _lib.check(self.lib.lhgt_counts_merge(self.h, C.c_void_p(dev_ptr), byte_offset, nbytes))
+
+    def filter_buffer(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_size_t(0)
+        _lib.check(self.lib.lhgt_filter_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- introspection (parity tests)
+    def counts_export(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = (1 << self.k) - first if n is None else n
+        out = np.zeros(n, dtype=np.uint8)
+        _lib.check(self.lib.lhgt_counts_export_u8(self.h, first, n, _ptr(out, C.c_uint8)))
+        return out
+
+    def counts_histogram(self) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(self.lib.lhgt_counts_histogram(self.h, _ptr(out, C.c_uint64)))
+        return out
+
+    def flags_export(self, first: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.uint8)
+        _lib.check(self.lib.lhgt_flags_export(self.h, first, n, _ptr(out, C.c_uint8)))
+        return out
+
+    def peaks_export(self, n: int) -> Tuple[np.ndarray, np.ndarray]:
+        loci = np.zeros(2 * max(n, 1), dtype=np.int32)
+        filt = np.zeros(max(n, 1), dtype=np.uint8)
+        _lib.check(self.lib.lhgt_peaks_export(self.h, _ptr(loci, C.c_int32), _ptr(filt, C.c_uint8), n))
+        return loci[:2 * n], filt[:n]
+
+    def peak_kmer_export(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = (1 << self.k) - first if n is None else n
+        out = np.zeros(n, dtype=np.uint32)
+        _lib.check(self.lib.lhgt_peak_kmer_export(self.h, first, n, _ptr(out, C.c_uint32)))
+        return out

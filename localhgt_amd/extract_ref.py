@@ -1,0 +1,125 @@
+"""`extract_ref` -- drop-in for the reference binary at scripts/pipeline.sh:35.
+
+    extract_ref fq1 fq2 ref.fa interval_out hit_ratio match_ratio threads k max_peak e seed sample
+
+Same 12 positional arguments, parsed the way the reference does (stod then truncation,
+/root/reference/src/extract_ref_normal_peak.cpp:1352-1371), same files read and written:
+`<ref>.k<k>.h<e>.index.dat` + `<ref>.genome.len.txt` (built when absent, reused when present,
+E:1401-1413) and the interval file (E:515-548).  All compute runs on the GPU through
+liblocalhgt_hip.so; `threads` is accepted and ignored for compute (results are the `-t 1` ones).
+
+Under `torch.distributed.run` (WORLD_SIZE > 1) every rank takes a shard of the read pairs and
+the count table / votes are exchanged over RCCL (localhgt_amd/dist.py)."""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from .engine import Engine
+
+
+@dataclass
+class Args:
+    fq1: str
+    fq2: str
+    fasta: str
+    interval: str
+    hit_ratio: float
+    match_ratio: float
+    threads: int
+    k: int
+    max_peak: int
+    e: int
+    seed: int
+    sample: float
+
+
+def parse_argv(argv) -> Args:
+    if len(argv) < 12:
+        raise SystemExit("usage: extract_ref fq1 fq2 ref.fa interval_out hit_ratio match_ratio threads k max_peak "
+                         "coder_num seed base_num")
+    f = [float(x) for x in argv[4:12]]  # stod
+    return Args(argv[0], argv[1], argv[2], argv[3], float(np.float32(f[0])), float(np.float32(f[1])), int(f[2]),
+                int(f[3]), int(f[4]), int(f[5]), int(f[6]) & 0xFFFFFFFF, f[7])
+
+
+def index_name(fasta: str, k: int, e: int) -> str:
+    return f"{fasta}.k{k}.h{e}.index.dat"  # E:1401
+
+
+def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
+    """The whole path A->D. `dist` is a localhgt_amd.dist.Exchange (or None for one GPU)."""
+    rank, world = (dist.rank, dist.world) if dist else (0, 1)
+    t0 = time.time()
+    eng = Engine(a.k, a.e, device)
+    log(f"kmer length is {a.k}\nseed is {a.seed}\nnum of hash functions is {a.e}")
+    eng.rng_seed(a.seed)                                       # E:1386
+    ratio = eng.sam_ratio(a.fq1, a.sample)                     # E:1392-1398
+    log(f"down-sampling ratio: {ratio}%.")
+    idx = index_name(a.fasta, a.k, a.e)
+    # E:1403-1410.  random_coder draws k*(e//3+1) values from the rand() stream before the sampling
+    # array is filled (quirk Q3), so every rank draws them when rank 0 has to build the index.
+    built = not os.path.exists(idx) if rank == 0 else False
+    if dist:
+        built = dist.broadcast_flag(built)
+    if built:
+        eng.coder_generate()
+        if rank == 0:
+            log("Reference index not detected, start index...")
+            eng.index_build(a.fasta, idx, a.fasta + ".genome.len.txt")
+        if dist:
+            dist.barrier()
+    n_contigs, n_bases = eng.index_load(idx)                   # E:1417 (+ resident copy of the hashes)
+    eng.sampling_init(ratio)                                   # E:1422
+    seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
+    t1 = time.time()
+    eng.count_kmers()                                          # phase A, E:1426-1448
+    if dist:
+        dist.merge_counts(eng)
+    t2 = time.time()
+    log(f"K-mer counting is finished. It costs {t2 - t0:.2f} seconds.")
+    n_peaks = eng.ref_scan(a.hit_ratio, a.match_ratio, a.max_peak)  # phase B, E:1468-1489
+    t3 = time.time()
+    log(f"Slided ref len: {n_bases} bp\tNo. of raw BKPs: {n_peaks}")
+    eng.vote()                                                 # phase C, E:1496-1507
+    if dist:
+        dist.sum_votes(eng)
+    t4 = time.time()
+    n_filtered = -1
+    if rank == 0:
+        n_filtered = eng.write_intervals(a.interval)           # phase D, E:1511
+    if dist:
+        dist.barrier()
+    t5 = time.time()
+    log(f"Finish with time:\t{t5 - t0:.2f}")
+    rep = dict(pairs_seen=seen, pairs_kept=kept, n_contigs=n_contigs, n_bases=n_bases, n_peaks=n_peaks,
+               n_filtered=n_filtered, ratio=ratio, index_built=built, ingest_s=t1 - t0, count_s=t2 - t1, scan_s=t3 - t2,
+               vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
+               vote_kernel_ms=eng.phase_ms(2))
+    eng.close()
+    return rep
+
+
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_argv(argv)
+    dist = None
+    device = 0
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from .dist import Exchange
+        dist = Exchange.from_env()
+        device = dist.local_rank
+    try:
+        run(a, device=device, dist=dist)
+    finally:
+        if dist:
+            dist.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

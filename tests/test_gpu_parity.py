@@ -1,0 +1,245 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the reference goldens.
+Bit-exact everywhere: this path is integer / index work."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from localhgt_amd.engine import Engine as E
+    return E
+
+
+# ------------------------------------------------------------------ row H: hashes
+@pytest.mark.parametrize("k,e,seed", [(24, 3, 1), (32, 3, 1), (21, 3, 9), (20, 2, 4), (22, 5, 2), (8, 9, 3), (31, 1, 5)])
+def test_hash_matches_oracle(Engine, oracle, k, e, seed):
+    rng = np.random.default_rng(100 + k + e)
+    seq = rng.choice(np.frombuffer(b"ACGTacgtNRn-", dtype=np.uint8), size=700,
+                     p=[.22, .22, .22, .22, .02, .02, .02, .02, .01, .01, .01, .01]).tobytes()
+    with Engine(k, e) as eng:
+        eng.rng_seed(seed)
+        eng.coder_generate()
+        cc = eng.coder_get()
+        got, valid = eng.hash_sequence(seq)
+    assert got.shape == (len(seq) - k + 1, e)
+    for j in range(len(seq) - k + 1):
+        ok, h = oracle.hash_kmer(seq[j:j + k], k, e, cc)
+        assert ok == valid[j], j
+        if ok:
+            assert (got[j] == h).all(), (j, got[j], h)
+        else:
+            assert (got[j] == 0).all()          # index convention: invalid -> 0 (quirk Q6)
+
+
+def test_hash_long_contig_word_boundaries(Engine, oracle):
+    """every in-word offset, plus a sequence long enough to cross many 32-base words"""
+    k, e = 32, 3
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5000)].tobytes()
+    with Engine(k, e) as eng:
+        eng.rng_seed(3)
+        eng.coder_generate()
+        cc = eng.coder_get()
+        got, valid = eng.hash_sequence(seq)
+    assert valid.all()
+    for j in list(range(0, 140)) + list(range(4900, 5000 - k + 1)):
+        ok, h = oracle.hash_kmer(seq[j:j + k], k, e, cc)
+        assert ok and (got[j] == h).all()
+
+
+# ------------------------------------------------------------------ stepwise parity on one case
+@pytest.mark.parametrize("name", ["k24_base", "k24_nrun_lower", "k20_e2"])
+def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    k, e = case.k, case.e
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    index = f"{fa2}.k{k}.h{e}.index.dat"
+    with Engine(k, e) as eng:
+        # R + I
+        eng.rng_seed(case.seed)
+        eng.coder_generate()
+        oracle.srand(case.seed)
+        cc = oracle.random_coder(k, e)
+        assert (eng.coder_get() == cc).all()
+        n_contigs, n_bases = eng.index_build(fa2, index, fa2 + ".genome.len.txt")
+        assert cases.sha256_file(index) == meta["sha256"]["index.dat"]
+        assert open(fa2 + ".genome.len.txt").read() == open(os.path.join(cases.GOLDEN_DIR, name, "genome.len.txt")).read()
+        assert eng.index_load(index) == (n_contigs, n_bases)
+        # A
+        ratio = eng.sam_ratio(f1, case.sample)
+        assert ratio == oracle.sam_ratio(f1, float(case.sample))
+        eng.sampling_init(ratio)
+        seen, kept = eng.pairs_load_fastq(f1, f2, ratio)
+        eng.count_kmers()
+        table = np.zeros(1 << k, dtype=np.uint8)
+        size1 = os.path.getsize(f1)
+        c1 = oracle.count(f1, size1, k, e, cc, ratio, None, table)
+        oracle.count(f2, size1, k, e, cc, ratio, None, table)
+        assert kept == c1 == seen
+        got = eng.counts_export()
+        assert (got == table).all(), f"{int((got != table).sum())} slots differ"
+        assert (eng.counts_histogram() == np.bincount(table, minlength=4)).all()
+        # B
+        flags_o = np.zeros(n_bases, dtype=np.uint8)
+        pk_o = np.zeros(1 << k, dtype=np.uint32)
+        n_o, loci_o, _ = oracle.ref_scan(index, table, k, e, np.float32(case.hit_ratio), np.float32(case.match_ratio),
+                                         case.max_peak, pk_o, flags_o)
+        n_g = eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak)
+        flags_g = eng.flags_export(0, n_bases)
+        assert ((flags_g & 0b1011) == (flags_o & 0b1011)).all(), "single/trio/peak flags differ"
+        assert (((flags_g >> 4) & 1) == ((flags_o >> 2) & 1)).all(), "good-interval mask differs"
+        assert n_g == n_o == meta["raw_peaks"]
+        loci_g, _ = eng.peaks_export(n_g)
+        assert (loci_g == loci_o[:2 * n_o]).all()
+        assert (eng.peak_kmer_export() == pk_o).all()
+        # C
+        eng.vote()
+        _, pf_o = oracle.vote(f1, f2, k, e, cc, ratio, None, pk_o, loci_o, n_o)
+        _, pf_g = eng.peaks_export(n_g)
+        assert (pf_g == pf_o[:n_g]).all()
+        # D
+        out = str(tmp_path / "interval.txt")
+        eng.write_intervals(out)
+        assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+
+
+# ------------------------------------------------------------------ the 12-argument contract against the reference goldens
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_extract_ref_matches_reference_golden(case_inputs, name, tmp_path):
+    from localhgt_amd import extract_ref, get_bed_file
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    interval = str(tmp_path / "interval.txt")
+    argv = cases.extract_ref_argv(case, f1, f2, fa2, interval)
+    for _ in range(2 if case.preexisting_index else 1):
+        rep = extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None)
+    gold = os.path.join(cases.GOLDEN_DIR, name)
+    assert rep["n_peaks"] == meta["raw_peaks"]
+    assert open(interval).read() == open(os.path.join(gold, "interval.txt")).read()
+    assert open(fa2 + ".genome.len.txt").read() == open(os.path.join(gold, "genome.len.txt")).read()
+    assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]
+    if case.bed_defined:
+        n = get_bed_file.write_bed(fa2, interval)
+        assert open(interval + ".bed").read() == open(os.path.join(gold, "interval.txt.bed")).read()
+        assert f"extracted ref length is: {n}\n" == meta["bed_stdout"]
+    else:
+        with pytest.raises(get_bed_file.InconsistentReferenceIds):
+            get_bed_file.write_bed(fa2, interval)
+
+
+# ------------------------------------------------------------------ edge cases
+def _pairs(reads1, reads2):
+    s1 = np.frombuffer(b"".join(reads1), dtype=np.uint8)
+    s2 = np.frombuffer(b"".join(reads2), dtype=np.uint8)
+    o1 = np.cumsum([0] + [len(r) for r in reads1]).astype(np.uint64)
+    o2 = np.cumsum([0] + [len(r) for r in reads2]).astype(np.uint64)
+    return s1, o1, s2, o2
+
+
+def _write_fq(path, reads, suffix):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@e%d/%s\n" % (i, suffix) + r + b"\n+\n" + b"I" * len(r) + b"\n")
+
+
+def test_ragged_and_degenerate_reads(Engine, oracle, tmp_path):
+    """reads shorter than k, exactly k, all-N, maximum length 500, empty; mates of unequal length"""
+    k, e = 24, 3
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return acgt[rng.integers(0, 4, n)].tobytes()
+    base = rnd(600)
+    reads1 = [b"", rnd(5), rnd(23), base[:24], b"N" * 100, base[:500], rnd(150), base[10:160], b"A" * 150, rnd(33)]
+    reads2 = [rnd(150), b"", rnd(24), base[100:124], rnd(100), base[100:600], b"n" * 30, base[10:160], b"T" * 150, rnd(32)]
+    f1, f2 = str(tmp_path / "e.1.fq"), str(tmp_path / "e.2.fq")
+    _write_fq(f1, reads1, b"1")
+    _write_fq(f2, reads2, b"2")
+    with Engine(k, e) as eng:
+        eng.rng_seed(1)
+        eng.coder_generate()
+        cc = eng.coder_get()
+        eng.sampling_init(100.0)
+        eng.pairs_append(*_pairs(reads1, reads2))
+        eng.count_kmers()
+        got = eng.counts_export()
+        table = np.zeros(1 << k, dtype=np.uint8)
+        big = 1 << 40
+        oracle.count(f1, big, k, e, cc, 100.0, None, table)
+        oracle.count(f2, big, k, e, cc, 100.0, None, table)
+        assert (got == table).all()
+        assert got.max() == 3     # poly-A / its reverse complement poly-T saturate one slot per hash
+        # same through the FASTQ parser
+        eng.counts_clear()
+        eng.pairs_clear()
+        assert eng.pairs_load_fastq(f1, f2, 100.0) == (10, 10)
+        eng.count_kmers()
+        assert (eng.counts_export() == table).all()
+
+
+def test_empty_inputs(Engine, tmp_path):
+    k, e = 24, 3
+    f1, f2 = str(tmp_path / "z.1.fq"), str(tmp_path / "z.2.fq")
+    open(f1, "w").close()
+    open(f2, "w").close()
+    fa = str(tmp_path / "ref.fa")
+    rng = np.random.default_rng(3)
+    with open(fa, "w") as f:
+        f.write(">c1 desc\n" + "".join("ACGT"[i] for i in rng.integers(0, 4, 3000)) + "\n>tiny\nACGT\n")
+    from localhgt_amd import extract_ref
+    interval = str(tmp_path / "i.txt")
+    rep = extract_ref.run(extract_ref.parse_argv([f1, f2, fa, interval, "0.1", "0.08", "1", str(k), "1000", str(e), "1", "1"]),
+                          log=lambda *a: None)
+    assert rep["pairs_kept"] == 0 and rep["n_peaks"] == 0
+    assert open(interval).read() == "1\t1\t1\n"          # the sentinel line alone (E:522-524, 542)
+    assert open(fa + ".genome.len.txt").read() == "c1\t1\t3000\t3000\n"
+
+
+def test_counts_merge_is_saturating_add(Engine):
+    k, e = 16, 3
+    rng = np.random.default_rng(9)
+    with Engine(k, e) as a, Engine(k, e) as b:
+        for eng, seed in ((a, 1), (b, 2)):
+            eng.rng_seed(7)
+            eng.coder_generate()
+            r = np.random.default_rng(seed)
+            reads = [np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, 150)].tobytes() for _ in range(3000)]
+            reads += [b"A" * 150] * 3
+            eng.pairs_append(*_pairs(reads, reads))
+            eng.count_kmers()
+        ta, tb = a.counts_export(), b.counts_export()
+        pb, nb = b.counts_buffer()
+        half = nb // 2
+        a.counts_merge(pb + half, half, nb - half)     # merge only the upper half, device pointer arithmetic
+        got = a.counts_export()
+        want = ta.copy()
+        lo = (half * 4)                                # 4 slots per byte
+        want[lo:] = np.minimum(3, ta[lo:].astype(int) + tb[lo:].astype(int))
+        assert (got == want).all()
+        assert (ta[lo:] != want[lo:]).any()
+
+
+def test_too_many_peaks_is_reported(Engine, case_inputs, tmp_path):
+    from localhgt_amd import extract_ref, _lib
+    case = cases.CASES["k24_base"]
+    fa, f1, f2, _ = case_inputs("k24_base")
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    argv = cases.extract_ref_argv(case, f1, f2, fa2, str(tmp_path / "i.txt"))
+    argv[8] = "10"   # max_peak
+    with pytest.raises(_lib.LocalHGTError) as ei:
+        extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None)
+    assert ei.value.code == 6 and "Too many peaks" in str(ei.value)

@@ -108,6 +108,12 @@ int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t
 int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci /*[2*n]*/, uint8_t* filter /*[n]*/, long n);
 int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint32_t* out);
 
+/* ---- synthetic workload generated on the device (bench.py / tests; no reference counterpart).
+ * Bases are a pure function of (seed, contig, position); see localhgt_amd/csrc/k_synth.hip. */
+int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, uint8_t* host_ascii_or_null);
+int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
+                     long first_pair, long n_pairs, int read_len, uint8_t* host_seq1_or_null, uint8_t* host_seq2_or_null);
+
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C*/, float* ms);
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream);

@@ -56,6 +56,8 @@ SIGNATURES = {
     "lhgt_flags_export": [_vp, C.c_uint64, C.c_uint64, _u8p],
     "lhgt_peaks_export": [_vp, _i32p, _u8p, _l],
     "lhgt_peak_kmer_export": [_vp, C.c_uint64, C.c_uint64, _u32p],
+    "lhgt_synth_reference": [_vp, C.c_uint64, _l, _l, _u8p],
+    "lhgt_synth_pairs": [_vp, C.c_uint64, C.c_uint64, _l, _l, _l, _l, _i, _u8p, _u8p],
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_stream": [_vp, C.POINTER(_vp)],
     "lhgt_synchronize": [_vp],

@@ -74,24 +74,30 @@ int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words) {
     return LHGT_OK;
 }
 
-// pack one host sequence into the workspace planes and hash all its positions into d_out
-int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid) {
+// pack one sequence that already sits in device memory and hash all its positions into d_out
+int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint32_t* d_out, uint8_t* d_valid) {
     if (len < ctx->k) return LHGT_OK;
     int wpr = (int)((len + 31) / 32) + 1;
-    LHGT_TRY(ws_reserve(ctx, (size_t)len + 32, (size_t)3 * wpr + 8));
+    LHGT_TRY(ws_reserve(ctx, 0, (size_t)3 * wpr + 8));
     uint64_t offs[3] = {0, (uint64_t)len, 0};  // byte_off[0..1], word_off[0]
     uint64_t* d_meta = (uint64_t*)(ctx->d_ws_words + (size_t)3 * wpr + 2 - ((size_t)3 * wpr) % 2);
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(d_meta, offs, sizeof offs, hipMemcpyHostToDevice, ctx->stream));
     long threads = wpr;
-    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_ascii,
+    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_ascii,
                        d_meta, d_meta + 2, 1L, wpr, ctx->d_ws_words);
     long nk = len - ctx->k + 1;
     hipLaunchKernelGGL(hash_positions, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_words, len,
                        ctx->hp, d_out, d_valid);
     LHGT_HIP(hipGetLastError());
-    LHGT_HIP(hipStreamSynchronize(ctx->stream));  // the host buffers above are stack/pageable
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));  // offs is on the stack; the workspace is reused by the next call
     return LHGT_OK;
+}
+
+int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid) {
+    if (len < ctx->k) return LHGT_OK;
+    LHGT_TRY(ws_reserve(ctx, (size_t)len + 32, 0));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    return hash_contig_dev_ascii(ctx, ctx->d_ws_ascii, len, d_out, d_valid);
 }
 
 // ---------------------------------------------------------------- resident pairs
@@ -99,29 +105,24 @@ static void free_batch(ReadBatch& b) {
     for (void*& p : b.alloc) if (p) { hipFree(p); p = nullptr; }
 }
 
-int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
-                 long n, const uint8_t* count_mate2) {
-    if (n <= 0) return LHGT_OK;
+// Install n pairs whose ASCII bases already sit in device memory: sequence r (r < n: mate 1 of
+// pair r, else mate 2 of pair r-n) is d_ascii[byte_off[r] .. byte_off[r+1]).
+int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const std::vector<uint64_t>& byte_off, long n,
+                            const uint8_t* count_mate2) {
     const int k = ctx->k;
-    size_t bytes1 = off1[n] - off1[0], bytes2 = off2[n] - off2[0];
-    std::vector<uint64_t> byte_off(2 * n + 1), word_off(2 * n);
+    std::vector<uint64_t> word_off(2 * n);
     std::vector<uint16_t> lens(2 * n);
     uint64_t words = 0, nkm = 0;
     int max_len = 0;
     for (long r = 0; r < 2 * n; r++) {
-        bool m2 = r >= n;
-        const uint64_t* off = m2 ? off2 : off1;
-        long p = m2 ? r - n : r;
-        uint64_t len = off[p + 1] - off[p];
+        uint64_t len = byte_off[r + 1] - byte_off[r];
         if (len > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read longer than %d bases", LHGT_MAX_READ_LEN);
-        byte_off[r] = (m2 ? bytes1 : 0) + (off[p] - off[0]);
         word_off[r] = words;
         lens[r] = (uint16_t)len;
         words += 3 * ((len + 31) / 32 + 1);
         if ((int)len > max_len) max_len = (int)len;
         if ((long)len >= k) nkm += len - k + 1;
     }
-    byte_off[2 * n] = bytes1 + bytes2;
     if (words >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "batch too large: %llu plane words (split the append)", (unsigned long long)words);
     ReadBatch b;
     b.n_words = words;
@@ -146,9 +147,6 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
     b.alloc[4] = d_byte_off;
     LHGT_HIP(hipMalloc(&d_word_off, (size_t)2 * n * 8));
     b.alloc[5] = d_word_off;
-    LHGT_TRY(ws_reserve(ctx, bytes1 + bytes2 + 32, 0));
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, seq1 + off1[0], bytes1, hipMemcpyHostToDevice, ctx->stream));
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + bytes1, seq2 + off2[0], bytes2, hipMemcpyHostToDevice, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(d_byte_off, byte_off.data(), byte_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(d_word_off, word_off.data(), word_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     std::vector<uint32_t> off32(word_off.begin(), word_off.end());
@@ -156,7 +154,7 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
     LHGT_HIP(hipMemcpyAsync(d_len, lens.data(), lens.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     int max_wpr = (max_len + 31) / 32 + 1;
     long threads = 2 * n * max_wpr;
-    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_ascii,
+    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_ascii,
                        d_byte_off, d_word_off, 2 * n, max_wpr, d_words);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
@@ -173,6 +171,22 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
     ctx->batches.push_back(b);
     ctx->n_pairs += n;
     return LHGT_OK;
+}
+
+int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
+                 long n, const uint8_t* count_mate2) {
+    if (n <= 0) return LHGT_OK;
+    size_t bytes1 = off1[n] - off1[0], bytes2 = off2[n] - off2[0];
+    std::vector<uint64_t> byte_off(2 * n + 1);
+    for (long p = 0; p < n; p++) {
+        byte_off[p] = off1[p] - off1[0];
+        byte_off[n + p] = bytes1 + (off2[p] - off2[0]);
+    }
+    byte_off[2 * n] = bytes1 + bytes2;
+    LHGT_TRY(ws_reserve(ctx, bytes1 + bytes2 + 32, 0));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, seq1 + off1[0], bytes1, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + bytes1, seq2 + off2[0], bytes2, hipMemcpyHostToDevice, ctx->stream));
+    return install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, byte_off, n, count_mate2);
 }
 
 // ---------------------------------------------------------------- index layout / install

@@ -1,0 +1,149 @@
+// k_synth.hip -- synthetic workload generated on the device from seeds: iid
+// uniform ACGT contigs, and 150 bp pairs drawn from a sample made of the first half of the
+// contigs taken in (recipient, donor) pairs with one 3 kb cut-and-paste transfer each.
+// Every base is a pure function of (seed, contig, position), so reads need no stored reference
+// and any rank can generate any shard.  Bench/test support only: not part of the reference.
+#include "lhgt_hash.hpp"
+
+namespace lhgt {
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t ref_code(uint64_t seed, uint32_t contig, uint64_t pos) {
+    return (uint32_t)(mix64(seed ^ mix64(((uint64_t)contig << 40) ^ pos)) >> 62);
+}
+
+struct SynthSpec {
+    uint64_t ref_seed, reads_seed;
+    uint32_t n_contigs;
+    uint64_t contig_len;
+    uint32_t transfer_len;  // 3000
+    uint32_t read_len;      // 150
+    uint32_t frag_min, frag_max;  // 300..500
+    uint32_t n_permille;    // reads carrying one N, per thousand (20)
+};
+
+// donor cut position / recipient insert position of sample pair i
+__host__ __device__ __forceinline__ void transfer_sites(const SynthSpec& s, uint32_t i, uint64_t* r0, uint64_t* d0) {
+    uint64_t h = mix64(s.ref_seed * 0x51ED2701ull + i);
+    uint64_t span = s.contig_len - 3ull * s.transfer_len;
+    *r0 = s.transfer_len + (h % span);
+    *d0 = s.transfer_len + (mix64(h) % span);
+}
+
+// base x of sample genome g (even g = recipient with the insert, odd g = donor with the deletion)
+__device__ __forceinline__ uint32_t sample_code(const SynthSpec& s, uint32_t g, uint64_t x) {
+    uint64_t r0, d0;
+    transfer_sites(s, g >> 1, &r0, &d0);
+    uint32_t rec = g & ~1u, don = g | 1u;
+    if (!(g & 1)) {
+        if (x < r0) return ref_code(s.ref_seed, rec, x);
+        if (x < r0 + s.transfer_len) return ref_code(s.ref_seed, don, d0 + (x - r0));
+        return ref_code(s.ref_seed, rec, x - s.transfer_len);
+    }
+    return ref_code(s.ref_seed, don, x < d0 ? x : x + s.transfer_len);
+}
+
+__global__ void __launch_bounds__(256) synth_contig_ascii(SynthSpec s, uint32_t contig, uint8_t* __restrict__ out) {
+    uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= s.contig_len) return;
+    out[pos] = "ACGT"[ref_code(s.ref_seed, contig, pos)];
+}
+
+// thread = one base of one mate; out1/out2 are [n][read_len] ASCII
+__global__ void __launch_bounds__(256) synth_pairs_ascii(SynthSpec s, uint64_t first_pair, uint64_t n_pairs,
+                                                         uint8_t* __restrict__ out1, uint8_t* __restrict__ out2) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t L = s.read_len;
+    if (t >= n_pairs * L) return;
+    uint64_t pi = t / L;
+    uint32_t b = (uint32_t)(t % L);
+    uint64_t p = first_pair + pi;
+    uint64_t h = mix64(s.reads_seed ^ mix64(p));
+    uint32_t n_sample = (s.n_contigs / 2) & ~1u;
+    uint32_t g = (uint32_t)(h % n_sample);
+    uint64_t h2 = mix64(h);
+    uint64_t glen = (g & 1) ? s.contig_len - s.transfer_len : s.contig_len + s.transfer_len;
+    uint64_t flen = s.frag_min + h2 % (s.frag_max - s.frag_min + 1);
+    uint64_t h3 = mix64(h2);
+    uint64_t start = h3 % (glen - flen + 1);
+    bool flip = (mix64(h3) >> 63) != 0;
+    // left mate reads the fragment forward, right mate is the reverse complement of its tail
+    uint32_t left = sample_code(s, g, start + b);
+    uint32_t right = 3u - sample_code(s, g, start + flen - 1 - b);
+    uint8_t c1 = "ACGT"[flip ? right : left], c2 = "ACGT"[flip ? left : right];
+    uint64_t h4 = mix64(h3 ^ 0xA5A5A5A5ull);
+    if (h4 % 1000 < s.n_permille) {
+        uint32_t col = (uint32_t)((h4 >> 20) % L);
+        if (col == b) { if ((h4 >> 40) & 1) c1 = 'N'; else c2 = 'N'; }
+    }
+    out1[pi * L + b] = c1;
+    out2[pi * L + b] = c2;
+}
+
+static SynthSpec make_spec(uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len, int read_len) {
+    SynthSpec s;
+    s.ref_seed = ref_seed; s.reads_seed = reads_seed;
+    s.n_contigs = (uint32_t)n_contigs; s.contig_len = (uint64_t)contig_len;
+    s.transfer_len = 3000; s.read_len = (uint32_t)read_len; s.frag_min = 300; s.frag_max = 500; s.n_permille = 20;
+    return s;
+}
+
+}  // namespace lhgt
+
+using namespace lhgt;
+
+extern "C" {
+
+// Build the resident index of a synthetic reference of n_contigs x contig_len bases.
+// host_ascii (optional, n_contigs*contig_len bytes) receives the bases for writing a FASTA.
+int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, uint8_t* host_ascii) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context");
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
+    if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32)) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
+    SynthSpec s = make_spec(ref_seed, 0, n_contigs, contig_len, 150);
+    std::vector<uint32_t> lens((size_t)n_contigs, (uint32_t)contig_len);
+    LHGT_TRY(index_layout(ctx, lens));
+    LHGT_TRY(ws_reserve(ctx, (size_t)contig_len + 32, 0));
+    for (long c = 0; c < n_contigs; c++) {
+        const ContigDev& cd = ctx->contigs[c];
+        hipLaunchKernelGGL(synth_contig_ascii, dim3((unsigned)((contig_len + 255) / 256)), dim3(256), 0, ctx->stream, s, (uint32_t)c, ctx->d_ws_ascii);
+        if (host_ascii) LHGT_HIP(hipMemcpyAsync(host_ascii + (size_t)c * contig_len, ctx->d_ws_ascii, (size_t)contig_len, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipMemcpyAsync(ctx->d_index + cd.hash_word - 1, &lens[c], 4, hipMemcpyHostToDevice, ctx->stream));
+        LHGT_TRY(hash_contig_dev_ascii(ctx, ctx->d_ws_ascii, contig_len, ctx->d_index + cd.hash_word, nullptr));
+    }
+    return LHGT_OK;
+}
+
+// Append pairs [first_pair, first_pair + n_pairs) of the synthetic sample to the resident store.
+// host_seq1/2 (optional, n_pairs*read_len bytes each) receive the bases for writing FASTQs.
+int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
+                     long first_pair, long n_pairs, int read_len, uint8_t* host_seq1, uint8_t* host_seq2) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context");
+    if (n_contigs < 4 || contig_len < 16000 || read_len < 1 || read_len > 300 || n_pairs < 0) LHGT_FAIL(LHGT_E_ARG, "bad synthetic spec");
+    SynthSpec s = make_spec(ref_seed, reads_seed, n_contigs, contig_len, read_len);
+    const long CH = 16L << 20;  // pairs per resident batch (one scan launch each)
+    for (long o = 0; o < n_pairs; o += CH) {
+        long n = n_pairs - o < CH ? n_pairs - o : CH;
+        size_t bytes = (size_t)n * read_len;
+        LHGT_TRY(ws_reserve(ctx, 2 * bytes + 32, 0));
+        uint8_t *d1 = ctx->d_ws_ascii, *d2 = ctx->d_ws_ascii + bytes;
+        hipLaunchKernelGGL(synth_pairs_ascii, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, s,
+                           (uint64_t)(first_pair + o), (uint64_t)n, d1, d2);
+        LHGT_HIP(hipGetLastError());
+        if (host_seq1) LHGT_HIP(hipMemcpyAsync(host_seq1 + (size_t)o * read_len, d1, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (host_seq2) LHGT_HIP(hipMemcpyAsync(host_seq2 + (size_t)o * read_len, d2, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<uint64_t> byte_off((size_t)2 * n + 1);
+        for (long r = 0; r <= 2 * n; r++) byte_off[r] = (uint64_t)r * read_len;
+        LHGT_TRY(install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, byte_off, n, nullptr));
+    }
+    return LHGT_OK;
+}
+
+}  // extern "C"

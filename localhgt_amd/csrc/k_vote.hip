@@ -11,7 +11,8 @@ namespace lhgt {
 
 struct ChrEntry { int chr, count, first_id; };
 
-// Per-wave LDS: events[max_ev][e] peak ids, then the contig table (<= max_ev entries).
+// Per-wave LDS: events[max_ev][e] of (peak id, contig) -- the contig of a hit is fetched by the
+// lane that found it, so the sequential part touches LDS only -- then the contig table (<= max_ev entries).
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
                                                    int max_ev, int waves_per_block) {
@@ -19,9 +20,9 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     if (wib >= waves_per_block) return;
     const int e = hp.e, k = hp.k;
-    const size_t per_wave = (size_t)max_ev * e + (size_t)max_ev * 3;
+    const size_t per_wave = (size_t)max_ev * e * 2 + (size_t)max_ev * 3;
     uint32_t* ev = lds + (size_t)wib * per_wave;
-    ChrEntry* tab = (ChrEntry*)(ev + (size_t)max_ev * e);
+    ChrEntry* tab = (ChrEntry*)(ev + (size_t)max_ev * e * 2);
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
     for (long p = wave; p < b.n_pairs; p += n_waves) {
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
             const uint32_t* rec = b.words + b.off[m][p];
             for (int j0 = 0; j0 < nk; j0 += 64) {
                 const int j = j0 + lane;
-                uint32_t ids[9];
+                uint32_t ids[9], chrs[9];
                 bool hit = false;
                 if (j < nk && plane_window(rec + 2 * wpr, j, k) == 0) {
                     uint32_t whi = plane_window(rec, j, k), wlo = plane_window(rec + wpr, j, k);
@@ -45,6 +46,9 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                             ids[i] = peak_kmer[hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i])];  // 0 = no peak (E:454)
                             hit |= ids[i] != 0;
                         }
+#pragma unroll
+                    for (int i = 0; i < 9; i++)
+                        if (i < e) chrs[i] = ids[i] ? (uint32_t)loci[2 * (long)ids[i]] : 0u;  // count_peak_kmer's peak_chr (E:455)
                 }
                 unsigned long long bal = __ballot(hit);
                 if (bal) {
@@ -52,7 +56,10 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                         int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
                         for (int i = 0; i < 9; i++)
-                            if (i < e) ev[(size_t)slot * e + i] = ids[i];
+                            if (i < e) {
+                                ev[((size_t)slot * e + i) * 2] = ids[i];
+                                ev[((size_t)slot * e + i) * 2 + 1] = chrs[i];
+                            }
                     }
                     n_ev += __popcll(bal);
                 }
@@ -60,39 +67,66 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
         }
         if (n_ev < 6) continue;  // base_hits = offsets with any hit (E:149-157, 496)
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            int n_tab = 0;
-            for (int q = 0; q < n_ev; q++) {
-                // judge_base: among the hashes that hit, prefer the contig with the largest running
-                // count (ties: later hash, `>=` at E:131); an unseen contig is taken only if nothing is selected yet
-                int sel_chr = 0, sel_id = 0, sel_num = 0, sel_slot = -1;
-                for (int i = 0; i < e; i++) {
-                    uint32_t id = ev[(size_t)q * e + i];
-                    if (!id) continue;
-                    int chr = loci[2 * (long)id];
-                    int s = -1;
-                    for (int u = 0; u < n_tab; u++) if (tab[u].chr == chr) { s = u; break; }
-                    if (s >= 0) {
-                        if (tab[s].count >= sel_num) { sel_id = (int)id; sel_chr = chr; sel_num = tab[s].count; sel_slot = s; }
-                    } else if (sel_id == 0) { sel_id = (int)id; sel_chr = chr; sel_num = 0; sel_slot = -1; }
+        // judge_base, sequential over events but wave-parallel inside one: every lane compares its
+        // table entries with the (<= e) candidate contigs of the event, ballots give the slots.
+        int n_tab = 0;
+        for (int q = 0; q < n_ev; q++) {
+            int sel_chr = 0, sel_id = 0, sel_num = 0, sel_slot = -1;
+            for (int i = 0; i < e; i++) {
+                const uint32_t id = ev[((size_t)q * e + i) * 2];       // same address in every lane: LDS broadcast
+                if (!id) continue;                                     // wave-uniform
+                const int chr = (int)ev[((size_t)q * e + i) * 2 + 1];
+                int s = -1, cnt = 0;
+                for (int t0 = 0; t0 < n_tab; t0 += 64) {
+                    const int u = t0 + lane;
+                    const bool m = u < n_tab && tab[u].chr == chr;
+                    const unsigned long long bal = __ballot(m);
+                    if (bal) {
+                        s = t0 + __ffsll((long long)bal) - 1;
+                        cnt = tab[s].count;
+                        break;
+                    }
                 }
-                if (sel_slot >= 0) tab[sel_slot].count++;
-                else { tab[n_tab].chr = sel_chr; tab[n_tab].count = 1; tab[n_tab].first_id = sel_id; n_tab++; }
+                // among the hashes that hit, prefer the contig with the largest running count (ties: later
+                // hash, `>=` at E:131); an unseen contig is taken only if nothing is selected yet (E:140-144)
+                if (s >= 0) {
+                    if (cnt >= sel_num) { sel_id = (int)id; sel_chr = chr; sel_num = cnt; sel_slot = s; }
+                } else if (sel_id == 0) { sel_id = (int)id; sel_chr = chr; sel_num = 0; sel_slot = -1; }
             }
-            // check_split: contigs with >= 6 offsets; the two largest counts (with multiplicity) vote
-            int largest = 0, second = 0, n_f = 0;
-            for (int u = 0; u < n_tab; u++) {
-                int c = tab[u].count;
-                if (c < 6) continue;
-                n_f++;
-                if (c >= largest) { second = largest; largest = c; }
-                else if (c >= second) second = c;
+            if (lane == 0) {
+                if (sel_slot >= 0) tab[sel_slot].count = sel_num + 1;
+                else { tab[n_tab].chr = sel_chr; tab[n_tab].count = 1; tab[n_tab].first_id = sel_id; }
             }
-            if (n_f > 1)
-                for (int u = 0; u < n_tab; u++) {
-                    int c = tab[u].count;
-                    if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[tab[u].first_id], 1u);  // clamped to 254 at export (E:194)
+            if (sel_slot < 0) n_tab++;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // check_split: contigs with >= 6 offsets; the two largest counts (with multiplicity) vote (E:161-202)
+        int largest = 0, n_f = 0, n_at_largest = 0;
+        for (int t0 = 0; t0 < n_tab; t0 += 64) {
+            const int u = t0 + lane;
+            const int c = u < n_tab ? tab[u].count : 0;
+            n_f += __popcll(__ballot(c >= 6));
+            int mx = c >= 6 ? c : 0;
+            for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+            if (mx > largest) { largest = mx; n_at_largest = 0; }
+            if (mx == largest && largest > 0) n_at_largest += __popcll(__ballot(c == largest));
+        }
+        if (n_f > 1) {
+            int second = largest;
+            if (n_at_largest < 2) {
+                second = 0;
+                for (int t0 = 0; t0 < n_tab; t0 += 64) {
+                    const int u = t0 + lane;
+                    const int c = u < n_tab ? tab[u].count : 0;
+                    int mx = (c >= 6 && c < largest) ? c : 0;
+                    for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+                    second = mx > second ? mx : second;
                 }
+            }
+            for (int u = lane; u < n_tab; u += 64) {
+                const int c = tab[u].count;
+                if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[tab[u].first_id], 1u);  // clamped to 254 at export (E:194)
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -113,7 +147,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
         int max_ev = 2 * nk;
-        size_t per_wave = ((size_t)max_ev * ctx->e + (size_t)max_ev * 3) * 4;
+        size_t per_wave = ((size_t)max_ev * ctx->e * 2 + (size_t)max_ev * 3) * 4;
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;

@@ -124,6 +124,22 @@ class Engine:
         _lib.check(self.lib.lhgt_pairs_count(self.h, C.byref(n)))
         return n.value
 
+    # ---- synthetic workload (bench / tests)
+    def synth_reference(self, ref_seed: int, n_contigs: int, contig_len: int, want_host: bool = False):
+        host = np.zeros(n_contigs * contig_len, dtype=np.uint8) if want_host else None
+        _lib.check(self.lib.lhgt_synth_reference(self.h, ref_seed, n_contigs, contig_len,
+                                                 None if host is None else _ptr(host, C.c_uint8)))
+        return host
+
+    def synth_pairs(self, ref_seed: int, reads_seed: int, n_contigs: int, contig_len: int, first_pair: int,
+                    n_pairs: int, read_len: int = 150, want_host: bool = False):
+        h1 = np.zeros(n_pairs * read_len, dtype=np.uint8) if want_host else None
+        h2 = np.zeros(n_pairs * read_len, dtype=np.uint8) if want_host else None
+        _lib.check(self.lib.lhgt_synth_pairs(self.h, ref_seed, reads_seed, n_contigs, contig_len, first_pair, n_pairs,
+                                             read_len, None if h1 is None else _ptr(h1, C.c_uint8),
+                                             None if h2 is None else _ptr(h2, C.c_uint8)))
+        return h1, h2
+
     # ---- phases
     def count_kmers(self):
         _lib.check(self.lib.lhgt_count_kmers(self.h))

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lhgt_pairs_clear": [_vp],
     "lhgt_pairs_count": [_vp, _lp],
     "lhgt_count_kmers": [_vp],
+    "lhgt_set_count_mode": [_vp, _i],
     "lhgt_counts_clear": [_vp],
     "lhgt_counts_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "lhgt_counts_merge": [_vp, _vp, C.c_size_t, C.c_size_t],

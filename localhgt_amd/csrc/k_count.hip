@@ -98,6 +98,10 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: load or build the index first");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     for (const ReadBatch& b : ctx->batches) {
+        if (ctx->count_mode == 1) {
+            LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
+            continue;
+        }
         long waves = 2 * b.d.n_pairs;
         long blocks = (waves + 3) / 4;
         if (blocks > 256L * 8 * 4) blocks = 256L * 8 * 4;
@@ -107,6 +111,12 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
     LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[0], ctx->ev0, ctx->ev1));
+    return LHGT_OK;
+}
+
+int lhgt_set_count_mode(lhgt_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 1) LHGT_FAIL(LHGT_E_ARG, "count mode must be 0 (direct) or 1 (partitioned)");
+    ctx->count_mode = mode;
     return LHGT_OK;
 }
 

@@ -1,0 +1,255 @@
+// k_count_part.hip -- phase A as a radix partition: the MI355X-first form of the k-mer count.
+//
+// Measured on MI355X (profiles/r01_probe_rates_microbench.txt): device atomics top out at
+// 18-27 G/s whatever the locality, random 4-byte loads at ~50 G/s, streaming at ~5 TB/s.  714
+// random read-modify-writes per read pair therefore cap the direct kernel (k_count.hip) at
+// ~33 M pairs/s.  Here the hashes are first routed by their top bits so that every final bucket
+// covers 2^18 table slots = one 64 KiB slice of the 2-bit table, which is then updated inside LDS:
+//   P0 part_hist      hash every k-mer, count keys per final bucket            (LDS histogram)
+//   P1 part_scatter_r hash again, route keys by the top B1 bits                (tile sort in LDS, 64 KiB)
+//   P2 part_scatter_k route each level-1 segment by the next B2 bits           (same tile sort)
+//   P3 part_apply     one workgroup per final bucket: slice -> LDS, saturating
+//                     2-bit increments by LDS compare-and-swap, slice -> HBM
+// HBM traffic is 16 B per key streamed plus one table sweep per chunk, instead of one random
+// 64-byte sector (and its write-back) per key.  The result is the same table: min(3, count).
+#include "lhgt_hash.hpp"
+
+namespace lhgt {
+
+constexpr int SLICE_BITS = 18;            // slots per final bucket (2-bit fields -> 64 KiB of LDS)
+constexpr int MAX_B1 = 7;                 // 128-way fan-out per scatter pass (B2 = k - 18 - B1 <= 7 for k <= 32)
+constexpr int PT = 256;                   // threads per partition workgroup
+constexpr int TILE_KEYS = 16384;          // keys sorted per workgroup tile (64 KiB of LDS)
+
+struct PartGeom {
+    int k, slot_bits, b1, b2;             // b1 + b2 = k - slot_bits
+    int nb1, nb2, nb;                     // buckets: level 1, per level-1 segment, final
+};
+
+__host__ inline PartGeom part_geom(int k) {
+    PartGeom g;
+    g.k = k;
+    g.slot_bits = k < SLICE_BITS ? k : SLICE_BITS;
+    int B = k - g.slot_bits;
+    g.b1 = B < MAX_B1 ? B : MAX_B1;
+    g.b2 = B - g.b1;
+    g.nb1 = 1 << g.b1; g.nb2 = 1 << g.b2; g.nb = 1 << B;
+    return g;
+}
+
+// keys of read (m, p) at offsets lane, lane+64, ...: calls f(key) for each of the e hashes of valid k-mers
+template <class F>
+__device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashParams& hp, long p, int m, int lane, F f) {
+    if (m == 1 && b.count2 && !b.count2[p]) return;  // quirk Q4
+    const int len = b.len[m][p];
+    const int nk = len - hp.k + 1;
+    if (nk <= 0) return;
+    const int wpr = ((len + 31) >> 5) + 1;
+    const uint32_t* rec = b.words + b.off[m][p];
+    for (int j = lane; j < nk; j += 64) {
+        if (plane_window(rec + 2 * wpr, j, hp.k) != 0) continue;
+        uint32_t whi = plane_window(rec, j, hp.k), wlo = plane_window(rec + wpr, j, hp.k);
+        uint32_t rhi = brev_k(whi, hp.k), rlo = brev_k(wlo, hp.k);
+        for (int i = 0; i < hp.e; i++) f(hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]));
+    }
+}
+
+// ---- P0: keys per final bucket for pairs [pair0, pair0+npairs)
+__global__ void __launch_bounds__(PT) part_hist(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
+                                                uint32_t* __restrict__ ghist) {
+    extern __shared__ uint32_t lh[];  // [g.nb]
+    for (int i = threadIdx.x; i < g.nb; i += PT) lh[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * PT + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * PT) >> 6;
+    const int sh = g.slot_bits;
+    for (long r = wave; r < 2 * npairs; r += n_waves)
+        for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, [&](uint32_t key) { atomicAdd(&lh[g.nb > 1 ? key >> sh : 0], 1u); });
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.nb; i += PT)
+        if (lh[i]) atomicAdd(&ghist[i], lh[i]);
+}
+
+// ---- exclusive scan of the final-bucket histogram; level-1/level-2 cursors start at their segment starts
+__global__ void __launch_bounds__(1024) part_offsets(const uint32_t* __restrict__ ghist, PartGeom g, uint32_t* __restrict__ off /*[nb+1]*/,
+                                                     uint32_t* __restrict__ cur1 /*[nb1]*/, uint32_t* __restrict__ cur2 /*[nb]*/) {
+    __shared__ uint32_t part[1024];
+    int ch = (g.nb + 1023) / 1024;
+    int b0 = threadIdx.x * ch, e0 = b0 + ch < g.nb ? b0 + ch : g.nb;
+    uint32_t s = 0;
+    for (int i = b0; i < e0; i++) s += ghist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    uint32_t o = 0;
+    for (int q = 0; q < (int)threadIdx.x; q++) o += part[q];
+    for (int i = b0; i < e0; i++) {
+        off[i] = o;
+        cur2[i] = o;
+        if ((i & (g.nb2 - 1)) == 0) cur1[i >> g.b2] = o;
+        o += ghist[i];
+    }
+    if (threadIdx.x == 1023) off[g.nb] = o;
+}
+
+// Sort the tile's keys (already counted into hist[nbk]) by bucket inside LDS and copy the runs out.
+// Called by the whole workgroup; `place(emit)` must call emit(key) for every key of the tile again.
+template <class Place>
+__device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase,
+                                                int nbk, int shift, uint32_t bmask, uint32_t* __restrict__ cursors,
+                                                uint32_t* __restrict__ out, Place place) {
+    // exclusive scan of hist (nbk <= 128) and reservation of the global runs
+    if ((int)threadIdx.x < nbk) {
+        uint32_t o = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) o += hist[q];
+        lofs[threadIdx.x] = o;
+        lcur[threadIdx.x] = o;
+        uint32_t c = hist[threadIdx.x];
+        gbase[threadIdx.x] = c ? atomicAdd(&cursors[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    place([&](uint32_t key) {
+        uint32_t bk = (key >> shift) & bmask;
+        sorted[atomicAdd(&lcur[bk], 1u)] = key;
+    });
+    __syncthreads();
+    const uint32_t total = lofs[nbk - 1] + hist[nbk - 1];
+    for (uint32_t i = threadIdx.x; i < total; i += PT) {
+        uint32_t key = sorted[i];
+        uint32_t bk = (key >> shift) & bmask;
+        out[gbase[bk] + (i - lofs[bk])] = key;   // consecutive i of one bucket -> consecutive addresses
+    }
+    __syncthreads();
+}
+
+// ---- P1: reads -> level-1 segments.  A tile = reads_per_tile reads (<= TILE_KEYS keys).
+__global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
+                                                         int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sorted[TILE_KEYS];
+    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int shift = g.k - g.b1;
+    const uint32_t bmask = (uint32_t)g.nb1 - 1u;
+    const long n_reads = 2 * npairs;
+    const long n_tiles = (n_reads + reads_per_tile - 1) / reads_per_tile;
+    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long r0 = t * reads_per_tile, r1 = r0 + reads_per_tile < n_reads ? r0 + reads_per_tile : n_reads;
+        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (long r = r0 + wib; r < r1; r += PT / 64)
+            for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
+        __syncthreads();
+        tile_sort_flush(sorted, hist, lofs, lcur, gbase, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, out, [&](auto emit) {
+            for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, emit);
+        });
+    }
+}
+
+// ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS keys, never straddling segments.
+__global__ void __launch_bounds__(PT) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ off /*[nb+1]*/, PartGeom g,
+                                                        uint32_t* __restrict__ cur2, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sorted[TILE_KEYS];
+    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    __shared__ uint32_t tile_pref[129];   // tiles before segment s
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int s = 0; s < g.nb1; s++) {
+            tile_pref[s] = a;
+            uint32_t len = off[(s + 1) << g.b2] - off[s << g.b2];
+            a += (len + TILE_KEYS - 1) / TILE_KEYS;
+        }
+        tile_pref[g.nb1] = a;
+    }
+    __syncthreads();
+    const uint32_t n_tiles = tile_pref[g.nb1];
+    const int shift = g.slot_bits;
+    const uint32_t bmask = (uint32_t)g.nb2 - 1u;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        int s = 0;
+        while (tile_pref[s + 1] <= t) s++;   // <= 128 steps, wave-uniform
+        const uint32_t seg0 = off[s << g.b2], seg1 = off[(s + 1) << g.b2];
+        const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS, k1 = k0 + TILE_KEYS < seg1 ? k0 + TILE_KEYS : seg1;
+        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = k0 + threadIdx.x; i < k1; i += PT) atomicAdd(&hist[(in[i] >> shift) & bmask], 1u);
+        __syncthreads();
+        tile_sort_flush(sorted, hist, lofs, lcur, gbase, g.nb2, shift, bmask, cur2 + ((size_t)s << g.b2), out, [&](auto emit) {
+            for (uint32_t i = k0 + threadIdx.x; i < k1; i += PT) emit(in[i]);   // second read of the tile: L2 hits
+        });
+    }
+}
+
+// ---- P3: apply one final bucket inside LDS
+__global__ void __launch_bounds__(PT) part_apply(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off, PartGeom g,
+                                                 uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t slice[];   // 2^slot_bits / 16 words
+    const uint32_t fb = blockIdx.x;
+    const uint32_t k0 = off[fb], k1 = off[fb + 1];
+    if (k0 == k1) return;                 // untouched slice: nothing to read or write
+    const int words = (1 << g.slot_bits) >> 4;
+    uint32_t* T = counts + (size_t)fb * words;
+    for (int i = threadIdx.x; i < words; i += PT) slice[i] = T[i];
+    __syncthreads();
+    const uint32_t smask = (1u << g.slot_bits) - 1u;
+    for (uint32_t i = k0 + threadIdx.x; i < k1; i += PT) {
+        uint32_t s = keys[i] & smask;
+        uint32_t* w = slice + (s >> 4);
+        uint32_t sh = (s & 15u) * 2u;
+        uint32_t old = *(volatile uint32_t*)w;
+        while (((old >> sh) & 3u) != 3u) {           // if (T[h] < 3) T[h]++  (E:1082-1084), race-free
+            uint32_t seen = atomicCAS(w, old, old + (1u << sh));
+            if (seen == old) break;
+            old = seen;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < words; i += PT) T[i] = slice[i];
+}
+
+}  // namespace lhgt
+
+using namespace lhgt;
+
+// Partitioned count of one resident batch; called by lhgt_count_kmers.  Key buffers live in ctx.
+int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
+    const PartGeom g = part_geom(ctx->k);
+    const int max_nk = b.max_len - ctx->k + 1;
+    if (max_nk <= 0) return LHGT_OK;
+    const long keys_per_pair = 2L * max_nk * ctx->e;
+    int reads_per_tile = (int)(TILE_KEYS / ((long)max_nk * ctx->e));
+    if (reads_per_tile < 1) LHGT_FAIL(LHGT_E_ARG, "read of %d bases with e=%d exceeds the partition tile", b.max_len, ctx->e);
+    // chunk of pairs whose keys fit the two key buffers (u32 offsets: < 2^32 keys per chunk)
+    long chunk_pairs = (long)((ctx->part_keys_cap ? ctx->part_keys_cap : 0) / keys_per_pair);
+    const long want = b.d.n_pairs < (4L << 20) ? b.d.n_pairs : (4L << 20);
+    if (chunk_pairs < want) {
+        size_t cap = (size_t)want * keys_per_pair;
+        if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+        for (int i = 0; i < 2; i++) {
+            if (ctx->d_part_keys[i]) hipFree(ctx->d_part_keys[i]);
+            ctx->d_part_keys[i] = nullptr;
+            LHGT_HIP(hipMalloc(&ctx->d_part_keys[i], cap * 4));
+        }
+        ctx->part_keys_cap = cap;
+        chunk_pairs = (long)(cap / keys_per_pair);
+    }
+    if (!ctx->d_part_meta) LHGT_HIP(hipMalloc(&ctx->d_part_meta, (size_t)(4 * 16384 + 256 + 8) * 4));
+    uint32_t* ghist = ctx->d_part_meta;
+    uint32_t* off = ghist + 16384;
+    uint32_t* cur2 = off + 16384 + 1;
+    uint32_t* cur1 = cur2 + 16384;
+    const int grid = 256 * 8;
+    for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
+        long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
+        LHGT_HIP(hipMemsetAsync(ghist, 0, (size_t)g.nb * 4, ctx->stream));
+        hipLaunchKernelGGL(part_hist, dim3(grid), dim3(PT), (size_t)g.nb * 4, ctx->stream, b.d, p0, np, ctx->hp, g, ghist);
+        hipLaunchKernelGGL(part_offsets, dim3(1), dim3(1024), 0, ctx->stream, ghist, g, off, cur1, cur2);
+        hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, cur1, ctx->d_part_keys[0]);
+        const uint32_t* final_keys = ctx->d_part_keys[0];
+        if (g.b2 > 0) {
+            hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PT), 0, ctx->stream, ctx->d_part_keys[0], off, g, cur2, ctx->d_part_keys[1]);
+            final_keys = ctx->d_part_keys[1];
+        }
+        hipLaunchKernelGGL(part_apply, dim3(g.nb), dim3(PT), (size_t)((1 << g.slot_bits) >> 4) * 4, ctx->stream, final_keys, off, g, ctx->d_counts);
+        LHGT_HIP(hipGetLastError());
+    }
+    return LHGT_OK;
+}

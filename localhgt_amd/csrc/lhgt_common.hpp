@@ -110,12 +110,19 @@ struct lhgt_ctx {
     uint32_t* d_tile_count = nullptr;
     long n_peaks = -1, max_peak = 0;
     bool voted = false;
+    // partitioned count (k_count_part.hip): two key buffers and the bucket histogram/offset block
+    uint32_t* d_part_keys[2] = {nullptr, nullptr};
+    size_t part_keys_cap = 0;  // keys per buffer
+    uint32_t* d_part_meta = nullptr;
+    int count_mode = 1;        // 0 = direct CAS kernel, 1 = radix partition
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)
     uint8_t* d_ws_ascii = nullptr;
     size_t ws_ascii_cap = 0;
     uint32_t* d_ws_words = nullptr;
     size_t ws_words_cap = 0;
 };
+
+int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
 
 namespace lhgt {
 // host helpers implemented across the .cpp/.hip files

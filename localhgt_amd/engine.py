@@ -144,6 +144,9 @@ class Engine:
     def count_kmers(self):
         _lib.check(self.lib.lhgt_count_kmers(self.h))
 
+    def set_count_mode(self, mode: int):
+        _lib.check(self.lib.lhgt_set_count_mode(self.h, mode))
+
     def counts_clear(self):
         _lib.check(self.lib.lhgt_counts_clear(self.h))
 

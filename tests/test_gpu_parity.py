@@ -243,3 +243,30 @@ def test_too_many_peaks_is_reported(Engine, case_inputs, tmp_path):
     with pytest.raises(_lib.LocalHGTError) as ei:
         extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None)
     assert ei.value.code == 6 and "Too many peaks" in str(ei.value)
+
+
+@pytest.mark.parametrize("k", [12, 18, 20, 25, 26, 32])
+def test_partitioned_count_equals_direct_count(Engine, k):
+    """the radix-partitioned phase A (default) and the direct CAS kernel fill the same table;
+    k sweeps the partition geometry: no partition (k<=18), one level (<=25), two levels"""
+    e = 3
+    rng = np.random.default_rng(k)
+    acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    reads1 = [acgt[rng.choice(5, size=int(rng.integers(0, 260)), p=[.248, .248, .248, .248, .008])].tobytes() for _ in range(6000)]
+    reads2 = [acgt[rng.choice(5, size=int(rng.integers(0, 260)), p=[.248, .248, .248, .248, .008])].tobytes() for _ in range(6000)]
+    reads1 += [b"A" * 200, b"ACAC" * 50] * 40          # hot slots
+    reads2 += [b"T" * 200, b"GTGT" * 50] * 40
+    c2 = (rng.random(len(reads1)) < 0.9).astype(np.uint8)
+    tables = []
+    for mode in (0, 1):
+        with Engine(k, e) as eng:
+            eng.rng_seed(11)
+            eng.coder_generate()
+            eng.set_count_mode(mode)
+            eng.pairs_append(*_pairs(reads1, reads2), count_mate2=c2)
+            eng.count_kmers()
+            eng.count_kmers()          # twice: the second pass meets pre-filled slices
+            tables.append(eng.counts_histogram() if k == 32 else eng.counts_export())
+            if k == 32:
+                tables[-1] = np.concatenate([tables[-1], eng.counts_export(0, 1 << 26).astype(np.uint64)])
+    assert (tables[0] == tables[1]).all()

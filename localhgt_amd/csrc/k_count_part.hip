@@ -18,8 +18,12 @@ namespace lhgt {
 
 constexpr int SLICE_BITS = 18;            // slots per final bucket (2-bit fields -> 64 KiB of LDS)
 constexpr int MAX_B1 = 7;                 // 128-way fan-out per scatter pass (B2 = k - 18 - B1 <= 7 for k <= 32)
-constexpr int PT = 256;                   // threads per partition workgroup
 constexpr int TILE_KEYS = 16384;          // keys sorted per workgroup tile (64 KiB of LDS)
+constexpr int TILE_KEYS_ = TILE_KEYS;
+constexpr int PT = 1024;                  // threads per workgroup in the read-side passes (16 waves hide the per-read load chain)
+constexpr int PK = 512;                   // threads per workgroup in the key scatter: 32 keys per thread stay in registers
+constexpr int KPT = TILE_KEYS_ / PK;
+constexpr int PA = 1024;                  // threads per workgroup in apply
 
 struct PartGeom {
     int k, slot_bits, b1, b2;             // b1 + b2 = k - slot_bits
@@ -93,7 +97,7 @@ __global__ void __launch_bounds__(1024) part_offsets(const uint32_t* __restrict_
 
 // Sort the tile's keys (already counted into hist[nbk]) by bucket inside LDS and copy the runs out.
 // Called by the whole workgroup; `place(emit)` must call emit(key) for every key of the tile again.
-template <class Place>
+template <int NT, class Place>
 __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase,
                                                 int nbk, int shift, uint32_t bmask, uint32_t* __restrict__ cursors,
                                                 uint32_t* __restrict__ out, Place place) {
@@ -113,7 +117,7 @@ __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist
     });
     __syncthreads();
     const uint32_t total = lofs[nbk - 1] + hist[nbk - 1];
-    for (uint32_t i = threadIdx.x; i < total; i += PT) {
+    for (uint32_t i = threadIdx.x; i < total; i += NT) {
         uint32_t key = sorted[i];
         uint32_t bk = (key >> shift) & bmask;
         out[gbase[bk] + (i - lofs[bk])] = key;   // consecutive i of one bucket -> consecutive addresses
@@ -138,14 +142,15 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
         for (long r = r0 + wib; r < r1; r += PT / 64)
             for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
         __syncthreads();
-        tile_sort_flush(sorted, hist, lofs, lcur, gbase, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, out, [&](auto emit) {
+        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, out, [&](auto emit) {
             for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, emit);
         });
     }
 }
 
 // ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS keys, never straddling segments.
-__global__ void __launch_bounds__(PT) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ off /*[nb+1]*/, PartGeom g,
+// A thread keeps its KPT keys in registers between the histogram and the placement, all loads in flight at once.
+__global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ off /*[nb+1]*/, PartGeom g,
                                                         uint32_t* __restrict__ cur2, uint32_t* __restrict__ out) {
     __shared__ uint32_t sorted[TILE_KEYS];
     __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
@@ -164,22 +169,33 @@ __global__ void __launch_bounds__(PT) part_scatter_keys(const uint32_t* __restri
     const int shift = g.slot_bits;
     const uint32_t bmask = (uint32_t)g.nb2 - 1u;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        int s = 0;
-        while (tile_pref[s + 1] <= t) s++;   // <= 128 steps, wave-uniform
+        int lo = 0, hi = g.nb1;             // segment of tile t: last s with tile_pref[s] <= t
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tile_pref[mid] <= t) lo = mid; else hi = mid; }
+        const int s = lo;
         const uint32_t seg0 = off[s << g.b2], seg1 = off[(s + 1) << g.b2];
         const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS, k1 = k0 + TILE_KEYS < seg1 ? k0 + TILE_KEYS : seg1;
         if (threadIdx.x < 128) hist[threadIdx.x] = 0;
         __syncthreads();
-        for (uint32_t i = k0 + threadIdx.x; i < k1; i += PT) atomicAdd(&hist[(in[i] >> shift) & bmask], 1u);
+        uint32_t key[KPT];
+#pragma unroll
+        for (int u = 0; u < KPT; u++) {
+            uint32_t i = k0 + u * PK + threadIdx.x;
+            key[u] = i < k1 ? in[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < KPT; u++)
+            if (k0 + u * PK + threadIdx.x < k1) atomicAdd(&hist[(key[u] >> shift) & bmask], 1u);
         __syncthreads();
-        tile_sort_flush(sorted, hist, lofs, lcur, gbase, g.nb2, shift, bmask, cur2 + ((size_t)s << g.b2), out, [&](auto emit) {
-            for (uint32_t i = k0 + threadIdx.x; i < k1; i += PT) emit(in[i]);   // second read of the tile: L2 hits
+        tile_sort_flush<PK>(sorted, hist, lofs, lcur, gbase, g.nb2, shift, bmask, cur2 + ((size_t)s << g.b2), out, [&](auto emit) {
+#pragma unroll
+            for (int u = 0; u < KPT; u++)
+                if (k0 + u * PK + threadIdx.x < k1) emit(key[u]);
         });
     }
 }
 
 // ---- P3: apply one final bucket inside LDS
-__global__ void __launch_bounds__(PT) part_apply(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off, PartGeom g,
+__global__ void __launch_bounds__(PA) part_apply(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off, PartGeom g,
                                                  uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t slice[];   // 2^slot_bits / 16 words
     const uint32_t fb = blockIdx.x;
@@ -187,22 +203,36 @@ __global__ void __launch_bounds__(PT) part_apply(const uint32_t* __restrict__ ke
     if (k0 == k1) return;                 // untouched slice: nothing to read or write
     const int words = (1 << g.slot_bits) >> 4;
     uint32_t* T = counts + (size_t)fb * words;
-    for (int i = threadIdx.x; i < words; i += PT) slice[i] = T[i];
+    for (int i = threadIdx.x; i < words; i += PA) slice[i] = T[i];
     __syncthreads();
     const uint32_t smask = (1u << g.slot_bits) - 1u;
-    for (uint32_t i = k0 + threadIdx.x; i < k1; i += PT) {
-        uint32_t s = keys[i] & smask;
-        uint32_t* w = slice + (s >> 4);
-        uint32_t sh = (s & 15u) * 2u;
-        uint32_t old = *(volatile uint32_t*)w;
-        while (((old >> sh) & 3u) != 3u) {           // if (T[h] < 3) T[h]++  (E:1082-1084), race-free
-            uint32_t seen = atomicCAS(w, old, old + (1u << sh));
-            if (seen == old) break;
-            old = seen;
+    constexpr int U = 8;                  // keys in flight per thread
+    for (uint32_t base = k0; base < k1; base += U * PA) {
+        uint32_t s[U], old[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t i = base + u * PA + threadIdx.x;
+            live[u] = i < k1;
+            s[u] = live[u] ? keys[i] & smask : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) old[u] = ((volatile uint32_t*)slice)[s[u] >> 4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!live[u]) continue;
+            uint32_t* w = slice + (s[u] >> 4);
+            const uint32_t sh = (s[u] & 15u) * 2u;
+            uint32_t o = old[u];
+            while (((o >> sh) & 3u) != 3u) {         // if (T[h] < 3) T[h]++  (E:1082-1084), race-free
+                uint32_t seen = atomicCAS(w, o, o + (1u << sh));
+                if (seen == o) break;
+                o = seen;
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < words; i += PT) T[i] = slice[i];
+    for (int i = threadIdx.x; i < words; i += PA) T[i] = slice[i];
 }
 
 }  // namespace lhgt
@@ -236,7 +266,7 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     uint32_t* off = ghist + 16384;
     uint32_t* cur2 = off + 16384 + 1;
     uint32_t* cur1 = cur2 + 16384;
-    const int grid = 256 * 8;
+    const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
     for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
         LHGT_HIP(hipMemsetAsync(ghist, 0, (size_t)g.nb * 4, ctx->stream));
@@ -245,10 +275,10 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, cur1, ctx->d_part_keys[0]);
         const uint32_t* final_keys = ctx->d_part_keys[0];
         if (g.b2 > 0) {
-            hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PT), 0, ctx->stream, ctx->d_part_keys[0], off, g, cur2, ctx->d_part_keys[1]);
+            hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], off, g, cur2, ctx->d_part_keys[1]);
             final_keys = ctx->d_part_keys[1];
         }
-        hipLaunchKernelGGL(part_apply, dim3(g.nb), dim3(PT), (size_t)((1 << g.slot_bits) >> 4) * 4, ctx->stream, final_keys, off, g, ctx->d_counts);
+        hipLaunchKernelGGL(part_apply, dim3(g.nb), dim3(PA), (size_t)((1 << g.slot_bits) >> 4) * 4, ctx->stream, final_keys, off, g, ctx->d_counts);
         LHGT_HIP(hipGetLastError());
     }
     return LHGT_OK;

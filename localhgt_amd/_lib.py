@@ -59,6 +59,7 @@ SIGNATURES = {
     "lhgt_peak_kmer_export": [_vp, C.c_uint64, C.c_uint64, _u32p],
     "lhgt_synth_reference": [_vp, C.c_uint64, _l, _l, _u8p],
     "lhgt_synth_pairs": [_vp, C.c_uint64, C.c_uint64, _l, _l, _l, _l, _i, _u8p, _u8p],
+    "lhgt_set_debug": [_vp, _i],
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_stream": [_vp, C.POINTER(_vp)],
     "lhgt_synchronize": [_vp],

@@ -74,6 +74,12 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     return LHGT_OK;
 }
 
+int lhgt_set_debug(lhgt_ctx* ctx, int flags) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    ctx->debug = flags;
+    return LHGT_OK;
+}
+
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase, float* ms) {
     if (!ctx || !ms || phase < 0 || phase > 2) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     *ms = ctx->phase_ms[phase];

@@ -9,20 +9,20 @@
 
 namespace lhgt {
 
-struct ChrEntry { int chr, count, first_id; };
-
-// Per-wave LDS: events[max_ev][e] of (peak id, contig) -- the contig of a hit is fetched by the
-// lane that found it, so the sequential part touches LDS only -- then the contig table (<= max_ev entries).
+// Per-wave LDS: events[max_ev][e] of (peak id, contig); the contig of a hit is fetched by the lane
+// that found it.  judge_base then runs out of registers: lane l holds events l, l+64, .. of the
+// current 64-event chunk and entries l, l+64, .. of the contig table (TR registers deep); an event
+// is broadcast with readlane, the table searched with one compare + ballot per register row.
+template <int TR>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
-                                                   int max_ev, int waves_per_block) {
+                                                   int max_ev, int waves_per_block, int debug) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     if (wib >= waves_per_block) return;
     const int e = hp.e, k = hp.k;
-    const size_t per_wave = (size_t)max_ev * e * 2 + (size_t)max_ev * 3;
+    const size_t per_wave = (size_t)max_ev * e * 2;
     uint32_t* ev = lds + (size_t)wib * per_wave;
-    ChrEntry* tab = (ChrEntry*)(ev + (size_t)max_ev * e * 2);
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
     for (long p = wave; p < b.n_pairs; p += n_waves) {
@@ -65,67 +65,91 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                 }
             }
         }
-        if (n_ev < 6) continue;  // base_hits = offsets with any hit (E:149-157, 496)
+        if (n_ev < 6 || (debug & 1)) continue;  // base_hits = offsets with any hit (E:149-157, 496)
         __builtin_amdgcn_wave_barrier();
-        // judge_base, sequential over events but wave-parallel inside one: every lane compares its
-        // table entries with the (<= e) candidate contigs of the event, ballots give the slots.
+        int tchr[TR], tcnt[TR], tfirst[TR];
+#pragma unroll
+        for (int r = 0; r < TR; r++) { tchr[r] = 0; tcnt[r] = 0; tfirst[r] = 0; }
         int n_tab = 0;
-        for (int q = 0; q < n_ev; q++) {
-            int sel_chr = 0, sel_id = 0, sel_num = 0, sel_slot = -1;
-            for (int i = 0; i < e; i++) {
-                const uint32_t id = ev[((size_t)q * e + i) * 2];       // same address in every lane: LDS broadcast
-                if (!id) continue;                                     // wave-uniform
-                const int chr = (int)ev[((size_t)q * e + i) * 2 + 1];
-                int s = -1, cnt = 0;
-                for (int t0 = 0; t0 < n_tab; t0 += 64) {
-                    const int u = t0 + lane;
-                    const bool m = u < n_tab && tab[u].chr == chr;
-                    const unsigned long long bal = __ballot(m);
-                    if (bal) {
-                        s = t0 + __ffsll((long long)bal) - 1;
-                        cnt = tab[s].count;
-                        break;
-                    }
+        for (int q0 = 0; q0 < n_ev; q0 += 64) {
+            uint32_t eid[9], echr[9];
+            const int myq = q0 + lane;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < e) {
+                    eid[i] = myq < n_ev ? ev[((size_t)myq * e + i) * 2] : 0u;
+                    echr[i] = myq < n_ev ? ev[((size_t)myq * e + i) * 2 + 1] : 0u;
                 }
-                // among the hashes that hit, prefer the contig with the largest running count (ties: later
-                // hash, `>=` at E:131); an unseen contig is taken only if nothing is selected yet (E:140-144)
-                if (s >= 0) {
-                    if (cnt >= sel_num) { sel_id = (int)id; sel_chr = chr; sel_num = cnt; sel_slot = s; }
-                } else if (sel_id == 0) { sel_id = (int)id; sel_chr = chr; sel_num = 0; sel_slot = -1; }
+            const int nq = n_ev - q0 < 64 ? n_ev - q0 : 64;
+            for (int qq = 0; qq < nq; qq++) {
+                const int q = __builtin_amdgcn_readfirstlane(qq);
+                int sel_chr = 0, sel_id = 0, sel_num = 0, sel_slot = -1;
+                int last_chr = -1, s = -1, cnt = 0;   // lookup of the previous hash of this event (counts do not move inside an event)
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    if (i >= e) continue;
+                    const int id = __builtin_amdgcn_readlane((int)eid[i], q);
+                    if (!id) continue;
+                    const int chr = __builtin_amdgcn_readlane((int)echr[i], q);
+                    if (chr != last_chr) {
+                        last_chr = chr;
+                        s = -1;
+                        cnt = 0;
+#pragma unroll
+                        for (int r = 0; r < TR; r++) {
+                            if (s >= 0 || r * 64 >= n_tab) continue;
+                            const unsigned long long bal = __ballot(r * 64 + lane < n_tab && tchr[r] == chr);
+                            if (bal) {
+                                const int l = __ffsll((long long)bal) - 1;
+                                s = r * 64 + l;
+                                cnt = __builtin_amdgcn_readlane(tcnt[r], l);
+                            }
+                        }
+                    }
+                    // among the hashes that hit, prefer the contig with the largest running count (ties: later
+                    // hash, `>=` at E:131); an unseen contig is taken only if nothing is selected yet (E:140-144)
+                    if (s >= 0) {
+                        if (cnt >= sel_num) { sel_id = id; sel_chr = chr; sel_num = cnt; sel_slot = s; }
+                    } else if (sel_id == 0) { sel_id = id; sel_chr = chr; sel_num = 0; sel_slot = -1; }
+                }
+                const int slot = sel_slot >= 0 ? sel_slot : n_tab;
+                const bool mine = lane == (slot & 63);
+#pragma unroll
+                for (int r = 0; r < TR; r++)
+                    if ((slot >> 6) == r) {                 // wave-uniform: only the owning row is touched
+                        if (sel_slot >= 0) tcnt[r] = mine ? sel_num + 1 : tcnt[r];
+                        else {                              // first peak of the contig (E:150-152)
+                            tchr[r] = mine ? sel_chr : tchr[r];
+                            tcnt[r] = mine ? 1 : tcnt[r];
+                            tfirst[r] = mine ? sel_id : tfirst[r];
+                        }
+                    }
+                if (sel_slot < 0) n_tab++;
             }
-            if (lane == 0) {
-                if (sel_slot >= 0) tab[sel_slot].count = sel_num + 1;
-                else { tab[n_tab].chr = sel_chr; tab[n_tab].count = 1; tab[n_tab].first_id = sel_id; }
-            }
-            if (sel_slot < 0) n_tab++;
-            __builtin_amdgcn_wave_barrier();
         }
         // check_split: contigs with >= 6 offsets; the two largest counts (with multiplicity) vote (E:161-202)
-        int largest = 0, n_f = 0, n_at_largest = 0;
-        for (int t0 = 0; t0 < n_tab; t0 += 64) {
-            const int u = t0 + lane;
-            const int c = u < n_tab ? tab[u].count : 0;
-            n_f += __popcll(__ballot(c >= 6));
-            int mx = c >= 6 ? c : 0;
-            for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-            if (mx > largest) { largest = mx; n_at_largest = 0; }
-            if (mx == largest && largest > 0) n_at_largest += __popcll(__ballot(c == largest));
+        int largest = 0, n_f = 0;
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+            const int c = (r * 64 + lane < n_tab && tcnt[r] >= 6) ? tcnt[r] : 0;
+            n_f += __popcll(__ballot(c > 0));
+            largest = c > largest ? c : largest;
         }
+        for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(largest, d); largest = o > largest ? o : largest; }
         if (n_f > 1) {
-            int second = largest;
-            if (n_at_largest < 2) {
-                second = 0;
-                for (int t0 = 0; t0 < n_tab; t0 += 64) {
-                    const int u = t0 + lane;
-                    const int c = u < n_tab ? tab[u].count : 0;
-                    int mx = (c >= 6 && c < largest) ? c : 0;
-                    for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-                    second = mx > second ? mx : second;
-                }
+            int n_at = 0, second = 0;
+#pragma unroll
+            for (int r = 0; r < TR; r++) {
+                const int c = (r * 64 + lane < n_tab && tcnt[r] >= 6) ? tcnt[r] : 0;
+                n_at += __popcll(__ballot(c == largest));
+                second = (c < largest && c > second) ? c : second;
             }
-            for (int u = lane; u < n_tab; u += 64) {
-                const int c = tab[u].count;
-                if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[tab[u].first_id], 1u);  // clamped to 254 at export (E:194)
+            for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(second, d); second = o > second ? o : second; }
+            if (n_at > 1) second = largest;
+#pragma unroll
+            for (int r = 0; r < TR; r++) {
+                const int c = (r * 64 + lane < n_tab) ? tcnt[r] : 0;
+                if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[tfirst[r]], 1u);  // clamped to 254 at export (E:194)
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -147,14 +171,18 @@ int lhgt_vote(lhgt_ctx* ctx) {
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
         int max_ev = 2 * nk;
-        size_t per_wave = ((size_t)max_ev * ctx->e * 2 + (size_t)max_ev * 3) * 4;
+        size_t per_wave = (size_t)max_ev * ctx->e * 2 * 4;
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;
         long blocks = (b.d.n_pairs + wpb - 1) / wpb;
         if (blocks > 256L * 16) blocks = 256L * 16;
-        hipLaunchKernelGGL(vote_kernel, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp,
-                           ctx->d_peak_kmer, ctx->d_loci, ctx->d_filter, max_ev, wpb);
+        if (max_ev <= 256)
+            hipLaunchKernelGGL(vote_kernel<4>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp,
+                               ctx->d_peak_kmer, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug);
+        else
+            hipLaunchKernelGGL(vote_kernel<16>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp,
+                               ctx->d_peak_kmer, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug);
     }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -164,6 +164,9 @@ class Engine:
         _lib.check(self.lib.lhgt_write_intervals(self.h, path.encode(), C.byref(n)))
         return n.value
 
+    def set_debug(self, flags: int):
+        _lib.check(self.lib.lhgt_set_debug(self.h, flags))
+
     def phase_ms(self, phase: int) -> float:
         ms = C.c_float(0)
         _lib.check(self.lib.lhgt_phase_ms(self.h, phase, C.byref(ms)))

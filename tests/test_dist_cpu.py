@@ -1,0 +1,84 @@
+"""world_size-2 run of the multi-GPU exchange (localhgt_amd/dist.py) on CPU with gloo: the packed
+saturating reduce-scatter/all-gather of the count table and the vote all-reduce.  The device side
+is replaced by a numpy adapter here; the GPU adapter is exercised by tests/test_gpu_dist.py."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def unpack(packed: np.ndarray) -> np.ndarray:
+    out = np.empty(packed.size * 4, dtype=np.uint8)
+    for f in range(4):
+        out[f::4] = (packed >> (2 * f)) & 3
+    return out
+
+
+def pack(fields: np.ndarray) -> np.ndarray:
+    f = fields.reshape(-1, 4).astype(np.uint8)
+    return (f[:, 0] | (f[:, 1] << 2) | (f[:, 2] << 4) | (f[:, 3] << 6)).astype(np.uint8)
+
+
+class FakeEngine:
+    def __init__(self, table_u8: np.ndarray, votes: np.ndarray):
+        self.table = torch.from_numpy(pack(table_u8))
+        self.votes = torch.from_numpy(votes.astype(np.int32))
+
+
+class NumpyAdapter:
+    def counts_tensor(self, eng):
+        return eng.table
+
+    def merge(self, eng, other, byte_offset):
+        mine = eng.table[byte_offset:byte_offset + other.numel()]
+        merged = np.minimum(3, unpack(mine.numpy()).astype(int) + unpack(other.numpy()).astype(int)).astype(np.uint8)
+        mine.copy_(torch.from_numpy(pack(merged)))
+
+    def filter_tensor(self, eng):
+        return eng.votes
+
+    def sync(self, eng):
+        pass
+
+
+def _worker(rank, world, port, n_bytes, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from localhgt_amd.dist import Exchange
+    ex = Exchange.from_env(backend="gloo", adapter=NumpyAdapter())
+    rng = np.random.default_rng(100 + rank)
+    table = rng.choice(4, size=n_bytes * 4, p=[.6, .2, .1, .1]).astype(np.uint8)
+    votes = rng.integers(0, 300, size=1000)
+    eng = FakeEngine(table, votes)
+    assert ex.broadcast_flag(rank == 0) is True
+    ex.merge_counts(eng)
+    ex.sum_votes(eng)
+    np.save(os.path.join(tmp, f"table_in_{rank}.npy"), table)
+    np.save(os.path.join(tmp, f"votes_in_{rank}.npy"), votes)
+    np.save(os.path.join(tmp, f"table_out_{rank}.npy"), unpack(eng.table.numpy()))
+    np.save(os.path.join(tmp, f"votes_out_{rank}.npy"), eng.votes.numpy())
+    ex.barrier()
+    ex.close()
+
+
+def test_exchange_world2_gloo(tmp_path):
+    world, n_bytes = 2, 1 << 16
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, n_bytes, str(tmp_path)), nprocs=world, join=True)
+    tin = [np.load(tmp_path / f"table_in_{r}.npy") for r in range(world)]
+    vin = [np.load(tmp_path / f"votes_in_{r}.npy") for r in range(world)]
+    want_t = np.minimum(3, sum(t.astype(int) for t in tin))
+    want_v = sum(vin)
+    for r in range(world):
+        assert (np.load(tmp_path / f"table_out_{r}.npy") == want_t).all()
+        assert (np.load(tmp_path / f"votes_out_{r}.npy") == want_v).all()
+
+
+def test_saturating_sum_identity():
+    """min(3, sum_r min(3, c_r)) == min(3, sum_r c_r): why per-rank saturated tables can be merged"""
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 9, size=(8, 10000))
+    assert (np.minimum(3, np.minimum(3, c).sum(0)) == np.minimum(3, c.sum(0))).all()

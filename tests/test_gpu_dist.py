@@ -1,0 +1,107 @@
+"""GPU side of the multi-GPU path on ONE GPU: read sharding by blocks of the global pair ordinal,
+the device merge kernel and the zero-copy torch views used for RCCL (world_size 1 over nccl)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_engines_merge_to_the_unsharded_result(case_inputs, tmp_path):
+    """two 'ranks' (run one after the other) each count their read shard; merging the tables and summing the
+    votes gives the single-GPU result, and the interval file equals the reference golden"""
+    from localhgt_amd.engine import Engine
+    name = "k24_sample_half_cached"      # sampling active: decisions must not depend on the shard
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    k, e = case.k, case.e
+    index = f"{fa2}.k{k}.h{e}.index.dat"
+    with Engine(k, e) as b:      # build the index first so every engine sees a cached one (as in the golden run)
+        b.rng_seed(case.seed)
+        b.coder_generate()
+        b.index_build(fa2, index, fa2 + ".genome.len.txt")
+    engs = []
+    world = 2
+    for rank in range(world):
+        eng = Engine(k, e)
+        eng.rng_seed(case.seed)
+        ratio = eng.sam_ratio(f1, case.sample)
+        eng.index_load(index)
+        eng.sampling_init(ratio)
+        seen, kept = eng.pairs_load_fastq(f1, f2, ratio, rank, world, block=64)
+        eng.count_kmers()
+        engs.append((eng, kept))
+    (e0, k0), (e1, k1) = engs
+    with Engine(k, e) as whole:
+        whole.rng_seed(case.seed)
+        whole.index_load(index)
+        whole.sampling_init(ratio)
+        _, kept_all = whole.pairs_load_fastq(f1, f2, ratio)
+        whole.count_kmers()
+        assert k0 + k1 == kept_all and k0 > 0 and k1 > 0
+        p1, n1 = e1.counts_buffer()
+        p0, n0 = e0.counts_buffer()
+        t0, t1 = e0.counts_export(), e1.counts_export()
+        import torch
+        from localhgt_amd.dist import device_tensor
+        t0_dev = device_tensor(p0, n0, 0).clone()          # rank 0's table before it is merged into
+        e0.counts_merge(p1, 0, n1)
+        e1.counts_merge(t0_dev.data_ptr(), 0, n0)
+        torch.cuda.synchronize()
+        assert (e0.counts_export() == whole.counts_export()).all()
+        assert (e0.counts_export() == np.minimum(3, t0.astype(int) + t1.astype(int))).all()
+        assert (e1.counts_export() == e0.counts_export()).all()
+        n = [x.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) for x in (e0, e1, whole)]
+        assert n[0] == n[1] == n[2] == meta["raw_peaks"]
+        for x in (e0, e1, whole):
+            x.vote()
+        f0, f1v, fw = (x.peaks_export(n[0])[1].astype(int) for x in (e0, e1, whole))
+        assert (np.minimum(254, f0 + f1v) == fw).all()
+    for eng, _ in engs:
+        eng.close()
+
+
+def test_exchange_world1_nccl_on_device_buffers(case_inputs, tmp_path):
+    """the torch views of the raw device buffers are zero-copy and the collectives run on them"""
+    import torch
+    from localhgt_amd.dist import Exchange, device_tensor
+    from localhgt_amd.engine import Engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    ex = Exchange.from_env(backend="nccl")
+    name = "k24_seed7"
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    try:
+        with Engine(case.k, case.e) as eng:
+            eng.rng_seed(case.seed)
+            eng.coder_generate()
+            index = f"{fa2}.k{case.k}.h{case.e}.index.dat"
+            eng.index_build(fa2, index, fa2 + ".genome.len.txt")
+            eng.index_load(index)
+            eng.sampling_init(100.0)
+            eng.pairs_load_fastq(f1, f2, 100.0)
+            eng.count_kmers()
+            before = eng.counts_export()
+            p, n = eng.counts_buffer()
+            view = device_tensor(p, n, 0)
+            assert view.data_ptr() == p and view.numel() == n and view.dtype == torch.uint8
+            ex.merge_counts(eng)
+            assert (eng.counts_export() == before).all()
+            n_peaks = eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak)
+            eng.vote()
+            votes = eng.peaks_export(n_peaks)[1].copy()
+            ex.sum_votes(eng)
+            assert (eng.peaks_export(n_peaks)[1] == votes).all()
+            out = str(tmp_path / "interval.txt")
+            eng.write_intervals(out)
+            assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+    finally:
+        ex.close()

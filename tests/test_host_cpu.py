@@ -1,0 +1,165 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the
+host rows (RNG/coder, sampling ratio) match libc / the oracle, BED and CLI match the
+reference's goldens."""
+import ctypes
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from localhgt_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "localhgt_hip.h")).read()
+    declared = set(re.findall(r"\b(lhgt_[a-z0-9_]+)\s*\(", header))
+    declared.discard("lhgt_ctx")
+    handle = lib.load(require_gpu=False)
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in include/localhgt_hip.h but not exported"
+    assert declared == set(lib.SIGNATURES), "python binding and header disagree"
+    assert handle.lhgt_abi_version() == 1
+
+
+def test_no_cpu_fallback(lib):
+    """device work on a host-only context fails loudly; creating a GPU context without a GPU fails too"""
+    from localhgt_amd.engine import Engine
+    eng = Engine(24, 3, device=-1)
+    with pytest.raises(lib.LocalHGTError) as ei:
+        eng.count_kmers()
+    assert ei.value.code == 8
+    with pytest.raises(lib.LocalHGTError):
+        eng.hash_sequence(b"ACGT" * 20)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises((lib.LocalHGTError, RuntimeError)):
+            Engine(24, 3, device=0)
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "localhgt_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_api" not in src and "lhgt_oracle" not in src and "oracle/" not in src, f
+
+
+@pytest.mark.parametrize("k,e,seed", [(24, 3, 1), (32, 3, 1), (32, 3, 7), (22, 5, 3), (20, 2, 0), (8, 9, 12345), (31, 4, 2**31 + 5)])
+def test_coder_matches_libc_rand(oracle, k, e, seed):
+    from localhgt_amd.engine import Engine
+    with Engine(k, e, device=-1) as eng:
+        eng.rng_seed(seed)
+        eng.coder_generate()
+        oracle.srand(seed)
+        assert (eng.coder_get() == oracle.random_coder(k, e)).all()
+
+
+def test_sampling_array_matches_libc_rand_after_coder(oracle):
+    """quirk Q3: the stream position of get_random depends on whether random_coder ran first"""
+    from localhgt_amd.engine import Engine
+    for with_coder in (True, False):
+        with Engine(24, 3, device=-1) as eng:
+            eng.rng_seed(5)
+            oracle.srand(5)
+            if with_coder:
+                eng.coder_generate()
+                oracle.random_coder(24, 3)
+            eng.sampling_init(50.0)
+            want = oracle.sampling_array(200000)
+            got = eng.sampling_get(200000)
+            assert got.dtype == np.float32 and (got == want).all()
+            assert got.max() < 100.0
+
+
+def test_sam_ratio_matches_oracle(oracle, case_inputs):
+    from localhgt_amd.engine import Engine
+    fa, f1, f2, _ = case_inputs("k24_seed7")
+    with Engine(24, 3, device=-1) as eng:
+        for sample in (1.0, 0.5, 0.001, 700000.0, 2e9):
+            assert eng.sam_ratio(f1, sample) == oracle.sam_ratio(f1, sample)
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c.bed_defined])
+def test_bed_matches_reference_script(name, tmp_path):
+    from localhgt_amd import get_bed_file
+    gold = os.path.join(cases.GOLDEN_DIR, name)
+    ref = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(gold, "genome.len.txt"), ref + ".genome.len.txt")
+    interval = str(tmp_path / "interval.txt")
+    shutil.copy(os.path.join(gold, "interval.txt"), interval)
+    n = get_bed_file.write_bed(ref, interval)
+    assert open(interval + ".bed").read() == open(os.path.join(gold, "interval.txt.bed")).read()
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    assert meta["bed_stdout"] == f"extracted ref length is: {n}\n"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "get_bed_file.py"), ref, interval],
+                         capture_output=True, text=True, check=True)
+    assert out.stdout == meta["bed_stdout"]
+
+
+def test_bed_reports_inconsistent_ids(tmp_path):
+    from localhgt_amd import get_bed_file
+    gold = os.path.join(cases.GOLDEN_DIR, "k24_short_mid")
+    ref = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(gold, "genome.len.txt"), ref + ".genome.len.txt")
+    interval = str(tmp_path / "interval.txt")
+    shutil.copy(os.path.join(gold, "interval.txt"), interval)
+    with pytest.raises(get_bed_file.InconsistentReferenceIds):
+        get_bed_file.write_bed(ref, interval)
+
+
+def test_cli_command_line_matches_reference_driver():
+    from localhgt_amd import cli
+    gold = json.load(open(os.path.join(cases.GOLDEN_DIR, "cmdline.json")))
+    parser = cli.build_parser()
+    for name in ("defaults", "sample_half", "all_flags"):
+        o = parser.parse_args(gold[name]["args"])
+        ours = cli.run_order(o, o.fq1, o.fq2, "/X/pipeline.sh")
+        theirs = re.sub(r"bash \S+/pipeline\.sh", "bash /X/pipeline.sh", gold[name]["os_system"][0])
+        assert ours == theirs
+
+
+def test_cli_help_lists_the_reference_flags():
+    from localhgt_amd import cli
+    gold = json.load(open(os.path.join(cases.GOLDEN_DIR, "cmdline.json")))["help"]["stdout"]
+    ours = cli.build_parser().format_help()
+    gold, ours = gold[gold.index("required arguments:"):], ours[ours.index("required arguments:"):]
+    ref_flags = set(re.findall(r"^\s+(--?[a-z_0-9]+)", gold, flags=re.M))
+    our_flags = set(re.findall(r"^\s+(--?[a-z_0-9]+)", ours, flags=re.M))
+    assert ref_flags <= our_flags
+    for flag in ref_flags - {"-h"}:  # same default text per flag
+        d_ref = re.search(re.escape(flag) + r" \x08.*?\(default:\s*([^)]*)\)", gold, flags=re.S)
+        d_our = re.search(re.escape(flag) + r" \x08.*?\(default:\s*([^)]*)\)", ours, flags=re.S)
+        assert d_ref and d_our and d_ref.group(1).split() == d_our.group(1).split(), flag
+
+
+def test_cli_dry_run_prints_pipeline_command(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "localhgt"), "bkp", "-r", "ref.fa", "--fq1", "a.1.fq",
+                          "--fq2", "a.2.fq", "--dry-run", "--pipeline", "/opt/LocalHGT/scripts/pipeline.sh"],
+                         capture_output=True, text=True, check=True)
+    assert "bash /opt/LocalHGT/scripts/pipeline.sh ref.fa a.1.fq a.2.fq sample ./ 0.1 0.08 10 32 300000000 3 1 2000000000 1 1 20" in out.stdout
+
+
+def test_extract_ref_argv_parsing():
+    from localhgt_amd import extract_ref
+    a = extract_ref.parse_argv(["a.fq", "b.fq", "r.fa", "out.txt", "0.1", "0.08", "10", "32", "300000000", "3", "1", "2000000000"])
+    assert (a.k, a.e, a.threads, a.max_peak, a.seed, a.sample) == (32, 3, 10, 300000000, 1, 2e9)
+    assert a.hit_ratio == float(np.float32(0.1)) and a.match_ratio == float(np.float32(0.08))
+    assert extract_ref.index_name("r.fa", 32, 3) == "r.fa.k32.h3.index.dat"
+    a = extract_ref.parse_argv(["a", "b", "r", "o", "0.2", "0.05", "4", "24.0", "1e3", "4", "9", "0.5"])   # stod accepts these
+    assert (a.k, a.max_peak, a.sample) == (24, 1000, 0.5)

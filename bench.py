@@ -133,16 +133,27 @@ def main():
         dt = float(t.item())
     if rank == 0:
         total_pairs = args.pairs * world * args.steps
-        count_ms = ms[0] / args.steps                       # HIP events on the engine's stream, one launch per step
-        algo = ALGO_BYTES_PER_PAIR(L, k, e) * args.pairs    # algorithmic bytes of one count launch
-        achieved = algo / (count_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_count_kernel.json")
+        algo = ALGO_BYTES_PER_PAIR(L, k, e) * args.pairs    # algorithmic bytes of one scan launch over this GPU's pairs
+        per = {"count_A": ms[0] / args.steps, "scan_B": ms[1] / args.steps, "vote_C": ms[2] / args.steps}   # HIP events on the engine stream
+
+        def roof(ms_launch, bytes_launch):
+            ach = bytes_launch / (ms_launch * 1e-3) / 1e9
+            return round(ach, 2), round(ach / HBM_PEAK_GBS, 4)
+
+        # measured HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
+        # FETCH_SIZE of random 4-byte probes = TCC_EA0_RDREQ x 64 B, the streaming kernels' FETCH_SIZE doubled per
+        # MI355X_MICROARCH.md section HBM); committed with the profile it came from
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))
             except Exception:
-                traffic = None
+                traffic = {}
+        vote_ach, vote_frac = roof(per["vote_C"], algo)
+        count_ach, count_frac = roof(per["count_A"], algo)
+        ref_bytes = args.contigs * args.contig_len * (4 * e + 64 * e)     # 204 B per reference base
+        scan_ach, scan_frac = roof(per["scan_B"], ref_bytes)
         line = {
             "metric": "M paired-reads/s k-mer sketch->peak, UHGG-scale ref; %HBM roofline @1/2/4/8 GPU",
             "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
@@ -154,9 +165,17 @@ def main():
                        "parallelism": f"reads sharded x{world}"},
             "phase_ms": {"count_A": round(ms[0] / args.steps, 3), "scan_B": round(ms[1] / args.steps, 3), "vote_C": round(ms[2] / args.steps, 3)},
             "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
-            "roofline": {"bound": "hbm", "kernel": "count_direct (phase A k-mer scan)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo, "launch_ms": round(count_ms, 3)},
+            "roofline": {"bound": "hbm", "kernel": "vote_kernel (phase C read re-scan: 714 probes/pair into peak_kmer; the dominant kernel)",
+                         "achieved": vote_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": vote_frac,
+                         "traffic": traffic.get("vote_kernel"), "algorithmic_bytes_per_launch": algo, "launch_ms": round(per["vote_C"], 3)},
+            "roofline_other": {
+                "count_A (part_hist+part_scatter_reads+part_scatter_keys+part_apply, all launches of one step)": {
+                    "achieved": count_ach, "frac": count_frac, "algorithmic_bytes": algo, "ms": round(per["count_A"], 3),
+                    "traffic": traffic.get("count_A"),
+                    "note": "radix partition + LDS apply moves ~16 B/key of streaming traffic instead of one 64 B sector per key, so the sector-model fraction can exceed the random-access ceiling"},
+                "scan_B (ref_flags+window_peak+interval_mask+tile_scan+register_peaks)": {
+                    "achieved": scan_ach, "frac": scan_frac, "algorithmic_bytes": ref_bytes, "ms": round(per["scan_B"], 3),
+                    "traffic": traffic.get("scan_B")}},
         }
         if world == 1 and not args.no_cpu_baseline:
             eng.pairs_clear()

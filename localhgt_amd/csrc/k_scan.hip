@@ -61,9 +61,16 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
 }
 
 // ---- B2
+// The contrast test of E:644-671 in closed form.  With W5[t] = singles over t-4..t, the literal update of
+// `left` (E:658) telescopes to left_m = W5[j-5] + W5[j-m-5] - W5[j-k-5], so
+//   the test run AT j marks j       iff  W5[j-5] - W5[j-k-5] - W5[j] + min_{m in [k,2k)} W5[j-m-5] <= -2
+//   a test run at j' = j+m+5 marks j iff  W5[j] + max_{t in [j+k, j+2k)} (W5[t] - W5[t-k] - W5[t+5]) >= 2
+// (t = j+m; tests exist only for 2k+10 < j' < len).  Both are sliding-window extrema of width k; a thread
+// owns 8 consecutive positions and shares the part of the window they have in common.
 __global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   int k, int one_min, int three_min, uint8_t* __restrict__ flags) {
     __shared__ int P1[N2], P3[N2], part[BT];
+    __shared__ int8_t W[N2], G[N2];
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
@@ -82,31 +89,55 @@ __global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ ti
     int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
     for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
     __syncthreads();
-#define W5(t_) (P1[(t_)] - P1[(t_) - 5])  /* singles over positions t-4..t */
-    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
-        long j = (long)t.j0 + jj;
-        if (j >= len) break;
-        const int i = jj + HL2;
-        int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
-        int good = one >= one_min && three >= three_min;
-        int peak = 0;
-        // the test run AT j: right = W5[j]; left_m = W5[j-5] + W5[j-m-5] - W5[j-k-5]  (E:647-660, literal update rule)
-        if (j > 2 * k + 10) {
-            int right = W5(i), base = W5(i - 5) - W5(i - k - 5);
-            for (int m = k; m < 2 * k; m++)
-                if (base + W5(i - m - 5) - right <= -2) { peak = 1; break; }
-        }
-        // tests run at j' = j+m+5 that mark THIS position (peak_hit[j'-m-w], E:662-664)
-        if (!peak) {
-            int me = W5(i);
-            for (int m = k; m < 2 * k; m++) {
-                long jp = j + m + 5;
-                if (jp > 2 * k + 10 && jp < len && W5(i + m) + me - W5(i + m - k) - W5(i + m + 5) >= 2) { peak = 1; break; }
-            }
-        }
-        F[j] = (uint8_t)((F[j] & 3) | (good << 2) | (peak << 3));
+    for (int i = threadIdx.x; i < N2; i += BT) W[i] = (int8_t)(i >= 5 ? P1[i] - P1[i - 5] : 0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < N2; i += BT) {
+        long jp = lo + i + 5;   // position of the test that uses t = i
+        bool ok = i >= k + 5 && i + 5 < N2 && jp > 2 * k + 10 && jp < len;
+        G[i] = (int8_t)(ok ? W[i] - W[i - k] - W[i + 5] : -100);
     }
-#undef W5
+    __syncthreads();
+    constexpr int PER = 8;
+    for (int blk = threadIdx.x; blk < TILE / PER; blk += BT) {
+        const int jj0 = blk * PER, i0 = jj0 + HL2;
+        // self test: window of W over [i-2k-4, i-k-5]; gather test: window of G over [i+k, i+2k-1]
+        const int sa = i0 - 2 * k - 4, sg = i0 + k;
+        int cmin = 127, cmax = -128;
+        for (int q = PER - 1; q < k; q++) {          // part shared by the 8 windows
+            int w = W[sa + q], g = G[sg + q];
+            cmin = w < cmin ? w : cmin;
+            cmax = g > cmax ? g : cmax;
+        }
+        int lmin[PER], lmax[PER], rmin[PER], rmax[PER];
+        lmin[PER - 1] = 127; lmax[PER - 1] = -128;   // suffix extrema of the first PER-1 values
+#pragma unroll
+        for (int q = PER - 2; q >= 0; q--) {
+            int w = W[sa + q], g = G[sg + q];
+            lmin[q] = w < lmin[q + 1] ? w : lmin[q + 1];
+            lmax[q] = g > lmax[q + 1] ? g : lmax[q + 1];
+        }
+        rmin[0] = 127; rmax[0] = -128;               // prefix extrema of the PER-1 values after the shared part
+#pragma unroll
+        for (int q = 1; q < PER; q++) {
+            int w = W[sa + k + q - 1], g = G[sg + k + q - 1];
+            rmin[q] = w < rmin[q - 1] ? w : rmin[q - 1];
+            rmax[q] = g > rmax[q - 1] ? g : rmax[q - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const long j = (long)t.j0 + jj0 + q;
+            if (j >= len) break;
+            const int i = i0 + q;
+            int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
+            int good = one >= one_min && three >= three_min;
+            int mn = lmin[q] < cmin ? lmin[q] : cmin;
+            mn = rmin[q] < mn ? rmin[q] : mn;
+            int mx = lmax[q] > cmax ? lmax[q] : cmax;
+            mx = rmax[q] > mx ? rmax[q] : mx;
+            int peak = (j > 2 * k + 10 && W[i - 5] - W[i - k - 5] - W[i] + mn <= -2) || (W[i] + mx >= 2);
+            F[j] = (uint8_t)((F[j] & 3) | (good << 2) | (peak << 3));
+        }
+    }
 }
 
 // ---- B3

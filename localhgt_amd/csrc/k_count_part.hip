@@ -148,6 +148,65 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
     }
 }
 
+// ---- P1, common case (<= 128 k-mer offsets per read, e <= 3): every lane keeps the keys of its offsets in
+// registers between the histogram and the placement, so reads are loaded and hashed once per tile.
+constexpr int RW = 4;   // reads per wave per tile -> at most 16*RW reads per tile
+__global__ void __launch_bounds__(PT) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
+                                                             int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sorted[TILE_KEYS];
+    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int shift = g.b1 ? g.k - g.b1 : 0;
+    const uint32_t bmask = g.b1 ? (uint32_t)g.nb1 - 1u : 0u;
+    const int k = hp.k, e = hp.e;
+    const long n_reads = 2 * npairs;
+    const long n_tiles = (n_reads + reads_per_tile - 1) / reads_per_tile;
+    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long r0 = t * reads_per_tile, r1 = r0 + reads_per_tile < n_reads ? r0 + reads_per_tile : n_reads;
+        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t key[RW][2][3];
+        uint32_t live = 0;   // bit (rr*6 + it*3 + i)
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) {
+            const long r = r0 + wib + rr * (PT / 64);
+            if (r >= r1) continue;
+            const long p = pair0 + (r >> 1);
+            const int m = (int)(r & 1);
+            if (m == 1 && b.count2 && !b.count2[p]) continue;   // quirk Q4
+            const int len = b.len[m][p];
+            const int nk = len - k + 1;
+            const int wpr = ((len + 31) >> 5) + 1;
+            const uint32_t* rec = b.words + b.off[m][p];
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int j = it * 64 + lane;
+                if (j >= nk || plane_window(rec + 2 * wpr, j, k) != 0) continue;
+                const uint32_t whi = plane_window(rec, j, k), wlo = plane_window(rec + wpr, j, k);
+                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if (i < e) {
+                        const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+                        key[rr][it][i] = h;
+                        live |= 1u << (rr * 6 + it * 3 + i);
+                        atomicAdd(&hist[(h >> shift) & bmask], 1u);
+                    }
+            }
+        }
+        __syncthreads();
+        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, g.nb1, shift, bmask, cur1, out, [&](auto emit) {
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++)
+#pragma unroll
+                for (int it = 0; it < 2; it++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                        if (live & (1u << (rr * 6 + it * 3 + i))) emit(key[rr][it][i]);
+        });
+    }
+}
+
 // ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS keys, never straddling segments.
 // A thread keeps its KPT keys in registers between the histogram and the placement, all loads in flight at once.
 __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ off /*[nb+1]*/, PartGeom g,
@@ -272,7 +331,11 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         LHGT_HIP(hipMemsetAsync(ghist, 0, (size_t)g.nb * 4, ctx->stream));
         hipLaunchKernelGGL(part_hist, dim3(grid), dim3(PT), (size_t)g.nb * 4, ctx->stream, b.d, p0, np, ctx->hp, g, ghist);
         hipLaunchKernelGGL(part_offsets, dim3(1), dim3(1024), 0, ctx->stream, ghist, g, off, cur1, cur2);
-        hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, cur1, ctx->d_part_keys[0]);
+        if (max_nk <= 128 && ctx->e <= 3) {
+            int rpt = reads_per_tile < 16 * RW ? reads_per_tile : 16 * RW;
+            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, cur1, ctx->d_part_keys[0]);
+        } else
+            hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, cur1, ctx->d_part_keys[0]);
         const uint32_t* final_keys = ctx->d_part_keys[0];
         if (g.b2 > 0) {
             hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], off, g, cur2, ctx->d_part_keys[1]);

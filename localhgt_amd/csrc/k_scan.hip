@@ -303,10 +303,13 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     ctx->n_peaks = -1;
     if ((long)total > max_peak)
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
-    if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
-    if (ctx->d_filter) { hipFree(ctx->d_filter); ctx->d_filter = nullptr; }
-    LHGT_HIP(hipMalloc(&ctx->d_loci, ((size_t)total + 1) * 8));
-    LHGT_HIP(hipMalloc(&ctx->d_filter, ((size_t)total + 1) * 4));
+    if ((long)total + 1 > ctx->peaks_cap) {     // grow-only: no allocator traffic in steady state
+        if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
+        if (ctx->d_filter) { hipFree(ctx->d_filter); ctx->d_filter = nullptr; }
+        ctx->peaks_cap = (long)total + 1 + total / 8;
+        LHGT_HIP(hipMalloc(&ctx->d_loci, (size_t)ctx->peaks_cap * 8));
+        LHGT_HIP(hipMalloc(&ctx->d_filter, (size_t)ctx->peaks_cap * 4));
+    }
     LHGT_HIP(hipMemsetAsync(ctx->d_filter, 0, ((size_t)total + 1) * 4, ctx->stream));  // E:1457
     LHGT_HIP(hipMemsetAsync(ctx->d_loci, 0, ((size_t)total + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(register_peaks, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts,

@@ -5,6 +5,7 @@
 // done by all lanes; offsets where some probe hits a peak are compacted, in offset order, into
 // an LDS event list.  Only pairs with >= 6 such offsets (MIN_BASE_NUM, E:29,496) run the
 // order-dependent judge_base logic, sequentially on lane 0 over the few events.
+#include <algorithm>
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
@@ -175,6 +176,20 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     }
 }
 
+// phase D helper: peaks with at least MIN_READS (1, E:37) votes, as (id, contig, pos) in any order;
+// the host sorts the few survivors by id, which is the order count_filtered_peak walks them (E:525).
+__global__ void __launch_bounds__(256) compact_voted(const uint32_t* __restrict__ filter, const int32_t* __restrict__ loci, long n,
+                                                     unsigned long long* __restrict__ counter, int32_t* __restrict__ out, long cap) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || filter[i] < 1) return;
+    unsigned long long slot = atomicAdd(counter, 1ull);
+    if ((long)slot < cap) {
+        out[3 * slot] = (int32_t)i;
+        out[3 * slot + 1] = loci[2 * i];
+        out[3 * slot + 2] = loci[2 * i + 1];
+    }
+}
+
 }  // namespace lhgt
 
 using namespace lhgt;
@@ -236,23 +251,46 @@ int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
 }
 
 // count_filtered_peak (E:515-548), single thread range: leading sentinel "1 1 1", merge while the
-// contig is the same and the gap to the running end is < 500.
+// contig is the same and the gap to the running end is < 500.  Only the voted peaks leave the GPU.
 int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
     if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
     if (!ctx || !path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
-    long n = ctx->n_peaks;
-    std::vector<int32_t> loci((size_t)2 * n + 2);
-    std::vector<uint8_t> filt((size_t)n + 1);
-    LHGT_TRY(lhgt_peaks_export(ctx, loci.data(), filt.data(), n));
+    const long n = ctx->n_peaks;
+    std::vector<int32_t> rec;
+    long nf = 0;
+    if (n > 0) {
+        long cap = ctx->voted_cap;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if (!ctx->d_voted) {
+                if (cap < 4096) cap = 4096;
+                LHGT_HIP(hipMalloc(&ctx->d_voted, (size_t)cap * 12 + 8));
+                ctx->voted_cap = cap;
+            }
+            unsigned long long* d_cnt = (unsigned long long*)((char*)ctx->d_voted + (size_t)ctx->voted_cap * 12);
+            LHGT_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(compact_voted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_filter, ctx->d_loci, n,
+                               d_cnt, (int32_t*)ctx->d_voted, ctx->voted_cap);
+            unsigned long long cnt = 0;
+            LHGT_HIP(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+            LHGT_HIP(hipStreamSynchronize(ctx->stream));
+            nf = (long)cnt;
+            if (nf <= ctx->voted_cap) break;
+            hipFree(ctx->d_voted);      // more voted peaks than room: grow once and redo
+            ctx->d_voted = nullptr;
+            cap = nf + nf / 8;
+        }
+        rec.resize((size_t)nf * 3);
+        if (nf) LHGT_HIP(hipMemcpy(rec.data(), ctx->d_voted, (size_t)nf * 12, hipMemcpyDeviceToHost));
+    }
+    std::vector<long> order((size_t)nf);
+    for (long i = 0; i < nf; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](long a, long b) { return rec[3 * a] < rec[3 * b]; });
     FILE* f = fopen(path, "w");
     if (!f) LHGT_FAIL(LHGT_E_IO, "cannot write %s", path);
     int start = 1, end = 1, chr = 1;
-    long nf = 0;
-    for (long i = 0; i < n; i++) {
-        if (filt[i] < 1) continue;  // MIN_READS (E:37)
-        nf++;
-        int c = loci[2 * i], pos = loci[2 * i + 1];
+    for (long q = 0; q < nf; q++) {
+        const int c = rec[3 * order[q] + 1], pos = rec[3 * order[q] + 2];
         if (chr == c && pos - 500 - end < 500) end = pos + 500;
         else {
             fprintf(f, "%d\t%d\t%d\n", chr, start, end);

@@ -109,6 +109,9 @@ struct lhgt_ctx {
     uint32_t* d_filter = nullptr;
     uint32_t* d_tile_count = nullptr;
     long n_peaks = -1, max_peak = 0;
+    long peaks_cap = 0;        // entries allocated in d_loci / d_filter (grow-only)
+    void* d_voted = nullptr;   // phase D: compacted (id, contig, pos) of voted peaks + counter
+    long voted_cap = 0;
     bool voted = false;
     // partitioned count (k_count_part.hip): two key buffers and the bucket histogram/offset block
     uint32_t* d_part_keys[2] = {nullptr, nullptr};

@@ -145,7 +145,8 @@ def main():
         # MI355X_MICROARCH.md section HBM); committed with the profile it came from
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tpath):
+        default_workload = (args.contigs, args.contig_len, args.pairs, k, e) == (1000, 1_000_000, 10_000_000, 32, 3)
+        if default_workload and os.path.exists(tpath):   # the PMC profile was taken on exactly this workload
             try:
                 traffic = json.load(open(tpath))
             except Exception:

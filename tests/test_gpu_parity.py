@@ -270,3 +270,25 @@ def test_partitioned_count_equals_direct_count(Engine, k):
             if k == 32:
                 tables[-1] = np.concatenate([tables[-1], eng.counts_export(0, 1 << 26).astype(np.uint64)])
     assert (tables[0] == tables[1]).all()
+
+
+def test_count_diff_kmer_tool(oracle, case_inputs):
+    """C-tool row: the printed rates are #(T==0)/2^k and #(T!=3)/2^k of phase A's table (count_diff_kmer.cpp:26-50)"""
+    import io
+    from localhgt_amd import count_diff_kmer
+    fa, f1, f2, _ = case_inputs("k24_seed7")
+    k = 20
+    buf = io.StringIO()
+    hist = count_diff_kmer.run(f1, f2, k, 100, seed=3, out=buf)
+    oracle.srand(3)
+    cc = oracle.random_coder(k, 3)
+    table = np.zeros(1 << k, dtype=np.uint8)
+    big = 1 << 40
+    oracle.count(f1, big, k, 3, cc, 100.0, None, table)
+    oracle.count(f2, big, k, 3, cc, 100.0, None, table)
+    want = np.bincount(table, minlength=4)
+    assert (hist == want).all()
+    lines = buf.getvalue().splitlines()
+    assert lines[0] == f"###kmer_is {k} sample_ratio_is 100"
+    size = 1 << k
+    assert lines[2] == "####%d\t%g\t%g" % (size, np.float32((size - want[3]) / size), np.float32(want[0] / size))

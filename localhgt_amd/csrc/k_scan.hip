@@ -20,7 +20,6 @@ constexpr int WINDOW = 500;    // E:556
 constexpr int HL2 = 512, HR2 = 80;          // halo of B2: 499 back for the window, 2k+5 forward for the contrast test
 constexpr int N2 = TILE + HL2 + HR2;
 constexpr int HALO3 = 2500;    // B3: 2*window on each side plus the 500 merge gap (E:618, 625, 629)
-constexpr int N3 = TILE + 2 * HALO3;
 
 __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uint32_t h) {
     return (T[h >> 4] >> ((h & 15u) * 2u)) & 3u;
@@ -141,44 +140,44 @@ __global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ ti
 }
 
 // ---- B3
+// Good-window bits of [j0-2560, j0+TILE+2560) as one ballot word per 64 positions; the nearest good window on
+// either side of a position is a clz/ctz inside its word or the carry of the neighbouring word.
+constexpr int H3 = 2560;                         // >= HALO3, multiple of 64
+constexpr int NW3 = (TILE + 2 * H3 + 63) / 64;   // ballot words per tile
 __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                     uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count) {
-    __shared__ int prevg[N3], nextg[N3], part[BT];
+    __shared__ unsigned long long gw[NW3];
+    __shared__ int prevw[NW3], nextw[NW3];       // last good index in words <= w / first good index in words >= w
     __shared__ uint8_t sel[TILE];
     __shared__ int n_new;
+    static_assert(H3 >= HALO3 && H3 % 64 == 0, "halo");
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
-    const long len = c.len, lo = (long)t.j0 - HALO3;
+    const long len = c.len, lo = (long)t.j0 - H3;
     uint8_t* F = flags + c.flat_base;
-    constexpr int CH = (N3 + BT - 1) / BT;
     constexpr int NONE_LO = -(1 << 28), NONE_HI = 1 << 28;
-    const int b = threadIdx.x * CH, en = b + CH < N3 ? b + CH : N3;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) n_new = 0;
-    // index (relative to lo) of the nearest good window at or before / at or after each position
-    int last = NONE_LO;
-    for (int i = b; i < en; i++) {
-        long pos = lo + i;
-        int g = (pos >= 0 && pos < len) ? (F[pos] >> 2) & 1 : 0;
-        if (g) last = i;
-        prevg[i] = last;
-        nextg[i] = g;  // staged: turned into the next-index below
+    for (int w = wv; w < NW3; w += BT / 64) {
+        long pos = lo + 64L * w + lane;
+        bool g = pos >= 0 && pos < len && ((F[pos] >> 2) & 1);
+        unsigned long long bal = __ballot(g);
+        if (lane == 0) gw[w] = bal;
     }
-    part[threadIdx.x] = last;
     __syncthreads();
-    int carry = NONE_LO;
-    for (int q = 0; q < (int)threadIdx.x; q++) carry = part[q] > carry ? part[q] : carry;
-    __syncthreads();
-    int nxt = NONE_HI;
-    for (int i = en - 1; i >= b; i--) {
-        if (prevg[i] < carry) prevg[i] = carry;
-        if (nextg[i]) nxt = i;
-        nextg[i] = nxt;
+    if (threadIdx.x == 0) {
+        int last = NONE_LO;
+        for (int w = 0; w < NW3; w++) {
+            if (gw[w]) last = 64 * w + 63 - __clzll((long long)gw[w]);
+            prevw[w] = last;
+        }
+    } else if (threadIdx.x == 64) {
+        int nxt = NONE_HI;
+        for (int w = NW3 - 1; w >= 0; w--) {
+            if (gw[w]) nxt = 64 * w + __ffsll((long long)gw[w]) - 1;
+            nextw[w] = nxt;
+        }
     }
-    part[threadIdx.x] = nxt;
-    __syncthreads();
-    carry = NONE_HI;
-    for (int q = BT - 1; q > (int)threadIdx.x; q--) carry = part[q] < carry ? part[q] : carry;
-    for (int i = b; i < en; i++) if (nextg[i] > carry) nextg[i] = carry;
     __syncthreads();
     // inside a merged interval: within 2*window of a good window (E:618, 625), or in a gap the
     // merge rule closes: start_next - end_prev < window  <=>  next - prev <= 4*window + window (E:629)
@@ -186,8 +185,12 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
         long j = (long)t.j0 + jj;
         uint8_t s = 0;
         if (j < len) {
-            int i = jj + HALO3;
-            int dp = i - prevg[i], dn = nextg[i] - i;  // huge when absent
+            const int i = jj + H3, w = i >> 6, bpos = i & 63;
+            const unsigned long long word = gw[w];
+            const unsigned long long below = word & ((2ull << bpos) - 1ull), above = (word >> bpos) << bpos;
+            const int p = below ? 64 * w + 63 - __clzll((long long)below) : (w > 0 ? prevw[w - 1] : NONE_LO);
+            const int n = above ? 64 * w + __ffsll((long long)above) - 1 : (w + 1 < NW3 ? nextw[w + 1] : NONE_HI);
+            const int dp = i - p, dn = n - i;   // huge when absent
             int inside = j >= 1 && (dp <= 2 * WINDOW || dn <= 2 * WINDOW || dp + dn <= 5 * WINDOW);
             uint8_t f = F[j];
             s = inside && ((f >> 3) & 1);

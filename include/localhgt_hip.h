@@ -117,7 +117,8 @@ int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long 
 int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
                      long first_pair, long n_pairs, int read_len, uint8_t* host_seq1_or_null, uint8_t* host_seq2_or_null);
 
-/* ablation switches for profiling only (bit0: lhgt_vote skips judge_base); outputs are wrong when non-zero */
+/* switches for profiling / A-B runs.  bit0: lhgt_vote skips judge_base (outputs wrong);
+ * bit2: never use the vote prefilter (outputs unchanged) */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */

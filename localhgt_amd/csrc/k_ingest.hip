@@ -219,7 +219,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens) {
     LHGT_HIP(hipMalloc(&ctx->d_contigs, ctx->contigs.size() * sizeof(ContigDev)));
     LHGT_HIP(hipMalloc(&ctx->d_tiles, tiles.size() * sizeof(TileDev)));
     LHGT_HIP(hipMalloc(&ctx->d_flags, flat));
-    LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 1) * 4));
+    LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 8) * 4));  // counts, total, then the u64 selected-position counter
     LHGT_HIP(hipMemcpy(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice));
     LHGT_HIP(hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice));
     return LHGT_OK;

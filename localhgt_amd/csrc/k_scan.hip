@@ -145,11 +145,12 @@ __global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ ti
 constexpr int H3 = 2560;                         // >= HALO3, multiple of 64
 constexpr int NW3 = (TILE + 2 * H3 + 63) / 64;   // ballot words per tile
 __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count) {
+                                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count,
+                                                    unsigned long long* __restrict__ n_selected) {
     __shared__ unsigned long long gw[NW3];
     __shared__ int prevw[NW3], nextw[NW3];       // last good index in words <= w / first good index in words >= w
     __shared__ uint8_t sel[TILE];
-    __shared__ int n_new;
+    __shared__ int n_new, n_sel;
     static_assert(H3 >= HALO3 && H3 % 64 == 0, "halo");
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
     uint8_t* F = flags + c.flat_base;
     constexpr int NONE_LO = -(1 << 28), NONE_HI = 1 << 28;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) n_new = 0;
+    if (threadIdx.x == 0) { n_new = 0; n_sel = 0; }
     for (int w = wv; w < NW3; w += BT / 64) {
         long pos = lo + 64L * w + lane;
         bool g = pos >= 0 && pos < len && ((F[pos] >> 2) & 1);
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
             F[j] = (uint8_t)((f & 15) | (inside << 4) | (s << 5));
         }
         sel[jj] = s;
+        if (s) atomicAdd(&n_sel, 1);
     }
     __syncthreads();
     // a selected position opens a new peak iff it is the first selected one of its 50-bp bucket (E:296)
@@ -211,7 +213,10 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = (uint32_t)n_new;
+    if (threadIdx.x == 0) {
+        tile_count[blockIdx.x] = (uint32_t)n_new;
+        if (n_sel) atomicAdd(n_selected, (unsigned long long)n_sel);
+    }
 }
 
 // ---- B4: in-place exclusive scan of tile_count[0..n); total lands in tile_count[n]
@@ -237,7 +242,8 @@ __global__ void __launch_bounds__(1024) tile_scan(uint32_t* __restrict__ v, long
 __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
                                                      const uint8_t* __restrict__ flags, const uint32_t* __restrict__ tile_base,
-                                                     int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer) {
+                                                     int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
+                                                     uint32_t* __restrict__ prefilter /* nullable */) {
     __shared__ int incl[TILE], part[BT];
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
@@ -270,7 +276,13 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
             const uint32_t* hp = index + c.hash_word + j * e;
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                if (h != 0 && count_of(counts, h) > 0) atomicMax(&peak_kmer[h], id);  // later (larger) id wins
+                if (h != 0 && count_of(counts, h) > 0) {
+                    atomicMax(&peak_kmer[h], id);  // later (larger) id wins
+                    if (prefilter) {
+                        const uint32_t fb = h & ((1u << PF_BITS) - 1u);
+                        atomicOr(&prefilter[fb >> 5], 1u << (fb & 31u));
+                    }
+                }
             }
         }
     }
@@ -297,12 +309,21 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     dim3 grid((unsigned)ctx->n_tiles), blk(BT);
     hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags);
     hipLaunchKernelGGL(window_peak, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, one_min, three_min, ctx->d_flags);
-    hipLaunchKernelGGL(interval_mask, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_flags, ctx->d_tile_count);
+    unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));
+    LHGT_HIP(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(interval_mask, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_flags, ctx->d_tile_count, d_nsel);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     uint32_t total = 0;
     LHGT_HIP(hipMemcpyAsync(&total, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(&ctx->n_selected, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    // vote prefilter (k_vote.hip): worth it while at most ~1/8 of its 2^PF_BITS bits would be set
+    ctx->prefilter_on = ctx->k > PF_BITS && !(ctx->debug & 4) && ctx->n_selected * (unsigned long long)e <= (1ull << PF_BITS) / 8;
+    if (ctx->prefilter_on) {
+        if (!ctx->d_prefilter) LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
+        LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, (size_t)(1u << PF_BITS) / 8, ctx->stream));
+    }
     ctx->n_peaks = -1;
     if ((long)total > max_peak)
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
@@ -316,7 +337,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     LHGT_HIP(hipMemsetAsync(ctx->d_filter, 0, ((size_t)total + 1) * 4, ctx->stream));  // E:1457
     LHGT_HIP(hipMemsetAsync(ctx->d_loci, 0, ((size_t)total + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(register_peaks, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts,
-                       ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer);
+                       ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));

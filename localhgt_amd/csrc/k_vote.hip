@@ -116,9 +116,12 @@ __device__ __forceinline__ void judge_pair(const uint32_t* ev, int n_ev, int e_r
     }
 }
 
-// General form: any read length up to 500, probes of one 64-offset slice at a time.
-template <int TR>
+// Any read length up to 500, probes of one 64-offset slice at a time.  PF: consult the L2-resident folded bitmap
+// first (exact negatives: a clear bit means no slot folding onto it holds a peak), so sparse peak sets never
+// touch the 16 GiB peak_kmer array except for true hits and the few false positives.
+template <int TR, bool PF>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
+                                                   const uint32_t* __restrict__ prefilter,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
                                                    int max_ev, int waves_per_block, int debug) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -146,7 +149,11 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
 #pragma unroll
                     for (int i = 0; i < 9; i++)
                         if (i < e) {
-                            ids[i] = peak_kmer[hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i])];  // 0 = no peak (E:454)
+                            const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+                            if (PF) {
+                                const uint32_t fb = h & ((1u << PF_BITS) - 1u);
+                                ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? peak_kmer[h] : 0u;
+                            } else ids[i] = peak_kmer[h];  // 0 = no peak (E:454)
                             hit |= ids[i] != 0;
                         }
 #pragma unroll
@@ -211,12 +218,12 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (wpb < 1) wpb = 1;
         long blocks = (b.d.n_pairs + wpb - 1) / wpb;
         if (blocks > 256L * 16) blocks = 256L * 16;
-        if (max_ev <= 256)
-            hipLaunchKernelGGL(vote_kernel<4>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp,
-                               ctx->d_peak_kmer, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug);
-        else
-            hipLaunchKernelGGL(vote_kernel<16>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp,
-                               ctx->d_peak_kmer, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug);
+#define LHGT_VOTE(TR_, PF_)                                                                                          \
+    hipLaunchKernelGGL((vote_kernel<TR_, PF_>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, \
+                       ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug)
+        if (max_ev <= 256) { if (ctx->prefilter_on) LHGT_VOTE(4, true); else LHGT_VOTE(4, false); }
+        else { if (ctx->prefilter_on) LHGT_VOTE(16, true); else LHGT_VOTE(16, false); }
+#undef LHGT_VOTE
     }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -66,6 +66,7 @@ struct ContigDev {
     uint32_t len;
     uint32_t ref_index;  // 1,2,3.. in index order (E:905,963; quirk Q7)
 };
+constexpr int PF_BITS = 25;  // vote prefilter: 2^25 bits = 4 MiB, one XCD's L2
 constexpr int TILE = 2000;  // positions per scan tile; multiple of 50 so peak buckets never straddle tiles
 struct TileDev {
     uint32_t contig;
@@ -109,6 +110,9 @@ struct lhgt_ctx {
     uint32_t* d_filter = nullptr;
     uint32_t* d_tile_count = nullptr;
     long n_peaks = -1, max_peak = 0;
+    uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
+    bool prefilter_on = false;
+    unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan
     long peaks_cap = 0;        // entries allocated in d_loci / d_filter (grow-only)
     void* d_voted = nullptr;   // phase D: compacted (id, contig, pos) of voted peaks + counter
     long voted_cap = 0;

@@ -292,3 +292,25 @@ def test_count_diff_kmer_tool(oracle, case_inputs):
     assert lines[0] == f"###kmer_is {k} sample_ratio_is 100"
     size = 1 << k
     assert lines[2] == "####%d\t%g\t%g" % (size, np.float32((size - want[3]) / size), np.float32(want[0] / size))
+
+
+def test_vote_prefilter_changes_nothing(Engine):
+    """the L2-resident folded bitmap in front of peak_kmer only skips probes that would return 0"""
+    k, e = 28, 3
+    with Engine(k, e) as eng:
+        eng.rng_seed(5)
+        eng.coder_generate()
+        eng.synth_reference(3, 16, 100_000)
+        eng.synth_pairs(3, 4, 16, 100_000, 0, 60_000)
+        eng.count_kmers()
+        votes = []
+        for flags in (0, 4):
+            eng.set_debug(flags)
+            n = eng.ref_scan(0.1, 0.08, 10**7)
+            eng.vote()
+            loci, v = eng.peaks_export(n)
+            votes.append((n, loci.copy(), v.copy()))
+        eng.set_debug(0)
+    assert votes[0][0] == votes[1][0] > 50
+    assert (votes[0][1] == votes[1][1]).all() and (votes[0][2] == votes[1][2]).all()
+    assert votes[0][2].max() >= 1

@@ -70,9 +70,14 @@ int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, 
 /* Parse both FASTQs in lock-step (E:350-359), keep pair n iff random_array[n % 5e7] < ratio
  * (E:413-419, 1037-1044), mark mate 2 as not-counted once its byte cursor passed size(fq1)
  * (E:1419-1445), keep pairs of block (n / shard_block) % shard_world == shard_rank, upload
- * and 2-bit pack them.  The store stays resident for phases A and C. */
+ * and 2-bit pack them.  The store stays resident for phases A and C.  Parsing is multi-threaded (LHGT_INGEST_THREADS,
+ * default min(32, cores)): the reference's pairing is purely line-indexed, so any line start is a split point. */
 int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent,
                           int shard_rank, int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept);
+/* host-only probe of the same parser (tests): FNV-1a digest of every kept pair in order; threads/chunk_bytes explicit */
+int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null,
+                            int shard_rank, int shard_world, long shard_block, int threads, long chunk_bytes,
+                            long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest);
 /* Append pairs from host memory: mate m of pair p is seq_m[off_m[p] .. off_m[p+1]).
  * count_mate2 (optional, one byte per pair) = 0 excludes mate 2 from phase A only. */
 int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,

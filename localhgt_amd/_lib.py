@@ -40,6 +40,7 @@ SIGNATURES = {
     "lhgt_index_from_memory": [_vp, _u8p, _u64p, _l],
     "lhgt_fastq_sam_ratio": [_cs, _d, _dp, _lp],
     "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
+    "lhgt_fastq_parse_digest": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _lp, _lp, _u64p],
     "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
     "lhgt_pairs_clear": [_vp],
     "lhgt_pairs_count": [_vp, _lp],

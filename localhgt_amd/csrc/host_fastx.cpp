@@ -3,7 +3,11 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <time.h>
 #include "lhgt_common.hpp"
 
 namespace lhgt {
@@ -119,6 +123,170 @@ int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, 
     return LHGT_OK;
 }
 
+// ---------------------------------------------------------------- parallel lock-step FASTQ parser
+// The reference pairs line i of fq1 with line i of fq2 and treats lines with i % 4 == 1 as sequences
+// (E:356-367, 403-419): purely line-indexed.  So ANY line start is a valid split point: pass 1 counts the
+// lines of byte chunks of both files, pass 2 parses the fq1 chunks in parallel, each thread locating its
+// first global line in fq2 through fq2's per-chunk line counts.  Results are delivered in file order.
+}  // extern "C"
+
+namespace lhgt {
+
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static bool ingest_trace() { static int t = getenv("LHGT_INGEST_TRACE") ? 1 : 0; return t != 0; }
+
+struct ParsedChunk {
+    std::vector<uint8_t> s1, s2, cnt2;
+    std::vector<uint64_t> o1, o2;
+    int rc = LHGT_OK;
+    std::string err;
+};
+
+struct ChunkPlan {
+    std::vector<size_t> start;   // byte offset of the first line of each chunk, plus file size at the end
+    std::vector<long> line0;     // global index of that line, plus total line count at the end
+};
+
+static size_t line_start_at_or_after(const uint8_t* p, size_t n, size_t from) {
+    if (from == 0) return 0;
+    if (from >= n) return n;
+    const uint8_t* nl = (const uint8_t*)memchr(p + from - 1, '\n', n - (from - 1));
+    return nl ? (size_t)(nl - p) + 1 : n;
+}
+
+static long count_lines(const uint8_t* p, size_t b0, size_t b1, size_t n) {
+    long c = 0;
+    const uint8_t* q = p + b0;
+    const uint8_t* end = p + b1;
+    while (q < end) {
+        const uint8_t* nl = (const uint8_t*)memchr(q, '\n', (size_t)(end - q));
+        if (!nl) break;
+        c++;
+        q = nl + 1;
+    }
+    if (b1 == n && n > b0 && p[n - 1] != '\n') c++;   // last line without a newline is still a line (std::getline)
+    return c;
+}
+
+template <class Fn>
+static void parallel_for(long n, int threads, Fn fn) {
+    if (threads <= 1 || n <= 1) { for (long i = 0; i < n; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<long> next{0};
+    int t = (int)(n < threads ? n : threads);
+    for (int w = 0; w < t; w++) th.emplace_back([&]() { for (long i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& x : th) x.join();
+}
+
+static ChunkPlan plan_chunks(const Mapped& m, size_t chunk_bytes, int threads) {
+    ChunkPlan pl;
+    size_t nchunks = m.n ? (m.n + chunk_bytes - 1) / chunk_bytes : 1;
+    for (size_t c = 0; c < nchunks; c++) {
+        size_t st = line_start_at_or_after(m.p, m.n, c * chunk_bytes);
+        if (pl.start.empty() || st > pl.start.back()) pl.start.push_back(st);
+    }
+    if (pl.start.empty()) pl.start.push_back(0);
+    if (pl.start.back() != m.n || pl.start.size() == 1) pl.start.push_back(m.n);
+    long nc = (long)pl.start.size() - 1;
+    std::vector<long> cnt((size_t)nc);
+    parallel_for(nc, threads, [&](long c) { cnt[c] = count_lines(m.p, pl.start[c], pl.start[c + 1], m.n); });
+    pl.line0.assign((size_t)nc + 1, 0);
+    for (long c = 0; c < nc; c++) pl.line0[c + 1] = pl.line0[c] + cnt[c];
+    return pl;
+}
+
+// Parse fq1 chunk c (all lines starting in it) against the same global lines of fq2.
+static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, const ChunkPlan& p2, long c, double ratio,
+                        const float* random_array, int shard_rank, int shard_world, long shard_block, ParsedChunk* out) {
+    out->o1.assign(1, 0);
+    out->o2.assign(1, 0);
+    const long g0 = p1.line0[c], g1 = p1.line0[c + 1];
+    if (g1 > p2.line0.back()) { out->rc = LHGT_E_FORMAT; out->err = "second FASTQ has fewer lines than the first"; return; }
+    if (g0 == g1) return;
+    // fq2 cursor at global line g0
+    long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g0) - p2.line0.begin()) - 1;
+    LineCursor k1(m1), k2(m2);
+    k1.cur = p1.start[c];
+    k2.cur = p2.start[c2];
+    const uint8_t *a, *b;
+    size_t la, lb, sa, sb;
+    for (long skip = g0 - p2.line0[c2]; skip > 0; skip--) k2.next(&b, &lb, &sb);
+    const size_t size1 = m1.n;
+    for (long g = g0; g < g1; g++) {
+        k1.next(&a, &la, &sa);
+        k2.next(&b, &lb, &sb);
+        if (g == 0) {  // E:368-402: the two first read IDs must agree
+            size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
+            if (ia != ib || memcmp(a, b, ia)) { out->rc = LHGT_E_FORMAT; out->err = "paired-end reads not consistent: first records differ"; return; }
+        }
+        if (g % 4 != 1) continue;
+        const long n = g / 4;
+        const bool keep = ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio;
+        if (!keep || (n / shard_block) % shard_world != shard_rank) continue;
+        if (la > LHGT_MAX_READ_LEN || lb > LHGT_MAX_READ_LEN) {
+            out->rc = LHGT_E_FORMAT;
+            out->err = "read " + std::to_string(n) + " longer than " + std::to_string(LHGT_MAX_READ_LEN) + " bases (the reference's buffers, E:1004)";
+            return;
+        }
+        out->s1.insert(out->s1.end(), a, a + la);
+        out->s2.insert(out->s2.end(), b, b + lb);
+        out->o1.push_back(out->s1.size());
+        out->o2.push_back(out->s2.size());
+        out->cnt2.push_back(sb <= size1 ? 1 : 0);  // quirk Q4: mate 2 counted only while its line starts at <= size(fq1)
+    }
+}
+
+// consume(chunk) is called on the calling thread, in file order.
+template <class Consume>
+static int parse_pairs(const char* fq1, const char* fq2, double ratio, const float* random_array, int shard_rank, int shard_world,
+                       long shard_block, int threads, size_t chunk_bytes, long* n_pairs_seen, Consume consume) {
+    Mapped m1, m2;
+    LHGT_TRY(m1.open(fq1));
+    LHGT_TRY(m2.open(fq2));
+    if (threads < 1) threads = 1;
+    double t0 = now_s();
+    ChunkPlan p1 = plan_chunks(m1, chunk_bytes, threads), p2 = plan_chunks(m2, chunk_bytes, threads);
+    double t_plan = now_s() - t0, t_parse = 0, t_consume = 0;
+    if (p2.line0.back() < p1.line0.back()) LHGT_FAIL(LHGT_E_FORMAT, "%s has fewer lines than %s", fq2, fq1);
+    if (p2.line0.back() > p1.line0.back()) LHGT_FAIL(LHGT_E_FORMAT, "%s has more lines than %s", fq2, fq1);
+    const long nc = (long)p1.start.size() - 1;
+    for (long base = 0; base < nc; base += threads) {
+        long n = nc - base < threads ? nc - base : threads;
+        std::vector<ParsedChunk> out((size_t)n);
+        double t1 = now_s();
+        parallel_for(n, threads, [&](long i) {
+            parse_chunk(m1, m2, p1, p2, base + i, ratio, random_array, shard_rank, shard_world, shard_block, &out[i]);
+        });
+        double t2 = now_s();
+        for (long i = 0; i < n; i++) {
+            if (out[i].rc != LHGT_OK) LHGT_FAIL(out[i].rc, "%s", out[i].err.c_str());
+            LHGT_TRY(consume(out[i]));
+        }
+        t_parse += t2 - t1;
+        t_consume += now_s() - t2;
+    }
+    if (ingest_trace())
+        fprintf(stderr, "[lhgt ingest] %d threads, %ld chunks: line count %.3fs, parse %.3fs, consume(+upload) %.3fs\n", threads, nc,
+                t_plan, t_parse, t_consume);
+    if (n_pairs_seen) *n_pairs_seen = (p1.line0.back() + 2) / 4;   // lines with index % 4 == 1
+    return LHGT_OK;
+}
+
+static int default_threads() {
+    const char* e = getenv("LHGT_INGEST_THREADS");
+    if (e && atoi(e) > 0) return atoi(e);
+    unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 4 : (hc > 32 ? 32 : (int)hc);
+}
+
+}  // namespace lhgt
+
+extern "C" {
+
 int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, int shard_rank,
                           int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept) {
     if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
@@ -127,58 +295,78 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
         LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d block %ld", shard_rank, shard_world, shard_block);
     if (ratio_percent < 100.0 && (long)ctx->random_array.size() != LHGT_MAX_RANDOM)
         LHGT_FAIL(LHGT_E_STATE, "lhgt_sampling_init(ratio) must precede lhgt_pairs_load_fastq when ratio < 100");
-    Mapped m1, m2;
-    LHGT_TRY(m1.open(fq1));
-    LHGT_TRY(m2.open(fq2));
-    const size_t size1 = m1.n;  // E:1419: both mates are cut at size(fq1) in phase A
-    LineCursor c1(m1), c2(m2);
-    const long CHUNK = 1 << 20;
-    std::vector<uint8_t> s1, s2, cnt2;
-    std::vector<uint64_t> o1{0}, o2{0};
-    long lines = 0, kept = 0;
-    const uint8_t *a, *b;
-    size_t la, lb, sa, sb;
+    // Parsed chunks go straight from their own buffers into the device staging area; only per-read metadata is kept
+    // on this (serial) path.  A device batch is closed at >= 4 M pairs or ~1 GiB of bases: every batch costs one sweep
+    // of the count table in phase A, so batches are kept large.
+    const long BATCH_PAIRS = 4L << 20;
+    const size_t BATCH_BYTES = (size_t)1 << 30, CHUNK = (size_t)64 << 20;
+    LHGT_TRY(ws_reserve(ctx, BATCH_BYTES + 4 * CHUNK, 0));
+    std::vector<uint64_t> st1, st2;
+    std::vector<uint16_t> ln1, ln2;
+    std::vector<uint8_t> cnt2;
+    size_t fill = 0;
+    long kept = 0;
     auto flush = [&]() -> int {
-        long n = (long)o1.size() - 1;
+        long n = (long)st1.size();
         if (n == 0) return LHGT_OK;
-        int rc = upload_pairs(ctx, s1.data(), o1.data(), s2.data(), o2.data(), n, cnt2.data());
-        s1.clear(); s2.clear(); cnt2.clear();
-        o1.assign(1, 0); o2.assign(1, 0);
+        st1.insert(st1.end(), st2.begin(), st2.end());
+        ln1.insert(ln1.end(), ln2.begin(), ln2.end());
+        int rc = install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, st1.data(), ln1.data(), n, cnt2.data());
+        st1.clear(); st2.clear(); ln1.clear(); ln2.clear(); cnt2.clear();
+        fill = 0;
         return rc;
     };
-    while (c1.next(&a, &la, &sa)) {
-        bool have2 = c2.next(&b, &lb, &sb);
-        if (!have2) LHGT_FAIL(LHGT_E_FORMAT, "%s has fewer lines than %s", fq2, fq1);
-        if (lines == 0) {  // E:368-402: the two first read IDs must agree
-            size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
-            if (ia != ib || memcmp(a, b, ia))
-                LHGT_FAIL(LHGT_E_FORMAT, "paired-end reads not consistent: first records of %s and %s differ", fq1, fq2);
-        }
-        if (lines % 4 == 1) {
-            long n = lines / 4;
-            bool keep = ratio_percent >= 100.0 || (double)ctx->random_array[n % LHGT_MAX_RANDOM] < ratio_percent;
-            if (keep && (n / shard_block) % shard_world == shard_rank) {
-                if (la > LHGT_MAX_READ_LEN || lb > LHGT_MAX_READ_LEN)
-                    LHGT_FAIL(LHGT_E_FORMAT, "read %ld longer than %d bases (the reference's buffers, E:1004)", n, LHGT_MAX_READ_LEN);
-                s1.insert(s1.end(), a, a + la);
-                s2.insert(s2.end(), b, b + lb);
-                o1.push_back(s1.size());
-                o2.push_back(s2.size());
-                cnt2.push_back(sb <= size1 ? 1 : 0);  // quirk Q4
-                kept++;
-                if ((long)o1.size() - 1 >= CHUNK) LHGT_TRY(flush());
-            }
-        }
-        lines++;
-    }
-    {   // the reference reads fq2 on its own in phase A; a longer fq2 would be counted but never voted
-        size_t extra_len, extra_start;
-        const uint8_t* extra;
-        if (c2.next(&extra, &extra_len, &extra_start))
-            LHGT_FAIL(LHGT_E_FORMAT, "%s has more lines than %s", fq2, fq1);
-    }
+    int rc = parse_pairs(fq1, fq2, ratio_percent, ctx->random_array.data(), shard_rank, shard_world, shard_block, default_threads(),
+                         CHUNK, n_pairs_seen, [&](ParsedChunk& ch) -> int {
+                             long n = (long)ch.o1.size() - 1;
+                             if (n == 0) return LHGT_OK;
+                             if (fill + ch.s1.size() + ch.s2.size() > ctx->ws_ascii_cap) LHGT_TRY(flush());
+                             kept += n;
+                             const size_t b1 = fill, b2 = fill + ch.s1.size();
+                             LHGT_TRY(stage_ascii(ctx, b1, ch.s1.data(), ch.s1.size()));
+                             LHGT_TRY(stage_ascii(ctx, b2, ch.s2.data(), ch.s2.size()));
+                             fill = b2 + ch.s2.size();
+                             for (long i = 0; i < n; i++) {
+                                 st1.push_back(b1 + ch.o1[i]);
+                                 st2.push_back(b2 + ch.o2[i]);
+                                 ln1.push_back((uint16_t)(ch.o1[i + 1] - ch.o1[i]));
+                                 ln2.push_back((uint16_t)(ch.o2[i + 1] - ch.o2[i]));
+                             }
+                             cnt2.insert(cnt2.end(), ch.cnt2.begin(), ch.cnt2.end());
+                             if ((long)st1.size() >= BATCH_PAIRS || fill >= BATCH_BYTES) return flush();
+                             return LHGT_OK;
+                         });
+    if (rc != LHGT_OK) return rc;
     LHGT_TRY(flush());
-    if (n_pairs_seen) *n_pairs_seen = lines / 4;
+    if (n_pairs_kept) *n_pairs_kept = kept;
+    return LHGT_OK;
+}
+
+// Host-only probe of the parser (tests): FNV-1a digest over every kept pair (lengths, bases, mate-2 flag) in order.
+int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
+                            int shard_world, long shard_block, int threads, long chunk_bytes, long* n_pairs_seen, long* n_pairs_kept,
+                            uint64_t* digest) {
+    if (!fq1 || !fq2 || !digest || chunk_bytes < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (ratio_percent < 100.0 && !random_array_or_null) LHGT_FAIL(LHGT_E_ARG, "sampling needs the random array");
+    uint64_t h = 1469598103934665603ull;
+    long kept = 0;
+    auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
+    int rc = parse_pairs(fq1, fq2, ratio_percent, random_array_or_null, shard_rank, shard_world, shard_block, threads, (size_t)chunk_bytes,
+                         n_pairs_seen, [&](ParsedChunk& ch) -> int {
+                             long n = (long)ch.o1.size() - 1;
+                             for (long i = 0; i < n; i++) {
+                                 uint64_t l1 = ch.o1[i + 1] - ch.o1[i], l2 = ch.o2[i + 1] - ch.o2[i];
+                                 mix((const uint8_t*)&l1, 8);
+                                 mix(ch.s1.data() + ch.o1[i], l1);
+                                 mix((const uint8_t*)&l2, 8);
+                                 mix(ch.s2.data() + ch.o2[i], l2);
+                                 mix(&ch.cnt2[i], 1);
+                             }
+                             kept += n;
+                             return LHGT_OK;
+                         });
+    if (rc != LHGT_OK) return rc;
+    *digest = h;
     if (n_pairs_kept) *n_pairs_kept = kept;
     return LHGT_OK;
 }

@@ -1,22 +1,25 @@
 // k_ingest.hip -- 2-bit packing of bases, the resident pair store, the index builder/loader.
 #include <cstring>
+#include <time.h>
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
 
 // ---------------------------------------------------------------- pack kernel
 // Thread (r, w) turns bases [32w, 32w+32) of sequence r into one word of each plane.
-// Sequence r is ascii[byte_off[r] .. byte_off[r+1]); its record starts at words[word_off[r]]
-// and is [hi | lo | not-a-base], wpr = ceil(len/32)+1 words each (last word = zero pad).
-__global__ void __launch_bounds__(256) pack_bases(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ byte_off,
+// Sequence r is ascii[start[r] .. start[r]+len); len = len16[r], or single_len when len16 is null (one contig).
+// Its record starts at words[word_off[r]] and is [hi | lo | not-a-base], wpr = ceil(len/32)+1 words each
+// (last word = zero pad).
+__global__ void __launch_bounds__(256) pack_bases(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ start,
+                                                  const uint16_t* __restrict__ len16, long single_len,
                                                   const uint64_t* __restrict__ word_off, long n_seq, int max_wpr,
                                                   uint32_t* __restrict__ words) {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long r = t / max_wpr;
     int w = (int)(t % max_wpr);
     if (r >= n_seq) return;
-    uint64_t b0 = byte_off[r];
-    long len = (long)(byte_off[r + 1] - b0);
+    uint64_t b0 = start[r];
+    long len = len16 ? (long)len16[r] : single_len;
     int wpr = (int)((len + 31) / 32) + 1;
     if (w >= wpr) return;
     uint32_t hi = 0, lo = 0, nb = 0;
@@ -79,12 +82,12 @@ int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint3
     if (len < ctx->k) return LHGT_OK;
     int wpr = (int)((len + 31) / 32) + 1;
     LHGT_TRY(ws_reserve(ctx, 0, (size_t)3 * wpr + 8));
-    uint64_t offs[3] = {0, (uint64_t)len, 0};  // byte_off[0..1], word_off[0]
+    uint64_t offs[2] = {0, 0};  // start[0], word_off[0]
     uint64_t* d_meta = (uint64_t*)(ctx->d_ws_words + (size_t)3 * wpr + 2 - ((size_t)3 * wpr) % 2);
     LHGT_HIP(hipMemcpyAsync(d_meta, offs, sizeof offs, hipMemcpyHostToDevice, ctx->stream));
     long threads = wpr;
     hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_ascii,
-                       d_meta, d_meta + 2, 1L, wpr, ctx->d_ws_words);
+                       d_meta, (const uint16_t*)nullptr, len, d_meta + 1, 1L, wpr, ctx->d_ws_words);
     long nk = len - ctx->k + 1;
     hipLaunchKernelGGL(hash_positions, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_words, len,
                        ctx->hp, d_out, d_valid);
@@ -100,25 +103,33 @@ int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_
     return hash_contig_dev_ascii(ctx, ctx->d_ws_ascii, len, d_out, d_valid);
 }
 
+// RAII hipHostRegister of a host range (no-op if the runtime refuses, e.g. for some file mappings)
+struct HostPin {
+    void* p = nullptr;
+    HostPin(const void* ptr, size_t bytes) {
+        if (bytes >= (1u << 20) && hipHostRegister((void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = (void*)ptr;
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) hipHostUnregister(p); }
+};
+
 // ---------------------------------------------------------------- resident pairs
 static void free_batch(ReadBatch& b) {
     for (void*& p : b.alloc) if (p) { hipFree(p); p = nullptr; }
 }
 
-// Install n pairs whose ASCII bases already sit in device memory: sequence r (r < n: mate 1 of
-// pair r, else mate 2 of pair r-n) is d_ascii[byte_off[r] .. byte_off[r+1]).
-int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const std::vector<uint64_t>& byte_off, long n,
+// Install n pairs whose ASCII bases already sit in device memory: sequence r (r < n: mate 1 of pair r, else
+// mate 2 of pair r-n) is d_ascii[start[r] .. start[r]+len[r]).
+int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
                             const uint8_t* count_mate2) {
     const int k = ctx->k;
     std::vector<uint64_t> word_off(2 * n);
-    std::vector<uint16_t> lens(2 * n);
     uint64_t words = 0, nkm = 0;
     int max_len = 0;
     for (long r = 0; r < 2 * n; r++) {
-        uint64_t len = byte_off[r + 1] - byte_off[r];
+        uint64_t len = lens[r];
         if (len > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read longer than %d bases", LHGT_MAX_READ_LEN);
         word_off[r] = words;
-        lens[r] = (uint16_t)len;
         words += 3 * ((len + 31) / 32 + 1);
         if ((int)len > max_len) max_len = (int)len;
         if ((long)len >= k) nkm += len - k + 1;
@@ -131,7 +142,7 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const std::ve
     uint32_t *d_words, *d_off32;
     uint16_t* d_len;
     uint8_t* d_cnt = nullptr;
-    uint64_t *d_byte_off, *d_word_off;
+    uint64_t *d_start, *d_word_off;
     LHGT_HIP(hipMalloc(&d_words, words * 4 + 16));
     b.alloc[0] = d_words;
     LHGT_HIP(hipMalloc(&d_off32, (size_t)2 * n * 4));
@@ -143,22 +154,22 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const std::ve
         b.alloc[3] = d_cnt;
         LHGT_HIP(hipMemcpyAsync(d_cnt, count_mate2, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     }
-    LHGT_HIP(hipMalloc(&d_byte_off, (size_t)(2 * n + 1) * 8));
-    b.alloc[4] = d_byte_off;
+    LHGT_HIP(hipMalloc(&d_start, (size_t)2 * n * 8));
+    b.alloc[4] = d_start;
     LHGT_HIP(hipMalloc(&d_word_off, (size_t)2 * n * 8));
     b.alloc[5] = d_word_off;
-    LHGT_HIP(hipMemcpyAsync(d_byte_off, byte_off.data(), byte_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_start, start, (size_t)2 * n * 8, hipMemcpyHostToDevice, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(d_word_off, word_off.data(), word_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     std::vector<uint32_t> off32(word_off.begin(), word_off.end());
     LHGT_HIP(hipMemcpyAsync(d_off32, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    LHGT_HIP(hipMemcpyAsync(d_len, lens.data(), lens.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_len, lens, (size_t)2 * n * 2, hipMemcpyHostToDevice, ctx->stream));
     int max_wpr = (max_len + 31) / 32 + 1;
     long threads = 2 * n * max_wpr;
     hipLaunchKernelGGL(pack_bases, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_ascii,
-                       d_byte_off, d_word_off, 2 * n, max_wpr, d_words);
+                       d_start, d_len, 0L, d_word_off, 2 * n, max_wpr, d_words);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(d_byte_off);
+    hipFree(d_start);
     hipFree(d_word_off);
     b.alloc[4] = b.alloc[5] = nullptr;
     b.d.words = d_words;
@@ -173,20 +184,37 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const std::ve
     return LHGT_OK;
 }
 
+// Copy a host range into the ASCII staging area at dev_off (pinned for the copy; the stream is drained before
+// returning so the pin and the caller's buffer may go away).
+int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes) {
+    if (!bytes) return LHGT_OK;
+    if (dev_off + bytes > ctx->ws_ascii_cap) LHGT_FAIL(LHGT_E_STATE, "ASCII staging overflow (%zu + %zu > %zu)", dev_off, bytes, ctx->ws_ascii_cap);
+    HostPin pin(src, bytes);
+    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + dev_off, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    return LHGT_OK;
+}
+
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
                  long n, const uint8_t* count_mate2) {
     if (n <= 0) return LHGT_OK;
     size_t bytes1 = off1[n] - off1[0], bytes2 = off2[n] - off2[0];
-    std::vector<uint64_t> byte_off(2 * n + 1);
+    std::vector<uint64_t> start(2 * n);
+    std::vector<uint16_t> lens(2 * n);
     for (long p = 0; p < n; p++) {
-        byte_off[p] = off1[p] - off1[0];
-        byte_off[n + p] = bytes1 + (off2[p] - off2[0]);
+        uint64_t l1 = off1[p + 1] - off1[p], l2 = off2[p + 1] - off2[p];
+        if (l1 > LHGT_MAX_READ_LEN || l2 > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read longer than %d bases", LHGT_MAX_READ_LEN);
+        start[p] = off1[p] - off1[0];
+        start[n + p] = bytes1 + (off2[p] - off2[0]);
+        lens[p] = (uint16_t)l1;
+        lens[n + p] = (uint16_t)l2;
     }
-    byte_off[2 * n] = bytes1 + bytes2;
     LHGT_TRY(ws_reserve(ctx, bytes1 + bytes2 + 32, 0));
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii, seq1 + off1[0], bytes1, hipMemcpyHostToDevice, ctx->stream));
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + bytes1, seq2 + off2[0], bytes2, hipMemcpyHostToDevice, ctx->stream));
-    return install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, byte_off, n, count_mate2);
+    // first-touch pageable H2D runs at ~5.6 GB/s on this platform, a registered range at ~57 GB/s, and
+    // registering costs ~25 ms/GiB (tools/h2d_rates.hip): stage_ascii pins each source range for its copy
+    LHGT_TRY(stage_ascii(ctx, 0, seq1 + off1[0], bytes1));
+    LHGT_TRY(stage_ascii(ctx, bytes1, seq2 + off2[0], bytes2));
+    return install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, start.data(), lens.data(), n, count_mate2);
 }
 
 // ---------------------------------------------------------------- index layout / install
@@ -238,9 +266,10 @@ int index_install(lhgt_ctx* ctx, const uint32_t* w, size_t n_words, bool /*words
         pos += step;
     }
     LHGT_TRY(index_layout(ctx, lens));
-    const size_t CH = 64u << 20;  // words per copy
+    const size_t CH = 256u << 20;  // words per copy (1 GiB); each piece is pinned for its copy when the runtime allows
     for (size_t o = 0; o < n_words; o += CH) {
         size_t n = n_words - o < CH ? n_words - o : CH;
+        HostPin pin(w + o, n * 4);
         LHGT_HIP(hipMemcpy(ctx->d_index + o, w + o, n * 4, hipMemcpyHostToDevice));
     }
     return LHGT_OK;

@@ -139,9 +139,10 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
         LHGT_HIP(hipGetLastError());
         if (host_seq1) LHGT_HIP(hipMemcpyAsync(host_seq1 + (size_t)o * read_len, d1, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (host_seq2) LHGT_HIP(hipMemcpyAsync(host_seq2 + (size_t)o * read_len, d2, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        std::vector<uint64_t> byte_off((size_t)2 * n + 1);
-        for (long r = 0; r <= 2 * n; r++) byte_off[r] = (uint64_t)r * read_len;
-        LHGT_TRY(install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, byte_off, n, nullptr));
+        std::vector<uint64_t> start((size_t)2 * n);
+        std::vector<uint16_t> lens((size_t)2 * n, (uint16_t)read_len);
+        for (long r = 0; r < 2 * n; r++) start[r] = (uint64_t)r * read_len;
+        LHGT_TRY(install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, start.data(), lens.data(), n, nullptr));
     }
     return LHGT_OK;
 }

@@ -143,6 +143,7 @@ int index_install(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, boo
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words);
 int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint32_t* d_out, uint8_t* d_valid);
-int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const std::vector<uint64_t>& byte_off, long n,
+int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
                             const uint8_t* count_mate2);
+int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes);
 }  // namespace lhgt

@@ -163,3 +163,68 @@ def test_extract_ref_argv_parsing():
     assert extract_ref.index_name("r.fa", 32, 3) == "r.fa.k32.h3.index.dat"
     a = extract_ref.parse_argv(["a", "b", "r", "o", "0.2", "0.05", "4", "24.0", "1e3", "4", "9", "0.5"])   # stod accepts these
     assert (a.k, a.max_peak, a.sample) == (24, 1000, 0.5)
+
+
+def _digest(lib, f1, f2, ratio=100.0, rnd=None, rank=0, world=1, block=64, threads=1, chunk=1 << 40):
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+    rp = rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None
+    rc = h.lhgt_fastq_parse_digest(f1.encode(), f2.encode(), float(ratio), rp, rank, world, block, threads, chunk,
+                                   C.byref(seen), C.byref(kept), C.byref(dig))
+    return rc, seen.value, kept.value, dig.value
+
+
+def test_parallel_fastq_parser_is_split_invariant(lib, oracle, case_inputs, tmp_path):
+    """any chunk size / thread count gives the same kept pairs, in the same order, with the same mate-2 flags"""
+    fa, f1, f2, _ = case_inputs("k24_fq2_longer")          # fq2 longer than fq1: exercises the Q4 flag
+    base = _digest(lib, f1, f2)
+    assert base[0] == 0 and base[1] == base[2] > 1000
+    for threads, chunk in ((1, 1000), (4, 1000), (8, 333), (3, 65536), (16, 150), (2, 40)):
+        assert _digest(lib, f1, f2, threads=threads, chunk=chunk) == base, (threads, chunk)
+    # sampling + sharding: the two shards partition the sampled set
+    oracle.srand(3)
+    rnd = oracle.sampling_array(50_000_000)
+    full = _digest(lib, f1, f2, ratio=40.0, rnd=rnd)
+    assert 0 < full[2] < base[2]
+    for threads, chunk in ((4, 777), (7, 4096)):
+        assert _digest(lib, f1, f2, ratio=40.0, rnd=rnd, threads=threads, chunk=chunk) == full
+        a = _digest(lib, f1, f2, ratio=40.0, rnd=rnd, rank=0, world=2, block=16, threads=threads, chunk=chunk)
+        b = _digest(lib, f1, f2, ratio=40.0, rnd=rnd, rank=1, world=2, block=16, threads=threads, chunk=chunk)
+        assert a[2] + b[2] == full[2] and a[2] > 0 and b[2] > 0
+    # no trailing newline, CRLF, truncated last record
+    raw1, raw2 = open(f1, "rb").read(), open(f2, "rb").read()
+    variants = {
+        "nonl": (raw1[:-1], raw2[:-1]),
+        "crlf": (raw1[:20000].replace(b"\n", b"\r\n"), raw2[:20800].replace(b"\n", b"\r\n")),
+    }
+    n_lines = raw1[:30000].count(b"\n")
+    cut1 = b"\n".join(raw1.split(b"\n")[: n_lines - n_lines % 4 + 2]) + b"\n"      # ends after a sequence line
+    cut2 = b"\n".join(raw2.split(b"\n")[: n_lines - n_lines % 4 + 2]) + b"\n"
+    variants["partial"] = (cut1, cut2)
+    for name, (a1, a2) in variants.items():
+        p1, p2 = str(tmp_path / f"{name}.1.fq"), str(tmp_path / f"{name}.2.fq")
+        open(p1, "wb").write(a1)
+        open(p2, "wb").write(a2)
+        if name == "crlf" and a1.count(b"\n") != a2.count(b"\n"):
+            n = min(a1.count(b"\n"), a2.count(b"\n"))
+            open(p1, "wb").write(b"\n".join(a1.split(b"\n")[:n]) + b"\n")
+            open(p2, "wb").write(b"\n".join(a2.split(b"\n")[:n]) + b"\n")
+        one = _digest(lib, p1, p2)
+        assert one[0] == 0, name
+        for threads, chunk in ((4, 500), (5, 97)):
+            assert _digest(lib, p1, p2, threads=threads, chunk=chunk) == one, (name, threads, chunk)
+    # unequal line counts are refused, whatever the split
+    p2s = str(tmp_path / "short.2.fq")
+    open(p2s, "wb").write(b"\n".join(raw2.split(b"\n")[:400]) + b"\n")
+    assert _digest(lib, f1, p2s, threads=4, chunk=1000)[0] == 4
+    assert _digest(lib, p2s, f2, threads=4, chunk=1000)[0] == 4
+
+
+def test_parser_counts_match_the_oracle_reader(lib, oracle, case_inputs):
+    """pairs seen == sequence lines the reference's getline loop would visit (oracle count with every read kept)"""
+    fa, f1, f2, _ = case_inputs("k24_seed7")
+    rc, seen, kept, _ = _digest(lib, f1, f2, threads=4, chunk=10000)
+    table = np.zeros(1 << 12, dtype=np.uint8)
+    cc = oracle.random_coder(12, 3)
+    assert rc == 0 and seen == kept == oracle.count(f1, 1 << 40, 12, 3, cc, 100.0, None, table)

@@ -29,6 +29,7 @@ def cpu_baseline(k, e, n_contigs, contig_len, n_pairs, seed_ref, seed_reads, eng
     import oracle_api
     from conftest import build_oracle
     orc = oracle_api.Oracle(build_oracle())
+    orc.set_pretouch(True)     # table page faults before the phase timers, like the reference's memsets (E:1416, 1458)
     cores = os.cpu_count() or 1
     with tempfile.TemporaryDirectory(prefix="lhgt_cpu_") as tmp:
         with eng_factory() as eng:

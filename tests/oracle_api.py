@@ -46,6 +46,9 @@ class Oracle:
                               C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(Report)]
 
     # ---- pieces
+    def set_pretouch(self, on: bool):
+        self.L.orc_set_pretouch(1 if on else 0)
+
     def srand(self, seed):
         self.L.orc_srand(C.c_uint(seed))
 

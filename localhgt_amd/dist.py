@@ -98,6 +98,7 @@ class Exchange:
         self.adapter.sync(eng)
         recv = torch.empty_like(table)
         dist.all_to_all_single(recv, table)              # recv[j*sl:(j+1)*sl] = rank j's copy of MY slice
+        self.adapter.sync(eng)                           # RCCL runs on torch's stream, the merge kernel on the engine's
         mine = self.rank * sl
         for j in range(w):
             if j != self.rank:

@@ -11,7 +11,7 @@
 __device__ __forceinline__ uint32_t mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
 }
-enum { LOAD = 0, OR_NORET = 1, OR_RET = 2, LOAD_CAS = 3, LOAD_U8 = 4, ADD_NORET = 5 };
+enum { LOAD = 0, OR_NORET = 1, OR_RET = 2, LOAD_CAS = 3, LOAD_U8 = 4, ADD_NORET = 5, STORE = 6, MAX_NORET = 7 };
 
 template <int MODE, int ILP>
 __global__ void __launch_bounds__(256) probe(uint32_t* __restrict__ table, uint64_t mask_words, int iters, uint32_t* sink, uint32_t salt) {
@@ -33,6 +33,12 @@ __global__ void __launch_bounds__(256) probe(uint32_t* __restrict__ table, uint6
         } else if (MODE == ADD_NORET) {
 #pragma unroll
             for (int u = 0; u < ILP; u++) atomicAdd(&table[h[u] & mask_words], 1u);
+        } else if (MODE == STORE) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) table[h[u] & mask_words] = h[u];
+        } else if (MODE == MAX_NORET) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) atomicMax(&table[h[u] & mask_words], h[u]);
         } else if (MODE == OR_RET) {
 #pragma unroll
             for (int u = 0; u < ILP; u++) acc += atomicOr(&table[h[u] & mask_words], 1u << (h[u] >> 27));
@@ -78,6 +84,14 @@ int main() {
     uint64_t max_bytes = 16ull << 30;
     uint32_t *table, *sink;
     CK(hipMalloc(&table, max_bytes)); CK(hipMalloc(&sink, 4));
+    if (getenv("STORES_ONLY")) {
+        for (uint64_t s : {1ull << 30, 16ull << 30}) {
+            run<STORE, 12>("store", table, s, sink);
+            run<MAX_NORET, 12>("max_noret", table, s, sink);
+            run<LOAD, 12>("load", table, s, sink);
+        }
+        return 0;
+    }
     uint64_t sizes[] = {4ull << 20, 32ull << 20, 128ull << 20, 512ull << 20, 1ull << 30, 4ull << 30, 16ull << 30};
     for (uint64_t s : sizes) {
         run<LOAD, 4>("load", table, s, sink);

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--contig-len", type=int, default=1_000_000)
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-e", type=int, default=3)
+    ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=150_000)
     args = ap.parse_args()
@@ -92,7 +93,11 @@ def main():
     eng.rng_seed(1)
     eng.coder_generate()
     t0 = time.time()
-    eng.synth_reference(1, args.contigs, args.contig_len)                       # index resident in HBM
+    shard_index = args.shard_index and world > 1
+    if shard_index:
+        eng.synth_reference_shard(1, args.contigs, args.contig_len, rank, world)  # this rank's contig range only
+    else:
+        eng.synth_reference(1, args.contigs, args.contig_len)                   # whole index resident in HBM
     eng.synth_pairs(1, 2, args.contigs, args.contig_len, rank * args.pairs, args.pairs, L)   # this rank's shard, packed, resident
     eng.synchronize()
     setup_s = time.time() - t0
@@ -103,7 +108,10 @@ def main():
         eng.count_kmers()
         if dist:
             dist.merge_counts(eng)
-        n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
+        if shard_index:
+            n_peaks = dist.sharded_scan(eng, 0.1, 0.08, 300_000_000)
+        else:
+            n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
         eng.vote()
         if dist:
             dist.sum_votes(eng)
@@ -164,7 +172,7 @@ def main():
             "config": {"workload": f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
                                    f"index resident), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
                        "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
-                       "parallelism": f"reads sharded x{world}"},
+                       "parallelism": f"reads sharded x{world}" + (", index sharded" if shard_index else ", phase B replicated" if world > 1 else "")},
             "phase_ms": {"count_A": round(ms[0] / args.steps, 3), "scan_B": round(ms[1] / args.steps, 3), "vote_C": round(ms[2] / args.steps, 3)},
             "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
             "roofline": {"bound": "hbm", "kernel": "vote_kernel (phase C read re-scan: 714 probes/pair into peak_kmer; the dominant kernel)",

@@ -61,6 +61,9 @@ int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* 
 int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_path, const char* genome_len_path,
                      long* n_contigs, long* n_bases);
 int lhgt_index_load(lhgt_ctx* ctx, const char* index_path, long* n_contigs, long* n_bases);
+/* only shard `rank` of `world` becomes resident: contiguous contig groups of about equal index bytes (the role of
+ * split_ref, E:1280-1330); contig numbers stay global.  For the reference-sharded phase B below. */
+int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank, int shard_world, long* n_contigs, long* n_bases);
 /* resident index straight from sequences already in host memory (bench / tests): contig c is
  * ascii[off[c] .. off[c+1]) */
 int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* off, long n_contigs);
@@ -103,6 +106,15 @@ int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes); /* u32 vot
  * add_peak/merge_peak E:239-301).  hit_ratio/match_ratio are the float32 values of E:1368-1369. */
 int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks);
 
+/* ---- B, reference-sharded (an index larger than one GPU): each rank scans its contig shard,
+ * ranks exchange new-peak counts (id_base = peaks of all lower ranks, contig order = rank order), then all-gather
+ * the peak loci and the (hash, id) registrations that lhgt_peaks_install replays into every rank's peak_kmer. */
+int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long* n_new_local, long* n_selected_local);
+int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** dev_loci /* int32[2*n_new_local] */,
+                       void** dev_regs /* uint32[2*n_regs]: hash, id */, long* n_regs);
+int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total, long max_peak, const void* dev_loci_all,
+                       const void* dev_regs_all, long n_regs_all);
+
 /* ---- C: read re-scan + split-read vote (slide_reads E:313-506, Split_reads E:91-202) */
 int lhgt_vote(lhgt_ctx* ctx);
 
@@ -119,6 +131,8 @@ int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, 
 /* ---- synthetic workload generated on the device (bench.py / tests; no reference counterpart).
  * Bases are a pure function of (seed, contig, position); see localhgt_amd/csrc/k_synth.hip. */
 int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, uint8_t* host_ascii_or_null);
+int lhgt_synth_reference_shard(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, int shard_rank, int shard_world,
+                               uint8_t* host_ascii_or_null);
 int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
                      long first_pair, long n_pairs, int read_len, uint8_t* host_seq1_or_null, uint8_t* host_seq2_or_null);
 

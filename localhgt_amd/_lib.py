@@ -37,6 +37,7 @@ SIGNATURES = {
     "lhgt_hash_sequence": [_vp, _cs, _l, _u32p, _u8p],
     "lhgt_index_build": [_vp, _cs, _cs, _cs, _lp, _lp],
     "lhgt_index_load": [_vp, _cs, _lp, _lp],
+    "lhgt_index_load_shard": [_vp, _cs, _i, _i, _lp, _lp],
     "lhgt_index_from_memory": [_vp, _u8p, _u64p, _l],
     "lhgt_fastq_sam_ratio": [_cs, _d, _dp, _lp],
     "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
@@ -51,6 +52,9 @@ SIGNATURES = {
     "lhgt_counts_merge": [_vp, _vp, C.c_size_t, C.c_size_t],
     "lhgt_filter_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "lhgt_ref_scan": [_vp, _f, _f, _l, _lp],
+    "lhgt_ref_scan_local": [_vp, _f, _f, _lp, _lp],
+    "lhgt_ref_scan_emit": [_vp, _l, C.POINTER(_vp), C.POINTER(_vp), _lp],
+    "lhgt_peaks_install": [_vp, _l, _l, _l, _vp, _vp, _l],
     "lhgt_vote": [_vp],
     "lhgt_write_intervals": [_vp, _cs, _lp],
     "lhgt_counts_export_u8": [_vp, C.c_uint64, C.c_uint64, _u8p],
@@ -59,6 +63,7 @@ SIGNATURES = {
     "lhgt_peaks_export": [_vp, _i32p, _u8p, _l],
     "lhgt_peak_kmer_export": [_vp, C.c_uint64, C.c_uint64, _u32p],
     "lhgt_synth_reference": [_vp, C.c_uint64, _l, _l, _u8p],
+    "lhgt_synth_reference_shard": [_vp, C.c_uint64, _l, _l, _i, _i, _u8p],
     "lhgt_synth_pairs": [_vp, C.c_uint64, C.c_uint64, _l, _l, _l, _l, _i, _u8p, _u8p],
     "lhgt_set_debug": [_vp, _i],
     "lhgt_phase_ms": [_vp, _i, _fp],

@@ -419,6 +419,10 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
 }
 
 int lhgt_index_load(lhgt_ctx* ctx, const char* index_path, long* n_contigs, long* n_bases) {
+    return lhgt_index_load_shard(ctx, index_path, 0, 1, n_contigs, n_bases);
+}
+
+int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank, int shard_world, long* n_contigs, long* n_bases) {
     if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
     if (!ctx || !index_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     Mapped m;
@@ -428,7 +432,8 @@ int lhgt_index_load(lhgt_ctx* ctx, const char* index_path, long* n_contigs, long
     int16_t cc[LHGT_CODER_SLOTS];
     for (int i = 0; i < LHGT_CODER_SLOTS; i++) cc[i] = (int16_t)w[i];  // saved_random_coder: low half of each word
     LHGT_TRY(lhgt_coder_set(ctx, cc));
-    LHGT_TRY(index_install(ctx, w + LHGT_CODER_SLOTS, m.n / 4 - LHGT_CODER_SLOTS, false));
+    if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d", shard_rank, shard_world);
+    LHGT_TRY(index_install_shard(ctx, w + LHGT_CODER_SLOTS, m.n / 4 - LHGT_CODER_SLOTS, shard_rank, shard_world));
     if (n_contigs) *n_contigs = (long)ctx->contigs.size();
     if (n_bases) *n_bases = (long)ctx->n_pos;
     return LHGT_OK;

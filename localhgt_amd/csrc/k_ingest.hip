@@ -218,7 +218,7 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
 }
 
 // ---------------------------------------------------------------- index layout / install
-int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens) {
+int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index) {
     const int k = ctx->k, e = ctx->e;
     for (void* p : {(void*)ctx->d_index, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_tile_count})
         if (p) hipFree(p);
@@ -226,7 +226,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens) {
     ctx->contigs.clear();
     std::vector<TileDev> tiles;
     uint64_t word = 0, flat = 0;
-    uint32_t ref_index = 1;
+    uint32_t ref_index = first_ref_index;   // contig numbers stay the global ones when only a shard is resident
     for (uint32_t len : lens) {
         if ((long)len <= k) LHGT_FAIL(LHGT_E_FORMAT, "contig of length %u <= k in the index", len);
         ContigDev c;
@@ -254,18 +254,39 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens) {
 }
 
 int index_install(lhgt_ctx* ctx, const uint32_t* w, size_t n_words, bool /*words_on_device*/) {
+    return index_install_shard(ctx, w, n_words, 0, 1);
+}
+
+// Keep only shard `rank` of `world`: contiguous contig groups of about equal index bytes (the role of
+// split_ref, E:1280-1330, but balanced exactly).  Contig numbers (ref_index) remain global.
+int index_install_shard(lhgt_ctx* ctx, const uint32_t* w_all, size_t n_words_all, int rank, int world) {
     const int k = ctx->k, e = ctx->e;
-    std::vector<uint32_t> lens;
+    std::vector<uint32_t> lens_all;
+    std::vector<size_t> starts;
     size_t pos = 0;
-    while (pos < n_words) {
-        uint32_t len = w[pos];
+    while (pos < n_words_all) {
+        uint32_t len = w_all[pos];
         if ((long)len <= k) LHGT_FAIL(LHGT_E_FORMAT, "index: contig length %u <= k at word %zu", len, pos);
         size_t step = 1 + (size_t)(len - k + 1) * e;
-        if (pos + step > n_words) LHGT_FAIL(LHGT_E_FORMAT, "index: truncated contig record at word %zu", pos);
-        lens.push_back(len);
+        if (pos + step > n_words_all) LHGT_FAIL(LHGT_E_FORMAT, "index: truncated contig record at word %zu", pos);
+        lens_all.push_back(len);
+        starts.push_back(pos);
         pos += step;
     }
-    LHGT_TRY(index_layout(ctx, lens));
+    starts.push_back(pos);
+    const size_t nc = lens_all.size();
+    size_t c0 = 0, c1 = nc;
+    if (world > 1) {   // contig c belongs to the shard its first word falls in
+        auto shard_of = [&](size_t c) { return (size_t)(((__uint128_t)starts[c] * world) / (n_words_all ? n_words_all : 1)); };
+        c0 = 0;
+        while (c0 < nc && shard_of(c0) < (size_t)rank) c0++;
+        c1 = c0;
+        while (c1 < nc && shard_of(c1) == (size_t)rank) c1++;
+    }
+    std::vector<uint32_t> lens(lens_all.begin() + c0, lens_all.begin() + c1);
+    const uint32_t* w = w_all + starts[c0];
+    const size_t n_words = starts[c1] - starts[c0];
+    LHGT_TRY(index_layout(ctx, lens, (uint32_t)c0 + 1));
     const size_t CH = 256u << 20;  // words per copy (1 GiB); each piece is pinned for its copy when the runtime allows
     for (size_t o = 0; o < n_words; o += CH) {
         size_t n = n_words - o < CH ? n_words - o : CH;

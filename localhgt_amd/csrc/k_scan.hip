@@ -288,24 +288,84 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
     }
 }
 
+// ---- B5 for a reference shard: the same walk as register_peaks, but the results leave as records for the
+// exchange instead of touching peak_kmer: loci of this shard's new peaks (their ids are id_base + local id), and
+// one (hash, id) registration per peak position and hash with count > 0.  Order of registrations is irrelevant
+// (they are replayed with atomicMax).
+__global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                 const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                 const uint8_t* __restrict__ flags, const uint32_t* __restrict__ tile_base,
+                                                 int k, int e, uint32_t id_base, int32_t* __restrict__ loci_out,
+                                                 uint32_t* __restrict__ regs_out, unsigned long long* __restrict__ n_regs) {
+    __shared__ int incl[TILE], part[BT];
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long len = c.len, nk = len - k + 1;
+    const uint8_t* F = flags + c.flat_base;
+    const uint32_t base = tile_base[blockIdx.x];
+    if (tile_base[blockIdx.x + 1] == base) return;
+    constexpr int CH = (TILE + BT - 1) / BT;
+    const int b = threadIdx.x * CH, en = b + CH < TILE ? b + CH : TILE;
+    int s = 0;
+    for (int jj = b; jj < en; jj++) {
+        long j = (long)t.j0 + jj;
+        s += (j < len) ? (F[j] >> 6) & 1 : 0;
+        incl[jj] = s;
+    }
+    int off = block_excl_sum(s, part);
+    for (int jj = b; jj < en; jj++) incl[jj] += off;
+    __syncthreads();
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= len) break;
+        uint8_t f = F[j];
+        if (!((f >> 5) & 1)) continue;
+        uint32_t lid = base + (uint32_t)incl[jj] - 1u;
+        if ((f >> 6) & 1) {
+            loci_out[2 * (long)lid] = (int32_t)c.ref_index;
+            loci_out[2 * (long)lid + 1] = (int32_t)j;
+        }
+        if (j < nk) {
+            const uint32_t* hp = index + c.hash_word + j * e;
+            for (int i = 0; i < e; i++) {
+                uint32_t h = hp[i];
+                if (h != 0 && count_of(counts, h) > 0) {
+                    unsigned long long slot = atomicAdd(n_regs, 1ull);
+                    regs_out[2 * slot] = h;
+                    regs_out[2 * slot + 1] = id_base + lid;
+                }
+            }
+        }
+    }
+}
+
+// replay of gathered registrations on every rank
+__global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ regs, long n, uint32_t* __restrict__ peak_kmer,
+                                                   uint32_t* __restrict__ prefilter /* nullable */) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t h = regs[2 * i], id = regs[2 * i + 1];
+        atomicMax(&peak_kmer[h], id);
+        if (prefilter) {
+            const uint32_t fb = h & ((1u << PF_BITS) - 1u);
+            atomicOr(&prefilter[fb >> 5], 1u << (fb & 31u));
+        }
+    }
+}
+
 }  // namespace lhgt
 
 using namespace lhgt;
 
-extern "C" {
-
-int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
-    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
-    if (!ctx->d_index || ctx->n_tiles == 0) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load first");
-    if (max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "max_peak must be positive");
+// B1-B4 on the resident contigs: flags, and tile_count turned into exclusive local ids.
+static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_t* total_new, unsigned long long* n_selected) {
     const int k = ctx->k, e = ctx->e;
+    *total_new = 0;
+    *n_selected = 0;
+    if (ctx->n_tiles == 0) return LHGT_OK;
     int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
     int three_min = (int)(WINDOW * match_ratio);
-    size_t slots = (size_t)1 << k;
-    if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
-    LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    LHGT_HIP(hipMemsetAsync(ctx->d_peak_kmer, 0, slots * 4, ctx->stream));  // E:1458
     dim3 grid((unsigned)ctx->n_tiles), blk(BT);
     hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags);
     hipLaunchKernelGGL(window_peak, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, one_min, three_min, ctx->d_flags);
@@ -314,19 +374,27 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     hipLaunchKernelGGL(interval_mask, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_flags, ctx->d_tile_count, d_nsel);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
-    uint32_t total = 0;
-    LHGT_HIP(hipMemcpyAsync(&total, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
-    LHGT_HIP(hipMemcpyAsync(&ctx->n_selected, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(total_new, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(n_selected, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    return LHGT_OK;
+}
+
+// peak tables sized for `total` peaks; peak_kmer cleared; prefilter decided from the global selected count
+static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_selected, long max_peak) {
+    const size_t slots = (size_t)1 << ctx->k;
+    ctx->n_peaks = -1;
+    ctx->n_selected = n_selected;
+    if ((long)total > max_peak)
+        LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
+    if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
+    LHGT_HIP(hipMemsetAsync(ctx->d_peak_kmer, 0, slots * 4, ctx->stream));  // E:1458
     // vote prefilter (k_vote.hip): worth it while at most ~1/8 of its 2^PF_BITS bits would be set
-    ctx->prefilter_on = ctx->k > PF_BITS && !(ctx->debug & 4) && ctx->n_selected * (unsigned long long)e <= (1ull << PF_BITS) / 8;
+    ctx->prefilter_on = ctx->k > PF_BITS && !(ctx->debug & 4) && n_selected * (unsigned long long)ctx->e <= (1ull << PF_BITS) / 8;
     if (ctx->prefilter_on) {
         if (!ctx->d_prefilter) LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
         LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, (size_t)(1u << PF_BITS) / 8, ctx->stream));
     }
-    ctx->n_peaks = -1;
-    if ((long)total > max_peak)
-        LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     if ((long)total + 1 > ctx->peaks_cap) {     // grow-only: no allocator traffic in steady state
         if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
         if (ctx->d_filter) { hipFree(ctx->d_filter); ctx->d_filter = nullptr; }
@@ -336,8 +404,25 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     }
     LHGT_HIP(hipMemsetAsync(ctx->d_filter, 0, ((size_t)total + 1) * 4, ctx->stream));  // E:1457
     LHGT_HIP(hipMemsetAsync(ctx->d_loci, 0, ((size_t)total + 1) * 8, ctx->stream));
-    hipLaunchKernelGGL(register_peaks, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts,
-                       ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr);
+    return LHGT_OK;
+}
+
+extern "C" {
+
+int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (!ctx->d_index || ctx->n_tiles == 0) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load first");
+    if (max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "max_peak must be positive");
+    const int k = ctx->k, e = ctx->e;
+    LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    uint32_t total = 0;
+    unsigned long long n_sel = 0;
+    LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));
+    LHGT_TRY(peaks_prepare(ctx, total, n_sel, max_peak));
+    hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
+                       ctx->d_counts, ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -346,6 +431,94 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     ctx->max_peak = max_peak;
     ctx->voted = false;
     if (n_peaks) *n_peaks = total;
+    return LHGT_OK;
+}
+
+// ---- reference-sharded phase B (BASELINE config #5: index larger than one GPU).
+// Every rank holds a contiguous contig range (lhgt_index_load_shard) and the complete count table.
+//   1. lhgt_ref_scan_local: B1-B4 on the local contigs -> #new peaks, #selected positions
+//   2. ranks exchange the counts; id_base = new peaks of all lower ranks (contig order = rank order)
+//   3. lhgt_ref_scan_emit: loci of the local new peaks and (hash, id) registrations as device records
+//   4. ranks all-gather both record sets; lhgt_peaks_install replays them into the local peak_kmer
+// after which lhgt_vote runs unchanged on this rank's read shard.
+int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long* n_new_local, long* n_selected_local) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !n_new_local || !n_selected_local) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    uint32_t total = 0;
+    unsigned long long n_sel = 0;
+    LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));
+    LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    LHGT_HIP(hipEventSynchronize(ctx->ev1));
+    LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[1], ctx->ev0, ctx->ev1));
+    ctx->local_new = total;
+    ctx->n_selected = n_sel;
+    ctx->n_peaks = -1;
+    *n_new_local = total;
+    *n_selected_local = (long)n_sel;
+    return LHGT_OK;
+}
+
+int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs, long* n_regs) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || !d_loci || !d_regs || !n_regs) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (ctx->local_new < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan_local must precede lhgt_ref_scan_emit");
+    if (id_base < 0 || id_base + ctx->local_new > 0xffffffffL) LHGT_FAIL(LHGT_E_ARG, "peak ids overflow 32 bits");
+    const long need_loci = ctx->local_new + 1, need_regs = (long)ctx->n_selected * ctx->e + 1;
+    if (need_loci > ctx->emit_loci_cap) {
+        if (ctx->d_emit_loci) hipFree(ctx->d_emit_loci);
+        ctx->d_emit_loci = nullptr;
+        ctx->emit_loci_cap = need_loci + need_loci / 8;
+        LHGT_HIP(hipMalloc(&ctx->d_emit_loci, (size_t)ctx->emit_loci_cap * 8));
+    }
+    if (need_regs > ctx->emit_regs_cap) {
+        if (ctx->d_emit_regs) hipFree(ctx->d_emit_regs);
+        ctx->d_emit_regs = nullptr;
+        ctx->emit_regs_cap = need_regs + need_regs / 8;
+        LHGT_HIP(hipMalloc(&ctx->d_emit_regs, (size_t)ctx->emit_regs_cap * 8 + 8));
+    }
+    unsigned long long* d_cnt = (unsigned long long*)(ctx->d_emit_regs + (size_t)ctx->emit_regs_cap * 2);
+    LHGT_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    unsigned long long cnt = 0;
+    if (ctx->n_tiles > 0 && ctx->local_new > 0) {
+        hipLaunchKernelGGL(emit_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
+                           ctx->d_counts, ctx->d_flags, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
+                           ctx->d_emit_regs, d_cnt);
+        LHGT_HIP(hipGetLastError());
+        LHGT_HIP(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    *d_loci = ctx->d_emit_loci;
+    *d_regs = ctx->d_emit_regs;
+    *n_regs = (long)cnt;
+    return LHGT_OK;
+}
+
+int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total, long max_peak, const void* d_loci_all,
+                       const void* d_regs_all, long n_regs_all) {
+    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    if (!ctx || n_peaks_total < 0 || n_regs_all < 0 || max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if ((n_peaks_total && !d_loci_all) || (n_regs_all && !d_regs_all)) LHGT_FAIL(LHGT_E_ARG, "null record buffer");
+    if (n_peaks_total > 0xffffffffL) LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "more than 2^32 peaks");
+    LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    LHGT_TRY(peaks_prepare(ctx, (uint32_t)n_peaks_total, (unsigned long long)n_selected_total, max_peak));
+    if (n_peaks_total)
+        LHGT_HIP(hipMemcpyAsync(ctx->d_loci, d_loci_all, (size_t)n_peaks_total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n_regs_all) {
+        long blocks = (n_regs_all + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(replay_regs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_regs_all, n_regs_all,
+                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr);
+        LHGT_HIP(hipGetLastError());
+    }
+    LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    LHGT_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    LHGT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->phase_ms[1] += ms;
+    ctx->n_peaks = n_peaks_total;
+    ctx->max_peak = max_peak;
+    ctx->voted = false;
     return LHGT_OK;
 }
 

@@ -102,19 +102,27 @@ extern "C" {
 // Build the resident index of a synthetic reference of n_contigs x contig_len bases.
 // host_ascii (optional, n_contigs*contig_len bytes) receives the bases for writing a FASTA.
 int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, uint8_t* host_ascii) {
+    return lhgt_synth_reference_shard(ctx, ref_seed, n_contigs, contig_len, 0, 1, host_ascii);
+}
+
+// Same reference, but only contigs [rank*n/world, (rank+1)*n/world) become resident (reference-sharded phase B).
+int lhgt_synth_reference_shard(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, int shard_rank, int shard_world,
+                               uint8_t* host_ascii) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d", shard_rank, shard_world);
     if (ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
     if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32)) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
     SynthSpec s = make_spec(ref_seed, 0, n_contigs, contig_len, 150);
-    std::vector<uint32_t> lens((size_t)n_contigs, (uint32_t)contig_len);
-    LHGT_TRY(index_layout(ctx, lens));
+    const long c0 = n_contigs * shard_rank / shard_world, c1 = n_contigs * (shard_rank + 1) / shard_world;
+    std::vector<uint32_t> lens((size_t)(c1 - c0), (uint32_t)contig_len);
+    LHGT_TRY(index_layout(ctx, lens, (uint32_t)c0 + 1));
     LHGT_TRY(ws_reserve(ctx, (size_t)contig_len + 32, 0));
-    for (long c = 0; c < n_contigs; c++) {
-        const ContigDev& cd = ctx->contigs[c];
+    for (long c = c0; c < c1; c++) {
+        const ContigDev& cd = ctx->contigs[c - c0];
         hipLaunchKernelGGL(synth_contig_ascii, dim3((unsigned)((contig_len + 255) / 256)), dim3(256), 0, ctx->stream, s, (uint32_t)c, ctx->d_ws_ascii);
-        if (host_ascii) LHGT_HIP(hipMemcpyAsync(host_ascii + (size_t)c * contig_len, ctx->d_ws_ascii, (size_t)contig_len, hipMemcpyDeviceToHost, ctx->stream));
-        LHGT_HIP(hipMemcpyAsync(ctx->d_index + cd.hash_word - 1, &lens[c], 4, hipMemcpyHostToDevice, ctx->stream));
+        if (host_ascii) LHGT_HIP(hipMemcpyAsync(host_ascii + (size_t)(c - c0) * contig_len, ctx->d_ws_ascii, (size_t)contig_len, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipMemcpyAsync(ctx->d_index + cd.hash_word - 1, &lens[c - c0], 4, hipMemcpyHostToDevice, ctx->stream));
         LHGT_TRY(hash_contig_dev_ascii(ctx, ctx->d_ws_ascii, contig_len, ctx->d_index + cd.hash_word, nullptr));
     }
     return LHGT_OK;

@@ -113,6 +113,11 @@ struct lhgt_ctx {
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
     bool prefilter_on = false;
     unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan
+    // reference-sharded scan (k_scan.hip): this rank's new peaks / registrations as records for the exchange
+    int32_t* d_emit_loci = nullptr;
+    uint32_t* d_emit_regs = nullptr;
+    long emit_loci_cap = 0, emit_regs_cap = 0;
+    long local_new = -1;       // new peaks found by the last lhgt_ref_scan_local
     long peaks_cap = 0;        // entries allocated in d_loci / d_filter (grow-only)
     void* d_voted = nullptr;   // phase D: compacted (id, contig, pos) of voted peaks + counter
     long voted_cap = 0;
@@ -138,8 +143,9 @@ int build_hash_params(const int16_t* cc, int k, int e, HashParams* hp);
 int rng_next(lhgt_ctx* ctx);  // one rand() draw from the private glibc stream
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
                  long n_pairs, const uint8_t* count_mate2);
-int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens);  // allocates d_index, tiles, flags
+int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index = 1);  // allocates d_index, tiles, flags
 int index_install(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, bool words_on_device);
+int index_install_shard(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, int rank, int world);
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words);
 int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint32_t* d_out, uint8_t* d_valid);

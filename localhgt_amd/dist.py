@@ -10,8 +10,10 @@ objects need reducing:
   table -- all_to_all of 1/world slices, local saturating merge (HIP kernel), all_gather -- which
   moves 2*(world-1)/world of the packed bytes per GPU instead of 4x that for a u8 all-reduce;
 * the per-peak vote counters after phase C: plain SUM all-reduce of u32 (clamped to 254 on export).
-Phase B runs replicated on every rank (identical inputs -> identical peak ids), so there is no
-peak exchange."""
+Phase B has two forms: replicated on every rank (identical inputs -> identical peak ids, no exchange;
+the default while the index fits one GPU), or reference-sharded (`sharded_scan`): each rank scans a contiguous
+contig range, new-peak counts are all-gathered to give every rank its id base (contig order = rank order, so ids
+equal the sequential ones), and peak loci + (hash, id) registrations are all-gathered and replayed everywhere."""
 from __future__ import annotations
 
 import os
@@ -45,6 +47,20 @@ class GpuAdapter:
     def filter_tensor(self, eng) -> Optional[torch.Tensor]:
         p, n = eng.filter_buffer()
         return device_tensor(p, n, eng.device).view(torch.int32) if n else None
+
+    # reference-sharded phase B
+    def scan_local(self, eng, hit_ratio, match_ratio):
+        return eng.ref_scan_local(hit_ratio, match_ratio)
+
+    def scan_emit(self, eng, id_base, n_new):
+        pl, pr, n_regs = eng.ref_scan_emit(id_base)
+        loci = device_tensor(pl, 8 * n_new, eng.device).view(torch.int32) if n_new else torch.empty(0, dtype=torch.int32, device=f"cuda:{eng.device}")
+        regs = device_tensor(pr, 8 * n_regs, eng.device).view(torch.int32) if n_regs else torch.empty(0, dtype=torch.int32, device=f"cuda:{eng.device}")
+        return loci, regs
+
+    def peaks_install(self, eng, n_total, n_sel_total, max_peak, loci_all, regs_all):
+        eng.peaks_install(n_total, n_sel_total, max_peak, loci_all.data_ptr() if loci_all.numel() else 0,
+                          regs_all.data_ptr() if regs_all.numel() else 0, regs_all.numel() // 2)
 
     def sync(self, eng):
         eng.synchronize()
@@ -107,6 +123,40 @@ class Exchange:
         del recv
         dist.all_gather_into_tensor(table, table[mine:mine + sl].clone())
         self.adapter.sync(eng)
+
+    # ---- phase B, reference-sharded
+    def all_gather_var(self, t: torch.Tensor) -> torch.Tensor:
+        """concatenation over ranks (in rank order) of 1-D tensors of different lengths"""
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        m = max(sizes)
+        if m == 0:
+            return t
+        padded = torch.zeros(m, dtype=t.dtype, device=t.device)
+        padded[:t.numel()] = t
+        out = torch.empty(m * self.world, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, padded)
+        return torch.cat([out[r * m:r * m + sizes[r]] for r in range(self.world)])
+
+    def sharded_scan(self, eng, hit_ratio: float, match_ratio: float, max_peak: int) -> int:
+        """phase B when every rank holds only its contig shard of the index; returns the global raw peak count"""
+        n_new, n_sel = self.adapter.scan_local(eng, hit_ratio, match_ratio)
+        mine = torch.tensor([n_new, n_sel], dtype=torch.int64, device=self._dev())
+        allc = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine)
+        news = [int(c[0].item()) for c in allc]
+        id_base = sum(news[:self.rank])
+        n_total, n_sel_total = sum(news), sum(int(c[1].item()) for c in allc)
+        loci, regs = self.adapter.scan_emit(eng, id_base, n_new)
+        self.adapter.sync(eng)
+        loci_all = self.all_gather_var(loci)
+        regs_all = self.all_gather_var(regs)
+        self.adapter.sync(eng)
+        self.adapter.peaks_install(eng, n_total, n_sel_total, max_peak, loci_all, regs_all)
+        self.adapter.sync(eng)
+        return n_total
 
     # ---- phase C
     def sum_votes(self, eng):

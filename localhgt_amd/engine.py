@@ -86,6 +86,11 @@ class Engine:
         _lib.check(self.lib.lhgt_index_load(self.h, index_path.encode(), C.byref(nc), C.byref(nb)))
         return nc.value, nb.value
 
+    def index_load_shard(self, index_path: str, rank: int, world: int) -> Tuple[int, int]:
+        nc, nb = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_index_load_shard(self.h, index_path.encode(), rank, world, C.byref(nc), C.byref(nb)))
+        return nc.value, nb.value
+
     def index_from_memory(self, ascii_bases: np.ndarray, offsets: np.ndarray):
         a = np.ascontiguousarray(ascii_bases, dtype=np.uint8)
         o = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -131,6 +136,9 @@ class Engine:
                                                  None if host is None else _ptr(host, C.c_uint8)))
         return host
 
+    def synth_reference_shard(self, ref_seed: int, n_contigs: int, contig_len: int, rank: int, world: int):
+        _lib.check(self.lib.lhgt_synth_reference_shard(self.h, ref_seed, n_contigs, contig_len, rank, world, None))
+
     def synth_pairs(self, ref_seed: int, reads_seed: int, n_contigs: int, contig_len: int, first_pair: int,
                     n_pairs: int, read_len: int = 150, want_host: bool = False):
         h1 = np.zeros(n_pairs * read_len, dtype=np.uint8) if want_host else None
@@ -155,6 +163,23 @@ class Engine:
         _lib.check(self.lib.lhgt_ref_scan(self.h, C.c_float(np.float32(hit_ratio)), C.c_float(np.float32(match_ratio)),
                                           int(max_peak), C.byref(n)))
         return n.value
+
+    # ---- reference-sharded phase B
+    def ref_scan_local(self, hit_ratio: float, match_ratio: float) -> Tuple[int, int]:
+        n, s = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_ref_scan_local(self.h, C.c_float(np.float32(hit_ratio)), C.c_float(np.float32(match_ratio)),
+                                                C.byref(n), C.byref(s)))
+        return n.value, s.value
+
+    def ref_scan_emit(self, id_base: int) -> Tuple[int, int, int]:
+        """(device ptr of int32 loci[2*n_new_local], device ptr of uint32 regs[2*n_regs], n_regs)"""
+        pl, pr, n = C.c_void_p(), C.c_void_p(), C.c_long(0)
+        _lib.check(self.lib.lhgt_ref_scan_emit(self.h, id_base, C.byref(pl), C.byref(pr), C.byref(n)))
+        return pl.value or 0, pr.value or 0, n.value
+
+    def peaks_install(self, n_peaks_total: int, n_selected_total: int, max_peak: int, loci_ptr: int, regs_ptr: int, n_regs: int):
+        _lib.check(self.lib.lhgt_peaks_install(self.h, n_peaks_total, n_selected_total, int(max_peak), C.c_void_p(loci_ptr),
+                                               C.c_void_p(regs_ptr), n_regs))
 
     def vote(self):
         _lib.check(self.lib.lhgt_vote(self.h))

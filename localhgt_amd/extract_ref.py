@@ -73,7 +73,16 @@ def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
             eng.index_build(a.fasta, idx, a.fasta + ".genome.len.txt")
         if dist:
             dist.barrier()
-    n_contigs, n_bases = eng.index_load(idx)                   # E:1417 (+ resident copy of the hashes)
+    # Phase B form: replicated index (default) or reference-sharded (LHGT_SHARD_INDEX=1, or =auto when the index
+    # does not fit next to the other tables of one GPU): see localhgt_amd/dist.py
+    shard_index = False
+    if dist:
+        mode = os.environ.get("LHGT_SHARD_INDEX", "auto")
+        shard_index = mode == "1" or (mode == "auto" and os.path.getsize(idx) > 180e9)
+    if shard_index:
+        n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
+    else:
+        n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
     eng.sampling_init(ratio)                                   # E:1422
     seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
     t1 = time.time()
@@ -82,7 +91,10 @@ def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
         dist.merge_counts(eng)
     t2 = time.time()
     log(f"K-mer counting is finished. It costs {t2 - t0:.2f} seconds.")
-    n_peaks = eng.ref_scan(a.hit_ratio, a.match_ratio, a.max_peak)  # phase B, E:1468-1489
+    if shard_index:                                            # phase B, E:1468-1489
+        n_peaks = dist.sharded_scan(eng, a.hit_ratio, a.match_ratio, a.max_peak)
+    else:
+        n_peaks = eng.ref_scan(a.hit_ratio, a.match_ratio, a.max_peak)
     t3 = time.time()
     log(f"Slided ref len: {n_bases} bp\tNo. of raw BKPs: {n_peaks}")
     eng.vote()                                                 # phase C, E:1496-1507

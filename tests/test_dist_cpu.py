@@ -42,6 +42,19 @@ class NumpyAdapter:
     def sync(self, eng):
         pass
 
+    # reference-sharded phase B: a fake rank "finds" eng.n_new peaks and 2 registrations per peak
+    def scan_local(self, eng, hit_ratio, match_ratio):
+        return eng.n_new, 3 * eng.n_new
+
+    def scan_emit(self, eng, id_base, n_new):
+        ids = torch.arange(id_base, id_base + n_new, dtype=torch.int32)
+        loci = torch.stack([torch.full((n_new,), eng.rank + 1, dtype=torch.int32), ids * 10], dim=1).reshape(-1)
+        regs = torch.stack([ids * 7 + 1, ids, ids * 7 + 2, ids], dim=1).reshape(-1).to(torch.int32)
+        return loci, regs
+
+    def peaks_install(self, eng, n_total, n_sel_total, max_peak, loci_all, regs_all):
+        eng.installed = (n_total, n_sel_total, loci_all.clone(), regs_all.clone())
+
 
 def _worker(rank, world, port, n_bytes, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -54,6 +67,21 @@ def _worker(rank, world, port, n_bytes, tmp):
     assert ex.broadcast_flag(rank == 0) is True
     ex.merge_counts(eng)
     ex.sum_votes(eng)
+    # variable-length all-gather, including an empty contribution
+    got = ex.all_gather_var(torch.arange(5 if rank == 0 else 0, dtype=torch.int32) + 100 * rank)
+    assert got.tolist() == [0, 1, 2, 3, 4]
+    got = ex.all_gather_var(torch.arange(2 + 3 * rank, dtype=torch.int32) + 100 * rank)
+    assert got.tolist() == [0, 1, 100, 101, 102, 103, 104]
+    # sharded scan: rank 0 finds 4 peaks, rank 1 finds 0 (empty shard) or 3
+    for n1 in (0, 3):
+        eng.rank, eng.n_new = rank, (4 if rank == 0 else n1)
+        assert ex.sharded_scan(eng, 0.1, 0.08, 1000) == 4 + n1
+        n_total, n_sel, loci, regs = eng.installed
+        assert (n_total, n_sel) == (4 + n1, 3 * (4 + n1))
+        ids = list(range(4 + n1))
+        assert loci.view(-1, 2)[:, 1].tolist() == [10 * i for i in ids]               # ids follow rank (= contig) order
+        assert loci.view(-1, 2)[:, 0].tolist() == [1] * 4 + [2] * n1
+        assert sorted(regs.view(-1, 2)[:, 1].tolist()) == sorted(ids + ids)
     np.save(os.path.join(tmp, f"table_in_{rank}.npy"), table)
     np.save(os.path.join(tmp, f"votes_in_{rank}.npy"), votes)
     np.save(os.path.join(tmp, f"table_out_{rank}.npy"), unpack(eng.table.numpy()))

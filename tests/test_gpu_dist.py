@@ -105,3 +105,101 @@ def test_exchange_world1_nccl_on_device_buffers(case_inputs, tmp_path):
             assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
     finally:
         ex.close()
+
+
+def _sharded_scan_sequential(engs, hit, match, max_peak):
+    """the exchange of Exchange.sharded_scan done by hand for 'ranks' that live one after the other on one GPU"""
+    import torch
+    from localhgt_amd.dist import device_tensor
+    counts = [e.ref_scan_local(hit, match) for e in engs]
+    news = [c[0] for c in counts]
+    n_total, n_sel = sum(news), sum(c[1] for c in counts)
+    loci_parts, regs_parts = [], []
+    for r, e in enumerate(engs):
+        pl, pr, n_regs = e.ref_scan_emit(sum(news[:r]))
+        loci_parts.append(device_tensor(pl, 8 * news[r], 0).view(torch.int32).clone() if news[r] else torch.empty(0, dtype=torch.int32, device="cuda:0"))
+        regs_parts.append(device_tensor(pr, 8 * n_regs, 0).view(torch.int32).clone() if n_regs else torch.empty(0, dtype=torch.int32, device="cuda:0"))
+    loci_all, regs_all = torch.cat(loci_parts), torch.cat(regs_parts)
+    torch.cuda.synchronize()
+    for e in engs:
+        e.peaks_install(n_total, n_sel, max_peak, loci_all.data_ptr(), regs_all.data_ptr(), regs_all.numel() // 2)
+    return n_total, news
+
+
+@pytest.mark.parametrize("name,world", [("k24_base", 3), ("k24_nrun_lower", 2), ("k32_base", 4), ("k24_seed7", 8)])
+def test_reference_sharded_scan_equals_whole_scan(case_inputs, tmp_path, name, world):
+    """each 'rank' holds a contig shard of the index and the full count table; after the record exchange every rank's
+    peak tables equal those of an unsharded scan, and the interval file equals the reference golden"""
+    from localhgt_amd.engine import Engine
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    k, e = case.k, case.e
+    index = f"{fa2}.k{k}.h{e}.index.dat"
+    with Engine(k, e) as whole:
+        whole.rng_seed(case.seed)
+        whole.coder_generate()
+        whole.index_build(fa2, index, fa2 + ".genome.len.txt")
+        nc_all, nb_all = whole.index_load(index)
+        whole.sampling_init(100.0)
+        whole.pairs_load_fastq(f1, f2, 100.0)
+        whole.count_kmers()
+        pw, nw = whole.counts_buffer()
+        engs, shards = [], []
+        for r in range(world):
+            g = Engine(k, e)
+            shards.append(g.index_load_shard(index, r, world))
+            g.counts_merge(pw, 0, nw)                      # the complete (already merged) count table
+            if r == world - 1:
+                g.sampling_init(100.0)
+                g.pairs_load_fastq(f1, f2, 100.0)          # one rank also carries the reads, to vote
+            engs.append(g)
+        assert sum(s[0] for s in shards) == nc_all and sum(s[1] for s in shards) == nb_all
+        if world <= nc_all:
+            assert all(s[0] > 0 for s in shards)
+        n_total, news = _sharded_scan_sequential(engs, case.hit_ratio, case.match_ratio, case.max_peak)
+        n_whole = whole.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak)
+        assert n_total == n_whole == meta["raw_peaks"]
+        loci_w, _ = whole.peaks_export(n_whole)
+        pk_w = whole.peak_kmer_export(0, min(1 << k, 1 << 26))
+        for g in engs:
+            assert (g.peaks_export(n_total)[0] == loci_w).all()
+            assert (g.peak_kmer_export(0, min(1 << k, 1 << 26)) == pk_w).all()
+        voter = engs[-1]
+        voter.vote()
+        out = str(tmp_path / "interval.txt")
+        voter.write_intervals(out)
+        assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+        for g in engs:
+            g.close()
+
+
+def test_exchange_sharded_scan_world1_nccl(case_inputs, tmp_path):
+    """Exchange.sharded_scan over nccl with one rank == lhgt_ref_scan"""
+    from localhgt_amd.dist import Exchange
+    from localhgt_amd.engine import Engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    ex = Exchange.from_env(backend="nccl")
+    name = "k24_base"
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    try:
+        with Engine(case.k, case.e) as eng:
+            eng.rng_seed(case.seed)
+            eng.coder_generate()
+            index = f"{fa2}.k{case.k}.h{case.e}.index.dat"
+            eng.index_build(fa2, index, fa2 + ".genome.len.txt")
+            eng.index_load_shard(index, 0, 1)
+            eng.sampling_init(100.0)
+            eng.pairs_load_fastq(f1, f2, 100.0)
+            eng.count_kmers()
+            assert ex.sharded_scan(eng, case.hit_ratio, case.match_ratio, case.max_peak) == meta["raw_peaks"]
+            eng.vote()
+            out = str(tmp_path / "interval.txt")
+            eng.write_intervals(out)
+            assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+    finally:
+        ex.close()

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-e", type=int, default=3)
     ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=150_000)
     args = ap.parse_args()
@@ -84,8 +85,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         from localhgt_amd.dist import Exchange
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(key, val)
         dist = Exchange.from_env(backend="nccl")
 
     k, e, L = args.k, args.e, 150
@@ -93,7 +96,7 @@ def main():
     eng.rng_seed(1)
     eng.coder_generate()
     t0 = time.time()
-    shard_index = args.shard_index and world > 1
+    shard_index = args.shard_index and dist is not None
     if shard_index:
         eng.synth_reference_shard(1, args.contigs, args.contig_len, rank, world)  # this rank's contig range only
     else:

@@ -242,6 +242,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     ctx->index_words = word;
     ctx->n_pos = flat;
     ctx->n_tiles = (long)tiles.size();
+    ctx->index_resident = true;
     if (ctx->contigs.empty()) return LHGT_OK;
     LHGT_HIP(hipMalloc(&ctx->d_index, word * 4));
     LHGT_HIP(hipMalloc(&ctx->d_contigs, ctx->contigs.size() * sizeof(ContigDev)));

@@ -412,15 +412,16 @@ extern "C" {
 int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks) {
     if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
-    if (!ctx->d_index || ctx->n_tiles == 0) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load first");
+    if (!ctx->index_resident) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load first");
     if (max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "max_peak must be positive");
     const int k = ctx->k, e = ctx->e;
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t total = 0;
     unsigned long long n_sel = 0;
-    LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));
+    LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));   // no contig longer than k: zero tiles, zero peaks
     LHGT_TRY(peaks_prepare(ctx, total, n_sel, max_peak));
-    hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
+    if (ctx->n_tiles > 0)
+        hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
                        ctx->d_counts, ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
                        ctx->prefilter_on ? ctx->d_prefilter : nullptr);
     LHGT_HIP(hipGetLastError());
@@ -444,6 +445,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
 int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long* n_new_local, long* n_selected_local) {
     if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
     if (!ctx || !n_new_local || !n_selected_local) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (!ctx->index_resident) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load_shard first");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t total = 0;
     unsigned long long n_sel = 0;

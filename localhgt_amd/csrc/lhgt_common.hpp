@@ -100,6 +100,7 @@ struct lhgt_ctx {
     lhgt::TileDev* d_tiles = nullptr;
     long n_tiles = 0;
     uint64_t n_pos = 0;
+    bool index_resident = false;  // an index (possibly with zero contigs longer than k) has been installed
     uint8_t* d_flags = nullptr;
     // reads
     std::vector<lhgt::ReadBatch> batches;

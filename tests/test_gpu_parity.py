@@ -314,3 +314,26 @@ def test_vote_prefilter_changes_nothing(Engine):
     assert votes[0][0] == votes[1][0] > 50
     assert (votes[0][1] == votes[1][1]).all() and (votes[0][2] == votes[1][2]).all()
     assert votes[0][2].max() >= 1
+
+
+def test_reference_without_indexable_contig(tmp_path, oracle):
+    """every contig <= k: the index holds only its header and the interval file only the sentinel line (E:542)"""
+    from localhgt_amd import extract_ref
+    fa = str(tmp_path / "ref.fa")
+    open(fa, "w").write(">a\nACGTACGTAC\n>b\nGGGTTTAAACCC\n")
+    f1, f2 = str(tmp_path / "s.1.fq"), str(tmp_path / "s.2.fq")
+    _write_fq(f1, [b"ACGT" * 30], b"1")
+    _write_fq(f2, [b"TTGCA" * 24], b"2")
+    interval = str(tmp_path / "i.txt")
+    args = [f1, f2, fa, interval, "0.1", "0.08", "1", "24", "1000", "3", "1", "1"]
+    rep = extract_ref.run(extract_ref.parse_argv(args), log=lambda *a: None)
+    assert rep["n_contigs"] == 0 and rep["n_peaks"] == 0 and rep["pairs_kept"] == 1
+    assert open(interval).read() == "1\t1\t1\n"
+    assert os.path.getsize(fa + ".k24.h3.index.dat") == 1200 and open(fa + ".genome.len.txt").read() == ""
+    d = tmp_path / "o"
+    d.mkdir()
+    fa2 = str(d / "ref.fa")
+    shutil.copy(fa, fa2)
+    rc, _ = oracle.run(f1, f2, fa2, str(d / "i.txt"), 0.1, 0.08, 1, 24, 1000, 3, 1, 1.0)
+    assert rc == 0 and open(d / "i.txt").read() == "1\t1\t1\n"
+    assert open(fa2 + ".k24.h3.index.dat", "rb").read() == open(fa + ".k24.h3.index.dat", "rb").read()

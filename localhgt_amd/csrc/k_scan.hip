@@ -28,24 +28,27 @@ __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uin
 // ---- B1
 __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                 const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
-                                                int k, int e, uint8_t* __restrict__ flags) {
+                                                int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ nzmask) {
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     for (int jj = threadIdx.x; jj < TILE; jj += BT) {
         long j = (long)t.j0 + jj;
         if (j >= c.len) break;
-        uint8_t f = 0;
+        uint8_t f = 0, nz = 0;
         if (j < nk) {  // the last k-1 positions have no k-mer: zero (quirk Q1 contract)
             const uint32_t* hp = index + c.hash_word + j * e;
             int hc = 0;
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                if (h != 0 && count_of(counts, h) == 3u) hc++;  // hash 0 = invalid (E:936-941); least_depth 3 (E:580)
+                uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;  // hash 0 = invalid (E:936-941)
+                if (cnt == 3u) hc++;                               // least_depth 3 (E:580)
+                if (cnt > 0u && i < 8) nz |= (uint8_t)(1u << i);    // record_ref_hit > 0 (E:250, 265), reused by register_peaks
             }
             f = (uint8_t)((hc > 0) | ((hc == e) << 1));
         }
         flags[c.flat_base + j] = f;
+        nzmask[c.flat_base + j] = nz;
     }
 }
 
@@ -241,7 +244,8 @@ __global__ void __launch_bounds__(1024) tile_scan(uint32_t* __restrict__ v, long
 // ---- B5
 __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
-                                                     const uint8_t* __restrict__ flags, const uint32_t* __restrict__ tile_base,
+                                                     const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
+                                                     const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
                                                      uint32_t* __restrict__ prefilter /* nullable */) {
     __shared__ int incl[TILE], part[BT];
@@ -274,9 +278,11 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
         }
         if (j < nk) {  // E:247,262; beyond nk the hit array is zero anyway
             const uint32_t* hp = index + c.hash_word + j * e;
+            const uint32_t nz = nzmask[c.flat_base + j];
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                if (h != 0 && count_of(counts, h) > 0) {
+                // hit > 0 for this hash: the bit ref_flags recorded (hashes 8.. are probed again, e <= 9)
+                if (i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
                         const uint32_t fb = h & ((1u << PF_BITS) - 1u);
@@ -294,7 +300,8 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
 // (they are replayed with atomicMax).
 __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                  const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
-                                                 const uint8_t* __restrict__ flags, const uint32_t* __restrict__ tile_base,
+                                                 const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
+                                                 const uint32_t* __restrict__ tile_base,
                                                  int k, int e, uint32_t id_base, int32_t* __restrict__ loci_out,
                                                  uint32_t* __restrict__ regs_out, unsigned long long* __restrict__ n_regs) {
     __shared__ int incl[TILE], part[BT];
@@ -327,9 +334,10 @@ __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ til
         }
         if (j < nk) {
             const uint32_t* hp = index + c.hash_word + j * e;
+            const uint32_t nz = nzmask[c.flat_base + j];
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                if (h != 0 && count_of(counts, h) > 0) {
+                if (i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     unsigned long long slot = atomicAdd(n_regs, 1ull);
                     regs_out[2 * slot] = h;
                     regs_out[2 * slot + 1] = id_base + lid;
@@ -367,7 +375,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
     int three_min = (int)(WINDOW * match_ratio);
     dim3 grid((unsigned)ctx->n_tiles), blk(BT);
-    hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags);
+    hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
     hipLaunchKernelGGL(window_peak, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, one_min, three_min, ctx->d_flags);
     unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));
     LHGT_HIP(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
@@ -422,7 +430,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     LHGT_TRY(peaks_prepare(ctx, total, n_sel, max_peak));
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
-                       ctx->d_counts, ctx->d_flags, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
+                       ctx->d_counts, ctx->d_flags, ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
                        ctx->prefilter_on ? ctx->d_prefilter : nullptr);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -484,7 +492,7 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
     unsigned long long cnt = 0;
     if (ctx->n_tiles > 0 && ctx->local_new > 0) {
         hipLaunchKernelGGL(emit_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
-                           ctx->d_counts, ctx->d_flags, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
+                           ctx->d_counts, ctx->d_flags, ctx->d_nzmask, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
                            ctx->d_emit_regs, d_cnt);
         LHGT_HIP(hipGetLastError());
         LHGT_HIP(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -102,6 +102,7 @@ struct lhgt_ctx {
     uint64_t n_pos = 0;
     bool index_resident = false;  // an index (possibly with zero contigs longer than k) has been installed
     uint8_t* d_flags = nullptr;
+    uint8_t* d_nzmask = nullptr;  // per position: bit i = hash i has a non-zero count (E:250's `record_ref_hit > 0`)
     // reads
     std::vector<lhgt::ReadBatch> batches;
     long n_pairs = 0;

@@ -337,3 +337,26 @@ def test_reference_without_indexable_contig(tmp_path, oracle):
     rc, _ = oracle.run(f1, f2, fa2, str(d / "i.txt"), 0.1, 0.08, 1, 24, 1000, 3, 1, 1.0)
     assert rc == 0 and open(d / "i.txt").read() == "1\t1\t1\n"
     assert open(fa2 + ".k24.h3.index.dat", "rb").read() == open(fa + ".k24.h3.index.dat", "rb").read()
+
+
+def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
+    """scripts/pipeline.sh:35-36 verbatim, with this repo's bin/ on PATH: extract_ref <12 args>; get_bed_file.py ref interval > log"""
+    import subprocess
+    import sys
+    name = "k24_base"
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PATH=os.path.join(root, "bin") + os.pathsep + os.environ["PATH"])
+    interval = str(tmp_path / "S.interval.txt")
+    script = (f'extract_ref {f1} {f2} {fa2} {interval} {case.hit_ratio} {case.match_ratio} 10 {case.k} {case.max_peak} {case.e} {case.seed} {case.sample}\n'
+              f'python3 {root}/bin/get_bed_file.py {fa2} {interval} > {tmp_path}/S.log\n')
+    res = subprocess.run(["bash", "-c", script], env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    gold = os.path.join(cases.GOLDEN_DIR, name)
+    assert open(interval).read() == open(os.path.join(gold, "interval.txt")).read()
+    assert open(interval + ".bed").read() == open(os.path.join(gold, "interval.txt.bed")).read()
+    assert open(tmp_path / "S.log").read() == meta["bed_stdout"]
+    assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]

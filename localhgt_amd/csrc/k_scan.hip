@@ -91,6 +91,9 @@ __global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ ti
     int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
     for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
     __syncthreads();
+    // no hit position in the tile or its halos: no good window and no contrast anywhere, and bits 2-3 of the flags
+    // ref_flags just wrote are already zero (most tiles of a large reference for a sparse sample)
+    if (P1[N2 - 1] == 0) return;
     for (int i = threadIdx.x; i < N2; i += BT) W[i] = (int8_t)(i >= 5 ? P1[i] - P1[i - 5] : 0);
     __syncthreads();
     for (int i = threadIdx.x; i < N2; i += BT) {
@@ -169,6 +172,14 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
         if (lane == 0) gw[w] = bal;
     }
     __syncthreads();
+    {   // no good window within reach: nothing of this tile is inside an interval, bits 4-6 stay zero
+        unsigned long long any = 0;
+        for (int w = 0; w < NW3; w++) any |= gw[w];   // LDS broadcast reads
+        if (!any) {
+            if (threadIdx.x == 0) tile_count[blockIdx.x] = 0u;
+            return;
+        }
+    }
     if (threadIdx.x == 0) {
         int last = NONE_LO;
         for (int w = 0; w < NW3; w++) {

@@ -360,3 +360,26 @@ def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
     assert open(interval + ".bed").read() == open(os.path.join(gold, "interval.txt.bed")).read()
     assert open(tmp_path / "S.log").read() == meta["bed_stdout"]
     assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]
+
+
+@pytest.mark.parametrize("k,e", [(20, 9), (33 - 1, 1), (16, 4)])
+def test_whole_run_matches_oracle_for_unusual_e(oracle, case_inputs, tmp_path, k, e):
+    """e = 9 (four rand() rows per position, 9th hash outside the 8-bit nzmask), e = 1 and e = 4: GPU run vs oracle run"""
+    from localhgt_amd import extract_ref
+    fa, f1, f2, _ = case_inputs("k24_seed7")
+    outs = {}
+    for who in ("gpu", "cpu"):
+        d = tmp_path / who
+        d.mkdir()
+        fa2 = str(d / "ref.fa")
+        shutil.copy(fa, fa2)
+        interval = str(d / "interval.txt")
+        if who == "gpu":
+            rep = extract_ref.run(extract_ref.parse_argv([f1, f2, fa2, interval, "0.1", "0.02", "1", str(k), "100000", str(e), "5", "0.7"]),
+                                  log=lambda *a: None)
+        else:
+            rc, orep = oracle.run(f1, f2, fa2, interval, 0.1, 0.02, 1, k, 100000, e, 5, 0.7)
+            assert rc == 0
+        outs[who] = (open(interval).read(), open(fa2 + ".genome.len.txt").read(), cases.sha256_file(f"{fa2}.k{k}.h{e}.index.dat"))
+    assert outs["gpu"] == outs["cpu"]
+    assert rep["n_peaks"] == orep.n_peaks and rep["pairs_kept"] == orep.pairs_voted

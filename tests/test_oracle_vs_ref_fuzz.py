@@ -1,0 +1,45 @@
+"""Extra pinning of the CPU restatement: the same random-case generator as tests/test_gpu_fuzz.py, but the oracle is
+compared with the REAL reference binary (oracle/_ref/extract_ref_z, built from /root/reference by oracle/build_ref.sh).
+Skipped where that binary is absent.  Cases the reference handles with undefined behaviour are left out: max_peak
+overflow (it writes past its arrays, E:272-274) and contigs shorter than half a window with a zero threshold
+(zero-sized interval array, E:565)."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_fuzz import _make_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "extract_ref_z")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/extract_ref_z not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("idx", range(16))
+def test_oracle_equals_reference_binary(oracle, tmp_path, idx):
+    r, c = tmp_path / "ref", tmp_path / "cpu"
+    r.mkdir()
+    k, e, seed, sample, hit, match, max_peak = _make_case(idx, str(r), k_max=26)
+    if max_peak < 1000:
+        max_peak = 100000
+    if hit == 0.0 or match == 0.0:
+        hit, match = max(hit, 0.05), max(match, 0.02)
+    shutil.copytree(r, c, dirs_exist_ok=True)
+    runs = 2 if idx % 3 == 0 else 1
+    for _ in range(runs):
+        res = subprocess.run([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt", repr(hit), repr(match), "1", str(k), str(max_peak), str(e),
+                              str(seed), repr(sample)], cwd=r, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-500:]
+        rc, orep = oracle.run(str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(hit)),
+                              float(np.float32(match)), 1, k, max_peak, e, seed, sample)
+        assert rc == 0
+    raw = re.findall(r"No\. of raw BKPs: (\d+)", res.stdout)   # absent when no contig is longer than k (no scan thread starts)
+    assert (int(raw[-1]) if raw else 0) == orep.n_peaks
+    assert open(r / "i.txt").read() == open(c / "i.txt").read(), (k, e, seed, sample, hit, match)
+    assert open(r / "ref.fa.genome.len.txt").read() == open(c / "ref.fa.genome.len.txt").read()
+    a, b = open(r / f"ref.fa.k{k}.h{e}.index.dat", "rb").read(), open(c / f"ref.fa.k{k}.h{e}.index.dat", "rb").read()
+    assert len(a) == len(b) and a[:1198] == b[:1198] and a[1200:] == b[1200:]   # bytes 1198-1199: past-the-array read in the reference

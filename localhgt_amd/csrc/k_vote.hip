@@ -152,8 +152,9 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                             const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                             if (PF) {
                                 const uint32_t fb = h & ((1u << PF_BITS) - 1u);
-                                ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? peak_kmer[h] : 0u;
-                            } else ids[i] = peak_kmer[h];  // 0 = no peak (E:454)
+                                ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? __builtin_nontemporal_load(peak_kmer + h) : 0u;
+                            } else ids[i] = __builtin_nontemporal_load(peak_kmer + h);  // 0 = no peak (E:454); `nt`: +11 % probe
+                            // rate on a 16 GiB table (profiles/r01_probe_policy_microbench.txt), nothing here is re-read
                             hit |= ids[i] != 0;
                         }
 #pragma unroll

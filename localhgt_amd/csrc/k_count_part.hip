@@ -120,7 +120,7 @@ __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist
     for (uint32_t i = threadIdx.x; i < total; i += NT) {
         uint32_t key = sorted[i];
         uint32_t bk = (key >> shift) & bmask;
-        __builtin_nontemporal_store(key, &out[gbase[bk] + (i - lofs[bk])]);   // consecutive i of one bucket -> consecutive addresses; written once, read once by the next pass
+        out[gbase[bk] + (i - lofs[bk])] = key;   // consecutive i of one bucket -> consecutive addresses
     }
     __syncthreads();
 }
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restri
 #pragma unroll
         for (int u = 0; u < KPT; u++) {
             uint32_t i = k0 + u * PK + threadIdx.x;
-            key[u] = i < k1 ? __builtin_nontemporal_load(in + i) : 0u;
+            key[u] = i < k1 ? in[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < KPT; u++)
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(PA) part_apply(const uint32_t* __restrict__ ke
         for (int u = 0; u < U; u++) {
             uint32_t i = base + u * PA + threadIdx.x;
             live[u] = i < k1;
-            s[u] = live[u] ? __builtin_nontemporal_load(keys + i) & smask : 0u;
+            s[u] = live[u] ? keys[i] & smask : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) old[u] = ((volatile uint32_t*)slice)[s[u] >> 4];

@@ -91,8 +91,8 @@ int lhgt_pairs_count(lhgt_ctx* ctx, long* n_pairs);
 /* ---- A: saturating k-mer count of every resident read into the 2-bit table (read_fastq E:981-1107).
  * Result per slot = min(3, occurrences): order independent, equal to the -t 1 reference. */
 int lhgt_count_kmers(lhgt_ctx* ctx);
-/* two implementations of the same result: 1 (default) = radix partition + LDS apply (k_count_part.hip),
- * 0 = one device compare-and-swap per hash (k_count.hip); kept for A/B measurement and parity. */
+/* two implementations of the same result: 1 = radix partition + LDS apply (k_count_part.hip), 0 = one device
+ * compare-and-swap per hash behind a pre-check load (k_count.hip); -1 (default) picks by k: partition from k >= 26. */
 int lhgt_set_count_mode(lhgt_ctx* ctx, int mode);
 int lhgt_counts_clear(lhgt_ctx* ctx);
 

@@ -97,8 +97,12 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: load or build the index first");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    // Which kernel: the radix partition needs many table slices to spread over the chip (16384 at k = 32) and wins from
+    // k = 26 up (bench workload: 102 vs 117 ms at k = 26, 60 vs 301 ms at k = 32); for smaller k the table is cache
+    // resident and saturates at once, so the direct kernel's pre-check load makes it read-mostly (45 vs 1021 ms at k = 21).
+    const int mode = ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);
     for (const ReadBatch& b : ctx->batches) {
-        if (ctx->count_mode == 1) {
+        if (mode == 1) {
             LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
             continue;
         }
@@ -115,7 +119,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
 }
 
 int lhgt_set_count_mode(lhgt_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 1) LHGT_FAIL(LHGT_E_ARG, "count mode must be 0 (direct) or 1 (partitioned)");
+    if (!ctx || mode < -1 || mode > 1) LHGT_FAIL(LHGT_E_ARG, "count mode must be -1 (by k), 0 (direct) or 1 (partitioned)");
     ctx->count_mode = mode;
     return LHGT_OK;
 }

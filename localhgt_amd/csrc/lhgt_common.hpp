@@ -128,7 +128,7 @@ struct lhgt_ctx {
     uint32_t* d_part_keys[2] = {nullptr, nullptr};
     size_t part_keys_cap = 0;  // keys per buffer
     uint32_t* d_part_meta = nullptr;
-    int count_mode = 1;        // 0 = direct CAS kernel, 1 = radix partition
+    int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)
     uint8_t* d_ws_ascii = nullptr;

@@ -119,7 +119,7 @@ __device__ __forceinline__ void judge_pair(const uint32_t* ev, int n_ev, int e_r
 // Any read length up to 500, probes of one 64-offset slice at a time.  PF: consult the L2-resident folded bitmap
 // first (exact negatives: a clear bit means no slot folding onto it holds a peak), so sparse peak sets never
 // touch the 16 GiB peak_kmer array except for true hits and the few false positives.
-template <int TR, bool PF>
+template <int TR, bool PF, bool NT>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                    const uint32_t* __restrict__ prefilter,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
@@ -152,9 +152,11 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                             const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                             if (PF) {
                                 const uint32_t fb = h & ((1u << PF_BITS) - 1u);
-                                ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? __builtin_nontemporal_load(peak_kmer + h) : 0u;
-                            } else ids[i] = __builtin_nontemporal_load(peak_kmer + h);  // 0 = no peak (E:454); `nt`: +11 % probe
-                            // rate on a 16 GiB table (profiles/r01_probe_policy_microbench.txt), nothing here is re-read
+                                ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? peak_kmer[h] : 0u;
+                            } else if (NT) {   // tables of 1 GiB and more (k >= 28): nothing to keep in the caches
+                                // `nt`: +11 % probe rate on a table far beyond the caches (profiles/r01_probe_policy_microbench.txt)
+                                ids[i] = __builtin_nontemporal_load(peak_kmer + h);
+                            } else ids[i] = peak_kmer[h];  // 0 = no peak (E:454)
                             hit |= ids[i] != 0;
                         }
 #pragma unroll
@@ -219,11 +221,19 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (wpb < 1) wpb = 1;
         long blocks = (b.d.n_pairs + wpb - 1) / wpb;
         if (blocks > 256L * 16) blocks = 256L * 16;
-#define LHGT_VOTE(TR_, PF_)                                                                                          \
-    hipLaunchKernelGGL((vote_kernel<TR_, PF_>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, \
+#define LHGT_VOTE(TR_, PF_, NT_)                                                                                          \
+    hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, \
                        ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug)
-        if (max_ev <= 256) { if (ctx->prefilter_on) LHGT_VOTE(4, true); else LHGT_VOTE(4, false); }
-        else { if (ctx->prefilter_on) LHGT_VOTE(16, true); else LHGT_VOTE(16, false); }
+        const bool nt = ctx->k >= 28;
+        if (max_ev <= 256) {
+            if (ctx->prefilter_on) LHGT_VOTE(4, true, false);
+            else if (nt) LHGT_VOTE(4, false, true);
+            else LHGT_VOTE(4, false, false);
+        } else {
+            if (ctx->prefilter_on) LHGT_VOTE(16, true, false);
+            else if (nt) LHGT_VOTE(16, false, true);
+            else LHGT_VOTE(16, false, false);
+        }
 #undef LHGT_VOTE
     }
     LHGT_HIP(hipGetLastError());

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                                                      const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
-                                                     uint32_t* __restrict__ prefilter /* nullable */) {
+                                                     uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask) {
     __shared__ int incl[TILE], part[BT];
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                 if (i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
-                        const uint32_t fb = h & ((1u << PF_BITS) - 1u);
+                        const uint32_t fb = h & pf_mask;
                         atomicOr(&prefilter[fb >> 5], 1u << (fb & 31u));
                     }
                 }
@@ -360,14 +360,14 @@ __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ til
 
 // replay of gathered registrations on every rank
 __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ regs, long n, uint32_t* __restrict__ peak_kmer,
-                                                   uint32_t* __restrict__ prefilter /* nullable */) {
+                                                   uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const uint32_t h = regs[2 * i], id = regs[2 * i + 1];
         atomicMax(&peak_kmer[h], id);
         if (prefilter) {
-            const uint32_t fb = h & ((1u << PF_BITS) - 1u);
+            const uint32_t fb = h & pf_mask;
             atomicOr(&prefilter[fb >> 5], 1u << (fb & 31u));
         }
     }
@@ -408,11 +408,14 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
     LHGT_HIP(hipMemsetAsync(ctx->d_peak_kmer, 0, slots * 4, ctx->stream));  // E:1458
-    // vote prefilter (k_vote.hip): worth it while at most ~1/8 of its 2^PF_BITS bits would be set
-    ctx->prefilter_on = ctx->k > PF_BITS && !(ctx->debug & 4) && n_selected * (unsigned long long)ctx->e <= (1ull << PF_BITS) / 8;
+    // vote prefilter (k_vote.hip): a bitmap of min(k, PF_BITS) address bits (exact below PF_BITS, folded above),
+    // worth it while at most ~1/8 of its bits would be set
+    const int pf_bits = ctx->k < PF_BITS ? ctx->k : PF_BITS;
+    ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
+    ctx->prefilter_on = !(ctx->debug & 4) && n_selected * (unsigned long long)ctx->e <= (1ull << pf_bits) / 8;
     if (ctx->prefilter_on) {
         if (!ctx->d_prefilter) LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
-        LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, (size_t)(1u << PF_BITS) / 8, ctx->stream));
+        LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ((size_t)1 << pf_bits) / 8, ctx->stream));
     }
     if ((long)total + 1 > ctx->peaks_cap) {     // grow-only: no allocator traffic in steady state
         if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
@@ -442,7 +445,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
                        ctx->d_counts, ctx->d_flags, ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -529,7 +532,7 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
         long blocks = (n_regs_all + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(replay_regs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_regs_all, n_regs_all,
-                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr);
+                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask);
         LHGT_HIP(hipGetLastError());
     }
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

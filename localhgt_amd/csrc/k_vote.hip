@@ -123,7 +123,7 @@ template <int TR, bool PF, bool NT>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                    const uint32_t* __restrict__ prefilter,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
-                                                   int max_ev, int waves_per_block, int debug) {
+                                                   int max_ev, int waves_per_block, int debug, uint32_t pf_mask) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     if (wib >= waves_per_block) return;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                         if (i < e) {
                             const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                             if (PF) {
-                                const uint32_t fb = h & ((1u << PF_BITS) - 1u);
+                                const uint32_t fb = h & pf_mask;
                                 ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? peak_kmer[h] : 0u;
                             } else if (NT) {   // tables of 1 GiB and more (k >= 28): nothing to keep in the caches
                                 // `nt`: +11 % probe rate on a table far beyond the caches (profiles/r01_probe_policy_microbench.txt)
@@ -223,7 +223,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (blocks > 256L * 16) blocks = 256L * 16;
 #define LHGT_VOTE(TR_, PF_, NT_)                                                                                          \
     hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, \
-                       ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug)
+                       ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask)
         const bool nt = ctx->k >= 28;
         if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, true, false);

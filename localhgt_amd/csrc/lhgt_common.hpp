@@ -114,6 +114,7 @@ struct lhgt_ctx {
     long n_peaks = -1, max_peak = 0;
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
     bool prefilter_on = false;
+    uint32_t pf_mask = 0;             // low address bits indexing the prefilter
     unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan
     // reference-sharded scan (k_scan.hip): this rank's new peaks / registrations as records for the exchange
     int32_t* d_emit_loci = nullptr;

@@ -3,9 +3,11 @@
 packed reads resident in HBM, on N GPUs of one node (one process per GPU, RCCL over xGMI).
 
 A step = counts_clear -> count_kmers (A) -> [count-table exchange] -> ref_scan (B) -> vote (C)
--> [vote all-reduce] -> write_intervals (D) over the synthetic workload of BASELINE.json
-configs[1]: 1 Gbase reference (1000 x 1 Mbp), 10 M 150 bp pairs PER GPU (weak scaling: read shards
-are independent), k=32 e=3, every read kept (--sample 1).  Prints ONE JSON line on rank 0.
+-> [vote all-reduce] -> write_intervals (D) over a synthetic workload of BASELINE.json.  Default =
+configs[2], the configuration the metric is quoted on ("UHGG-scale ref") and the largest that fits one
+GPU: 13 Gbase reference (13000 x 1 Mbp, 156 GB of index resident in HBM), 100 M 150 bp pairs PER GPU
+(weak scaling: read shards are independent), k=32 e=3, every read kept (--sample 1).
+`--workload 1g` = configs[1] (1 Gbase, 10 M pairs).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -65,8 +67,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU")
-    ap.add_argument("--contigs", type=int, default=1000)
+    ap.add_argument("--workload", choices=["uhgg", "1g"], default="uhgg",
+                    help="uhgg = BASELINE configs[2] (13000 x 1 Mbp, 100 M pairs/GPU); 1g = configs[1] (1000 x 1 Mbp, 10 M pairs/GPU)")
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (overrides the workload's)")
+    ap.add_argument("--contigs", type=int, default=None, help="contigs of the synthetic reference (overrides the workload's)")
     ap.add_argument("--contig-len", type=int, default=1_000_000)
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-e", type=int, default=3)
@@ -76,6 +80,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=150_000)
     args = ap.parse_args()
+    wl_contigs, wl_pairs = (13000, 100_000_000) if args.workload == "uhgg" else (1000, 10_000_000)
+    args.contigs = args.contigs or wl_contigs
+    args.pairs = args.pairs or wl_pairs
 
     import torch
     from localhgt_amd.engine import Engine
@@ -135,10 +142,10 @@ def main():
         step()
     fence()
     t0 = time.time()
-    ms = [0.0, 0.0, 0.0]
+    ms = [0.0, 0.0, 0.0, 0.0]
     for _ in range(args.steps):
         n_peaks, nf = step()
-        for ph in range(3):
+        for ph in range(4):
             ms[ph] += eng.phase_ms(ph)
     fence()
     dt = time.time() - t0
@@ -159,39 +166,51 @@ def main():
         # FETCH_SIZE of random 4-byte probes = TCC_EA0_RDREQ x 64 B, the streaming kernels' FETCH_SIZE doubled per
         # MI355X_MICROARCH.md section HBM); committed with the profile it came from
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        default_workload = (args.contigs, args.contig_len, args.pairs, k, e) == (1000, 1_000_000, 10_000_000, 32, 3)
-        if default_workload and os.path.exists(tpath):   # the PMC profile was taken on exactly this workload
+        tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")   # {workload tag: {phase: bytes}}
+        if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))
             except Exception:
                 traffic = {}
-        vote_ach, vote_frac = roof(per["vote_C"], algo)
-        count_ach, count_frac = roof(per["count_A"], algo)
         ref_bytes = args.contigs * args.contig_len * (4 * e + 64 * e)     # 204 B per reference base
-        scan_ach, scan_frac = roof(per["scan_B"], ref_bytes)
+        # candidates for "the dominant kernel": single kernels timed by their own HIP events (ref_flags: one launch per step;
+        # vote_kernel: one launch per resident batch of <= 16 Mi pairs, phase C holds nothing else), and phase A's kernel family
+        n_batches = -(-args.pairs // (16 << 20))
+        kern = {"count_A": per["count_A"], "ref_flags": ms[3] / args.steps, "vote_C": per["vote_C"]}
+        phases = {
+            "count_A": ("phase A kernel family (part_hist + part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
+                        "count_direct below k = 26): 714 table updates per pair", algo, None),
+            "ref_flags": ("ref_flags (phase B: e random 2-bit table probes + e index words per reference base), 1 launch per step", ref_bytes, 1),
+            "vote_C": (f"vote_kernel (phase C read re-scan: 714 probes per pair into peak_kmer), {n_batches} launches per step", algo, n_batches),
+        }
+        dominant = max(kern, key=kern.get)
+        dom_ach, dom_frac = roof(kern[dominant], phases[dominant][1])
+        tkey = {"count_A": "count_A", "ref_flags": "ref_flags", "vote_C": "vote_kernel"}
+        workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}"
+        tr = traffic.get(workload_tag, {})
         line = {
             "metric": "M paired-reads/s k-mer sketch->peak, UHGG-scale ref; %HBM roofline @1/2/4/8 GPU",
             "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
+            "config": {"workload": f"BASELINE configs[{2 if (args.contigs, args.pairs) == (13000, 100_000_000) else 1 if (args.contigs, args.pairs) == (1000, 10_000_000) else '-'}]: "
+                                   f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
                                    f"index resident), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
                        "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
                        "parallelism": f"reads sharded x{world}" + (", index sharded" if shard_index else ", phase B replicated" if world > 1 else "")},
-            "phase_ms": {"count_A": round(ms[0] / args.steps, 3), "scan_B": round(ms[1] / args.steps, 3), "vote_C": round(ms[2] / args.steps, 3)},
+            "phase_ms": {kk: round(v, 3) for kk, v in per.items()},
             "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
-            "roofline": {"bound": "hbm", "kernel": "vote_kernel (phase C read re-scan: 714 probes/pair into peak_kmer; the dominant kernel)",
-                         "achieved": vote_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": vote_frac,
-                         "traffic": traffic.get("vote_kernel"), "algorithmic_bytes_per_launch": algo, "launch_ms": round(per["vote_C"], 3)},
-            "roofline_other": {
-                "count_A (part_hist+part_scatter_reads+part_scatter_keys+part_apply, all launches of one step)": {
-                    "achieved": count_ach, "frac": count_frac, "algorithmic_bytes": algo, "ms": round(per["count_A"], 3),
-                    "traffic": traffic.get("count_A"),
-                    "note": "radix partition + LDS apply moves ~16 B/key of streaming traffic instead of one 64 B sector per key, so the sector-model fraction can exceed the random-access ceiling"},
-                "scan_B (ref_flags+window_peak+interval_mask+tile_scan+register_peaks)": {
-                    "achieved": scan_ach, "frac": scan_frac, "algorithmic_bytes": ref_bytes, "ms": round(per["scan_B"], 3),
-                    "traffic": traffic.get("scan_B")}},
+            "roofline": {"bound": "hbm", "kernel": phases[dominant][0] + " -- the dominant kernel of this workload",
+                         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_frac,
+                         "traffic": tr.get(tkey[dominant]), "algorithmic_bytes_per_step": phases[dominant][1],
+                         "ms_per_step": round(kern[dominant], 3), "launches_per_step": phases[dominant][2],
+                         "launch_ms": round(kern[dominant] / phases[dominant][2], 3) if phases[dominant][2] else None},
+            "roofline_other": {ph: {"kernel": phases[ph][0], "achieved": roof(kern[ph], phases[ph][1])[0], "frac": roof(kern[ph], phases[ph][1])[1],
+                                    "algorithmic_bytes_per_step": phases[ph][1], "ms_per_step": round(kern[ph], 3),
+                                    "launches_per_step": phases[ph][2], "traffic": tr.get(tkey[ph])}
+                               for ph in kern if ph != dominant},
+            "note": "fractions use SURVEY 8d's sector model (one 64 B sector per probe); the radix-partitioned count and the L2-resident vote "
+                    "prefilter move far fewer bytes than that model, so their fractions can exceed the random-access ceiling (DESIGN.md 4)",
         }
         if world == 1 and not args.no_cpu_baseline:
             eng.pairs_clear()

@@ -141,7 +141,7 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */
-int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C*/, float* ms);
+int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the phase), 3 = the ref_flags kernel alone*/, float* ms);
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream);
 int lhgt_synchronize(lhgt_ctx* ctx);
 

@@ -43,6 +43,8 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     hipError_t he = hipStreamCreate(&c->stream);
     if (he == hipSuccess) he = hipEventCreate(&c->ev0);
     if (he == hipSuccess) he = hipEventCreate(&c->ev1);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev2);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev3);
     if (he == hipSuccess) he = hipMalloc(&c->d_counts, c->counts_words * 4);
     if (he == hipSuccess) he = hipMemsetAsync(c->d_counts, 0, c->counts_words * 4, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
@@ -68,6 +70,8 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
         if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->ev3) hipEventDestroy(c->ev3);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c->rng);
     delete c;
@@ -81,7 +85,7 @@ int lhgt_set_debug(lhgt_ctx* ctx, int flags) {
 }
 
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase, float* ms) {
-    if (!ctx || !ms || phase < 0 || phase > 2) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (!ctx || !ms || phase < 0 || phase > 3) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     *ms = ctx->phase_ms[phase];
     return LHGT_OK;
 }

@@ -386,7 +386,9 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
     int three_min = (int)(WINDOW * match_ratio);
     dim3 grid((unsigned)ctx->n_tiles), blk(BT);
+    LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
+    LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
     hipLaunchKernelGGL(window_peak, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, one_min, three_min, ctx->d_flags);
     unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));
     LHGT_HIP(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
@@ -396,6 +398,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     LHGT_HIP(hipMemcpyAsync(total_new, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(n_selected, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[3], ctx->ev2, ctx->ev3));
     return LHGT_OK;
 }
 

@@ -78,8 +78,8 @@ struct TileDev {
 struct lhgt_ctx {
     int device = 0, k = 0, e = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float phase_ms[3] = {0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    float phase_ms[4] = {0, 0, 0, 0};   // A, B, C (all their kernels), and the ref_flags kernel alone
     // R
     char rng_state[128];
     void* rng = nullptr;  // struct random_data*

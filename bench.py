@@ -76,6 +76,7 @@ def main():
     ap.add_argument("-e", type=int, default=3)
     ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index")
     ap.add_argument("--count-mode", type=int, default=-1, help="-1 = engine default (adaptive), 0 = direct CAS kernel, 1 = radix partition")
+    ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=150_000)
@@ -105,6 +106,8 @@ def main():
     eng.coder_generate()
     if args.count_mode >= 0:
         eng.set_count_mode(args.count_mode)
+    if args.debug:
+        eng.set_debug(args.debug)
     t0 = time.time()
     shard_index = args.shard_index and dist is not None
     if shard_index:

@@ -137,7 +137,8 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
                      long first_pair, long n_pairs, int read_len, uint8_t* host_seq1_or_null, uint8_t* host_seq2_or_null);
 
 /* switches for profiling / A-B runs.  bit0: lhgt_vote skips judge_base (outputs wrong);
- * bit2: never use the vote prefilter (outputs unchanged) */
+ * bit2: never use the vote prefilter; bit4: without its LDS-resident first level; bit5: generic vote kernel even on the
+ * sparse path; bit6: ref_flags never uses the saturated-line summary (outputs unchanged) */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */

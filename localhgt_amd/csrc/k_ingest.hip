@@ -220,9 +220,9 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
 // ---------------------------------------------------------------- index layout / install
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index) {
     const int k = ctx->k, e = ctx->e;
-    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_count})
+    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count})
         if (p) hipFree(p);
-    ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_count = nullptr;
+    ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr;
     ctx->contigs.clear();
     std::vector<TileDev> tiles;
     uint64_t word = 0, flat = 0;
@@ -249,7 +249,9 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     LHGT_HIP(hipMalloc(&ctx->d_tiles, tiles.size() * sizeof(TileDev)));
     LHGT_HIP(hipMalloc(&ctx->d_flags, flat));
     LHGT_HIP(hipMalloc(&ctx->d_nzmask, flat));
-    LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 8) * 4));  // counts, total, then the u64 selected-position counter
+    LHGT_HIP(hipMalloc(&ctx->d_tile_good, tiles.size() + 8));
+    LHGT_HIP(hipMalloc(&ctx->d_active_tiles, (tiles.size() + 1) * 4));
+    LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 16) * 4));  // counts, total, then small counters (selected positions, active tiles, saturated lines)
     LHGT_HIP(hipMemcpy(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice));
     LHGT_HIP(hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice));
     return LHGT_OK;

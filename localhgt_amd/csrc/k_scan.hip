@@ -4,12 +4,13 @@
 // The reference walks every contig sequentially; here each step is restated as an
 // order-independent per-position rule over tiles of TILE positions (TILE % 50 == 0):
 //   B1 ref_flags      single/trio from the e gathered counts                     (E:573-595, 933-945)
-//   B2 window_peak    500-wide window sums -> good-window bit; 5-wide contrast   (E:597-615, 644-671)
-//   B3 interval_mask  "inside a merged good interval" from the nearest good       (E:617-638, 675-686)
-//                     window on each side; first-peak-of-its-50bp-bucket flags     (E:288-301)
+//   B2 window_good    500-wide window sums -> good-window bit, per-tile summary    (E:597-615)
+//   B3 interval_select "inside a merged good interval" from the nearest good      (E:617-638, 675-686)
+//                     window on each side; 5-wide contrast peaks inside it        (E:644-671)
+//                     and first-peak-of-its-50bp-bucket flags                      (E:288-301)
 //   B4 tile_scan      exclusive scan of new-peak counts = sequential peak ids     (E:232-235, 275)
 //   B5 register       peak_loci + peak_kmer[h] = max id (ids grow in write order) (E:247-267)
-// flags byte per reference position: bit0 single, bit1 trio, bit2 good window, bit3 peak,
+// flags byte per reference position: bit0 single, bit1 trio, bit2 good window, bit3 peak (computed inside intervals only),
 // bit4 inside a good interval, bit5 selected (peak & interval), bit6 new peak.
 #include "lhgt_hash.hpp"
 
@@ -25,10 +26,32 @@ __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uin
     return (T[h >> 4] >> ((h & 15u) * 2u)) & 3u;
 }
 
+// ---- B0: one bit per 64-byte line of the count table (256 slots): every slot of the line holds 3.  When most lines are like
+// that (a deep sample saturates the table: 100 M pairs put 71 G increments on 4.3 G slots), ref_flags asks this 2 MiB,
+// L2-resident bitmap first and touches HBM only for the mixed lines.
+__global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __restrict__ counts, size_t n_lines, uint32_t* __restrict__ satline,
+                                                          unsigned long long* __restrict__ n_sat) {
+    size_t line = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool sat = false;
+    if (line < n_lines) {
+        const uint4* p = (const uint4*)(counts + line * 16);
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        sat = (a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) == 0xffffffffu;
+    }
+    unsigned long long bal = __ballot(sat);
+    if ((threadIdx.x & 63) == 0 && line < n_lines) {
+        satline[line >> 5] = (uint32_t)bal;            // lines of this wave: 64 consecutive -> two words
+        satline[(line >> 5) + 1] = (uint32_t)(bal >> 32);
+        if (bal) atomicAdd(n_sat, (unsigned long long)__popcll(bal));
+    }
+}
+
 // ---- B1
+template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                 const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
-                                                int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ nzmask) {
+                                                int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ nzmask,
+                                                const uint32_t* __restrict__ satline) {
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
@@ -41,7 +64,11 @@ __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tile
             int hc = 0;
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;  // hash 0 = invalid (E:936-941)
+                uint32_t cnt = 0u;                                 // hash 0 = invalid (E:936-941)
+                if (h != 0) {
+                    if (SAT && ((satline[h >> 13] >> ((h >> 8) & 31u)) & 1u)) cnt = 3u;   // the whole 256-slot line is saturated
+                    else cnt = count_of(counts, h);
+                }
                 if (cnt == 3u) hc++;                               // least_depth 3 (E:580)
                 if (cnt > 0u && i < 8) nz |= (uint8_t)(1u << i);    // record_ref_hit > 0 (E:250, 265), reused by register_peaks
             }
@@ -62,23 +89,19 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
     return s;
 }
 
-// ---- B2
-// The contrast test of E:644-671 in closed form.  With W5[t] = singles over t-4..t, the literal update of
-// `left` (E:658) telescopes to left_m = W5[j-5] + W5[j-m-5] - W5[j-k-5], so
-//   the test run AT j marks j       iff  W5[j-5] - W5[j-k-5] - W5[j] + min_{m in [k,2k)} W5[j-m-5] <= -2
-//   a test run at j' = j+m+5 marks j iff  W5[j] + max_{t in [j+k, j+2k)} (W5[t] - W5[t-k] - W5[t+5]) >= 2
-// (t = j+m; tests exist only for 2k+10 < j' < len).  Both are sliding-window extrema of width k; a thread
-// owns 8 consecutive positions and shares the part of the window they have in common.
-__global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                  int k, int one_min, int three_min, uint8_t* __restrict__ flags) {
+// ---- B2: good-window bit per position (E:597-615) and one byte per tile saying whether the tile has any.
+__global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                  int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good) {
     __shared__ int P1[N2], P3[N2], part[BT];
-    __shared__ int8_t W[N2], G[N2];
+    __shared__ int any_good;
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
     uint8_t* F = flags + c.flat_base;
-    constexpr int CH = (N2 + BT - 1) / BT;
-    const int b = threadIdx.x * CH, en = b + CH < N2 ? b + CH : N2;
+    constexpr int NW = TILE + HL2;   // the window sums look back only
+    constexpr int CH = (NW + BT - 1) / BT;
+    const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
+    if (threadIdx.x == 0) any_good = 0;
     int s1 = 0, s3 = 0;
     for (int i = b; i < en; i++) {
         long pos = lo + i;
@@ -91,80 +114,72 @@ __global__ void __launch_bounds__(BT) window_peak(const TileDev* __restrict__ ti
     int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
     for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
     __syncthreads();
-    // no hit position in the tile or its halos: no good window and no contrast anywhere, and bits 2-3 of the flags
-    // ref_flags just wrote are already zero (most tiles of a large reference for a sparse sample)
-    if (P1[N2 - 1] == 0) return;
-    for (int i = threadIdx.x; i < N2; i += BT) W[i] = (int8_t)(i >= 5 ? P1[i] - P1[i - 5] : 0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < N2; i += BT) {
-        long jp = lo + i + 5;   // position of the test that uses t = i
-        bool ok = i >= k + 5 && i + 5 < N2 && jp > 2 * k + 10 && jp < len;
-        G[i] = (int8_t)(ok ? W[i] - W[i - k] - W[i + 5] : -100);
-    }
-    __syncthreads();
-    constexpr int PER = 8;
-    for (int blk = threadIdx.x; blk < TILE / PER; blk += BT) {
-        const int jj0 = blk * PER, i0 = jj0 + HL2;
-        // self test: window of W over [i-2k-4, i-k-5]; gather test: window of G over [i+k, i+2k-1]
-        const int sa = i0 - 2 * k - 4, sg = i0 + k;
-        int cmin = 127, cmax = -128;
-        for (int q = PER - 1; q < k; q++) {          // part shared by the 8 windows
-            int w = W[sa + q], g = G[sg + q];
-            cmin = w < cmin ? w : cmin;
-            cmax = g > cmax ? g : cmax;
-        }
-        int lmin[PER], lmax[PER], rmin[PER], rmax[PER];
-        lmin[PER - 1] = 127; lmax[PER - 1] = -128;   // suffix extrema of the first PER-1 values
-#pragma unroll
-        for (int q = PER - 2; q >= 0; q--) {
-            int w = W[sa + q], g = G[sg + q];
-            lmin[q] = w < lmin[q + 1] ? w : lmin[q + 1];
-            lmax[q] = g > lmax[q + 1] ? g : lmax[q + 1];
-        }
-        rmin[0] = 127; rmax[0] = -128;               // prefix extrema of the PER-1 values after the shared part
-#pragma unroll
-        for (int q = 1; q < PER; q++) {
-            int w = W[sa + k + q - 1], g = G[sg + k + q - 1];
-            rmin[q] = w < rmin[q - 1] ? w : rmin[q - 1];
-            rmax[q] = g > rmax[q - 1] ? g : rmax[q - 1];
-        }
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const long j = (long)t.j0 + jj0 + q;
+    int mine = 0;
+    if (P1[NW - 1] >= one_min && P3[NW - 1] >= three_min) {   // otherwise no window of this tile can reach the thresholds
+        for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+            long j = (long)t.j0 + jj;
             if (j >= len) break;
-            const int i = i0 + q;
+            const int i = jj + HL2;
             int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
-            int good = one >= one_min && three >= three_min;
-            int mn = lmin[q] < cmin ? lmin[q] : cmin;
-            mn = rmin[q] < mn ? rmin[q] : mn;
-            int mx = lmax[q] > cmax ? lmax[q] : cmax;
-            mx = rmax[q] > mx ? rmax[q] : mx;
-            int peak = (j > 2 * k + 10 && W[i - 5] - W[i - k - 5] - W[i] + mn <= -2) || (W[i] + mx >= 2);
-            F[j] = (uint8_t)((F[j] & 3) | (good << 2) | (peak << 3));
+            if (one >= one_min && three >= three_min) {
+                F[j] = (uint8_t)((F[j] & 3) | 4);
+                mine = 1;
+            }
         }
     }
+    if (mine) any_good = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_good[blockIdx.x] = (uint8_t)any_good;
 }
 
-// ---- B3
-// Good-window bits of [j0-2560, j0+TILE+2560) as one ballot word per 64 positions; the nearest good window on
-// either side of a position is a clz/ctz inside its word or the carry of the neighbouring word.
+// ---- B3: interval mask, contrast peaks inside it, new-peak flags.
+// (1) Good-window bits of [j0-2560, j0+TILE+2560) as one ballot word per 64 positions; the nearest good window on either side
+//     of a position is a clz/ctz inside its word or the carry of a neighbouring word; "inside a merged interval" follows
+//     (E:617-638, 675-686).  Tiles with no good window in themselves or their two neighbours on either side stop after reading
+//     five bytes: nothing of them can be inside.
+// (2) The contrast test of E:644-671 in closed form, only for tiles that have positions inside an interval (peaks elsewhere are
+//     never looked at, E:688-692).  With W5[t] = singles over t-4..t, the literal update of `left` (E:658) telescopes to
+//     left_m = W5[j-5] + W5[j-m-5] - W5[j-k-5], so
+//       the test run AT j marks j       iff  W5[j-5] - W5[j-k-5] - W5[j] + min_{m in [k,2k)} W5[j-m-5] <= -2
+//       a test run at j' = j+m+5 marks j iff  W5[j] + max_{t in [j+k, j+2k)} (W5[t] - W5[t-k] - W5[t+5]) >= 2
+//     (t = j+m; tests exist only for 2k+10 < j' < len): sliding-window extrema of width k; a thread owns 8 consecutive
+//     positions and shares the part of the window they have in common.
 constexpr int H3 = 2560;                         // >= HALO3, multiple of 64
 constexpr int NW3 = (TILE + 2 * H3 + 63) / 64;   // ballot words per tile
-__global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count,
-                                                    unsigned long long* __restrict__ n_selected) {
+constexpr int HL4 = 96, HR4 = 80;                // halo of the contrast test: 2k+14 back, 2k+9 forward
+constexpr int N4 = TILE + HL4 + HR4;
+__global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restrict__ tiles, const uint8_t* __restrict__ tile_good, long n_tiles,
+                                                         uint32_t* __restrict__ active, unsigned int* __restrict__ n_active) {
+    long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q0 >= n_tiles) return;
+    const uint32_t contig = tiles[q0].contig;
+    bool reach = false;   // the 2560-position halo spans at most two tiles of the same contig on either side
+    for (long q = q0 - 2; q <= q0 + 2; q++)
+        if (q >= 0 && q < n_tiles && tiles[q].contig == contig && tile_good[q]) reach = true;
+    if (reach) active[atomicAdd(n_active, 1u)] = (uint32_t)q0;
+}
+
+// one workgroup per ACTIVE tile (a tile with a good window in itself or within two tiles: launching millions of workgroups
+// that return at once costs ~25 ns each in the dispatcher); tile_count of the others was zeroed by the caller
+__global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, int k,
+                                                      const uint32_t* __restrict__ active,
+                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count,
+                                                      unsigned long long* __restrict__ n_selected) {
     __shared__ unsigned long long gw[NW3];
     __shared__ int prevw[NW3], nextw[NW3];       // last good index in words <= w / first good index in words >= w
-    __shared__ uint8_t sel[TILE];
-    __shared__ int n_new, n_sel;
-    static_assert(H3 >= HALO3 && H3 % 64 == 0, "halo");
-    const TileDev t = tiles[blockIdx.x];
+    __shared__ int P1[N4], part[BT];
+    __shared__ int8_t W[N4], G[N4];
+    __shared__ uint8_t sel[TILE], ins[TILE];
+    __shared__ int n_new, n_sel, n_ins;
+    static_assert(H3 >= HALO3 && H3 % 64 == 0 && H3 <= 2 * TILE, "halo");
+    const uint32_t tile = active[blockIdx.x];
+    const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - H3;
     uint8_t* F = flags + c.flat_base;
     constexpr int NONE_LO = -(1 << 28), NONE_HI = 1 << 28;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { n_new = 0; n_sel = 0; }
+    if (threadIdx.x == 0) { n_new = 0; n_sel = 0; n_ins = 0; }
     for (int w = wv; w < NW3; w += BT / 64) {
         long pos = lo + 64L * w + lane;
         bool g = pos >= 0 && pos < len && ((F[pos] >> 2) & 1);
@@ -172,14 +187,6 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
         if (lane == 0) gw[w] = bal;
     }
     __syncthreads();
-    {   // no good window within reach: nothing of this tile is inside an interval, bits 4-6 stay zero
-        unsigned long long any = 0;
-        for (int w = 0; w < NW3; w++) any |= gw[w];   // LDS broadcast reads
-        if (!any) {
-            if (threadIdx.x == 0) tile_count[blockIdx.x] = 0u;
-            return;
-        }
-    }
     if (threadIdx.x == 0) {
         int last = NONE_LO;
         for (int w = 0; w < NW3; w++) {
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
     // merge rule closes: start_next - end_prev < window  <=>  next - prev <= 4*window + window (E:629)
     for (int jj = threadIdx.x; jj < TILE; jj += BT) {
         long j = (long)t.j0 + jj;
-        uint8_t s = 0;
+        uint8_t inside = 0;
         if (j < len) {
             const int i = jj + H3, w = i >> 6, bpos = i & 63;
             const unsigned long long word = gw[w];
@@ -206,13 +213,92 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
             const int p = below ? 64 * w + 63 - __clzll((long long)below) : (w > 0 ? prevw[w - 1] : NONE_LO);
             const int n = above ? 64 * w + __ffsll((long long)above) - 1 : (w + 1 < NW3 ? nextw[w + 1] : NONE_HI);
             const int dp = i - p, dn = n - i;   // huge when absent
-            int inside = j >= 1 && (dp <= 2 * WINDOW || dn <= 2 * WINDOW || dp + dn <= 5 * WINDOW);
-            uint8_t f = F[j];
-            s = inside && ((f >> 3) & 1);
-            F[j] = (uint8_t)((f & 15) | (inside << 4) | (s << 5));
+            inside = j >= 1 && (dp <= 2 * WINDOW || dn <= 2 * WINDOW || dp + dn <= 5 * WINDOW);
         }
-        sel[jj] = s;
-        if (s) atomicAdd(&n_sel, 1);
+        ins[jj] = inside;
+        sel[jj] = 0;
+        if (inside) n_ins = 1;
+    }
+    __syncthreads();
+    if (!n_ins) {
+        if (threadIdx.x == 0) tile_count[tile] = 0u;
+        return;
+    }
+    // contrast peaks
+    {
+        const long lo4 = (long)t.j0 - HL4;
+        constexpr int CH = (N4 + BT - 1) / BT;
+        const int b = threadIdx.x * CH, en = b + CH < N4 ? b + CH : N4;
+        int s1 = 0;
+        for (int i = b; i < en; i++) {
+            long pos = lo4 + i;
+            s1 += (pos >= 0 && pos < len) ? (F[pos] & 1) : 0;
+            P1[i] = s1;
+        }
+        int o1 = block_excl_sum(s1, part);
+        for (int i = b; i < en; i++) P1[i] += o1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < N4; i += BT) W[i] = (int8_t)(i >= 5 ? P1[i] - P1[i - 5] : 0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < N4; i += BT) {
+            long jp = lo4 + i + 5;   // position of the test that uses t = i
+            bool ok = i >= k + 5 && i + 5 < N4 && jp > 2 * k + 10 && jp < len;
+            G[i] = (int8_t)(ok ? W[i] - W[i - k] - W[i + 5] : -100);
+        }
+        __syncthreads();
+        constexpr int PER = 8;
+        for (int blk = threadIdx.x; blk < TILE / PER; blk += BT) {
+            const int jj0 = blk * PER, i0 = jj0 + HL4;
+            bool need = false;
+#pragma unroll
+            for (int q = 0; q < PER; q++) need |= ins[jj0 + q] != 0;
+            if (!need) continue;
+            // self test: window of W over [i-2k-4, i-k-5]; gather test: window of G over [i+k, i+2k-1]
+            const int sa = i0 - 2 * k - 4, sg = i0 + k;
+            int cmin = 127, cmax = -128;
+            for (int q = PER - 1; q < k; q++) {          // part shared by the 8 windows
+                int w = W[sa + q], g = G[sg + q];
+                cmin = w < cmin ? w : cmin;
+                cmax = g > cmax ? g : cmax;
+            }
+            int lmin[PER], lmax[PER], rmin[PER], rmax[PER];
+            lmin[PER - 1] = 127; lmax[PER - 1] = -128;   // suffix extrema of the first PER-1 values
+#pragma unroll
+            for (int q = PER - 2; q >= 0; q--) {
+                int w = W[sa + q], g = G[sg + q];
+                lmin[q] = w < lmin[q + 1] ? w : lmin[q + 1];
+                lmax[q] = g > lmax[q + 1] ? g : lmax[q + 1];
+            }
+            rmin[0] = 127; rmax[0] = -128;               // prefix extrema of the PER-1 values after the shared part
+#pragma unroll
+            for (int q = 1; q < PER; q++) {
+                int w = W[sa + k + q - 1], g = G[sg + k + q - 1];
+                rmin[q] = w < rmin[q - 1] ? w : rmin[q - 1];
+                rmax[q] = g > rmax[q - 1] ? g : rmax[q - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const long j = (long)t.j0 + jj0 + q;
+                if (j >= len || !ins[jj0 + q]) continue;
+                const int i = i0 + q;
+                int mn = lmin[q] < cmin ? lmin[q] : cmin;
+                mn = rmin[q] < mn ? rmin[q] : mn;
+                int mx = lmax[q] > cmax ? lmax[q] : cmax;
+                mx = rmax[q] > mx ? rmax[q] : mx;
+                int peak = (j > 2 * k + 10 && W[i - 5] - W[i - k - 5] - W[i] + mn <= -2) || (W[i] + mx >= 2);
+                sel[jj0 + q] = (uint8_t)peak;
+            }
+        }
+        __syncthreads();
+    }
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= len) break;
+        if (ins[jj]) {
+            const uint8_t s = sel[jj];
+            F[j] = (uint8_t)((F[j] & 7) | (s << 3) | (1 << 4) | (s << 5));   // peak (inside intervals only), inside, selected
+            if (s) atomicAdd(&n_sel, 1);
+        }
     }
     __syncthreads();
     // a selected position opens a new peak iff it is the first selected one of its 50-bp bucket (E:296)
@@ -228,7 +314,7 @@ __global__ void __launch_bounds__(BT) interval_mask(const TileDev* __restrict__ 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        tile_count[blockIdx.x] = (uint32_t)n_new;
+        tile_count[tile] = (uint32_t)n_new;
         if (n_sel) atomicAdd(n_selected, (unsigned long long)n_sel);
     }
 }
@@ -386,13 +472,42 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
     int three_min = (int)(WINDOW * match_ratio);
     dim3 grid((unsigned)ctx->n_tiles), blk(BT);
+    // line summary of the count table (one streaming pass, ~0.3 ms per GiB); used when at least half the lines are saturated
+    bool use_sat = false;
+    const size_t n_lines = ctx->counts_words / 16;
+    if (n_lines >= 64 && !(ctx->debug & 64)) {
+        if (!ctx->d_satline) LHGT_HIP(hipMalloc(&ctx->d_satline, n_lines / 8 + 16));
+        unsigned long long* d_nsat = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L)) + 2;
+        LHGT_HIP(hipMemsetAsync(d_nsat, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(table_line_summary, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_counts, n_lines,
+                           ctx->d_satline, d_nsat);
+        unsigned long long n_sat = 0;
+        LHGT_HIP(hipMemcpyAsync(&n_sat, d_nsat, 8, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        use_sat = 2 * n_sat >= n_lines;
+    }
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
-    hipLaunchKernelGGL(ref_flags, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
+    if (use_sat)
+        hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                           ctx->d_nzmask, ctx->d_satline);
+    else
+        hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                           ctx->d_nzmask, ctx->d_satline);
     LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
-    hipLaunchKernelGGL(window_peak, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, one_min, three_min, ctx->d_flags);
+    hipLaunchKernelGGL(window_good, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good);
     unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));
     LHGT_HIP(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(interval_mask, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_flags, ctx->d_tile_count, d_nsel);
+    unsigned int* d_nact = (unsigned int*)(d_nsel + 1);
+    LHGT_HIP(hipMemsetAsync(d_nact, 0, 4, ctx->stream));
+    LHGT_HIP(hipMemsetAsync(ctx->d_tile_count, 0, (size_t)(ctx->n_tiles + 1) * 4, ctx->stream));
+    hipLaunchKernelGGL(mark_active_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_tile_good,
+                       ctx->n_tiles, ctx->d_active_tiles, d_nact);
+    unsigned int n_active = 0;
+    LHGT_HIP(hipMemcpyAsync(&n_active, d_nact, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_active)
+        hipLaunchKernelGGL(interval_select, dim3(n_active), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, ctx->d_active_tiles,
+                           ctx->d_flags, ctx->d_tile_count, d_nsel);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipMemcpyAsync(total_new, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -411,13 +526,21 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
     LHGT_HIP(hipMemsetAsync(ctx->d_peak_kmer, 0, slots * 4, ctx->stream));  // E:1458
-    // vote prefilter (k_vote.hip): a bitmap of min(k, PF_BITS) address bits (exact below PF_BITS, folded above),
-    // worth it while at most ~1/8 of its bits would be set
-    const int pf_bits = ctx->k < PF_BITS ? ctx->k : PF_BITS;
+    // vote prefilter (k_vote.hip): a bitmap over the low pf_bits address bits (exact when pf_bits = k, folded otherwise).
+    // Sized at >= 16 bits per registered k-mer (false positives <= 6 %) but no larger: a 4 MiB bitmap does not stay
+    // resident in a 4 MiB L2 next to the read stream (21 % of its probes missed), a 256 KiB one does.
+    const int pf_max = ctx->k < PF_BITS ? ctx->k : PF_BITS;
+    const unsigned long long n_keys = n_selected * (unsigned long long)ctx->e;
+    int pf_bits = 19;
+    while (pf_bits < pf_max && (1ull << pf_bits) < 16 * n_keys) pf_bits++;
+    if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
-    ctx->prefilter_on = !(ctx->debug & 4) && n_selected * (unsigned long long)ctx->e <= (1ull << pf_bits) / 8;
+    ctx->prefilter_on = !(ctx->debug & 4) && n_keys <= (1ull << pf_bits) / 8;
     if (ctx->prefilter_on) {
-        if (!ctx->d_prefilter) LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
+        if (!ctx->d_prefilter) {
+            LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
+            LHGT_HIP(hipMalloc(&ctx->d_prefilter_fold, (size_t)64 * 1024));
+        }
         LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ((size_t)1 << pf_bits) / 8, ctx->stream));
     }
     if ((long)total + 1 > ctx->peaks_cap) {     // grow-only: no allocator traffic in steady state

@@ -10,6 +10,9 @@
 
 namespace lhgt {
 
+constexpr int LF_BITS = 19;                 // LDS-resident fold of the vote prefilter: 2^19 bits = 64 KiB
+constexpr int LF_WORDS = (1 << LF_BITS) / 32;
+
 // Per-wave LDS: events[max_ev][e] of (peak id, contig); the contig of a hit is fetched by the lane
 // that found it.  judge_base then runs out of registers: lane l holds events l, l+64, .. of the
 // current 64-event chunk and entries l, l+64, .. of the contig table (TR registers deep); an event
@@ -119,15 +122,15 @@ __device__ __forceinline__ void judge_pair(const uint32_t* ev, int n_ev, int e_r
 // Any read length up to 500, probes of one 64-offset slice at a time.  PF: consult the L2-resident folded bitmap
 // first (exact negatives: a clear bit means no slot folding onto it holds a peak), so sparse peak sets never
 // touch the 16 GiB peak_kmer array except for true hits and the few false positives.
-template <int TR, bool PF, bool NT>
+template <int TR, int PF, bool NT>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
-                                                   const uint32_t* __restrict__ prefilter,
+                                                   const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
                                                    int max_ev, int waves_per_block, int debug, uint32_t pf_mask) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    if (wib >= waves_per_block) return;
     const int e = hp.e, k = hp.k;
+    if (wib >= waves_per_block) return;
     uint32_t* ev = lds + (size_t)wib * max_ev * e * 2;
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                     for (int i = 0; i < 9; i++)
                         if (i < e) {
                             const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
-                            if (PF) {
+                            if (PF == 1) {
                                 const uint32_t fb = h & pf_mask;
                                 ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? peak_kmer[h] : 0u;
                             } else if (NT) {   // tables of 1 GiB and more (k >= 28): nothing to keep in the caches
@@ -184,6 +187,124 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
         else judge_pair<TR, 0>(ev, n_ev, e, lane, filter);
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Sparse-path form (prefilter on, <= 128 k-mer offsets per mate, e <= 3).  The generic kernel walks a pair slice by slice
+// and every slice costs three dependent round trips; when the probes are cache hits that chain, not bandwidth, is the cost.
+// Here the pair's four slices are handled together: all window words in flight at once, then all 12 filter probes at once,
+// then the rare peak_kmer / contig loads.
+template <int PF>
+__global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
+                                                                           const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
+                                                                           const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
+                                                                           int max_ev, int waves_per_block, int debug, uint32_t pf_mask) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int e = hp.e, k = hp.k;
+    const uint32_t* lfilter = lds;
+    if (PF == 2) {
+        for (int i = threadIdx.x; i < LF_WORDS; i += blockDim.x) lds[i] = lds_fold[i];
+        __syncthreads();
+    }
+    if (wib >= waves_per_block) return;
+    uint32_t* ev = lds + (PF == 2 ? LF_WORDS : 0) + (size_t)wib * max_ev * e * 2;
+    const long wave = (long)blockIdx.x * waves_per_block + wib;
+    const long n_waves = (long)gridDim.x * waves_per_block;
+    for (long p = wave; p < b.n_pairs; p += n_waves) {
+        int nk[2], wpr[2];
+        const uint32_t* rec[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int len = b.len[m][p];
+            nk[m] = len - k + 1;
+            wpr[m] = ((len + 31) >> 5) + 1;
+            rec[m] = b.words + b.off[m][p];
+        }
+        uint32_t w[4][6];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int m = s >> 1, j = (s & 1) * 64 + lane;
+            const uint32_t* q = rec[m] + (j < nk[m] ? (j >> 5) : 0);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {   // branch-free: out-of-range lanes re-read the record's first words
+                w[s][2 * pl] = q[pl * wpr[m]];
+                w[s][2 * pl + 1] = q[pl * wpr[m] + 1];
+            }
+        }
+        uint32_t hs[4][3], ids[4][3];
+        bool ok[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
+            auto win = [&](uint32_t a, uint32_t c) { return (uint32_t)(((((uint64_t)a << 32) | c) << r) >> 32) >> (32 - k); };
+            const uint32_t whi = win(w[s][0], w[s][1]), wlo = win(w[s][2], w[s][3]), wnb = win(w[s][4], w[s][5]);
+            const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+            ok[s] = j < nk[m] && wnb == 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) hs[s][i] = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
+        }
+        // first filter level for all 12 hashes, then the second, then the table itself: each level only for survivors
+        uint32_t f1[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const uint32_t h = hs[s][i];
+                if (PF == 2) { const uint32_t lb = h & ((1u << LF_BITS) - 1u); f1[s][i] = (lfilter[lb >> 5] >> (lb & 31u)) & 1u; }
+                else { const uint32_t fb = h & pf_mask; f1[s][i] = (prefilter[fb >> 5] >> (fb & 31u)) & 1u; }
+                if (!(ok[s] && i < e)) f1[s][i] = 0u;
+            }
+        if (PF == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if (f1[s][i]) { const uint32_t fb = hs[s][i] & pf_mask; f1[s][i] = (prefilter[fb >> 5] >> (fb & 31u)) & 1u; }
+        }
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                ids[s][i] = f1[s][i] ? peak_kmer[hs[s][i]] : 0u;   // 0 = no peak (E:454)
+                any |= ids[s][i] != 0u;
+            }
+        if (!__ballot(any)) continue;   // the usual case on the sparse path: no lane of the pair hit anything
+        int n_ev = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {   // slices in offset order: mate 1 (0..63, 64..127), mate 2 (E:430-495)
+            bool hit = false;
+#pragma unroll
+            for (int i = 0; i < 3; i++) hit |= ids[s][i] != 0u;
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+                if (hit) {
+                    const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                        if (i < e) {
+                            ev[((size_t)slot * e + i) * 2] = ids[s][i];
+                            ev[((size_t)slot * e + i) * 2 + 1] = ids[s][i] ? (uint32_t)loci[2 * (long)ids[s][i]] : 0u;
+                        }
+                }
+                n_ev += __popcll(bal);
+            }
+        }
+        if (n_ev < 6 || (debug & 1)) continue;
+        __builtin_amdgcn_wave_barrier();
+        if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
+        else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// 64 KiB fold of the 2^PF_BITS-bit bitmap: word w = OR of the bitmap words w, w + LF_WORDS, ... (same low address bits)
+__global__ void __launch_bounds__(256) fold_prefilter(const uint32_t* __restrict__ prefilter, int words, uint32_t* __restrict__ fold) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= LF_WORDS) return;
+    uint32_t acc = 0;
+    for (int j = w; j < words; j += LF_WORDS) acc |= prefilter[j];
+    fold[w] = acc;
 }
 
 // phase D helper: peaks with at least MIN_READS (1, E:37) votes, as (id, contig, pos) in any order;
@@ -221,20 +342,42 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (wpb < 1) wpb = 1;
         long blocks = (b.d.n_pairs + wpb - 1) / wpb;
         if (blocks > 256L * 16) blocks = 256L * 16;
-#define LHGT_VOTE(TR_, PF_, NT_)                                                                                          \
-    hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, \
-                       ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask)
+#define LHGT_VOTE(TR_, PF_, NT_, THREADS_, LDS_)                                                                           \
+    hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
+                       ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
+                       ctx->debug, ctx->pf_mask)
         const bool nt = ctx->k >= 28;
-        if (max_ev <= 256) {
-            if (ctx->prefilter_on) LHGT_VOTE(4, true, false);
-            else if (nt) LHGT_VOTE(4, false, true);
-            else LHGT_VOTE(4, false, false);
+        // sparse peak sets on a folded (k > PF_BITS) bitmap: 16-wave workgroups that keep a 64 KiB fold of it in LDS
+        const size_t lds2 = (size_t)LF_WORDS * 4 + 16 * per_wave;
+        const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
+#define LHGT_VOTE_SPARSE(PF_, THREADS_, LDS_)                                                                                  \
+    hipLaunchKernelGGL((vote_kernel_sparse<PF_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,     \
+                       ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
+                       ctx->debug, ctx->pf_mask)
+        if (sparse_ok && ctx->k > PF_BITS && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {   // LDS first level (495 vs 530 ms on configs[2])
+            wpb = 16;
+            blocks = (b.d.n_pairs + wpb - 1) / wpb;
+            if (blocks > 256) blocks = 256;     // one resident workgroup per CU
+            static bool attr_set = false;
+            if (!attr_set) {
+                LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold);
+            LHGT_VOTE_SPARSE(2, 1024, lds2);
+        } else if (sparse_ok) {
+            LHGT_VOTE_SPARSE(1, 64 * wpb, per_wave * wpb);
+        } else if (max_ev <= 256) {
+            if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
+            else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);
+            else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave * wpb);
         } else {
-            if (ctx->prefilter_on) LHGT_VOTE(16, true, false);
-            else if (nt) LHGT_VOTE(16, false, true);
-            else LHGT_VOTE(16, false, false);
+            if (ctx->prefilter_on) LHGT_VOTE(16, 1, false, 64 * wpb, per_wave * wpb);
+            else if (nt) LHGT_VOTE(16, 0, true, 64 * wpb, per_wave * wpb);
+            else LHGT_VOTE(16, 0, false, 64 * wpb, per_wave * wpb);
         }
 #undef LHGT_VOTE
+#undef LHGT_VOTE_SPARSE
     }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -102,6 +102,9 @@ struct lhgt_ctx {
     uint64_t n_pos = 0;
     bool index_resident = false;  // an index (possibly with zero contigs longer than k) has been installed
     uint8_t* d_flags = nullptr;
+    uint32_t* d_satline = nullptr;   // one bit per 64-byte line of the count table: all 256 slots hold 3
+    uint8_t* d_tile_good = nullptr;  // per tile: it contains a good window
+    uint32_t* d_active_tiles = nullptr;  // tiles with a good window within reach (compacted per scan)
     uint8_t* d_nzmask = nullptr;  // per position: bit i = hash i has a non-zero count (E:250's `record_ref_hit > 0`)
     // reads
     std::vector<lhgt::ReadBatch> batches;
@@ -113,6 +116,7 @@ struct lhgt_ctx {
     uint32_t* d_tile_count = nullptr;
     long n_peaks = -1, max_peak = 0;
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
+    uint32_t* d_prefilter_fold = nullptr;  // 64 KiB fold of it, copied into LDS by the sparse-path vote kernel
     bool prefilter_on = false;
     uint32_t pf_mask = 0;             // low address bits indexing the prefilter
     unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan

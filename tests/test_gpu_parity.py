@@ -96,8 +96,11 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
                                          case.max_peak, pk_o, flags_o)
         n_g = eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak)
         flags_g = eng.flags_export(0, n_bases)
-        assert ((flags_g & 0b1011) == (flags_o & 0b1011)).all(), "single/trio/peak flags differ"
-        assert (((flags_g >> 4) & 1) == ((flags_o >> 2) & 1)).all(), "good-interval mask differs"
+        assert ((flags_g & 0b0011) == (flags_o & 0b0011)).all(), "single/trio flags differ"
+        inside_o = (flags_o >> 2) & 1
+        assert (((flags_g >> 4) & 1) == inside_o).all(), "good-interval mask differs"
+        # the contrast peak flag is only computed (and only ever used, E:688-692) inside good intervals
+        assert (((flags_g >> 3) & 1) == (((flags_o >> 3) & 1) & inside_o)).all(), "peak flags differ"
         assert n_g == n_o == meta["raw_peaks"]
         loci_g, _ = eng.peaks_export(n_g)
         assert (loci_g == loci_o[:2 * n_o]).all()
@@ -304,15 +307,16 @@ def test_vote_prefilter_changes_nothing(Engine):
         eng.synth_pairs(3, 4, 16, 100_000, 0, 60_000)
         eng.count_kmers()
         votes = []
-        for flags in (0, 4):
+        for flags in (0, 16, 32, 4):  # batched sparse kernel, + LDS first level, generic kernel with bitmap, no prefilter
             eng.set_debug(flags)
             n = eng.ref_scan(0.1, 0.08, 10**7)
             eng.vote()
             loci, v = eng.peaks_export(n)
             votes.append((n, loci.copy(), v.copy()))
         eng.set_debug(0)
-    assert votes[0][0] == votes[1][0] > 50
-    assert (votes[0][1] == votes[1][1]).all() and (votes[0][2] == votes[1][2]).all()
+    assert votes[0][0] == votes[1][0] == votes[2][0] == votes[3][0] > 50
+    for other in votes[1:]:
+        assert (votes[0][1] == other[1]).all() and (votes[0][2] == other[2]).all()
     assert votes[0][2].max() >= 1
 
 
@@ -383,3 +387,38 @@ def test_whole_run_matches_oracle_for_unusual_e(oracle, case_inputs, tmp_path, k
         outs[who] = (open(interval).read(), open(fa2 + ".genome.len.txt").read(), cases.sha256_file(f"{fa2}.k{k}.h{e}.index.dat"))
     assert outs["gpu"] == outs["cpu"]
     assert rep["n_peaks"] == orep.n_peaks and rep["pairs_kept"] == orep.pairs_voted
+
+
+def test_saturated_table_line_summary(Engine, oracle, case_inputs, tmp_path):
+    """a table that the reads saturate (k = 16): ref_flags answers from the saturated-line bitmap; same flags, peaks and
+    interval file as without it and as the oracle"""
+    from localhgt_amd import extract_ref
+    fa, f1, f2, _ = case_inputs("k24_base")
+    k, e = 16, 3
+    outs = {}
+    for who in ("gpu", "cpu"):
+        d = tmp_path / who
+        d.mkdir()
+        fa2 = str(d / "ref.fa")
+        shutil.copy(fa, fa2)
+        interval = str(d / "i.txt")
+        if who == "gpu":
+            extract_ref.run(extract_ref.parse_argv([f1, f2, fa2, interval, "0.1", "0.08", "1", str(k), "100000", str(e), "1", "1"]), log=lambda *a: None)
+        else:
+            assert oracle.run(f1, f2, fa2, interval, 0.1, 0.08, 1, k, 100000, e, 1, 1.0)[0] == 0
+        outs[who] = open(interval).read()
+    assert outs["gpu"] == outs["cpu"]
+    index = str(tmp_path / "gpu" / f"ref.fa.k{k}.h{e}.index.dat")
+    with Engine(k, e) as eng:
+        _, n_bases = eng.index_load(index)
+        eng.sampling_init(100.0)
+        eng.pairs_load_fastq(f1, f2, 100.0)
+        eng.count_kmers()
+        hist = eng.counts_histogram()
+        assert hist[3] > 0.9 * (1 << k), "the case is meant to saturate the table"
+        res = []
+        for flags in (0, 64):
+            eng.set_debug(flags)
+            n = eng.ref_scan(0.1, 0.08, 100000)
+            res.append((n, eng.flags_export(0, n_bases).copy(), eng.peaks_export(n)[0].copy()))
+        assert res[0][0] == res[1][0] and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()

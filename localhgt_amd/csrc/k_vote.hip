@@ -220,17 +220,28 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
             wpr[m] = ((len + 31) >> 5) + 1;
             rec[m] = b.words + b.off[m][p];
         }
+        // LDS-staged windows: the wave fetches each read's record (3 planes x wpr words, <= 18 words for 159 bases) with one
+        // coalesced load and every lane cuts its windows out of LDS -- 2 vector-memory instructions per pair instead of 24.
+        // (Prefetching the next pair's metadata and words one iteration ahead was tried and was slower.)
+        uint32_t* stage = ev;   // the event area is free until the compaction below
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int nw = 3 * wpr[m];
+            if (lane < nw) stage[m * 32 + lane] = rec[m][lane];
+        }
+        __builtin_amdgcn_wave_barrier();
         uint32_t w[4][6];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int m = s >> 1, j = (s & 1) * 64 + lane;
-            const uint32_t* q = rec[m] + (j < nk[m] ? (j >> 5) : 0);
+            const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {   // branch-free: out-of-range lanes re-read the record's first words
+            for (int pl = 0; pl < 3; pl++) {
                 w[s][2 * pl] = q[pl * wpr[m]];
                 w[s][2 * pl + 1] = q[pl * wpr[m] + 1];
             }
         }
+        __builtin_amdgcn_wave_barrier();
         uint32_t hs[4][3], ids[4][3];
         bool ok[4];
 #pragma unroll
@@ -337,6 +348,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (nk <= 0) continue;
         int max_ev = 2 * nk;
         size_t per_wave = (size_t)max_ev * ctx->e * 2 * 4;
+        if (per_wave < 256) per_wave = 256;   // the sparse kernel stages both reads' words (2 x 32) in the event area
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;

@@ -41,18 +41,23 @@ __host__ inline PartGeom part_geom(int k) {
     return g;
 }
 
-// keys of read (m, p) at offsets lane, lane+64, ...: calls f(key) for each of the e hashes of valid k-mers
+// keys of read (m, p) at offsets lane, lane+64, ...: calls f(key) for each of the e hashes of valid k-mers.
+// LDS-staged windows: the wave fetches the read's record (3 planes x wpr words, <= 51 words for 500 bases) with one coalesced
+// load into its 64-word LDS area `stage`, and every lane cuts its windows out of LDS (instead of 6 global loads per offset).
 template <class F>
-__device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashParams& hp, long p, int m, int lane, F f) {
+__device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashParams& hp, long p, int m, int lane, uint32_t* stage, F f) {
     if (m == 1 && b.count2 && !b.count2[p]) return;  // quirk Q4
     const int len = b.len[m][p];
     const int nk = len - hp.k + 1;
     if (nk <= 0) return;
     const int wpr = ((len + 31) >> 5) + 1;
     const uint32_t* rec = b.words + b.off[m][p];
+    __builtin_amdgcn_wave_barrier();                 // the previous read's windows have been cut
+    if (lane < 3 * wpr) stage[lane] = rec[lane];
+    __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < nk; j += 64) {
-        if (plane_window(rec + 2 * wpr, j, hp.k) != 0) continue;
-        uint32_t whi = plane_window(rec, j, hp.k), wlo = plane_window(rec + wpr, j, hp.k);
+        if (plane_window(stage + 2 * wpr, j, hp.k) != 0) continue;
+        uint32_t whi = plane_window(stage, j, hp.k), wlo = plane_window(stage + wpr, j, hp.k);
         uint32_t rhi = brev_k(whi, hp.k), rlo = brev_k(wlo, hp.k);
         for (int i = 0; i < hp.e; i++) f(hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]));
     }
@@ -61,14 +66,15 @@ __device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashPa
 // ---- P0: keys per final bucket for pairs [pair0, pair0+npairs)
 __global__ void __launch_bounds__(PT) part_hist(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
                                                 uint32_t* __restrict__ ghist) {
-    extern __shared__ uint32_t lh[];  // [g.nb]
+    extern __shared__ uint32_t lh[];  // [g.nb] histogram, then 64 staging words per wave
     for (int i = threadIdx.x; i < g.nb; i += PT) lh[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    uint32_t* stage = lh + g.nb + (threadIdx.x >> 6) * 64;
     const long wave = ((long)blockIdx.x * PT + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * PT) >> 6;
     const int sh = g.slot_bits;
     for (long r = wave; r < 2 * npairs; r += n_waves)
-        for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, [&](uint32_t key) { atomicAdd(&lh[g.nb > 1 ? key >> sh : 0], 1u); });
+        for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, [&](uint32_t key) { atomicAdd(&lh[g.nb > 1 ? key >> sh : 0], 1u); });
     __syncthreads();
     for (int i = threadIdx.x; i < g.nb; i += PT)
         if (lh[i]) atomicAdd(&ghist[i], lh[i]);
@@ -130,7 +136,9 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
                                                          int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
     __shared__ uint32_t sorted[TILE_KEYS];
     __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    __shared__ uint32_t stage_all[(PT / 64) * 64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint32_t* stage = stage_all + wib * 64;
     const int shift = g.k - g.b1;
     const uint32_t bmask = (uint32_t)g.nb1 - 1u;
     const long n_reads = 2 * npairs;
@@ -140,10 +148,10 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
         if (threadIdx.x < 128) hist[threadIdx.x] = 0;
         __syncthreads();
         for (long r = r0 + wib; r < r1; r += PT / 64)
-            for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
+            for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
         __syncthreads();
         tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, out, [&](auto emit) {
-            for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, emit);
+            for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, emit);
         });
     }
 }
@@ -155,7 +163,9 @@ __global__ void __launch_bounds__(PT) part_scatter_reads_reg(ReadBatchDev b, lon
                                                              int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
     __shared__ uint32_t sorted[TILE_KEYS];
     __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    __shared__ uint32_t stage_all[(PT / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint32_t* stage = stage_all + wib * 32;
     const int shift = g.b1 ? g.k - g.b1 : 0;
     const uint32_t bmask = g.b1 ? (uint32_t)g.nb1 - 1u : 0u;
     const int k = hp.k, e = hp.e;
@@ -178,11 +188,14 @@ __global__ void __launch_bounds__(PT) part_scatter_reads_reg(ReadBatchDev b, lon
             const int nk = len - k + 1;
             const int wpr = ((len + 31) >> 5) + 1;
             const uint32_t* rec = b.words + b.off[m][p];
+            __builtin_amdgcn_wave_barrier();             // the previous read's windows have been cut
+            if (lane < 3 * wpr) stage[lane] = rec[lane];  // one coalesced load per read, windows cut out of LDS
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int j = it * 64 + lane;
-                if (j >= nk || plane_window(rec + 2 * wpr, j, k) != 0) continue;
-                const uint32_t whi = plane_window(rec, j, k), wlo = plane_window(rec + wpr, j, k);
+                if (j >= nk || plane_window(stage + 2 * wpr, j, k) != 0) continue;
+                const uint32_t whi = plane_window(stage, j, k), wlo = plane_window(stage + wpr, j, k);
                 const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
 #pragma unroll
                 for (int i = 0; i < 3; i++)
@@ -326,10 +339,15 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     uint32_t* cur2 = off + 16384 + 1;
     uint32_t* cur1 = cur2 + 16384;
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
+    static bool hist_attr = false;
+    if (!hist_attr) {   // 64 KiB of histogram + per-wave staging words exceed the default dynamic-LDS limit
+        LHGT_HIP(hipFuncSetAttribute((const void*)part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        hist_attr = true;
+    }
     for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
         LHGT_HIP(hipMemsetAsync(ghist, 0, (size_t)g.nb * 4, ctx->stream));
-        hipLaunchKernelGGL(part_hist, dim3(grid), dim3(PT), (size_t)g.nb * 4, ctx->stream, b.d, p0, np, ctx->hp, g, ghist);
+        hipLaunchKernelGGL(part_hist, dim3(grid), dim3(PT), (size_t)g.nb * 4 + (PT / 64) * 256, ctx->stream, b.d, p0, np, ctx->hp, g, ghist);
         hipLaunchKernelGGL(part_offsets, dim3(1), dim3(1024), 0, ctx->stream, ghist, g, off, cur1, cur2);
         if (max_nk <= 128 && ctx->e <= 3) {
             int rpt = reads_per_tile < 16 * RW ? reads_per_tile : 16 * RW;

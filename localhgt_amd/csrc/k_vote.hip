@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
     if (wib >= waves_per_block) return;
-    uint32_t* ev = lds + (size_t)wib * max_ev * e * 2;
+    uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64);
+    uint32_t* stage = ev + (size_t)max_ev * e * 2;   // 64 words: the current read's record, staged once per read
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
     for (long p = wave; p < b.n_pairs; p += n_waves) {
@@ -142,12 +143,15 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
             if (nk <= 0) continue;
             const int wpr = ((len + 31) >> 5) + 1;
             const uint32_t* rec = b.words + b.off[m][p];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 3 * wpr) stage[lane] = rec[lane];     // <= 51 words for 500 bases, one coalesced load
+            __builtin_amdgcn_wave_barrier();
             for (int j0 = 0; j0 < nk; j0 += 64) {
                 const int j = j0 + lane;
                 uint32_t ids[9], chrs[9];
                 bool hit = false;
-                if (j < nk && plane_window(rec + 2 * wpr, j, k) == 0) {
-                    uint32_t whi = plane_window(rec, j, k), wlo = plane_window(rec + wpr, j, k);
+                if (j < nk && plane_window(stage + 2 * wpr, j, k) == 0) {
+                    uint32_t whi = plane_window(stage, j, k), wlo = plane_window(stage + wpr, j, k);
                     uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
 #pragma unroll
                     for (int i = 0; i < 9; i++)
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
         __syncthreads();
     }
     if (wib >= waves_per_block) return;
-    uint32_t* ev = lds + (PF == 2 ? LF_WORDS : 0) + (size_t)wib * max_ev * e * 2;
+    uint32_t* ev = lds + (PF == 2 ? LF_WORDS : 0) + (size_t)wib * (max_ev * e * 2 + 64);   // same per-wave stride as the generic kernel
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
     for (long p = wave; p < b.n_pairs; p += n_waves) {
@@ -347,8 +351,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
         int max_ev = 2 * nk;
-        size_t per_wave = (size_t)max_ev * ctx->e * 2 * 4;
-        if (per_wave < 256) per_wave = 256;   // the sparse kernel stages both reads' words (2 x 32) in the event area
+        size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words (the sparse kernel stages inside the event area)
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;

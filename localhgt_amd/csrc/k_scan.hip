@@ -319,23 +319,34 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
     }
 }
 
-// ---- B4: in-place exclusive scan of tile_count[0..n); total lands in tile_count[n]
+// ---- B4: in-place exclusive scan of tile_count[0..n); total lands in tile_count[n].  One 1024-thread block walks the
+// array in coalesced pieces of 1024 with a running carry (wave shuffles + 16 wave totals in LDS per piece).
 __global__ void __launch_bounds__(1024) tile_scan(uint32_t* __restrict__ v, long n) {
-    __shared__ unsigned long long part[1024];
-    long ch = (n + 1023) / 1024;
-    long b = threadIdx.x * ch, en = b + ch < n ? b + ch : n;
-    unsigned long long s = 0;
-    for (long i = b; i < en; i++) s += v[i];
-    part[threadIdx.x] = s;
+    __shared__ unsigned long long wtot[16];
+    __shared__ unsigned long long carry_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    unsigned long long off = 0;
-    for (int q = 0; q < (int)threadIdx.x; q++) off += part[q];
-    for (long i = b; i < en; i++) {
-        uint32_t x = v[i];
-        v[i] = (uint32_t)(off > 0xffffffffull ? 0xffffffffull : off);
-        off += x;
+    for (long base = 0; base < n; base += 1024) {
+        const long i = base + threadIdx.x;
+        const unsigned long long x = i < n ? v[i] : 0ull;
+        unsigned long long incl = x;
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        unsigned long long woff = 0;
+        for (int q = 0; q < wv; q++) woff += wtot[q];
+        const unsigned long long carry = carry_s;
+        const unsigned long long excl = carry + woff + incl - x;
+        if (i < n) v[i] = (uint32_t)(excl > 0xffffffffull ? 0xffffffffull : excl);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
     }
-    if (threadIdx.x == 1023) v[n] = (uint32_t)(off > 0xffffffffull ? 0xffffffffull : off);
+    if (threadIdx.x == 0) v[n] = (uint32_t)(carry_s > 0xffffffffull ? 0xffffffffull : carry_s);
 }
 
 // ---- B5

@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                                                      const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
-                                                     uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask) {
+                                                     uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2) {
     __shared__ int incl[TILE], part[BT];
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
                         const uint32_t fb = h & pf_mask;
-                        atomicOr(&prefilter[fb >> 5], 1u << (fb & 31u));
+                        atomicOr(&prefilter[fb >> 5], pf_word_bits(h, pf2));
                     }
                 }
             }
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ til
 
 // replay of gathered registrations on every rank
 __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ regs, long n, uint32_t* __restrict__ peak_kmer,
-                                                   uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask) {
+                                                   uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
         atomicMax(&peak_kmer[h], id);
         if (prefilter) {
             const uint32_t fb = h & pf_mask;
-            atomicOr(&prefilter[fb >> 5], 1u << (fb & 31u));
+            atomicOr(&prefilter[fb >> 5], pf_word_bits(h, pf2));
         }
     }
 }
@@ -546,7 +546,9 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     while (pf_bits < pf_max && (1ull << pf_bits) < 16 * n_keys) pf_bits++;
     if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
+    ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key
     ctx->prefilter_on = !(ctx->debug & 4) && n_keys <= (1ull << pf_bits) / 8;
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] peaks %u, registered positions %llu (%llu k-mers), prefilter 2^%d bits %s\n", total, n_selected, n_keys, pf_bits, ctx->prefilter_on ? "on" : "off");
     if (ctx->prefilter_on) {
         if (!ctx->d_prefilter) {
             LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
@@ -582,7 +584,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
                        ctx->d_counts, ctx->d_flags, ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -669,7 +671,7 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
         long blocks = (n_regs_all + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(replay_regs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_regs_all, n_regs_all,
-                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask);
+                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2);
         LHGT_HIP(hipGetLastError());
     }
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

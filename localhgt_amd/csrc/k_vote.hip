@@ -126,7 +126,7 @@ template <int TR, int PF, bool NT>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                    const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
-                                                   int max_ev, int waves_per_block, int debug, uint32_t pf_mask) {
+                                                   int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                             const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                             if (PF == 1) {
                                 const uint32_t fb = h & pf_mask;
-                                ids[i] = ((prefilter[fb >> 5] >> (fb & 31u)) & 1u) ? peak_kmer[h] : 0u;
+                                ids[i] = pf_pass(prefilter[fb >> 5], h, pf2) ? peak_kmer[h] : 0u;
                             } else if (NT) {   // tables of 1 GiB and more (k >= 28): nothing to keep in the caches
                                 // `nt`: +11 % probe rate on a table far beyond the caches (profiles/r01_probe_policy_microbench.txt)
                                 ids[i] = __builtin_nontemporal_load(peak_kmer + h);
@@ -193,15 +193,28 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     }
 }
 
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
 // Sparse-path form (prefilter on, <= 128 k-mer offsets per mate, e <= 3).  The generic kernel walks a pair slice by slice
 // and every slice costs three dependent round trips; when the probes are cache hits that chain, not bandwidth, is the cost.
-// Here the pair's four slices are handled together: all window words in flight at once, then all 12 filter probes at once,
-// then the rare peak_kmer / contig loads.
-template <int PF>
+// Here a wave handles NP pairs per iteration with their eight slices together: records staged in LDS by one coalesced load each,
+// all windows cut from LDS, all 12*NP first-level filter probes at once.  The survivors are then PACKED (wave prefix sum, LDS
+// queue) and the next levels probed with full-width loads: a gather instruction costs the memory pipeline the same whether 9
+// or 64 of its lanes are live (1.2e9 nine-lane gathers took 245 ms on configs[2], the instruction rate of full ones), so the
+// 12*NP sparse gathers per level become ceil(survivors / 64) dense ones.  Only an iteration in which some probe finds a peak
+// (or a queue overflows) falls back to the lane-per-offset form below, which rebuilds the hits in offset order for the judge.
+template <int PF, int NP>
 __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                                            const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                                            const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
-                                                                           int max_ev, int waves_per_block, int debug, uint32_t pf_mask) {
+                                                                           int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
@@ -211,105 +224,191 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
         __syncthreads();
     }
     if (wib >= waves_per_block) return;
-    uint32_t* ev = lds + (PF == 2 ? LF_WORDS : 0) + (size_t)wib * (max_ev * e * 2 + 64);   // same per-wave stride as the generic kernel
+    const int ev_words = max_ev * e * 2 > 64 * NP ? max_ev * e * 2 : 64 * NP;
+    uint32_t* ev = lds + (PF == 2 ? LF_WORDS : 0) + (size_t)wib * ev_words;   // events; the same words stage the records first
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
-    for (long p = wave; p < b.n_pairs; p += n_waves) {
-        int nk[2], wpr[2];
-        const uint32_t* rec[2];
+    for (long p0 = wave; p0 < b.n_pairs; p0 += (long)NP * n_waves) {
+        long pp[NP];
+        bool live[NP];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int len = b.len[m][p];
-            nk[m] = len - k + 1;
-            wpr[m] = ((len + 31) >> 5) + 1;
-            rec[m] = b.words + b.off[m][p];
+        for (int u = 0; u < NP; u++) {
+            pp[u] = p0 + (long)u * n_waves;
+            live[u] = pp[u] < b.n_pairs;
+            if (!live[u]) pp[u] = p0;          // a duplicate keeps every load unconditional; its result is dropped
         }
-        // LDS-staged windows: the wave fetches each read's record (3 planes x wpr words, <= 18 words for 159 bases) with one
-        // coalesced load and every lane cuts its windows out of LDS -- 2 vector-memory instructions per pair instead of 24.
-        // (Prefetching the next pair's metadata and words one iteration ahead was tried and was slower.)
-        uint32_t* stage = ev;   // the event area is free until the compaction below
+        int nk[NP][2], wpr[NP][2];
+        const uint32_t* rec[NP][2];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int nw = 3 * wpr[m];
-            if (lane < nw) stage[m * 32 + lane] = rec[m][lane];
-        }
-        __builtin_amdgcn_wave_barrier();
-        uint32_t w[4][6];
+        for (int u = 0; u < NP; u++)
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int m = s >> 1, j = (s & 1) * 64 + lane;
-            const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                w[s][2 * pl] = q[pl * wpr[m]];
-                w[s][2 * pl + 1] = q[pl * wpr[m] + 1];
+            for (int m = 0; m < 2; m++) {
+                const int len = b.len[m][pp[u]];
+                nk[u][m] = len - k + 1;
+                wpr[u][m] = ((len + 31) >> 5) + 1;
+                rec[u][m] = b.words + b.off[m][pp[u]];
             }
-        }
+        uint32_t* stage = ev;   // the event area is free until a compaction below
+        uint32_t rw[NP][2];
+#pragma unroll
+        for (int u = 0; u < NP; u++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) rw[u][m] = lane < 3 * wpr[u][m] ? rec[u][m][lane] : 0u;   // all loads first, see w2 below
+#pragma unroll
+        for (int u = 0; u < NP; u++)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                if (lane < 32) stage[(u * 2 + m) * 32 + lane] = rw[u][m];
         __builtin_amdgcn_wave_barrier();
-        uint32_t hs[4][3], ids[4][3];
-        bool ok[4];
+        uint32_t hs[NP][4][3], ids[NP][4][3];
+        bool ok[NP][4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
-            auto win = [&](uint32_t a, uint32_t c) { return (uint32_t)(((((uint64_t)a << 32) | c) << r) >> 32) >> (32 - k); };
-            const uint32_t whi = win(w[s][0], w[s][1]), wlo = win(w[s][2], w[s][3]), wnb = win(w[s][4], w[s][5]);
-            const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
-            ok[s] = j < nk[m] && wnb == 0;
+        for (int u = 0; u < NP; u++)
 #pragma unroll
-            for (int i = 0; i < 3; i++) hs[s][i] = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
-        }
-        // first filter level for all 12 hashes, then the second, then the table itself: each level only for survivors
-        uint32_t f1[4][3];
+            for (int s = 0; s < 4; s++) {
+                const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
+                const uint32_t* q = stage + (u * 2 + m) * 32 + (j < nk[u][m] ? (j >> 5) : 0);
+                const int wp = wpr[u][m];
+                auto win = [&](uint32_t a, uint32_t c) { return (uint32_t)(((((uint64_t)a << 32) | c) << r) >> 32) >> (32 - k); };
+                const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
+                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+                ok[u][s] = j < nk[u][m] && wnb == 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const uint32_t h = hs[s][i];
-                if (PF == 2) { const uint32_t lb = h & ((1u << LF_BITS) - 1u); f1[s][i] = (lfilter[lb >> 5] >> (lb & 31u)) & 1u; }
-                else { const uint32_t fb = h & pf_mask; f1[s][i] = (prefilter[fb >> 5] >> (fb & 31u)) & 1u; }
-                if (!(ok[s] && i < e)) f1[s][i] = 0u;
+                for (int i = 0; i < 3; i++) hs[u][s][i] = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
             }
-        if (PF == 2) {
+        __builtin_amdgcn_wave_barrier();
+        // first filter level for all hashes, then the second, then the table itself: each level only for survivors
+        const uint32_t m512 = (debug & 512) ? 0u : ~0u, m1024 = (debug & 1024) ? 0u : ~0u;   // stage ablation (tools/ablate_vote.py)
+        uint32_t f1[NP][4][3];
+#pragma unroll
+        for (int u = 0; u < NP; u++)
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int i = 0; i < 3; i++)
-                    if (f1[s][i]) { const uint32_t fb = hs[s][i] & pf_mask; f1[s][i] = (prefilter[fb >> 5] >> (fb & 31u)) & 1u; }
-        }
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                ids[s][i] = f1[s][i] ? peak_kmer[hs[s][i]] : 0u;   // 0 = no peak (E:454)
-                any |= ids[s][i] != 0u;
-            }
-        if (!__ballot(any)) continue;   // the usual case on the sparse path: no lane of the pair hit anything
-        int n_ev = 0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {   // slices in offset order: mate 1 (0..63, 64..127), mate 2 (E:430-495)
-            bool hit = false;
-#pragma unroll
-            for (int i = 0; i < 3; i++) hit |= ids[s][i] != 0u;
-            const unsigned long long bal = __ballot(hit);
-            if (bal) {
-                if (hit) {
-                    const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-                        if (i < e) {
-                            ev[((size_t)slot * e + i) * 2] = ids[s][i];
-                            ev[((size_t)slot * e + i) * 2 + 1] = ids[s][i] ? (uint32_t)loci[2 * (long)ids[s][i]] : 0u;
-                        }
+                for (int i = 0; i < 3; i++) {
+                    const uint32_t h = hs[u][s][i];
+                    if (PF == 2) f1[u][s][i] = pf_pass(lfilter[(h & ((1u << LF_BITS) - 1u)) >> 5], h, pf2);
+                    else f1[u][s][i] = pf_pass(prefilter[(h & pf_mask) >> 5], h, pf2);
+                    if (!(ok[u][s] && i < e && live[u])) f1[u][s][i] = 0u;
+                    f1[u][s][i] &= m512;
                 }
-                n_ev += __popcll(bal);
+        {
+            const int qcap = (ev_words - 64) * 3 / 4, q2cap = ev_words - 64 - qcap;
+            uint32_t* Q = ev;
+            uint32_t* Q2 = PF == 2 ? ev + qcap : ev;
+            uint32_t* dump = ev + ev_words - 64;
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) c += (int)f1[u][s][i];
+            const int incl = wave_incl_scan(c, lane);
+            const int T = __shfl(incl, 63, 64);
+            if (T == 0) continue;
+            if (T <= qcap) {
+                int slot = incl - c;
+#pragma unroll
+                for (int u = 0; u < NP; u++)
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            uint32_t* dst = f1[u][s][i] ? Q + slot : dump + lane;   // no branch: dead candidates land in a scratch word
+                            *dst = hs[u][s][i];
+                            slot += (int)f1[u][s][i];
+                        }
+                __builtin_amdgcn_wave_barrier();
+                int T2 = T;
+                if (PF == 2) {
+                    T2 = 0;
+                    for (int q0 = 0; q0 < T; q0 += 128) {   // two gathers in flight per round
+                        const int qa = q0 + lane, qb = qa + 64;
+                        const uint32_t ha = qa < T ? Q[qa] : 0u, hb = qb < T ? Q[qb] : 0u;
+                        const uint32_t wa = qa < T ? prefilter[(ha & pf_mask) >> 5] : 0u;
+                        const uint32_t wb = qb < T ? prefilter[(hb & pf_mask) >> 5] : 0u;
+                        const bool pa = qa < T && pf_pass(wa, ha, pf2), pb = qb < T && pf_pass(wb, hb, pf2);
+                        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+                        const int sa = T2 + __popcll(ba & ((1ull << lane) - 1ull));
+                        const int sb = T2 + __popcll(ba) + __popcll(bb & ((1ull << lane) - 1ull));
+                        if (pa && sa < q2cap) Q2[sa] = ha;
+                        if (pb && sb < q2cap) Q2[sb] = hb;
+                        T2 += __popcll(ba) + __popcll(bb);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                T2 &= (int)m1024;
+                if (T2 <= (PF == 2 ? q2cap : qcap)) {
+                    bool hit = false;
+                    for (int q0 = 0; q0 < T2; q0 += 64) {
+                        const int q = q0 + lane;
+                        if (q < T2) hit |= peak_kmer[Q2[q]] != 0u;
+                    }
+                    if (!__ballot(hit)) continue;   // the usual case on the sparse path: nothing of these pairs is a peak k-mer
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (n_ev < 6 || (debug & 1)) continue;
-        __builtin_amdgcn_wave_barrier();
-        if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
-        else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
-        __builtin_amdgcn_wave_barrier();
+        // lane-per-offset form: some probe hit (or a queue overflowed)
+        if (PF == 2) {
+            // only the load sits under the lane mask; the bit is cut out after all of them are in flight (a use inside the
+            // branch would make the compiler wait for each load on its own: 12 round trips in a row instead of one)
+            uint32_t w2[NP][4][3];
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) w2[u][s][i] = f1[u][s][i] ? prefilter[(hs[u][s][i] & pf_mask) >> 5] : 0u;
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) f1[u][s][i] = (f1[u][s][i] && pf_pass(w2[u][s][i], hs[u][s][i], pf2)) & m1024;
+        }
+        bool any[NP];
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            any[u] = false;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    ids[u][s][i] = f1[u][s][i] ? peak_kmer[hs[u][s][i]] : 0u;   // 0 = no peak (E:454)
+                    any[u] |= ids[u][s][i] != 0u;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            if (!__ballot(any[u])) continue;
+            int n_ev = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {   // slices in offset order: mate 1 (0..63, 64..127), mate 2 (E:430-495)
+                bool hit = false;
+#pragma unroll
+                for (int i = 0; i < 3; i++) hit |= ids[u][s][i] != 0u;
+                const unsigned long long bal = __ballot(hit);
+                if (bal) {
+                    if (hit) {
+                        const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                        for (int i = 0; i < 3; i++)
+                            if (i < e) {
+                                ev[((size_t)slot * e + i) * 2] = ids[u][s][i];
+                                ev[((size_t)slot * e + i) * 2 + 1] = ids[u][s][i] ? (uint32_t)loci[2 * (long)ids[u][s][i]] : 0u;
+                            }
+                    }
+                    n_ev += __popcll(bal);
+                }
+            }
+            if (n_ev < 6 || (debug & 1)) continue;
+            __builtin_amdgcn_wave_barrier();
+            if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
+            else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -351,7 +450,8 @@ int lhgt_vote(lhgt_ctx* ctx) {
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
         int max_ev = 2 * nk;
-        size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words (the sparse kernel stages inside the event area)
+        size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words
+        size_t per_wave_sp = (size_t)std::max(max_ev * ctx->e * 2, 128) * 4;   // sparse kernel: staging (2 pairs x 64 words) inside the event area
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;
@@ -360,28 +460,30 @@ int lhgt_vote(lhgt_ctx* ctx) {
 #define LHGT_VOTE(TR_, PF_, NT_, THREADS_, LDS_)                                                                           \
     hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                        ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                       ctx->debug, ctx->pf_mask)
+                       ctx->debug, ctx->pf_mask, ctx->pf2)
         const bool nt = ctx->k >= 28;
         // sparse peak sets on a folded (k > PF_BITS) bitmap: 16-wave workgroups that keep a 64 KiB fold of it in LDS
-        const size_t lds2 = (size_t)LF_WORDS * 4 + 16 * per_wave;
+        const size_t lds2 = (size_t)LF_WORDS * 4 + 16 * per_wave_sp;
         const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
 #define LHGT_VOTE_SPARSE(PF_, THREADS_, LDS_)                                                                                  \
-    hipLaunchKernelGGL((vote_kernel_sparse<PF_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,     \
+    hipLaunchKernelGGL((vote_kernel_sparse<PF_, 2>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                        ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                       ctx->debug, ctx->pf_mask)
-        if (sparse_ok && ctx->k > PF_BITS && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {   // LDS first level (495 vs 530 ms on configs[2])
+                       ctx->debug, ctx->pf_mask, ctx->pf2)
+        // LDS first level only while the fold still screens: at most a quarter of its bits set (2.3 M k-mers on configs[2] fill it)
+        const bool fold_ok = ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1) <= (1ull << LF_BITS) / 4;
+        if (sparse_ok && ctx->k > PF_BITS && fold_ok && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {
             wpb = 16;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256) blocks = 256;     // one resident workgroup per CU
             static bool attr_set = false;
             if (!attr_set) {
-                LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_set = true;
             }
             hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold);
             LHGT_VOTE_SPARSE(2, 1024, lds2);
         } else if (sparse_ok) {
-            LHGT_VOTE_SPARSE(1, 64 * wpb, per_wave * wpb);
+            LHGT_VOTE_SPARSE(1, 64 * wpb, per_wave_sp * wpb);
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);

@@ -119,6 +119,7 @@ struct lhgt_ctx {
     uint32_t* d_prefilter_fold = nullptr;  // 64 KiB fold of it, copied into LDS by the sparse-path vote kernel
     bool prefilter_on = false;
     uint32_t pf_mask = 0;             // low address bits indexing the prefilter
+    int pf2 = 0;                      // folded prefilter: shift of the address bits picking a key's second bit (0 = one bit per key)
     unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan
     // reference-sharded scan (k_scan.hip): this rank's new peaks / registrations as records for the exchange
     int32_t* d_emit_loci = nullptr;

@@ -40,4 +40,16 @@ __host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
     }
 }
 
+// Vote prefilter (k_scan.hip registers, k_vote.hip tests): word (h & pf_mask) >> 5 of the bitmap, bit h & 31 in it.  When the
+// bitmap is a fold of the table (pf2 != 0: fewer address bits than k) a key also sets a second bit of the same word, chosen by
+// the address bits above the fold -- a one-load blocked Bloom filter: 2.3 M keys in 2^25 bits pass 1.6 % of foreign probes
+// instead of 6.9 %.  A clear bit is still an exact negative.
+__device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
+    return (1u << (h & 31u)) | (pf2 ? 1u << ((h >> pf2) & 31u) : 0u);
+}
+__device__ __forceinline__ bool pf_pass(uint32_t word, uint32_t h, int pf2) {
+    const uint32_t m = pf_word_bits(h, pf2);
+    return (word & m) == m;
+}
+
 }  // namespace lhgt

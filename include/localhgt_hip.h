@@ -121,6 +121,15 @@ int lhgt_vote(lhgt_ctx* ctx);
 /* ---- D: interval file (count_filtered_peak E:515-548) */
 int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered);
 
+/* ---- next row, SURVEY.md 8(f) rank 3: BED -> extracted FASTA without samtools (host only, no context needed).
+ *      lhgt_faidx_extract replaces `samtools faidx -r ${interval_file}.bed $original_ref > $extracted_ref` (scripts/pipeline.sh:37):
+ *      one ">NAME:BEG-END" record per region line, bases as stored, line_width (<= 0: 60) per line, END truncated at the contig's
+ *      length; out_path "-" = stdout.  lhgt_faidx_build replaces `samtools faidx $ref` (scripts/infer_HGT_breakpoint.py:156) and
+ *      writes the five-column .fai (fai_path may be NULL to validate only).  samtools is absent here: parity unpinned. */
+int lhgt_faidx_build(const char* fasta_path, const char* fai_path, long* n_sequences);
+int lhgt_faidx_extract(const char* fasta_path, const char* regions_path, const char* out_path, int line_width, long* n_regions,
+                       long* n_bases);
+
 /* ---- introspection for parity tests (device -> host copies) */
 int lhgt_counts_export_u8(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint8_t* out);
 int lhgt_counts_histogram(lhgt_ctx* ctx, uint64_t out[4]);            /* cal_tab_empty_rate, count_diff_kmer.cpp:26-50 */

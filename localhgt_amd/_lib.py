@@ -57,6 +57,8 @@ SIGNATURES = {
     "lhgt_peaks_install": [_vp, _l, _l, _l, _vp, _vp, _l],
     "lhgt_vote": [_vp],
     "lhgt_write_intervals": [_vp, _cs, _lp],
+    "lhgt_faidx_build": [_cs, _cs, _lp],
+    "lhgt_faidx_extract": [_cs, _cs, _cs, _i, _lp, _lp],
     "lhgt_counts_export_u8": [_vp, C.c_uint64, C.c_uint64, _u8p],
     "lhgt_counts_histogram": [_vp, _u64p],
     "lhgt_flags_export": [_vp, C.c_uint64, C.c_uint64, _u8p],

@@ -79,14 +79,22 @@ __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tile
     }
 }
 
-// exclusive prefix over the block's per-thread values (simple: every thread sums its predecessors)
+// exclusive prefix over the block's per-thread values: shuffle scan inside each wave, then the few wave totals through LDS
+// (the first version had every thread add up its predecessors: a third of interval_select's instructions)
 __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
-    sh[threadIdx.x] = v;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) sh[wv] = incl;
     __syncthreads();
-    int s = 0;
-    for (int i = 0; i < (int)threadIdx.x; i++) s += sh[i];
+    int off = 0;
+    for (int q = 0; q < wv; q++) off += sh[q];
     __syncthreads();
-    return s;
+    return off + incl - v;
 }
 
 // ---- B2: good-window bit per position (E:597-615) and one byte per tile saying whether the tile has any.
@@ -238,6 +246,10 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
         int o1 = block_excl_sum(s1, part);
         for (int i = b; i < en; i++) P1[i] += o1;
         __syncthreads();
+        // every position of the tile and its halo has a hit and none of it hangs over a contig end: all 5-wide sums are 5, both
+        // contrasts are 0 - 5 + 5 and no position can be a peak (a present genome is one long run of such tiles)
+        const bool flat = lo4 >= 0 && lo4 + N4 <= len && P1[N4 - 1] == N4;
+        if (!flat) {
         for (int i = threadIdx.x; i < N4; i += BT) W[i] = (int8_t)(i >= 5 ? P1[i] - P1[i - 5] : 0);
         __syncthreads();
         for (int i = threadIdx.x; i < N4; i += BT) {
@@ -288,6 +300,7 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
                 int peak = (j > 2 * k + 10 && W[i - 5] - W[i - k - 5] - W[i] + mn <= -2) || (W[i] + mx >= 2);
                 sel[jj0 + q] = (uint8_t)peak;
             }
+        }
         }
         __syncthreads();
     }

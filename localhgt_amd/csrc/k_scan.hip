@@ -97,11 +97,14 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
     return off + incl - v;
 }
 
-// ---- B2: good-window bit per position (E:597-615) and one byte per tile saying whether the tile has any.
+// ---- B2: good-window bit per position (E:597-615).  A good position lies inside a merged interval whatever its neighbours do
+// (distance 0 to a good window, E:618), so its "inside" bit is set here as well.  One byte per tile: bit 0 some position is
+// good, bit 1 all are, bit 2 all have a hit (`single`) -- mark_active_tiles uses them to keep whole runs of covered reference
+// away from interval_select.
 __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good) {
     __shared__ int P1[N2], P3[N2], part[BT];
-    __shared__ int any_good;
+    __shared__ int any_good, n_good;
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
     constexpr int NW = TILE + HL2;   // the window sums look back only
     constexpr int CH = (NW + BT - 1) / BT;
     const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
-    if (threadIdx.x == 0) any_good = 0;
+    if (threadIdx.x == 0) { any_good = 0; n_good = 0; }
     int s1 = 0, s3 = 0;
     for (int i = b; i < en; i++) {
         long pos = lo + i;
@@ -130,14 +133,19 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
             const int i = jj + HL2;
             int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
             if (one >= one_min && three >= three_min) {
-                F[j] = (uint8_t)((F[j] & 3) | 4);
-                mine = 1;
+                F[j] = (uint8_t)((F[j] & 3) | 4 | (j >= 1 ? 16 : 0));
+                mine++;
             }
         }
     }
-    if (mine) any_good = 1;
+    if (mine) { any_good = 1; atomicAdd(&n_good, mine); }
     __syncthreads();
-    if (threadIdx.x == 0) tile_good[blockIdx.x] = (uint8_t)any_good;
+    if (threadIdx.x == 0) {
+        const long rest = len - (long)t.j0;
+        const int n_here = rest < TILE ? (int)rest : TILE;
+        const int all_good = n_good == n_here, all_single = P1[NW - 1] - P1[HL2 - 1] == n_here;
+        tile_good[blockIdx.x] = (uint8_t)(any_good | (all_good << 1) | (all_single << 2));
+    }
 }
 
 // ---- B3: interval mask, contrast peaks inside it, new-peak flags.
@@ -156,15 +164,23 @@ constexpr int H3 = 2560;                         // >= HALO3, multiple of 64
 constexpr int NW3 = (TILE + 2 * H3 + 63) / 64;   // ballot words per tile
 constexpr int HL4 = 96, HR4 = 80;                // halo of the contrast test: 2k+14 back, 2k+9 forward
 constexpr int N4 = TILE + HL4 + HR4;
-__global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restrict__ tiles, const uint8_t* __restrict__ tile_good, long n_tiles,
+__global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                         const uint8_t* __restrict__ tile_good, long n_tiles,
                                                          uint32_t* __restrict__ active, unsigned int* __restrict__ n_active) {
     long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q0 >= n_tiles) return;
     const uint32_t contig = tiles[q0].contig;
     bool reach = false;   // the 2560-position halo spans at most two tiles of the same contig on either side
     for (long q = q0 - 2; q <= q0 + 2; q++)
-        if (q >= 0 && q < n_tiles && tiles[q].contig == contig && tile_good[q]) reach = true;
-    if (reach) active[atomicAdd(n_active, 1u)] = (uint32_t)q0;
+        if (q >= 0 && q < n_tiles && tiles[q].contig == contig && (tile_good[q] & 1)) reach = true;
+    if (!reach) return;
+    // settled by window_good alone: every position of the tile is good (so inside, bit already set) and every position the
+    // contrast test can look at -- HL4 before to HR4 after the tile, all inside the contig -- has a hit, so no sum differs from its
+    // neighbours and no position is a peak: nothing selected, no new peak (tile_count stays 0)
+    const long j0 = tiles[q0].j0, len = contigs[contig].len;
+    const bool settled = (tile_good[q0] & 6) == 6 && j0 >= HL4 && j0 + TILE + HR4 <= len && q0 > 0 && q0 + 1 < n_tiles &&
+                         tiles[q0 - 1].contig == contig && tiles[q0 + 1].contig == contig && (tile_good[q0 - 1] & 4) && (tile_good[q0 + 1] & 4);
+    if (!settled) active[atomicAdd(n_active, 1u)] = (uint32_t)q0;
 }
 
 // one workgroup per ACTIVE tile (a tile with a good window in itself or within two tiles: launching millions of workgroups
@@ -524,8 +540,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     unsigned int* d_nact = (unsigned int*)(d_nsel + 1);
     LHGT_HIP(hipMemsetAsync(d_nact, 0, 4, ctx->stream));
     LHGT_HIP(hipMemsetAsync(ctx->d_tile_count, 0, (size_t)(ctx->n_tiles + 1) * 4, ctx->stream));
-    hipLaunchKernelGGL(mark_active_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_tile_good,
-                       ctx->n_tiles, ctx->d_active_tiles, d_nact);
+    hipLaunchKernelGGL(mark_active_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs,
+                       ctx->d_tile_good, ctx->n_tiles, ctx->d_active_tiles, d_nact);
     unsigned int n_active = 0;
     LHGT_HIP(hipMemcpyAsync(&n_active, d_nact, 4, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));

@@ -147,7 +147,9 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
 
 /* switches for profiling / A-B runs.  bit0: lhgt_vote skips judge_base (outputs wrong);
  * bit2: never use the vote prefilter; bit4: without its LDS-resident first level; bit5: generic vote kernel even on the
- * sparse path; bit6: ref_flags never uses the saturated-line summary (outputs unchanged) */
+ * sparse path; bit6: ref_flags never uses the saturated-line summary; bit7: chunked tile scan at any size; bit8: no tile is
+ * settled by window_good alone (bits 2-8: outputs unchanged); bit9 / bit10: the sparse vote kernel stops after its first /
+ * second filter level (stage timing, outputs wrong) */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */

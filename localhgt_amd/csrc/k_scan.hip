@@ -166,7 +166,7 @@ constexpr int HL4 = 96, HR4 = 80;                // halo of the contrast test: 2
 constexpr int N4 = TILE + HL4 + HR4;
 __global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                          const uint8_t* __restrict__ tile_good, long n_tiles,
-                                                         uint32_t* __restrict__ active, unsigned int* __restrict__ n_active) {
+                                                         uint32_t* __restrict__ active, unsigned int* __restrict__ n_active, int no_settle) {
     long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q0 >= n_tiles) return;
     const uint32_t contig = tiles[q0].contig;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restri
     const long j0 = tiles[q0].j0, len = contigs[contig].len;
     const bool settled = (tile_good[q0] & 6) == 6 && j0 >= HL4 && j0 + TILE + HR4 <= len && q0 > 0 && q0 + 1 < n_tiles &&
                          tiles[q0 - 1].contig == contig && tiles[q0 + 1].contig == contig && (tile_good[q0 - 1] & 4) && (tile_good[q0 + 1] & 4);
-    if (!settled) active[atomicAdd(n_active, 1u)] = (uint32_t)q0;
+    if (!settled || no_settle) active[atomicAdd(n_active, 1u)] = (uint32_t)q0;
 }
 
 // one workgroup per ACTIVE tile (a tile with a good window in itself or within two tiles: launching millions of workgroups
@@ -378,6 +378,69 @@ __global__ void __launch_bounds__(1024) tile_scan(uint32_t* __restrict__ v, long
     if (threadIdx.x == 0) v[n] = (uint32_t)(carry_s > 0xffffffffull ? 0xffffffffull : carry_s);
 }
 
+// the same scan for long arrays (configs[2] has 6.5 M tiles: 10 ms in one workgroup): chunk sums, their scan, chunk-local scans
+constexpr int SCAN_PER = 16, SCAN_CHUNK = 1024 * SCAN_PER;
+__device__ __forceinline__ unsigned long long block_excl_sum_u64(unsigned long long v, unsigned long long* sh /*[16]*/, unsigned long long* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    unsigned long long off = 0, all = 0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); q++) {
+        if (q < wv) off += sh[q];
+        all += sh[q];
+    }
+    __syncthreads();
+    if (total) *total = all;
+    return off + incl - v;
+}
+__global__ void __launch_bounds__(1024) tile_chunk_sums(const uint32_t* __restrict__ v, long n, unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long sh[16];
+    const long b = (long)blockIdx.x * SCAN_CHUNK + (long)threadIdx.x * SCAN_PER;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; q++) s += b + q < n ? v[b + q] : 0u;
+    unsigned long long total;
+    block_excl_sum_u64(s, sh, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) chunk_bases(unsigned long long* __restrict__ sums, long n_chunks) {   // in place; total -> sums[n_chunks]
+    __shared__ unsigned long long sh[16];
+    unsigned long long carry = 0;
+    for (long base = 0; base < n_chunks; base += 1024) {
+        const long i = base + threadIdx.x;
+        const unsigned long long x = i < n_chunks ? sums[i] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_excl_sum_u64(x, sh, &total);
+        if (i < n_chunks) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[n_chunks] = carry;
+}
+__global__ void __launch_bounds__(1024) tile_chunk_scan(uint32_t* __restrict__ v, long n, const unsigned long long* __restrict__ sums, long n_chunks) {
+    __shared__ unsigned long long sh[16];
+    const long b = (long)blockIdx.x * SCAN_CHUNK + (long)threadIdx.x * SCAN_PER;
+    uint32_t x[SCAN_PER];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; q++) { x[q] = b + q < n ? v[b + q] : 0u; s += x[q]; }
+    unsigned long long run = sums[blockIdx.x] + block_excl_sum_u64(s, sh, nullptr);
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; q++) {
+        if (b + q < n) v[b + q] = (uint32_t)(run > 0xffffffffull ? 0xffffffffull : run);
+        run += x[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long total = sums[n_chunks];
+        v[n] = (uint32_t)(total > 0xffffffffull ? 0xffffffffull : total);
+    }
+}
+
 // ---- B5
 __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
@@ -541,14 +604,22 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     LHGT_HIP(hipMemsetAsync(d_nact, 0, 4, ctx->stream));
     LHGT_HIP(hipMemsetAsync(ctx->d_tile_count, 0, (size_t)(ctx->n_tiles + 1) * 4, ctx->stream));
     hipLaunchKernelGGL(mark_active_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs,
-                       ctx->d_tile_good, ctx->n_tiles, ctx->d_active_tiles, d_nact);
+                       ctx->d_tile_good, ctx->n_tiles, ctx->d_active_tiles, d_nact, ctx->debug & 256);
     unsigned int n_active = 0;
     LHGT_HIP(hipMemcpyAsync(&n_active, d_nact, 4, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
     if (n_active)
         hipLaunchKernelGGL(interval_select, dim3(n_active), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, ctx->d_active_tiles,
                            ctx->d_flags, ctx->d_tile_count, d_nsel);
-    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
+    if (ctx->n_tiles <= 4L * SCAN_CHUNK && !((ctx->debug & 128) && ctx->n_tiles >= 3))
+        hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
+    else {   // the active-tile list is free again: its first words hold the chunk sums (u64, far fewer than n_tiles / 2)
+        const long n_chunks = (ctx->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        unsigned long long* sums = (unsigned long long*)ctx->d_active_tiles;
+        hipLaunchKernelGGL(tile_chunk_sums, dim3((unsigned)n_chunks), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles, sums);
+        hipLaunchKernelGGL(chunk_bases, dim3(1), dim3(1024), 0, ctx->stream, sums, n_chunks);
+        hipLaunchKernelGGL(tile_chunk_scan, dim3((unsigned)n_chunks), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles, sums, n_chunks);
+    }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipMemcpyAsync(total_new, ctx->d_tile_count + ctx->n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(n_selected, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -5,7 +5,9 @@ path raises.  `load(require_gpu=False)` is only for symbol checks on a CPU-only 
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocalhgt_hip.so")
@@ -83,6 +85,23 @@ class LocalHGTError(RuntimeError):
 _lib = None
 
 
+def _bind_one_hip_runtime():
+    """One HIP runtime per process.  torch ships its own libamdhip64.so.7 (and HSA runtime) next to libtorch; this library is
+    linked against /opt/rocm's.  Same SONAME, different builds: whichever is loaded first serves both, and when /opt/rocm's
+    comes first torch later reports "No HIP GPUs are available".  So if torch is installed and not loaded yet, load ITS runtime
+    before ours (no `import torch`: single-GPU runs never need it); when torch is already in, ours binds to it by SONAME."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load(require_gpu: bool = True):
     """Load the shared library and bind every declared symbol. Raises if it is not built."""
     global _lib
@@ -91,6 +110,7 @@ def load(require_gpu: bool = True):
             raise ImportError(
                 f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). localhgt_amd has no CPU fallback.")
+        _bind_one_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header and library out of sync

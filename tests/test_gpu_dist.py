@@ -203,3 +203,40 @@ def test_exchange_sharded_scan_world1_nccl(case_inputs, tmp_path):
             assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_synthetic_reference_shards_scan_like_the_whole(world):
+    """bench.py's sharded form: every 'rank' generates only its contig range of the synthetic reference on the device
+    (lhgt_synth_reference_shard); the exchanged scan must give the peak tables of one engine holding the whole reference"""
+    from localhgt_amd.engine import Engine
+    k, e, n_contigs, contig_len = 26, 3, 21, 60_000
+    with Engine(k, e) as whole:
+        whole.rng_seed(9)
+        whole.coder_generate()
+        coder = whole.coder_get()
+        whole.synth_reference(7, n_contigs, contig_len)
+        whole.synth_pairs(7, 8, n_contigs, contig_len, 0, 50_000)
+        whole.count_kmers()
+        pw, nw = whole.counts_buffer()
+        engs = []
+        for r in range(world):
+            g = Engine(k, e)
+            g.coder_set(coder)
+            g.synth_reference_shard(7, n_contigs, contig_len, r, world)
+            g.counts_merge(pw, 0, nw)
+            engs.append(g)
+        engs[-1].synth_pairs(7, 8, n_contigs, contig_len, 0, 50_000)     # one rank also carries the reads, to vote
+        n_total, news = _sharded_scan_sequential(engs, 0.1, 0.08, 10**7)
+        n_whole = whole.ref_scan(0.1, 0.08, 10**7)
+        assert n_total == n_whole > 20 and sum(news) == n_total
+        loci_w, _ = whole.peaks_export(n_whole)
+        pk_w = whole.peak_kmer_export(0, 1 << k)
+        for g in engs:
+            assert (g.peaks_export(n_total)[0] == loci_w).all()
+            assert (g.peak_kmer_export(0, 1 << k) == pk_w).all()
+        whole.vote()
+        engs[-1].vote()
+        assert (engs[-1].peaks_export(n_total)[1] == whole.peaks_export(n_whole)[1]).all()
+        for g in engs:
+            g.close()

@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--contig-len", type=int, default=1_000_000)
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-e", type=int, default=3)
-    ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index")
+    ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index (the default at N > 1)")
+    ap.add_argument("--replicate-index", action="store_true", help="at N > 1 keep the whole index on every GPU and scan it redundantly (no exchange in phase B)")
     ap.add_argument("--count-mode", type=int, default=-1, help="-1 = engine default (adaptive), 0 = direct CAS kernel, 1 = radix partition")
     ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
@@ -109,7 +110,8 @@ def main():
     if args.debug:
         eng.set_debug(args.debug)
     t0 = time.time()
-    shard_index = args.shard_index and dist is not None
+    # phase B shards by contig range -- each rank scans 1/N of the reference and the peaks are exchanged
+    shard_index = dist is not None and (args.shard_index or (world > 1 and not args.replicate_index))
     if shard_index:
         eng.synth_reference_shard(1, args.contigs, args.contig_len, rank, world)  # this rank's contig range only
     else:
@@ -176,6 +178,8 @@ def main():
             except Exception:
                 traffic = {}
         ref_bytes = args.contigs * args.contig_len * (4 * e + 64 * e)     # 204 B per reference base
+        if shard_index:
+            ref_bytes = (args.contigs * (rank + 1) // world - args.contigs * rank // world) * args.contig_len * (4 * e + 64 * e)   # this rank's contig range
         # candidates for "the dominant kernel": single kernels timed by their own HIP events (ref_flags: one launch per step;
         # vote_kernel: one launch per resident batch of <= 16 Mi pairs, phase C holds nothing else), and phase A's kernel family
         n_batches = -(-args.pairs // (16 << 20))
@@ -190,7 +194,7 @@ def main():
         dom_ach, dom_frac = roof(kern[dominant], phases[dominant][1])
         tkey = {"count_A": "count_A", "ref_flags": "ref_flags", "vote_C": "vote_kernel"}
         workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}"
-        tr = traffic.get(workload_tag, {})
+        tr = traffic.get(workload_tag, {}) if not (shard_index and world > 1) else {}   # measured on the single-GPU, whole-index run
         line = {
             "metric": "M paired-reads/s k-mer sketch->peak, UHGG-scale ref; %HBM roofline @1/2/4/8 GPU",
             "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
@@ -221,6 +225,11 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(k, e, 20, 1_000_000, args.cpu_pairs, 1, 2, lambda: Engine(k, e, device=local))
             except Exception as ex:  # the baseline must never sink the measurement
                 line["cpu_baseline"] = {"error": str(ex)}
+        # RCCL writes its version banner through C stdio, which on a pipe is flushed at exit, i.e. after Python's output:
+        # flush it now so that the JSON line is the last thing on stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist:

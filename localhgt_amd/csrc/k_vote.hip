@@ -466,7 +466,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         const size_t lds2 = (size_t)LF_WORDS * 4 + 16 * per_wave_sp;
         const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
 #define LHGT_VOTE_SPARSE(PF_, THREADS_, LDS_)                                                                                  \
-    hipLaunchKernelGGL((vote_kernel_sparse<PF_, 2>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
+    hipLaunchKernelGGL((vote_kernel_sparse<PF_, (PF_ == 2 ? 2 : 1)>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                        ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
                        ctx->debug, ctx->pf_mask, ctx->pf2)
         // LDS first level only while the fold still screens: at most a quarter of its bits set (2.3 M k-mers on configs[2] fill it)

@@ -158,12 +158,17 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
 
 // ---- P1, common case (<= 128 k-mer offsets per read, e <= 3): every lane keeps the keys of its offsets in
 // registers between the histogram and the placement, so reads are loaded and hashed once per tile.
-constexpr int RW = 4;   // reads per wave per tile -> at most 16*RW reads per tile
-__global__ void __launch_bounds__(PT) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
+// Measured split of one launch (3.3 M pairs, configs[1]): hashing 2.6 ms, histogram atomics 0.1, placement 1.9, the 9.5 GB of
+// stores 2.2 (4.2 TB/s) -- they add up to the 6.9 ms of the launch.
+// 512-thread workgroups: with ~100 VGPRs only 16 waves fit a CU, and as ONE 1024-thread workgroup its phases (hash: VALU, place:
+// LDS, flush: HBM) ran strictly one after the other; two independent workgroups of 8 waves overlap them.
+constexpr int PT1 = 512;
+constexpr int RW = 6;   // reads per wave per tile -> at most (PT1/64)*RW = 48 reads per tile (45 at 150 bp, e = 3)
+__global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
                                                              int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
     __shared__ uint32_t sorted[TILE_KEYS];
     __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
-    __shared__ uint32_t stage_all[(PT / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
+    __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 32;
     const int shift = g.b1 ? g.k - g.b1 : 0;
@@ -176,10 +181,10 @@ __global__ void __launch_bounds__(PT) part_scatter_reads_reg(ReadBatchDev b, lon
         if (threadIdx.x < 128) hist[threadIdx.x] = 0;
         __syncthreads();
         uint32_t key[RW][2][3];
-        uint32_t live = 0;   // bit (rr*6 + it*3 + i)
+        unsigned long long live = 0;   // bit (rr*6 + it*3 + i)
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
-            const long r = r0 + wib + rr * (PT / 64);
+            const long r = r0 + wib + rr * (PT1 / 64);
             if (r >= r1) continue;
             const long p = pair0 + (r >> 1);
             const int m = (int)(r & 1);
@@ -202,20 +207,20 @@ __global__ void __launch_bounds__(PT) part_scatter_reads_reg(ReadBatchDev b, lon
                     if (i < e) {
                         const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                         key[rr][it][i] = h;
-                        live |= 1u << (rr * 6 + it * 3 + i);
+                        live |= 1ull << (rr * 6 + it * 3 + i);
                         atomicAdd(&hist[(h >> shift) & bmask], 1u);
                     }
             }
         }
         __syncthreads();
-        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, g.nb1, shift, bmask, cur1, out, [&](auto emit) {
+        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, gbase, g.nb1, shift, bmask, cur1, out, [&](auto emit) {
 #pragma unroll
             for (int rr = 0; rr < RW; rr++)
 #pragma unroll
                 for (int it = 0; it < 2; it++)
 #pragma unroll
                     for (int i = 0; i < 3; i++)
-                        if (live & (1u << (rr * 6 + it * 3 + i))) emit(key[rr][it][i]);
+                        if (live & (1ull << (rr * 6 + it * 3 + i))) emit(key[rr][it][i]);
         });
     }
 }
@@ -350,8 +355,8 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         hipLaunchKernelGGL(part_hist, dim3(grid), dim3(PT), (size_t)g.nb * 4 + (PT / 64) * 256, ctx->stream, b.d, p0, np, ctx->hp, g, ghist);
         hipLaunchKernelGGL(part_offsets, dim3(1), dim3(1024), 0, ctx->stream, ghist, g, off, cur1, cur2);
         if (max_nk <= 128 && ctx->e <= 3) {
-            int rpt = reads_per_tile < 16 * RW ? reads_per_tile : 16 * RW;
-            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, cur1, ctx->d_part_keys[0]);
+            int rpt = reads_per_tile < (PT1 / 64) * RW ? reads_per_tile : (PT1 / 64) * RW;
+            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(grid), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, cur1, ctx->d_part_keys[0]);
         } else
             hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, cur1, ctx->d_part_keys[0]);
         const uint32_t* final_keys = ctx->d_part_keys[0];

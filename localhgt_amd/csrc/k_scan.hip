@@ -20,6 +20,7 @@ constexpr int BT = 256;        // threads per scan block
 constexpr int WINDOW = 500;    // E:556
 constexpr int HL2 = 512, HR2 = 80;          // halo of B2: 499 back for the window, 2k+5 forward for the contrast test
 constexpr int N2 = TILE + HL2 + HR2;
+constexpr int HL4 = 96, HR4 = 80;                // halo of the contrast test: 2k+14 back, 2k+9 forward
 constexpr int HALO3 = 2500;    // B3: 2*window on each side plus the 500 merge gap (E:618, 625, 629)
 
 __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uint32_t h) {
@@ -133,18 +134,27 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
             const int i = jj + HL2;
             int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
             if (one >= one_min && three >= three_min) {
-                F[j] = (uint8_t)((F[j] & 3) | 4 | (j >= 1 ? 16 : 0));
+                const int low = (P1[i] - P1[i - 1]) | ((P3[i] - P3[i - 1]) << 1);   // the position's own two flags, without re-reading them
+                F[j] = (uint8_t)(low | 4 | (j >= 1 ? 16 : 0));
                 mine++;
             }
         }
     }
-    if (mine) { any_good = 1; atomicAdd(&n_good, mine); }
+    {   // one LDS atomic per wave, not per thread (every thread has some on covered reference)
+        int wsum = mine;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+        if ((threadIdx.x & 63) == 0 && wsum) { any_good = 1; atomicAdd(&n_good, wsum); }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const long rest = len - (long)t.j0;
         const int n_here = rest < TILE ? (int)rest : TILE;
         const int all_good = n_good == n_here, all_single = P1[NW - 1] - P1[HL2 - 1] == n_here;
-        tile_good[blockIdx.x] = (uint8_t)(any_good | (all_good << 1) | (all_single << 2));
+        // bits 3 / 4: the first HR4 / last HL4 positions all have a hit -- what the neighbouring tiles' contrast tests reach into
+        const int head = n_here >= HR4 && P1[HL2 + HR4 - 1] - P1[HL2 - 1] == HR4;
+        const int tail = n_here == TILE && P1[NW - 1] - P1[NW - 1 - HL4] == HL4;
+        tile_good[blockIdx.x] = (uint8_t)(any_good | (all_good << 1) | (all_single << 2) | (head << 3) | (tail << 4));
     }
 }
 
@@ -162,7 +172,6 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
 //     positions and shares the part of the window they have in common.
 constexpr int H3 = 2560;                         // >= HALO3, multiple of 64
 constexpr int NW3 = (TILE + 2 * H3 + 63) / 64;   // ballot words per tile
-constexpr int HL4 = 96, HR4 = 80;                // halo of the contrast test: 2k+14 back, 2k+9 forward
 constexpr int N4 = TILE + HL4 + HR4;
 __global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                          const uint8_t* __restrict__ tile_good, long n_tiles,
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restri
     // neighbours and no position is a peak: nothing selected, no new peak (tile_count stays 0)
     const long j0 = tiles[q0].j0, len = contigs[contig].len;
     const bool settled = (tile_good[q0] & 6) == 6 && j0 >= HL4 && j0 + TILE + HR4 <= len && q0 > 0 && q0 + 1 < n_tiles &&
-                         tiles[q0 - 1].contig == contig && tiles[q0 + 1].contig == contig && (tile_good[q0 - 1] & 4) && (tile_good[q0 + 1] & 4);
+                         tiles[q0 - 1].contig == contig && tiles[q0 + 1].contig == contig && (tile_good[q0 - 1] & 16) && (tile_good[q0 + 1] & 8);
     if (!settled || no_settle) active[atomicAdd(n_active, 1u)] = (uint32_t)q0;
 }
 
@@ -608,6 +617,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     unsigned int n_active = 0;
     LHGT_HIP(hipMemcpyAsync(&n_active, d_nact, 4, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, for interval_select %u\n", ctx->n_tiles, n_active);
     if (n_active)
         hipLaunchKernelGGL(interval_select, dim3(n_active), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, ctx->d_active_tiles,
                            ctx->d_flags, ctx->d_tile_count, d_nsel);

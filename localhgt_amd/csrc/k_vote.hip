@@ -203,13 +203,14 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 }
 
 // Sparse-path form (prefilter on, <= 128 k-mer offsets per mate, e <= 3).  The generic kernel walks a pair slice by slice
-// and every slice costs three dependent round trips; when the probes are cache hits that chain, not bandwidth, is the cost.
-// Here a wave handles NP pairs per iteration with their eight slices together: records staged in LDS by one coalesced load each,
-// all windows cut from LDS, all 12*NP first-level filter probes at once.  The survivors are then PACKED (wave prefix sum, LDS
-// queue) and the next levels probed with full-width loads: a gather instruction costs the memory pipeline the same whether 9
-// or 64 of its lanes are live (1.2e9 nine-lane gathers took 245 ms on configs[2], the instruction rate of full ones), so the
-// 12*NP sparse gathers per level become ceil(survivors / 64) dense ones.  Only an iteration in which some probe finds a peak
-// (or a queue overflows) falls back to the lane-per-offset form below, which rebuilds the hits in offset order for the judge.
+// and every slice costs three dependent round trips.  Here a wave handles NP pairs per iteration with all their slices together:
+// records staged in LDS by one coalesced load each, all windows cut from LDS, all 12*NP first-level filter probes at once (a use of
+// a loaded word inside a lane-masked branch would make the compiler wait after every single load: only the loads sit under masks).
+// The survivors are then PACKED (wave prefix sum, LDS queue) and the next level probed with full-width gathers; only an iteration in
+// which some probe finds a peak (or a queue overflows) falls back to the lane-per-offset form below, which rebuilds the hits in
+// offset order for the judge.  PF = 1: first level = the L2-resident bitmap (12 gathers per pair, 257 G probes/s on configs[2] --
+// the L2 random-access ceiling -- then ~12 packed peak_kmer probes per pair).  PF = 2: a 64 KiB LDS fold of the bitmap in front,
+// for peak sets small enough to leave it mostly clear.
 template <int PF, int NP>
 __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                                            const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,

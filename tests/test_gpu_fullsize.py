@@ -85,3 +85,28 @@ def test_shards_merge_to_whole_and_votes_are_linear(eng):
     assert (np.diff(key) > 0).all()
     same = np.diff(contig) == 0
     assert (np.diff(pos // 50)[same] > 0).all()
+
+
+def test_settled_tiles_change_nothing_on_a_saturated_table(eng):
+    """every k-mer of the sampled half of the reference at count 3: its 2000-position tiles are settled by window_good alone (all
+    positions good, contrast neighbourhood fully hit) and never reach interval_select; the other half is hit by collisions only.
+    Same flags for every position and same peaks as with that shortcut switched off"""
+    eng.counts_clear()
+    for part in range(4):                        # 40 M different pairs (24x coverage), each batch counted three times: hit slots end at 3
+        eng.pairs_clear()
+        eng.synth_pairs(1, 2, NC, CL, part * NP, NP)
+        for _ in range(3):
+            eng.count_kmers()
+    hist = eng.counts_histogram()
+    assert hist[3] > 0.2 * (1 << 32) and hist[1] == hist[2] == 0, hist
+    res = []
+    for flags in (0, 256):
+        eng.set_debug(flags)
+        n = eng.ref_scan(0.1, 0.08, 300_000_000)
+        res.append((n, eng.peaks_export(n)[0].copy(), eng.flags_export(0, NC * CL)))
+    eng.set_debug(0)
+    assert res[0][0] == res[1][0]
+    assert (res[0][1] == res[1][1]).all()
+    assert (res[0][2] == res[1][2]).all()
+    inside = (res[0][2] >> 4) & 1
+    assert 0.3 < inside.mean() < 0.7             # the sampled contigs lie inside good intervals, the others do not

@@ -413,6 +413,196 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
     }
 }
 
+// Sparse path without the LDS fold (the usual one: bitmap exact for k <= 25, or too many k-mers for a 64 KiB fold).  One pair
+// per wave iteration as above, first level = the L2-resident bitmap.  Its few survivors (12 of a pair's 714 probes on configs[2])
+// are not probed at once -- that is one HBM round trip per pair for a dozen lanes -- but QUEUED across pairs, tagged with the
+// pair's iteration number, and probed 64 at a time by a full-width gather.  A pair one of whose probes finds a peak id is then
+// voted from scratch in the lane-per-offset form (hits in offset order for the judge); the others are done.  A pair's entries
+// are appended together and never split over two flushes, so no pair is voted twice.  (Straight-line code, one site per step:
+// as lambdas called from several places the steps became real calls with their captures in scratch memory.)
+constexpr int VQ_CAP = 256, VQ_FLUSH = 64;
+__global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
+                                                          const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
+                                                          uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,
+                                                          uint32_t pf_mask, int pf2) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int e = hp.e, k = hp.k;
+    if (wib >= waves_per_block) return;
+    // per wave: [queue hashes | queue tags | 64 dump words | 64 staging words of the scan] and, over the same words, the vote's
+    // [events | 64 staging words]: by the time a pair is voted the queue is empty and the tags to vote sit in registers
+    const int ev_words = max_ev * e * 2;
+    const int wave_words = ev_words + 64 > 2 * VQ_CAP + 128 ? ev_words + 64 : 2 * VQ_CAP + 128;
+    uint32_t* qh = lds + (size_t)wib * wave_words;
+    uint32_t* qi = qh + VQ_CAP;    // tags; during a flush its front collects the pairs to vote
+    uint32_t* stage = qh + 2 * VQ_CAP + 64;
+    uint32_t* ev = qh;
+    uint32_t* vstage = ev + ev_words;
+    const long wave = (long)blockIdx.x * waves_per_block + wib;
+    const long n_waves = (long)gridDim.x * waves_per_block;
+    const uint32_t m512 = (debug & 512) ? 0u : 1u;   // stage ablation: stop after the bitmap / (1024) before the peak_kmer gathers
+    const bool skip_gather = (debug & 1024) != 0;
+    int qn = 0;
+    uint32_t it = 0;
+    for (long p = wave;; p += n_waves, it++) {
+        const bool live = p < b.n_pairs;   // one more round after the last pair drains the queue
+        int T = 0;
+        if (live) {
+            // two round trips: the four descriptors together, then both records (lane index clamped instead of a lane-masked
+            // load, which the compiler would wait for on its own)
+            const int len0 = b.len[0][p], len1 = b.len[1][p];
+            const uint32_t* rec0 = b.words + b.off[0][p];
+            const uint32_t* rec1 = b.words + b.off[1][p];
+            const int nk[2] = {len0 - k + 1, len1 - k + 1};
+            const int wpr[2] = {((len0 + 31) >> 5) + 1, ((len1 + 31) >> 5) + 1};
+            const uint32_t rw[2] = {rec0[lane < 3 * wpr[0] ? lane : 3 * wpr[0] - 1], rec1[lane < 3 * wpr[1] ? lane : 3 * wpr[1] - 1]};
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                if (lane < 32) stage[m * 32 + lane] = rw[m];
+            __builtin_amdgcn_wave_barrier();
+            uint32_t hs[4][3], f1[4][3];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
+                const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
+                const int wp = wpr[m];
+                auto win = [&](uint32_t a, uint32_t c) { return (uint32_t)(((((uint64_t)a << 32) | c) << r) >> 32) >> (32 - k); };
+                const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
+                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+                const bool ok = j < nk[m] && wnb == 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const uint32_t h = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
+                    hs[s][i] = h;
+                    // unconditional load (a dead lane probes word 0), masked afterwards: under `ok &&` every load would sit in its own
+                    // lane-masked branch next to its use and be waited for singly
+                    const uint32_t pass = pf_pass(prefilter[(h & pf_mask) >> 5], h, pf2) ? 1u : 0u;
+                    f1[s][i] = (ok && i < e) ? (pass & m512) : 0u;
+                }
+            }
+            int c = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) c += (int)f1[s][i];
+            const int incl = wave_incl_scan(c, lane);
+            T = __shfl(incl, 63, 64);
+            if (T > 0 && T <= VQ_CAP - VQ_FLUSH) {   // qn < VQ_FLUSH here, so the pair's entries always fit
+                int slot = qn + incl - c;
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int at = f1[s][i] ? slot : 2 * VQ_CAP + lane;   // dead candidates land in the dump words behind the tags
+                        qh[at] = hs[s][i];
+                        if (f1[s][i]) qi[slot] = it;
+                        slot += (int)f1[s][i];
+                    }
+                qn += T;
+            }
+        }
+        const bool direct = T > VQ_CAP - VQ_FLUSH;   // not a sparse pair: vote it as it is
+        if (qn >= VQ_FLUSH || direct || !live) {
+            // flush: full-width gathers over the queue; the tags of pairs with a hit are collected at the front of qi
+            __builtin_amdgcn_wave_barrier();
+            int nv = 0, cur_cnt = 0;
+            uint32_t cur = 0xffffffffu;   // a pair's entries are contiguous (possibly over two rounds): count its hit entries as they come
+            for (int q0 = 0; q0 < qn && !skip_gather; q0 += 64) {
+                const int q = q0 + lane;
+                const uint32_t h = q < qn ? qh[q] : 0u, tag = q < qn ? qi[q] : 0xffffffffu;
+                uint32_t id = 0u;
+                if (q < qn) id = peak_kmer[h];
+                const bool hit = id != 0u;
+                unsigned long long bal = __ballot(hit);
+                while (bal) {
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tag, __ffsll((long long)bal) - 1);
+                    const unsigned long long same = __ballot(hit && tag == t);
+                    bal &= ~same;
+                    if (t != cur) {
+                        // base_hits >= 6 (E:496) needs six offsets with a hit, so at least six hit entries: fewer cannot vote
+                        if (cur_cnt >= 6) { if (lane == 0) qi[nv] = cur; nv++; }
+                        cur = t;
+                        cur_cnt = 0;
+                    }
+                    cur_cnt += __popcll(same);
+                }
+            }
+            if (cur_cnt >= 6) { if (lane == 0) qi[nv] = cur; nv++; }
+            qn = 0;
+            if (direct) {
+                if (lane == 0) qi[nv] = it;
+                nv++;
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t vt[VQ_CAP / 64];   // the tags leave LDS: the events below are written over the queue
+#pragma unroll
+            for (int u = 0; u < VQ_CAP / 64; u++) vt[u] = u * 64 + lane < nv ? qi[u * 64 + lane] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            // the generic kernel's treatment of those pairs: every offset, masked probes, hits compacted in offset order, judge
+            for (int v = 0; v < nv; v++) {
+                uint32_t tv = 0;
+#pragma unroll
+                for (int u = 0; u < VQ_CAP / 64; u++)
+                    if ((v >> 6) == u) tv = (uint32_t)__builtin_amdgcn_readlane((int)vt[u], v & 63);
+                const long pv = wave + (long)tv * n_waves;
+                int n_ev = 0;
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const int len = b.len[m][pv];
+                    const int nkm = len - k + 1;
+                    if (nkm <= 0) continue;
+                    const int wprm = ((len + 31) >> 5) + 1;
+                    const uint32_t* rec = b.words + b.off[m][pv];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 3 * wprm) vstage[lane] = rec[lane];
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j0 = 0; j0 < nkm; j0 += 64) {
+                        const int j = j0 + lane;
+                        uint32_t ids[3] = {0u, 0u, 0u}, chrs[3] = {0u, 0u, 0u};
+                        bool hit = false;
+                        if (j < nkm && plane_window(vstage + 2 * wprm, j, k) == 0) {
+                            const uint32_t whi = plane_window(vstage, j, k), wlo = plane_window(vstage + wprm, j, k);
+                            const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+#pragma unroll
+                            for (int i = 0; i < 3; i++)
+                                if (i < e) {
+                                    const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+                                    ids[i] = pf_pass(prefilter[(h & pf_mask) >> 5], h, pf2) ? peak_kmer[h] : 0u;   // 0 = no peak (E:454)
+                                    hit |= ids[i] != 0u;
+                                }
+#pragma unroll
+                            for (int i = 0; i < 3; i++)
+                                if (i < e) chrs[i] = ids[i] ? (uint32_t)loci[2 * (long)ids[i]] : 0u;
+                        }
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            if (hit) {
+                                const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                                for (int i = 0; i < 3; i++)
+                                    if (i < e) {
+                                        ev[((size_t)slot * e + i) * 2] = ids[i];
+                                        ev[((size_t)slot * e + i) * 2 + 1] = chrs[i];
+                                    }
+                            }
+                            n_ev += __popcll(bal);
+                        }
+                    }
+                }
+                if (n_ev >= 6 && !(debug & 1)) {   // base_hits = offsets with any hit (E:149-157, 496)
+                    __builtin_amdgcn_wave_barrier();
+                    if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
+                    else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!live) break;
+    }
+}
+
 // 64 KiB fold of the 2^PF_BITS-bit bitmap: word w = OR of the bitmap words w, w + LF_WORDS, ... (same low address bits)
 __global__ void __launch_bounds__(256) fold_prefilter(const uint32_t* __restrict__ prefilter, int words, uint32_t* __restrict__ fold) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,7 +674,14 @@ int lhgt_vote(lhgt_ctx* ctx) {
             hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold);
             LHGT_VOTE_SPARSE(2, 1024, lds2);
         } else if (sparse_ok) {
-            LHGT_VOTE_SPARSE(1, 64 * wpb, per_wave_sp * wpb);
+            const size_t per_wave_q = (size_t)std::max(max_ev * ctx->e * 2 + 64, 2 * VQ_CAP + 128) * 4;
+            wpb = (int)(65536 / per_wave_q);
+            if (wpb > 4) wpb = 4;
+            if (wpb < 1) wpb = 1;
+            blocks = (b.d.n_pairs + wpb - 1) / wpb;
+            if (blocks > 256L * 16) blocks = 256L * 16;
+            hipLaunchKernelGGL(vote_kernel_queued, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
+                               ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2);
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
 // voted from scratch in the lane-per-offset form (hits in offset order for the judge); the others are done.  A pair's entries
 // are appended together and never split over two flushes, so no pair is voted twice.  (Straight-line code, one site per step:
 // as lambdas called from several places the steps became real calls with their captures in scratch memory.)
-constexpr int VQ_CAP = 256, VQ_FLUSH = 64;
+constexpr int VQ_CAP = 384, VQ_FLUSH = 192;
 __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                           const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
                                                           uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,
@@ -508,12 +508,19 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
             __builtin_amdgcn_wave_barrier();
             int nv = 0, cur_cnt = 0;
             uint32_t cur = 0xffffffffu;   // a pair's entries are contiguous (possibly over two rounds): count its hit entries as they come
-            for (int q0 = 0; q0 < qn && !skip_gather; q0 += 64) {
-                const int q = q0 + lane;
-                const uint32_t h = q < qn ? qh[q] : 0u, tag = q < qn ? qi[q] : 0xffffffffu;
-                uint32_t id = 0u;
-                if (q < qn) id = peak_kmer[h];
-                const bool hit = id != 0u;
+            uint32_t idv[VQ_CAP / 64], tagv[VQ_CAP / 64];
+#pragma unroll
+            for (int u = 0; u < VQ_CAP / 64; u++) {   // all gathers of the flush in flight together
+                const int q = u * 64 + lane;
+                const bool in = q < qn && !skip_gather;
+                tagv[u] = in ? qi[q] : 0xffffffffu;
+                idv[u] = 0u;
+                if (in) idv[u] = peak_kmer[qh[q]];
+            }
+#pragma unroll
+            for (int u = 0; u < VQ_CAP / 64; u++) {
+                const uint32_t tag = tagv[u];
+                const bool hit = idv[u] != 0u;
                 unsigned long long bal = __ballot(hit);
                 while (bal) {
                     const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tag, __ffsll((long long)bal) - 1);

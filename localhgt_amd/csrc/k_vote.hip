@@ -208,9 +208,9 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // a loaded word inside a lane-masked branch would make the compiler wait after every single load: only the loads sit under masks).
 // The survivors are then PACKED (wave prefix sum, LDS queue) and the next level probed with full-width gathers; only an iteration in
 // which some probe finds a peak (or a queue overflows) falls back to the lane-per-offset form below, which rebuilds the hits in
-// offset order for the judge.  PF = 1: first level = the L2-resident bitmap (12 gathers per pair, 257 G probes/s on configs[2] --
-// the L2 random-access ceiling -- then ~12 packed peak_kmer probes per pair).  PF = 2: a 64 KiB LDS fold of the bitmap in front,
-// for peak sets small enough to leave it mostly clear.
+// offset order for the judge.  Launched with PF = 2: a 64 KiB LDS fold of the bitmap in front of it, for peak sets small enough to
+// leave the fold mostly clear; everything else on the sparse path goes to vote_kernel_queued below (PF = 1, the bitmap as first
+// level, is kept for A/B runs).
 template <int PF, int NP>
 __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                                            const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,

@@ -149,7 +149,8 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
  * bit2: never use the vote prefilter; bit4: without its LDS-resident first level; bit5: generic vote kernel even on the
  * sparse path; bit6: ref_flags never uses the saturated-line summary; bit7: chunked tile scan at any size; bit8: no tile is
  * settled by window_good alone (bits 2-8: outputs unchanged); bit9 / bit10: the sparse vote kernel stops after its first /
- * second filter level (stage timing, outputs wrong) */
+ * second filter level (stage timing, outputs wrong); bit11: the queued sparse vote kernel votes every pair with more than 8 bitmap
+ * survivors directly (exercises that branch; outputs unchanged) */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */

@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                 for (int i = 0; i < 3; i++) c += (int)f1[s][i];
             const int incl = wave_incl_scan(c, lane);
             T = __shfl(incl, 63, 64);
-            if (T > 0 && T <= VQ_CAP - VQ_FLUSH) {   // qn < VQ_FLUSH here, so the pair's entries always fit
+            if (T > 0 && T <= ((debug & 2048) ? 8 : VQ_CAP - VQ_FLUSH)) {   // qn < VQ_FLUSH here, so the pair's entries always fit
                 int slot = qn + incl - c;
 #pragma unroll
                 for (int s = 0; s < 4; s++)
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                 qn += T;
             }
         }
-        const bool direct = T > VQ_CAP - VQ_FLUSH;   // not a sparse pair: vote it as it is
+        const bool direct = T > ((debug & 2048) ? 8 : VQ_CAP - VQ_FLUSH);   // not a sparse pair: vote it as it is (bit 11: test hook)
         if (qn >= VQ_FLUSH || direct || !live) {
             // flush: full-width gathers over the queue; the tags of pairs with a hit are collected at the front of qi
             __builtin_amdgcn_wave_barrier();

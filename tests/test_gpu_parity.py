@@ -110,6 +110,12 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         _, pf_o = oracle.vote(f1, f2, k, e, cc, ratio, None, pk_o, loci_o, n_o)
         _, pf_g = eng.peaks_export(n_g)
         assert (pf_g == pf_o[:n_g]).all()
+        for flags in (2048, 32, 4):     # every vote kernel: queued with its direct branch forced, generic with / without the bitmap
+            eng.set_debug(flags)
+            assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
+            eng.vote()
+            assert (eng.peaks_export(n_g)[1] == pf_o[:n_g]).all(), f"votes differ with debug flags {flags}"
+        eng.set_debug(0)
         # D
         out = str(tmp_path / "interval.txt")
         eng.write_intervals(out)
@@ -307,7 +313,7 @@ def test_vote_prefilter_changes_nothing(Engine):
         eng.synth_pairs(3, 4, 16, 100_000, 0, 60_000)
         eng.count_kmers()
         votes = []
-        for flags in (0, 16, 32, 4, 128, 256):  # batched sparse kernel, - LDS first level, generic kernel with bitmap, no prefilter, scan variants
+        for flags in (0, 16, 32, 4, 128, 256, 16 | 2048):  # fold kernel, queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
             eng.set_debug(flags)
             n = eng.ref_scan(0.1, 0.08, 10**7)
             eng.vote()

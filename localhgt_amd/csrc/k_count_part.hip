@@ -5,16 +5,34 @@
 // random read-modify-writes per read pair therefore cap the direct kernel (k_count.hip) at
 // ~33 M pairs/s.  Here the hashes are first routed by their top bits so that every final bucket
 // covers 2^18 table slots = one 64 KiB slice of the 2-bit table, which is then updated inside LDS:
-//   P0 part_hist      hash every k-mer, count keys per final bucket            (LDS histogram)
-//   P1 part_scatter_r hash again, route keys by the top B1 bits                (tile sort in LDS, 64 KiB)
+//   P1 part_scatter_r hash every k-mer, route keys by the top B1 bits            (tile sort in LDS, 64 KiB)
 //   P2 part_scatter_k route each level-1 segment by the next B2 bits           (same tile sort)
 //   P3 part_apply     one workgroup per final bucket: slice -> LDS, saturating
 //                     2-bit increments by LDS compare-and-swap, slice -> HBM
+// No histogram pass: every bucket owns a fixed region of the key buffer sized by its EXPECTED load plus 1/16 and 1024 keys, and
+// runs are placed with one global atomicAdd per tile and bucket.  A hash is min(forward word, reverse-complement word), the
+// minimum of two roughly uniform values, so its density falls linearly (2(1-x)): bucket q of nb expects the share
+// (2(nb-q)-1)/nb^2 of the keys -- twice the mean for the first, next to nothing for the last (part_region below).  A key that finds its bucket full -- heavily repeated k-mers: poly-A, adapters -- is applied to the table at once with
+// the direct kernel's CAS loop; part_apply of the same chunk starts after the scatters and loads its slice from the table, so
+// nothing is lost or counted twice and the result does not depend on how much overflowed.  (The first version counted the keys
+// of every final bucket in a separate pass that hashed all reads once more: 69 ms of 534 on configs[2].)
 // HBM traffic is 16 B per key streamed plus one table sweep per chunk, instead of one random
 // 64-byte sector (and its write-back) per key.  The result is the same table: min(3, count).
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
+
+// if (T[h] < 3) T[h]++ on the packed table in HBM (E:1082-1084), race-free; k_count.hip holds the same loop for the direct kernel
+__device__ __forceinline__ void part_sat_inc(uint32_t* __restrict__ T, uint32_t h) {
+    uint32_t* w = T + (h >> 4);
+    const uint32_t sh = (h & 15u) * 2u;
+    uint32_t old = *w;
+    while (((old >> sh) & 3u) != 3u) {
+        const uint32_t seen = atomicCAS(w, old, old + (1u << sh));
+        if (seen == old) break;
+        old = seen;
+    }
+}
 
 constexpr int SLICE_BITS = 18;            // slots per final bucket (2-bit fields -> 64 KiB of LDS)
 constexpr int MAX_B1 = 7;                 // 128-way fan-out per scatter pass (B2 = k - 18 - B1 <= 7 for k <= 32)
@@ -41,6 +59,18 @@ __host__ inline PartGeom part_geom(int k) {
     return g;
 }
 
+// Region layout of a key buffer for a chunk of at most n keys: final bucket q owns [part_region(q), part_region(q + 1)); a
+// level-1 segment is the union of its nb2 final buckets, so both buffers use the same coordinates.
+struct PartCap {
+    unsigned long long n;
+    uint32_t nb;
+};
+__host__ __device__ inline uint32_t part_region(const PartCap& c, uint32_t q) {
+    const unsigned long long tri = (unsigned long long)q * (2ull * c.nb - q);                 // nb^2 (1 - (1 - q/nb)^2)
+    const unsigned long long share = c.n * tri / ((unsigned long long)c.nb * c.nb);           // n * tri < 2^32 * 2^28
+    return (uint32_t)(share + share / 16 + (unsigned long long)q * 1024ull);
+}
+
 // keys of read (m, p) at offsets lane, lane+64, ...: calls f(key) for each of the e hashes of valid k-mers.
 // LDS-staged windows: the wave fetches the read's record (3 planes x wpr words, <= 51 words for 500 bases) with one coalesced
 // load into its 64-word LDS area `stage`, and every lane cuts its windows out of LDS (instead of 6 global loads per offset).
@@ -63,50 +93,15 @@ __device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashPa
     }
 }
 
-// ---- P0: keys per final bucket for pairs [pair0, pair0+npairs)
-__global__ void __launch_bounds__(PT) part_hist(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
-                                                uint32_t* __restrict__ ghist) {
-    extern __shared__ uint32_t lh[];  // [g.nb] histogram, then 64 staging words per wave
-    for (int i = threadIdx.x; i < g.nb; i += PT) lh[i] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    uint32_t* stage = lh + g.nb + (threadIdx.x >> 6) * 64;
-    const long wave = ((long)blockIdx.x * PT + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * PT) >> 6;
-    const int sh = g.slot_bits;
-    for (long r = wave; r < 2 * npairs; r += n_waves)
-        for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, [&](uint32_t key) { atomicAdd(&lh[g.nb > 1 ? key >> sh : 0], 1u); });
-    __syncthreads();
-    for (int i = threadIdx.x; i < g.nb; i += PT)
-        if (lh[i]) atomicAdd(&ghist[i], lh[i]);
-}
-
-// ---- exclusive scan of the final-bucket histogram; level-1/level-2 cursors start at their segment starts
-__global__ void __launch_bounds__(1024) part_offsets(const uint32_t* __restrict__ ghist, PartGeom g, uint32_t* __restrict__ off /*[nb+1]*/,
-                                                     uint32_t* __restrict__ cur1 /*[nb1]*/, uint32_t* __restrict__ cur2 /*[nb]*/) {
-    __shared__ uint32_t part[1024];
-    int ch = (g.nb + 1023) / 1024;
-    int b0 = threadIdx.x * ch, e0 = b0 + ch < g.nb ? b0 + ch : g.nb;
-    uint32_t s = 0;
-    for (int i = b0; i < e0; i++) s += ghist[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    uint32_t o = 0;
-    for (int q = 0; q < (int)threadIdx.x; q++) o += part[q];
-    for (int i = b0; i < e0; i++) {
-        off[i] = o;
-        cur2[i] = o;
-        if ((i & (g.nb2 - 1)) == 0) cur1[i >> g.b2] = o;
-        o += ghist[i];
-    }
-    if (threadIdx.x == 1023) off[g.nb] = o;
-}
-
 // Sort the tile's keys (already counted into hist[nbk]) by bucket inside LDS and copy the runs out.
 // Called by the whole workgroup; `place(emit)` must call emit(key) for every key of the tile again.
+// Tile bucket q is the union of the final buckets first + q*step .. first + (q+1)*step - 1 and owns their regions of `out`;
+// cursors[q] counts the keys sent to it so far (it may run past the region: the keys beyond go straight to the table).
 template <int NT, class Place>
 __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase,
-                                                int nbk, int shift, uint32_t bmask, uint32_t* __restrict__ cursors,
-                                                uint32_t* __restrict__ out, Place place) {
+                                                uint32_t* rstart, uint32_t* rcap, int nbk, int shift, uint32_t bmask,
+                                                uint32_t* __restrict__ cursors, PartCap pc, uint32_t first, uint32_t step,
+                                                uint32_t* __restrict__ out, uint32_t* __restrict__ counts, Place place) {
     // exclusive scan of hist (nbk <= 128) and reservation of the global runs
     if ((int)threadIdx.x < nbk) {
         uint32_t o = 0;
@@ -115,6 +110,9 @@ __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist
         lcur[threadIdx.x] = o;
         uint32_t c = hist[threadIdx.x];
         gbase[threadIdx.x] = c ? atomicAdd(&cursors[threadIdx.x], c) : 0u;
+        const uint32_t r0 = part_region(pc, first + threadIdx.x * step);
+        rstart[threadIdx.x] = r0;
+        rcap[threadIdx.x] = part_region(pc, first + (threadIdx.x + 1) * step) - r0;
     }
     __syncthreads();
     place([&](uint32_t key) {
@@ -126,16 +124,19 @@ __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist
     for (uint32_t i = threadIdx.x; i < total; i += NT) {
         uint32_t key = sorted[i];
         uint32_t bk = (key >> shift) & bmask;
-        out[gbase[bk] + (i - lofs[bk])] = key;   // consecutive i of one bucket -> consecutive addresses
+        const uint32_t pos = gbase[bk] + (i - lofs[bk]);   // consecutive i of one bucket -> consecutive addresses
+        if (pos < rcap[bk]) out[rstart[bk] + pos] = key;
+        else part_sat_inc(counts, key);                     // region full: count it now (see the header)
     }
     __syncthreads();
 }
 
 // ---- P1: reads -> level-1 segments.  A tile = reads_per_tile reads (<= TILE_KEYS keys).
 __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
-                                                         int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
+                                                         int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS];
-    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
     __shared__ uint32_t stage_all[(PT / 64) * 64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 64;
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
         for (long r = r0 + wib; r < r1; r += PT / 64)
             for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
         __syncthreads();
-        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, out, [&](auto emit) {
+        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, rstart, rcap, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
             for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, emit);
         });
     }
@@ -165,9 +166,10 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
 constexpr int PT1 = 512;
 constexpr int RW = 6;   // reads per wave per tile -> at most (PT1/64)*RW = 48 reads per tile (45 at 150 bp, e = 3)
 __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
-                                                             int reads_per_tile, uint32_t* __restrict__ cur1, uint32_t* __restrict__ out) {
+                                                             int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
+                                                             uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS];
-    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
     __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 32;
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
             }
         }
         __syncthreads();
-        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, gbase, g.nb1, shift, bmask, cur1, out, [&](auto emit) {
+        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, gbase, rstart, rcap, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
 #pragma unroll
             for (int rr = 0; rr < RW; rr++)
 #pragma unroll
@@ -227,17 +229,25 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
 
 // ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS keys, never straddling segments.
 // A thread keeps its KPT keys in registers between the histogram and the placement, all loads in flight at once.
-__global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ off /*[nb+1]*/, PartGeom g,
-                                                        uint32_t* __restrict__ cur2, uint32_t* __restrict__ out) {
+// Segment s holds the keys that fitted its region of `in`; its final buckets own the same coordinates of `out`.
+__global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cur1, PartGeom g,
+                                                        PartCap pc, uint32_t* __restrict__ cur2, uint32_t* __restrict__ out,
+                                                        uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS];
-    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128];
+    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
     __shared__ uint32_t tile_pref[129];   // tiles before segment s
+    __shared__ uint32_t seg_at[128], seg_len[128];
+    if ((int)threadIdx.x < g.nb1) {
+        const uint32_t s = threadIdx.x, r0 = part_region(pc, s << g.b2), cap = part_region(pc, (s + 1) << g.b2) - r0;
+        seg_at[s] = r0;
+        seg_len[s] = cur1[s] < cap ? cur1[s] : cap;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t a = 0;
         for (int s = 0; s < g.nb1; s++) {
             tile_pref[s] = a;
-            uint32_t len = off[(s + 1) << g.b2] - off[s << g.b2];
-            a += (len + TILE_KEYS - 1) / TILE_KEYS;
+            a += (seg_len[s] + TILE_KEYS - 1) / TILE_KEYS;
         }
         tile_pref[g.nb1] = a;
     }
@@ -249,7 +259,7 @@ __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restri
         int lo = 0, hi = g.nb1;             // segment of tile t: last s with tile_pref[s] <= t
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tile_pref[mid] <= t) lo = mid; else hi = mid; }
         const int s = lo;
-        const uint32_t seg0 = off[s << g.b2], seg1 = off[(s + 1) << g.b2];
+        const uint32_t seg0 = seg_at[s], seg1 = seg0 + seg_len[s];
         const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS, k1 = k0 + TILE_KEYS < seg1 ? k0 + TILE_KEYS : seg1;
         if (threadIdx.x < 128) hist[threadIdx.x] = 0;
         __syncthreads();
@@ -263,7 +273,7 @@ __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restri
         for (int u = 0; u < KPT; u++)
             if (k0 + u * PK + threadIdx.x < k1) atomicAdd(&hist[(key[u] >> shift) & bmask], 1u);
         __syncthreads();
-        tile_sort_flush<PK>(sorted, hist, lofs, lcur, gbase, g.nb2, shift, bmask, cur2 + ((size_t)s << g.b2), out, [&](auto emit) {
+        tile_sort_flush<PK>(sorted, hist, lofs, lcur, gbase, rstart, rcap, g.nb2, shift, bmask, cur2 + ((size_t)s << g.b2), pc, (uint32_t)s << g.b2, 1u, out, counts, [&](auto emit) {
 #pragma unroll
             for (int u = 0; u < KPT; u++)
                 if (k0 + u * PK + threadIdx.x < k1) emit(key[u]);
@@ -272,11 +282,12 @@ __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restri
 }
 
 // ---- P3: apply one final bucket inside LDS
-__global__ void __launch_bounds__(PA) part_apply(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off, PartGeom g,
-                                                 uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(PA) part_apply(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_keys /*[nb]*/, PartGeom g,
+                                                 PartCap pc, uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t slice[];   // 2^slot_bits / 16 words
     const uint32_t fb = blockIdx.x;
-    const uint32_t k0 = off[fb], k1 = off[fb + 1];
+    const uint32_t k0 = part_region(pc, fb), cap = part_region(pc, fb + 1) - k0;
+    const uint32_t k1 = k0 + (n_keys[fb] < cap ? n_keys[fb] : cap);
     if (k0 == k1) return;                 // untouched slice: nothing to read or write
     const int words = (1 << g.slot_bits) >> 4;
     uint32_t* T = counts + (size_t)fb * words;
@@ -324,47 +335,49 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     const long keys_per_pair = 2L * max_nk * ctx->e;
     int reads_per_tile = (int)(TILE_KEYS / ((long)max_nk * ctx->e));
     if (reads_per_tile < 1) LHGT_FAIL(LHGT_E_ARG, "read of %d bases with e=%d exceeds the partition tile", b.max_len, ctx->e);
-    // chunk of pairs whose keys fit the two key buffers (u32 offsets: < 2^32 keys per chunk)
-    long chunk_pairs = (long)((ctx->part_keys_cap ? ctx->part_keys_cap : 0) / keys_per_pair);
-    const long want = b.d.n_pairs < (4L << 20) ? b.d.n_pairs : (4L << 20);
-    if (chunk_pairs < want) {
-        size_t cap = (size_t)want * keys_per_pair;
-        if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+    // chunk of pairs whose bucket regions fit the two key buffers (u32 offsets: < 2^32 keys per buffer)
+    auto cap_of = [&](long np) { return PartCap{(unsigned long long)np * keys_per_pair, (uint32_t)g.nb}; };
+    auto need_of = [&](long np) {
+        const PartCap c = cap_of(np);
+        return c.n + c.n / 16 + (unsigned long long)g.nb * 1024ull + 64;
+    };
+    long want = b.d.n_pairs < (4L << 20) ? b.d.n_pairs : (4L << 20);
+    while (want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
+    const size_t need = (size_t)need_of(want);
+    if (ctx->part_keys_cap < need) {
         for (int i = 0; i < 2; i++) {
             if (ctx->d_part_keys[i]) hipFree(ctx->d_part_keys[i]);
             ctx->d_part_keys[i] = nullptr;
-            LHGT_HIP(hipMalloc(&ctx->d_part_keys[i], cap * 4));
+            LHGT_HIP(hipMalloc(&ctx->d_part_keys[i], need * 4));
         }
-        ctx->part_keys_cap = cap;
-        chunk_pairs = (long)(cap / keys_per_pair);
+        ctx->part_keys_cap = need;
     }
-    if (!ctx->d_part_meta) LHGT_HIP(hipMalloc(&ctx->d_part_meta, (size_t)(4 * 16384 + 256 + 8) * 4));
-    uint32_t* ghist = ctx->d_part_meta;
-    uint32_t* off = ghist + 16384;
-    uint32_t* cur2 = off + 16384 + 1;
-    uint32_t* cur1 = cur2 + 16384;
+    const long chunk_pairs = want;
+    if (!ctx->d_part_meta) LHGT_HIP(hipMalloc(&ctx->d_part_meta, (size_t)(16384 + 128) * 4));
+    uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket
+    uint32_t* cur1 = cur2 + 16384;         // keys sent to each level-1 segment
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
-    static bool hist_attr = false;
-    if (!hist_attr) {   // 64 KiB of histogram + per-wave staging words exceed the default dynamic-LDS limit
-        LHGT_HIP(hipFuncSetAttribute((const void*)part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        hist_attr = true;
-    }
     for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
-        LHGT_HIP(hipMemsetAsync(ghist, 0, (size_t)g.nb * 4, ctx->stream));
-        hipLaunchKernelGGL(part_hist, dim3(grid), dim3(PT), (size_t)g.nb * 4 + (PT / 64) * 256, ctx->stream, b.d, p0, np, ctx->hp, g, ghist);
-        hipLaunchKernelGGL(part_offsets, dim3(1), dim3(1024), 0, ctx->stream, ghist, g, off, cur1, cur2);
+        const PartCap pc = cap_of(np);
+        LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(16384 + 128) * 4, ctx->stream));
         if (max_nk <= 128 && ctx->e <= 3) {
             int rpt = reads_per_tile < (PT1 / 64) * RW ? reads_per_tile : (PT1 / 64) * RW;
-            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(grid), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, cur1, ctx->d_part_keys[0]);
+            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(grid), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, pc, cur1,
+                               ctx->d_part_keys[0], ctx->d_counts);
         } else
-            hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, cur1, ctx->d_part_keys[0]);
+            hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, pc, cur1,
+                               ctx->d_part_keys[0], ctx->d_counts);
         const uint32_t* final_keys = ctx->d_part_keys[0];
+        const uint32_t* final_n = cur1;    // without a second level the level-1 segments are the final buckets
         if (g.b2 > 0) {
-            hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], off, g, cur2, ctx->d_part_keys[1]);
+            hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], cur1, g, pc, cur2,
+                               ctx->d_part_keys[1], ctx->d_counts);
             final_keys = ctx->d_part_keys[1];
+            final_n = cur2;
         }
-        hipLaunchKernelGGL(part_apply, dim3(g.nb), dim3(PA), (size_t)((1 << g.slot_bits) >> 4) * 4, ctx->stream, final_keys, off, g, ctx->d_counts);
+        hipLaunchKernelGGL(part_apply, dim3(g.nb), dim3(PA), (size_t)((1 << g.slot_bits) >> 4) * 4, ctx->stream, final_keys, final_n, g, pc,
+                           ctx->d_counts);
         LHGT_HIP(hipGetLastError());
     }
     return LHGT_OK;

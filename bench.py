@@ -185,7 +185,7 @@ def main():
         n_batches = -(-args.pairs // (16 << 20))
         kern = {"count_A": per["count_A"], "ref_flags": ms[3] / args.steps, "vote_C": per["vote_C"]}
         phases = {
-            "count_A": ("phase A kernel family (part_hist + part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
+            "count_A": ("phase A kernel family (part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
                         "count_direct below k = 26): 714 table updates per pair", algo, None),
             "ref_flags": ("ref_flags (phase B: e random 2-bit table probes + e index words per reference base), 1 launch per step", ref_bytes, 1),
             "vote_C": (f"vote_kernel (phase C read re-scan: 714 probes per pair into peak_kmer), {n_batches} launches per step", algo, n_batches),

@@ -39,8 +39,9 @@ constexpr int MAX_B1 = 7;                 // 128-way fan-out per scatter pass (B
 constexpr int TILE_KEYS = 16384;          // keys sorted per workgroup tile (64 KiB of LDS)
 constexpr int TILE_KEYS_ = TILE_KEYS;
 constexpr int PT = 1024;                  // threads per workgroup in the read-side passes (16 waves hide the per-read load chain)
+constexpr int TILE_KEYS2 = TILE_KEYS;     // keys per tile of the key scatter: two 64 KiB workgroups per CU (one of 128 KiB: +14 ms on configs[2])
 constexpr int PK = 512;                   // threads per workgroup in the key scatter: 32 keys per thread stay in registers
-constexpr int KPT = TILE_KEYS_ / PK;
+constexpr int KPT = TILE_KEYS2 / PK;
 constexpr int PA = 1024;                  // threads per workgroup in apply
 
 struct PartGeom {
@@ -161,14 +162,16 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
 // registers between the histogram and the placement, so reads are loaded and hashed once per tile.
 // Measured split of one launch (3.3 M pairs, configs[1]): hashing 2.6 ms, histogram atomics 0.1, placement 1.9, the 9.5 GB of
 // stores 2.2 (4.2 TB/s) -- they add up to the 6.9 ms of the launch.
-// 512-thread workgroups: with ~100 VGPRs only 16 waves fit a CU, and as ONE 1024-thread workgroup its phases (hash: VALU, place:
-// LDS, flush: HBM) ran strictly one after the other; two independent workgroups of 8 waves overlap them.
-constexpr int PT1 = 512;
-constexpr int RW = 6;   // reads per wave per tile -> at most (PT1/64)*RW = 48 reads per tile (45 at 150 bp, e = 3)
+// One 1024-thread workgroup per CU with a 128 KiB tile: 256-key (1 KiB) runs.  Phase A on configs[2]: 64 KiB tiles in two
+// 512-thread workgroups per CU 460 ms, 48 KiB x 3 581 ms, 128 KiB x 1 450 ms (earlier, with the histogram pass: 64 KiB x 1 540,
+// 64 KiB x 2 520, 32 KiB x 4 568): run length matters more than overlapping the phases of several workgroups.
+constexpr int PT1 = 1024;
+constexpr int TILE_KEYS1 = 32768;   // 128 KiB tile: one workgroup per CU, runs of 256 keys
+constexpr int RW = 6;   // reads per wave per tile -> at most (PT1/64)*RW = 96 reads per tile (91 at 150 bp, e = 3)
 __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
                                                              int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                              uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t sorted[TILE_KEYS];
+    __shared__ uint32_t sorted[TILE_KEYS1];
     __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
     __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
         if (threadIdx.x < 128) hist[threadIdx.x] = 0;
         __syncthreads();
         uint32_t key[RW][2][3];
-        unsigned long long live = 0;   // bit (rr*6 + it*3 + i)
+        unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const long r = r0 + wib + rr * (PT1 / 64);
@@ -227,13 +230,13 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
     }
 }
 
-// ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS keys, never straddling segments.
+// ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS2 keys, never straddling segments.
 // A thread keeps its KPT keys in registers between the histogram and the placement, all loads in flight at once.
 // Segment s holds the keys that fitted its region of `in`; its final buckets own the same coordinates of `out`.
 __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cur1, PartGeom g,
                                                         PartCap pc, uint32_t* __restrict__ cur2, uint32_t* __restrict__ out,
                                                         uint32_t* __restrict__ counts) {
-    __shared__ uint32_t sorted[TILE_KEYS];
+    __shared__ uint32_t sorted[TILE_KEYS2];
     __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
     __shared__ uint32_t tile_pref[129];   // tiles before segment s
     __shared__ uint32_t seg_at[128], seg_len[128];
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restri
         uint32_t a = 0;
         for (int s = 0; s < g.nb1; s++) {
             tile_pref[s] = a;
-            a += (seg_len[s] + TILE_KEYS - 1) / TILE_KEYS;
+            a += (seg_len[s] + TILE_KEYS2 - 1) / TILE_KEYS2;
         }
         tile_pref[g.nb1] = a;
     }
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restri
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tile_pref[mid] <= t) lo = mid; else hi = mid; }
         const int s = lo;
         const uint32_t seg0 = seg_at[s], seg1 = seg0 + seg_len[s];
-        const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS, k1 = k0 + TILE_KEYS < seg1 ? k0 + TILE_KEYS : seg1;
+        const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS2, k1 = k0 + TILE_KEYS2 < seg1 ? k0 + TILE_KEYS2 : seg1;
         if (threadIdx.x < 128) hist[threadIdx.x] = 0;
         __syncthreads();
         uint32_t key[KPT];
@@ -362,8 +365,9 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         const PartCap pc = cap_of(np);
         LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(16384 + 128) * 4, ctx->stream));
         if (max_nk <= 128 && ctx->e <= 3) {
-            int rpt = reads_per_tile < (PT1 / 64) * RW ? reads_per_tile : (PT1 / 64) * RW;
-            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(grid), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, pc, cur1,
+            int rpt = (int)(TILE_KEYS1 / ((long)max_nk * ctx->e));
+            if (rpt > (PT1 / 64) * RW) rpt = (PT1 / 64) * RW;
+            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(256), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, pc, cur1,
                                ctx->d_part_keys[0], ctx->d_counts);
         } else
             hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, pc, cur1,

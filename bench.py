@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=150_000)
+    ap.add_argument("--cpu-pairs", type=int, default=400_000)
     args = ap.parse_args()
     wl_contigs, wl_pairs = (13000, 100_000_000) if args.workload == "uhgg" else (1000, 10_000_000)
     args.contigs = args.contigs or wl_contigs

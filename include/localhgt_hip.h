@@ -150,11 +150,16 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
  * sparse path; bit6: ref_flags never uses the saturated-line summary; bit7: chunked tile scan at any size; bit8: no tile is
  * settled by window_good alone (bits 2-8: outputs unchanged); bit9 / bit10: the sparse vote kernel stops after its first /
  * second filter level (stage timing, outputs wrong); bit11: the queued sparse vote kernel votes every pair with more than 8 bitmap
- * survivors directly (exercises that branch; outputs unchanged) */
+ * survivors directly (exercises that branch; outputs unchanged); bit12 / bit13: lhgt_ref_scan takes the lite / the exact form of its
+ * first two steps whatever the table looks like (default: lite when >= 60 % of the slots hold 3 and e <= 3; outputs unchanged).
+ * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the phase), 3 = the ref_flags kernel alone*/, float* ms);
+/* ---- which form the last lhgt_ref_scan took (k_scan.hip: lite = one probe per position until a hash reads 3, complete probes at
+ *      every 8th position and in the tiles that cannot be settled from that; exact = all e probes everywhere) */
+int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact);
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream);
 int lhgt_synchronize(lhgt_ctx* ctx);
 

@@ -38,6 +38,7 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     c->k = k;
     c->e = e;
     memset(c->cc, 0, sizeof c->cc);
+    if (const char* dbg = getenv("LHGT_DEBUG")) c->debug = atoi(dbg);   // lhgt_set_debug's switches for whole-program runs (tests)
     memset(c->rng_state, 0, sizeof c->rng_state);
     c->counts_words = ((size_t)1 << k) / 16;
     hipError_t he = hipStreamCreate(&c->stream);
@@ -87,6 +88,15 @@ int lhgt_set_debug(lhgt_ctx* ctx, int flags) {
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase, float* ms) {
     if (!ctx || !ms || phase < 0 || phase > 3) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     *ms = ctx->phase_ms[phase];
+    return LHGT_OK;
+}
+
+int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (lite) *lite = ctx->scan_lite ? 1 : 0;
+    if (frac_slots_at_3) *frac_slots_at_3 = ctx->scan_frac3;
+    if (n_tiles) *n_tiles = ctx->n_tiles;
+    if (n_tiles_exact) *n_tiles_exact = ctx->scan_lite ? ctx->scan_n_need : ctx->n_tiles;
     return LHGT_OK;
 }
 

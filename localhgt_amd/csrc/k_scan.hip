@@ -30,20 +30,28 @@ __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uin
 // ---- B0: one bit per 64-byte line of the count table (256 slots): every slot of the line holds 3.  When most lines are like
 // that (a deep sample saturates the table: 100 M pairs put 71 G increments on 4.3 G slots), ref_flags asks this 2 MiB,
 // L2-resident bitmap first and touches HBM only for the mixed lines.
+// n_sat[0] = saturated lines, n_sat[1] = slots holding 3 (how full the table is decides between the two forms of B1 below).
 __global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __restrict__ counts, size_t n_lines, uint32_t* __restrict__ satline,
                                                           unsigned long long* __restrict__ n_sat) {
     size_t line = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool sat = false;
+    int slots3 = 0;
     if (line < n_lines) {
         const uint4* p = (const uint4*)(counts + line * 16);
         uint4 a = p[0], b = p[1], c = p[2], d = p[3];
         sat = (a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) == 0xffffffffu;
+        const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++) slots3 += __popc(w[q] & (w[q] >> 1) & 0x55555555u);
     }
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) slots3 += __shfl_xor(slots3, dd, 64);
     unsigned long long bal = __ballot(sat);
     if ((threadIdx.x & 63) == 0 && line < n_lines) {
         satline[line >> 5] = (uint32_t)bal;            // lines of this wave: 64 consecutive -> two words
         satline[(line >> 5) + 1] = (uint32_t)(bal >> 32);
         if (bal) atomicAdd(n_sat, (unsigned long long)__popcll(bal));
+        if (slots3) atomicAdd(n_sat + 1, (unsigned long long)slots3);
     }
 }
 
@@ -80,6 +88,89 @@ __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tile
     }
 }
 
+// ---- B1 for a nearly saturated table ("lite").  What the later steps need from a tile is (1) the exact `single` bit of every
+// position and (2) whether every position is a good window; `trio` only enters through the window sums.  With most slots at 3,
+//   * `single` is settled by the first hash that reads 3: 1.03 probes per position instead of e;
+//   * every 8th position is probed completely, and the exact trio count of those alone is a LOWER bound of a window's
+//     `three` -- 58 of 62 sampled positions on configs[2] against the 40 needed -- so "every position of this tile is a good
+//     window" is proven without the other probes (window_lite);
+//   * only tiles that cannot be proven that way get their remaining hashes probed (ref_flags_fill, with the 512 positions their
+//     window sums look back on) and go through the exact window_good.
+// flags bit 7 = "all e hashes probed: the trio bit is exact"; pstate = per hash: bits 0-2 reads 3, bits 4-6 probed.
+// Same peaks, ids and votes as the exact form (every consumer sees exact inputs); the trio bit of positions inside proven
+// tiles stays a lower bound, nothing reads it.  e <= 3.
+template <bool SAT>
+__global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                     int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
+                                                     const uint32_t* __restrict__ satline) {
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    const uint32_t full = (1u << e) - 1u;
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= c.len) break;
+        uint8_t f = 0x80, ps = 0x70;   // the last k-1 positions have no k-mer: exact zeros (quirk Q1 contract)
+        if (j < nk) {
+            const uint32_t* hp = index + c.hash_word + j * e;
+            uint32_t h[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) h[i] = i < e ? hp[i] : 0u;
+            const bool sample = (j & 7) == 0;
+            uint32_t known = 0, is3 = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if (i < e && (sample || is3 == 0u)) {
+                    uint32_t cnt = 0u;                                 // hash 0 = invalid (E:936-941)
+                    if (h[i] != 0) {
+                        if (SAT && ((satline[h[i] >> 13] >> ((h[i] >> 8) & 31u)) & 1u)) cnt = 3u;
+                        else cnt = count_of(counts, h[i]);
+                    }
+                    known |= 1u << i;
+                    if (cnt == 3u) is3 |= 1u << i;                     // least_depth 3 (E:580)
+                }
+            const bool exact = known == full;
+            f = (uint8_t)((is3 != 0u) | ((exact && is3 == full) << 1) | (exact ? 0x80 : 0));
+            ps = (uint8_t)(is3 | (known << 4));
+        }
+        flags[c.flat_base + j] = f;
+        pstate[c.flat_base + j] = ps;
+    }
+}
+
+// the remaining probes of the listed tiles and of the HL2 positions their window sums look back on
+__global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ index,
+                                                     const uint32_t* __restrict__ counts, int k, int e, uint8_t* __restrict__ flags,
+                                                     uint8_t* __restrict__ pstate) {
+    const TileDev t = tiles[list[blockIdx.x]];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    const uint32_t full = (1u << e) - 1u;
+    for (int i0 = threadIdx.x; i0 < TILE + HL2; i0 += BT) {
+        const long j = (long)t.j0 - HL2 + i0;
+        if (j < 0 || j >= c.len) continue;
+        const uint8_t f = flags[c.flat_base + j];
+        if (f & 0x80) continue;                     // already exact (a neighbouring workgroup may write the same values meanwhile)
+        const uint8_t ps = pstate[c.flat_base + j];
+        uint32_t known = ps >> 4, is3 = ps & 7u;
+        if (j < nk) {
+            const uint32_t* hp = index + c.hash_word + j * e;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if (i < e && !((known >> i) & 1u)) {
+                    const uint32_t h = hp[i];
+                    const uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;
+                    if (cnt == 3u) is3 |= 1u << i;
+                }
+        }
+        known = full;
+        flags[c.flat_base + j] = (uint8_t)((f & 0x7c) | (is3 != 0u) | ((is3 == full) << 1) | 0x80);
+        pstate[c.flat_base + j] = (uint8_t)(is3 | (known << 4));
+    }
+}
+
 // exclusive prefix over the block's per-thread values: shuffle scan inside each wave, then the few wave totals through LDS
 // (the first version had every thread add up its predecessors: a third of interval_select's instructions)
 __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
@@ -103,10 +194,12 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
 // good, bit 1 all are, bit 2 all have a hit (`single`) -- mark_active_tiles uses them to keep whole runs of covered reference
 // away from interval_select.
 __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                  const uint32_t* __restrict__ list /* nullable: the tiles to do */, int keep7,
                                                   int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good) {
     __shared__ int P1[N2], P3[N2], part[BT];
     __shared__ int any_good, n_good;
-    const TileDev t = tiles[blockIdx.x];
+    const uint32_t tile = list ? list[blockIdx.x] : blockIdx.x;
+    const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
     uint8_t* F = flags + c.flat_base;
@@ -135,7 +228,7 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
             int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
             if (one >= one_min && three >= three_min) {
                 const int low = (P1[i] - P1[i - 1]) | ((P3[i] - P3[i - 1]) << 1);   // the position's own two flags, without re-reading them
-                F[j] = (uint8_t)(low | 4 | (j >= 1 ? 16 : 0));
+                F[j] = (uint8_t)(low | 4 | (j >= 1 ? 16 : 0) | keep7);
                 mine++;
             }
         }
@@ -154,7 +247,65 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
         // bits 3 / 4: the first HR4 / last HL4 positions all have a hit -- what the neighbouring tiles' contrast tests reach into
         const int head = n_here >= HR4 && P1[HL2 + HR4 - 1] - P1[HL2 - 1] == HR4;
         const int tail = n_here == TILE && P1[NW - 1] - P1[NW - 1 - HL4] == HL4;
-        tile_good[blockIdx.x] = (uint8_t)(any_good | (all_good << 1) | (all_single << 2) | (head << 3) | (tail << 4));
+        tile_good[tile] = (uint8_t)(any_good | (all_good << 1) | (all_single << 2) | (head << 3) | (tail << 4));
+    }
+}
+
+// ---- B2 on the lite flags: the single sums are exact, the trio sums count only completely probed positions (a lower bound).
+// A tile all of whose positions pass both thresholds with those sums is settled as window_good would settle it: all good, all
+// inside.  Any other tile is listed for the exact treatment (ref_flags_fill + window_good) and left untouched.
+__global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                  int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good,
+                                                  uint32_t* __restrict__ need, unsigned int* __restrict__ n_need) {
+    __shared__ int P1[N2], P3[N2], part[BT];
+    __shared__ int n_good;
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long len = c.len, lo = (long)t.j0 - HL2;
+    uint8_t* F = flags + c.flat_base;
+    constexpr int NW = TILE + HL2;
+    constexpr int CH = (NW + BT - 1) / BT;
+    const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
+    if (threadIdx.x == 0) n_good = 0;
+    int s1 = 0, s3 = 0;
+    for (int i = b; i < en; i++) {
+        long pos = lo + i;
+        int f = (pos >= 0 && pos < len) ? F[pos] : 0;
+        s1 += f & 1;
+        s3 += (f & 0x82) == 0x82;
+        P1[i] = s1;
+        P3[i] = s3;
+    }
+    int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
+    for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
+    __syncthreads();
+    const long rest = len - (long)t.j0;
+    const int n_here = rest < TILE ? (int)rest : TILE;
+    int mine = 0;
+    for (int jj = threadIdx.x; jj < n_here; jj += BT) {
+        const int i = jj + HL2;
+        mine += P1[i] - P1[i - WINDOW] >= one_min && P3[i] - P3[i - WINDOW] >= three_min;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_good, mine);
+    __syncthreads();
+    if (n_good != n_here) {          // not provable from the lower bound: exact treatment
+        if (threadIdx.x == 0) {
+            tile_good[blockIdx.x] = 0;
+            need[atomicAdd(n_need, 1u)] = blockIdx.x;
+        }
+        return;
+    }
+    for (int jj = threadIdx.x; jj < n_here; jj += BT) {
+        const long j = (long)t.j0 + jj;
+        F[j] = (uint8_t)(F[j] | 4 | (j >= 1 ? 16 : 0));
+    }
+    if (threadIdx.x == 0) {
+        const int all_single = P1[NW - 1] - P1[HL2 - 1] == n_here;
+        const int head = n_here >= HR4 && P1[HL2 + HR4 - 1] - P1[HL2 - 1] == HR4;
+        const int tail = n_here == TILE && P1[NW - 1] - P1[NW - 1 - HL4] == HL4;
+        tile_good[blockIdx.x] = (uint8_t)(1 | 2 | (all_single << 2) | (head << 3) | (tail << 4));
     }
 }
 
@@ -487,11 +638,11 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
         }
         if (j < nk) {  // E:247,262; beyond nk the hit array is zero anyway
             const uint32_t* hp = index + c.hash_word + j * e;
-            const uint32_t nz = nzmask[c.flat_base + j];
+            const uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u;
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                // hit > 0 for this hash: the bit ref_flags recorded (hashes 8.. are probed again, e <= 9)
-                if (i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
+                // hit > 0 for this hash: the bit ref_flags recorded (hashes 8.., and all of them after the lite form, are probed again)
+                if (nzmask && i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
                         const uint32_t fb = h & pf_mask;
@@ -543,10 +694,10 @@ __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ til
         }
         if (j < nk) {
             const uint32_t* hp = index + c.hash_word + j * e;
-            const uint32_t nz = nzmask[c.flat_base + j];
+            const uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u;
             for (int i = 0; i < e; i++) {
                 uint32_t h = hp[i];
-                if (i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
+                if (nzmask && i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     unsigned long long slot = atomicAdd(n_regs, 1ull);
                     regs_out[2 * slot] = h;
                     regs_out[2 * slot + 1] = id_base + lid;
@@ -584,29 +735,64 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
     int three_min = (int)(WINDOW * match_ratio);
     dim3 grid((unsigned)ctx->n_tiles), blk(BT);
-    // line summary of the count table (one streaming pass, ~0.3 ms per GiB); used when at least half the lines are saturated
+    // summary of the count table (one streaming pass, ~0.3 ms per GiB): saturated 64-byte lines (their bitmap is consulted first
+    // when at least half the lines are) and slots holding 3 (a nearly full table takes the lite form of B1/B2)
     bool use_sat = false;
+    double frac3 = 0.0;
     const size_t n_lines = ctx->counts_words / 16;
+    unsigned long long* d_nsat = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L)) + 2;   // [2], then the need count
     if (n_lines >= 64 && !(ctx->debug & 64)) {
         if (!ctx->d_satline) LHGT_HIP(hipMalloc(&ctx->d_satline, n_lines / 8 + 16));
-        unsigned long long* d_nsat = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L)) + 2;
-        LHGT_HIP(hipMemsetAsync(d_nsat, 0, 8, ctx->stream));
+        LHGT_HIP(hipMemsetAsync(d_nsat, 0, 16, ctx->stream));
         hipLaunchKernelGGL(table_line_summary, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_counts, n_lines,
                            ctx->d_satline, d_nsat);
-        unsigned long long n_sat = 0;
-        LHGT_HIP(hipMemcpyAsync(&n_sat, d_nsat, 8, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long n_sat[2] = {0, 0};
+        LHGT_HIP(hipMemcpyAsync(n_sat, d_nsat, 16, hipMemcpyDeviceToHost, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
-        use_sat = 2 * n_sat >= n_lines;
+        use_sat = 2 * n_sat[0] >= n_lines;
+        frac3 = (double)n_sat[1] / ((double)n_lines * 256.0);
     }
+    // bit 12 forces the lite form, bit 13 the exact one
+    ctx->scan_frac3 = frac3;
+    ctx->scan_n_need = 0;
+    // measured: 81.8 % of the slots at 3 (configs[2]) -> phase B 791 -> 368 ms; 24.5 % (configs[1]) -> 97 -> 105 ms when forced
+    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || frac3 >= 0.6);
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3 -> %s B1\n", 100.0 * frac3, ctx->scan_lite ? "lite" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
-    if (use_sat)
-        hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
-                           ctx->d_nzmask, ctx->d_satline);
-    else
-        hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
-                           ctx->d_nzmask, ctx->d_satline);
-    LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
-    hipLaunchKernelGGL(window_good, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good);
+    if (ctx->scan_lite) {
+        if (use_sat)
+            hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                               ctx->d_nzmask, ctx->d_satline);
+        else
+            hipLaunchKernelGGL(ref_flags_lite<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                               ctx->d_nzmask, ctx->d_satline);
+        LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
+        unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
+        LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(window_lite, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
+                           ctx->d_active_tiles, d_nneed);
+        unsigned int n_need = 0;
+        LHGT_HIP(hipMemcpyAsync(&n_need, d_nneed, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, not settled by the lower bound %u\n", ctx->n_tiles, n_need);
+        ctx->scan_n_need = n_need;
+        if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
+            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_index,
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
+            hipLaunchKernelGGL(window_good, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
+                               ctx->d_flags, ctx->d_tile_good);
+        }
+    } else {
+        if (use_sat)
+            hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                               ctx->d_nzmask, ctx->d_satline);
+        else
+            hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                               ctx->d_nzmask, ctx->d_satline);
+        LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
+        hipLaunchKernelGGL(window_good, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, (const uint32_t*)nullptr, 0, one_min, three_min,
+                           ctx->d_flags, ctx->d_tile_good);
+    }
     unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));
     LHGT_HIP(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
     unsigned int* d_nact = (unsigned int*)(d_nsel + 1);
@@ -693,7 +879,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     LHGT_TRY(peaks_prepare(ctx, total, n_sel, max_peak));
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
-                       ctx->d_counts, ctx->d_flags, ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
+                       ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
                        ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -755,7 +941,7 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
     unsigned long long cnt = 0;
     if (ctx->n_tiles > 0 && ctx->local_new > 0) {
         hipLaunchKernelGGL(emit_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
-                           ctx->d_counts, ctx->d_flags, ctx->d_nzmask, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
+                           ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
                            ctx->d_emit_regs, d_cnt);
         LHGT_HIP(hipGetLastError());
         LHGT_HIP(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));

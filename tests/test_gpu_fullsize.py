@@ -100,13 +100,14 @@ def test_settled_tiles_change_nothing_on_a_saturated_table(eng):
     hist = eng.counts_histogram()
     assert hist[3] > 0.2 * (1 << 32) and hist[1] == hist[2] == 0, hist
     res = []
-    for flags in (0, 256):
+    for flags in (8192, 8192 | 256, 4096):       # exact scan with / without settled tiles, lite scan
         eng.set_debug(flags)
         n = eng.ref_scan(0.1, 0.08, 300_000_000)
-        res.append((n, eng.peaks_export(n)[0].copy(), eng.flags_export(0, NC * CL)))
+        res.append((n, eng.peaks_export(n)[0].copy(), eng.flags_export(0, NC * CL) & 0b1111101))   # the trio bit is a lower bound after the lite form
     eng.set_debug(0)
-    assert res[0][0] == res[1][0]
-    assert (res[0][1] == res[1][1]).all()
-    assert (res[0][2] == res[1][2]).all()
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        assert (res[0][1] == other[1]).all()
+        assert (res[0][2] == other[2]).all()
     inside = (res[0][2] >> 4) & 1
     assert 0.3 < inside.mean() < 0.7             # the sampled contigs lie inside good intervals, the others do not

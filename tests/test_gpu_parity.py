@@ -110,11 +110,18 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         _, pf_o = oracle.vote(f1, f2, k, e, cc, ratio, None, pk_o, loci_o, n_o)
         _, pf_g = eng.peaks_export(n_g)
         assert (pf_g == pf_o[:n_g]).all()
-        for flags in (2048, 32, 4):     # every vote kernel: queued with its direct branch forced, generic with / without the bitmap
-            eng.set_debug(flags)
+        for flags in (2048, 32, 4, 4096, 4096 | 256):   # every vote kernel (queued with its direct branch forced, generic with / without the
+            eng.set_debug(flags)                          # bitmap); the lite form of the scan, also with no tile settled early
             assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
             eng.vote()
             assert (eng.peaks_export(n_g)[1] == pf_o[:n_g]).all(), f"votes differ with debug flags {flags}"
+            if flags & 4096:
+                fl = eng.flags_export(0, n_bases)
+                assert (((fl ^ flags_g) & 0b1111101) == 0).all(), "lite scan: single / good / peak / inside / selected / new flags differ"
+                exact = (fl & 0x80) != 0
+                assert (((fl ^ flags_g) & 0b10)[exact] == 0).all(), "lite scan: trio flag differs where it claims to be exact"
+                assert (((fl & ~flags_g) & 0b10) == 0).all(), "lite scan: trio flag is not a lower bound"
+                assert (eng.peaks_export(n_g)[0] == loci_o[:2 * n_o]).all() and (eng.peak_kmer_export() == pk_o).all()
         eng.set_debug(0)
         # D
         out = str(tmp_path / "interval.txt")
@@ -423,9 +430,9 @@ def test_saturated_table_line_summary(Engine, oracle, case_inputs, tmp_path):
         hist = eng.counts_histogram()
         assert hist[3] > 0.9 * (1 << k), "the case is meant to saturate the table"
         res = []
-        for flags in (0, 64, 128, 256, 384):   # + chunked tile scan, + no tile settled by window_good alone
+        for flags in (0, 64, 128, 256, 384, 4096, 8192):   # + chunked tile scan, + no tile settled by window_good alone, lite / exact scan forced
             eng.set_debug(flags)
             n = eng.ref_scan(0.1, 0.08, 100000)
-            res.append((n, eng.flags_export(0, n_bases).copy(), eng.peaks_export(n)[0].copy()))
+            res.append((n, eng.flags_export(0, n_bases) & 0b1111101, eng.peaks_export(n)[0].copy()))   # the trio bit is a lower bound after the lite form
         for other in res[1:]:
             assert res[0][0] == other[0] and (res[0][1] == other[1]).all() and (res[0][2] == other[2]).all()

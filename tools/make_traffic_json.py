@@ -8,7 +8,7 @@ d = json.load(open(src))
 KiB = 1024
 RANDOM = ("vote_kernel", "ref_flags", "register_peaks", "count_direct")
 phase = {"count_A": ("part_hist", "part_scatter_reads", "part_scatter_keys", "part_apply", "part_offsets", "count_direct"),
-         "scan_B": ("ref_flags", "window_peak", "window_good", "interval_mask", "interval_select", "mark_active_tiles", "table_line_summary", "tile_scan", "register_peaks"),
+         "scan_B": ("ref_flags", "window_peak", "window_good", "window_lite", "interval_mask", "interval_select", "mark_active_tiles", "table_line_summary", "tile_scan", "register_peaks"),
          "ref_flags": ("ref_flags",),
          "vote_kernel": ("vote_kernel",)}
 out = {}

@@ -30,7 +30,8 @@ __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uin
 // ---- B0: one bit per 64-byte line of the count table (256 slots): every slot of the line holds 3.  When most lines are like
 // that (a deep sample saturates the table: 100 M pairs put 71 G increments on 4.3 G slots), ref_flags asks this 2 MiB,
 // L2-resident bitmap first and touches HBM only for the mixed lines.
-// n_sat[0] = saturated lines, n_sat[1] = slots holding 3 (how full the table is decides between the two forms of B1 below).
+// n_sat[0] = saturated lines, n_sat[1] = slots holding 3 in every 16th line (how full the table is decides between the two forms
+// of B1 below).
 __global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __restrict__ counts, size_t n_lines, uint32_t* __restrict__ satline,
                                                           unsigned long long* __restrict__ n_sat) {
     size_t line = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,9 +41,11 @@ __global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __rest
         const uint4* p = (const uint4*)(counts + line * 16);
         uint4 a = p[0], b = p[1], c = p[2], d = p[3];
         sat = (a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) == 0xffffffffu;
-        const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        if ((line & 15) == 0) {   // every 16th line is plenty for a fraction (1 M lines of the k = 32 table)
+            const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-        for (int q = 0; q < 16; q++) slots3 += __popc(w[q] & (w[q] >> 1) & 0x55555555u);
+            for (int q = 0; q < 16; q++) slots3 += __popc(w[q] & (w[q] >> 1) & 0x55555555u);
+        }
     }
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) slots3 += __shfl_xor(slots3, dd, 64);
@@ -750,7 +753,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipMemcpyAsync(n_sat, d_nsat, 16, hipMemcpyDeviceToHost, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
         use_sat = 2 * n_sat[0] >= n_lines;
-        frac3 = (double)n_sat[1] / ((double)n_lines * 256.0);
+        frac3 = (double)n_sat[1] / ((double)((n_lines + 15) / 16) * 256.0);
     }
     // bit 12 forces the lite form, bit 13 the exact one
     ctx->scan_frac3 = frac3;

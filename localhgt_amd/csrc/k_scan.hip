@@ -758,8 +758,9 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // bit 12 forces the lite form, bit 13 the exact one
     ctx->scan_frac3 = frac3;
     ctx->scan_n_need = 0;
-    // measured: 81.8 % of the slots at 3 (configs[2]) -> phase B 791 -> 368 ms; 24.5 % (configs[1]) -> 97 -> 105 ms when forced
-    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || frac3 >= 0.6);
+    // measured (13 Gbase; phase B exact -> lite, ms): 81.8 % of the slots at 3 (100 M pairs) 791 -> 368; 74.2 % (50 M) 878 -> 494;
+    // 58.6 % (25 M) 1067 -> 1169, hardly a tile settles; 24.5 % (configs[1]) 97 -> 105
+    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || frac3 >= 0.65);
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3 -> %s B1\n", 100.0 * frac3, ctx->scan_lite ? "lite" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (ctx->scan_lite) {

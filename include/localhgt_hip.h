@@ -151,7 +151,7 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
  * settled by window_good alone (bits 2-8: outputs unchanged); bit9 / bit10: the sparse vote kernel stops after its first /
  * second filter level (stage timing, outputs wrong); bit11: the queued sparse vote kernel votes every pair with more than 8 bitmap
  * survivors directly (exercises that branch; outputs unchanged); bit12 / bit13: lhgt_ref_scan takes the lite / the exact form of its
- * first two steps whatever the table looks like (default: lite when >= 65 % of the slots hold 3 and e <= 3; outputs unchanged).
+ * first two steps whatever the table looks like (default for e <= 3: by how full the table is and, in between, by a trial on a few runs of tiles; outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 

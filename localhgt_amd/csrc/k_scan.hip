@@ -106,8 +106,8 @@ template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
                                                      int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
-                                                     const uint32_t* __restrict__ satline) {
-    const TileDev t = tiles[blockIdx.x];
+                                                     const uint32_t* __restrict__ satline, const uint32_t* __restrict__ list /* nullable */) {
+    const TileDev t = tiles[list ? list[blockIdx.x] : blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     const uint32_t full = (1u << e) - 1u;
@@ -259,10 +259,12 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
 // inside.  Any other tile is listed for the exact treatment (ref_flags_fill + window_good) and left untouched.
 __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good,
-                                                  uint32_t* __restrict__ need, unsigned int* __restrict__ n_need) {
+                                                  uint32_t* __restrict__ need, unsigned int* __restrict__ n_need,
+                                                  const uint32_t* __restrict__ pilot /* nullable: only count, over these tiles */) {
     __shared__ int P1[N2], P3[N2], part[BT];
     __shared__ int n_good;
-    const TileDev t = tiles[blockIdx.x];
+    const uint32_t tile = pilot ? pilot[blockIdx.x] : blockIdx.x;
+    const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
     uint8_t* F = flags + c.flat_base;
@@ -293,10 +295,14 @@ __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ ti
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_good, mine);
     __syncthreads();
+    if (pilot) {                     // trial run over a few runs of tiles: how many would the lower bound settle?
+        if (threadIdx.x == 0 && n_good != n_here) atomicAdd(n_need, 1u);
+        return;
+    }
     if (n_good != n_here) {          // not provable from the lower bound: exact treatment
         if (threadIdx.x == 0) {
-            tile_good[blockIdx.x] = 0;
-            need[atomicAdd(n_need, 1u)] = blockIdx.x;
+            tile_good[tile] = 0;
+            need[atomicAdd(n_need, 1u)] = tile;
         }
         return;
     }
@@ -308,7 +314,7 @@ __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ ti
         const int all_single = P1[NW - 1] - P1[HL2 - 1] == n_here;
         const int head = n_here >= HR4 && P1[HL2 + HR4 - 1] - P1[HL2 - 1] == HR4;
         const int tail = n_here == TILE && P1[NW - 1] - P1[NW - 1 - HL4] == HL4;
-        tile_good[blockIdx.x] = (uint8_t)(1 | 2 | (all_single << 2) | (head << 3) | (tail << 4));
+        tile_good[tile] = (uint8_t)(1 | 2 | (all_single << 2) | (head << 3) | (tail << 4));
     }
 }
 
@@ -758,23 +764,49 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // bit 12 forces the lite form, bit 13 the exact one
     ctx->scan_frac3 = frac3;
     ctx->scan_n_need = 0;
-    // measured (13 Gbase; phase B exact -> lite, ms): 81.8 % of the slots at 3 (100 M pairs) 791 -> 368; 74.2 % (50 M) 878 -> 494;
-    // 58.6 % (25 M) 1067 -> 1169, hardly a tile settles; 24.5 % (configs[1]) 97 -> 105
-    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || frac3 >= 0.65);
-    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3 -> %s B1\n", 100.0 * frac3, ctx->scan_lite ? "lite" : "exact");
+    // In between the clear cases a trial decides: the lite kernels on 64 runs of 65 consecutive tiles spread over the reference
+    // (the first tile of a run only supplies the look-back of the second); lite if they settle at least a quarter of the others.
+    double pilot_settled = -1.0;
+    if (e <= 3 && !(ctx->debug & (4096 | 8192)) && frac3 >= 0.3 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
+        std::vector<uint32_t> pl, pw;
+        for (int r = 0; r < 64; r++) {
+            const long t0 = (ctx->n_tiles - 65) * r / 63;
+            for (int q = 0; q < 65; q++) {
+                pl.push_back((uint32_t)(t0 + q));
+                if (q) pw.push_back((uint32_t)(t0 + q));
+            }
+        }
+        unsigned int* d_cnt = (unsigned int*)(d_nsat + 2);
+        uint32_t* d_list = ctx->d_active_tiles;
+        LHGT_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        LHGT_HIP(hipMemcpyAsync(d_list, pl.data(), pl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LHGT_HIP(hipMemcpyAsync(d_list + pl.size(), pw.data(), pw.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ref_flags_lite<false>, dim3((unsigned)pl.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts,
+                           k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list);
+        hipLaunchKernelGGL(window_lite, dim3((unsigned)pw.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags,
+                           ctx->d_tile_good, (uint32_t*)nullptr, d_cnt, d_list + pl.size());
+        unsigned int n_not = 0;
+        LHGT_HIP(hipMemcpyAsync(&n_not, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        pilot_settled = 1.0 - (double)n_not / (double)pw.size();
+    }
+    // measured (13 Gbase; slots at 3 / tiles the trial settles: phase B exact -> lite, ms): 81.8 % / 99.9 % (100 M pairs) 791 -> 368;
+    // 74.2 % / 92.7 % (50 M) 878 -> 494; 67.4 % / 32.3 % (35 M) 946 -> 890; 58.6 % / 0.5 % (25 M) 1067 -> 1169; 24.5 % (configs[1]) 97 -> 105
+    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.25 : frac3 >= 0.65));
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, ctx->scan_lite ? "lite" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (ctx->scan_lite) {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline);
+                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);
         else
             hipLaunchKernelGGL(ref_flags_lite<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline);
+                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(window_lite, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
-                           ctx->d_active_tiles, d_nneed);
+                           ctx->d_active_tiles, d_nneed, (const uint32_t*)nullptr);
         unsigned int n_need = 0;
         LHGT_HIP(hipMemcpyAsync(&n_need, d_nneed, 4, hipMemcpyDeviceToHost, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));

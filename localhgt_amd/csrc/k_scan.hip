@@ -765,9 +765,9 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     ctx->scan_frac3 = frac3;
     ctx->scan_n_need = 0;
     // In between the clear cases a trial decides: the lite kernels on 64 runs of 65 consecutive tiles spread over the reference
-    // (the first tile of a run only supplies the look-back of the second); lite if they settle at least a quarter of the others.
+    // (the first tile of a run only supplies the look-back of the second); lite if they settle at least 40 % of the others.
     double pilot_settled = -1.0;
-    if (e <= 3 && !(ctx->debug & (4096 | 8192)) && frac3 >= 0.3 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
+    if (e <= 3 && !(ctx->debug & (4096 | 8192)) && frac3 >= 0.2 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
         std::vector<uint32_t> pl, pw;
         for (int r = 0; r < 64; r++) {
             const long t0 = (ctx->n_tiles - 65) * r / 63;
@@ -791,8 +791,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         pilot_settled = 1.0 - (double)n_not / (double)pw.size();
     }
     // measured (13 Gbase; slots at 3 / tiles the trial settles: phase B exact -> lite, ms): 81.8 % / 99.9 % (100 M pairs) 791 -> 368;
-    // 74.2 % / 92.7 % (50 M) 878 -> 494; 67.4 % / 32.3 % (35 M) 946 -> 890; 58.6 % / 0.5 % (25 M) 1067 -> 1169; 24.5 % (configs[1]) 97 -> 105
-    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.25 : frac3 >= 0.65));
+    // 74.2 % / 92.7 % (50 M) 878 -> 494; 67.4 % / 32.3 % (35 M) 946 -> 890; 58.6 % / 0.5 % (25 M) 1067 -> 1169; 24.5 % / 25.1 % (configs[1]) 97 -> 105
+    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.4 : frac3 >= 0.65));
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, ctx->scan_lite ? "lite" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (ctx->scan_lite) {

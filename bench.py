@@ -221,8 +221,10 @@ def main():
                                     "algorithmic_bytes_per_step": phases[ph][1], "ms_per_step": round(kern[ph], 3),
                                     "launches_per_step": phases[ph][2], "traffic": tr.get(tkey[ph])}
                                for ph in kern if ph != dominant},
-            "note": "fractions use SURVEY 8d's sector model (one 64 B sector per probe); the radix-partitioned count and the L2-resident vote "
-                    "prefilter move far fewer bytes than that model, so their fractions can exceed the random-access ceiling (DESIGN.md 4)",
+            "note": "fractions use SURVEY 8d's sector model (one 64 B HBM sector per probe); the radix-partitioned count, the L2-resident vote "
+                    "prefilter and the lite reference scan do the same work with far fewer HBM bytes (roofline.traffic is the measured figure), so "
+                    "their fractions can exceed 1. The limits they actually run against are request rates measured by microbenchmark "
+                    "(profiles/r01_probe_*): ~55 G random requests/s from HBM (ref_flags: 96 % of it), ~254 G/s from L2 (sparse vote: 80 % of it); DESIGN.md 4",
         }
         if world == 1 and not args.no_cpu_baseline:
             eng.pairs_clear()

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
                 const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
                 const uint32_t* q = stage + (u * 2 + m) * 32 + (j < nk[u][m] ? (j >> 5) : 0);
                 const int wp = wpr[u][m];
-                auto win = [&](uint32_t a, uint32_t c) { return (uint32_t)(((((uint64_t)a << 32) | c) << r) >> 32) >> (32 - k); };
+                auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
                 const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
                 const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
                 ok[u][s] = j < nk[u][m] && wnb == 0;
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                 const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
                 const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
                 const int wp = wpr[m];
-                auto win = [&](uint32_t a, uint32_t c) { return (uint32_t)(((((uint64_t)a << 32) | c) << r) >> 32) >> (32 - k); };
+                auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
                 const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
                 const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
                 const bool ok = j < nk[m] && wnb == 0;

@@ -14,10 +14,13 @@
 namespace lhgt {
 
 // k-bit window starting at base j of a plane (32 bases per word, first base at the MSB).
+// v_alignbit_b32 takes the 32 bits that start r bits into the word pair in one full-rate instruction (a 64-bit shift runs at a quarter)
+__device__ __forceinline__ uint32_t window32(uint32_t hi, uint32_t lo, int r) {
+    return r ? __builtin_amdgcn_alignbit(hi, lo, 32 - r) : hi;
+}
 __device__ __forceinline__ uint32_t plane_window(const uint32_t* __restrict__ w, int j, int k) {
     int q = j >> 5, r = j & 31;
-    uint64_t v = ((uint64_t)w[q] << 32) | w[q + 1];
-    return (uint32_t)((v << r) >> 32) >> (32 - k);
+    return window32(w[q], w[q + 1], r) >> (32 - k);
 }
 
 __device__ __forceinline__ uint32_t brev_k(uint32_t x, int k) { return __brev(x) >> (32 - k); }

@@ -85,6 +85,11 @@ int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_perce
  * count_mate2 (optional, one byte per pair) = 0 excludes mate 2 from phase A only. */
 int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
                       const uint64_t* off2, long n_pairs, const uint8_t* count_mate2);
+/* The same with one flag byte per pair: bit 0 / bit 1 = mate 1 / mate 2 is counted in phase A, bit 2 = the pair is re-scanned
+ * and voted in phase C (NULL = 7 for every pair).  What a reference thread chunk boundary loses (E:1022-1026) or a longer
+ * fq2 adds (E:1438-1445) is expressed this way by lhgt_pairs_load_fastq. */
+int lhgt_pairs_append_flags(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
+                            const uint64_t* off2, long n_pairs, const uint8_t* pair_flags);
 int lhgt_pairs_clear(lhgt_ctx* ctx);
 int lhgt_pairs_count(lhgt_ctx* ctx, long* n_pairs);
 
@@ -142,8 +147,17 @@ int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, 
 int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, uint8_t* host_ascii_or_null);
 int lhgt_synth_reference_shard(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, int shard_rank, int shard_world,
                                uint8_t* host_ascii_or_null);
+/* the same base stream cut into contigs at cuts[0] = 0 < ... < cuts[n_cuts-1] = n_contigs*contig_len (pieces of <= k bases are not
+ * indexed, E:772): a reference with a ragged length distribution under the same synthetic reads */
+int lhgt_synth_reference_cuts(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, const uint64_t* cuts, long n_cuts,
+                              uint8_t* host_ascii_or_null);
 int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
                      long first_pair, long n_pairs, int read_len, uint8_t* host_seq1_or_null, uint8_t* host_seq2_or_null);
+
+/* knobs of the synthetic sample: positions per thousand at which a sample genome differs from the reference (default 0; 10 =
+ * the "snp0.01" of the reference's test data), reads per thousand carrying one N (default 20), number of contigs the sample is
+ * drawn from (0 = half of the reference; a metagenome holds far fewer of a catalogue's genomes). */
+int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sample_contigs);
 
 /* switches for profiling / A-B runs.  bit0: lhgt_vote skips judge_base (outputs wrong);
  * bit2: never use the vote prefilter; bit4: without its LDS-resident first level; bit5: generic vote kernel even on the

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
     "lhgt_fastq_parse_digest": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _lp, _lp, _u64p],
     "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
+    "lhgt_pairs_append_flags": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
     "lhgt_pairs_clear": [_vp],
     "lhgt_pairs_count": [_vp, _lp],
     "lhgt_count_kmers": [_vp],
@@ -68,7 +69,9 @@ SIGNATURES = {
     "lhgt_peak_kmer_export": [_vp, C.c_uint64, C.c_uint64, _u32p],
     "lhgt_synth_reference": [_vp, C.c_uint64, _l, _l, _u8p],
     "lhgt_synth_reference_shard": [_vp, C.c_uint64, _l, _l, _i, _i, _u8p],
+    "lhgt_synth_reference_cuts": [_vp, C.c_uint64, _l, _l, _u64p, _l, _u8p],
     "lhgt_synth_pairs": [_vp, C.c_uint64, C.c_uint64, _l, _l, _l, _l, _i, _u8p, _u8p],
+    "lhgt_synth_options": [_vp, _i, _i, _l],
     "lhgt_set_debug": [_vp, _i],
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_scan_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), _lp, _lp],

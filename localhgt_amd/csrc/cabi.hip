@@ -101,14 +101,14 @@ int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_ti
 }
 
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !hip_stream) LHGT_FAIL(LHGT_E_ARG, "null argument");
     *hip_stream = (void*)ctx->stream;
     return LHGT_OK;
 }
 
 int lhgt_synchronize(lhgt_ctx* ctx) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
     return LHGT_OK;

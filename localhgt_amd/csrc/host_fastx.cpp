@@ -140,7 +140,7 @@ static double now_s() {
 static bool ingest_trace() { static int t = getenv("LHGT_INGEST_TRACE") ? 1 : 0; return t != 0; }
 
 struct ParsedChunk {
-    std::vector<uint8_t> s1, s2, cnt2;
+    std::vector<uint8_t> s1, s2, flags;   // flags: PAIR_COUNT1 | PAIR_COUNT2 | PAIR_VOTE per kept pair
     std::vector<uint64_t> o1, o2;
     int rc = LHGT_OK;
     std::string err;
@@ -205,7 +205,6 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
     out->o1.assign(1, 0);
     out->o2.assign(1, 0);
     const long g0 = p1.line0[c], g1 = p1.line0[c + 1];
-    if (g1 > p2.line0.back()) { out->rc = LHGT_E_FORMAT; out->err = "second FASTQ has fewer lines than the first"; return; }
     if (g0 == g1) return;
     // fq2 cursor at global line g0
     long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g0) - p2.line0.begin()) - 1;
@@ -218,7 +217,7 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
     const size_t size1 = m1.n;
     for (long g = g0; g < g1; g++) {
         k1.next(&a, &la, &sa);
-        k2.next(&b, &lb, &sb);
+        if (!k2.next(&b, &lb, &sb)) { b = a; lb = 0; sb = m2.n; }   // fq1's trailing non-sequence line without a partner (checked by parse_pairs)
         if (g == 0) {  // E:368-402: the two first read IDs must agree
             size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
             if (ia != ib || memcmp(a, b, ia)) { out->rc = LHGT_E_FORMAT; out->err = "paired-end reads not consistent: first records differ"; return; }
@@ -236,7 +235,7 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
         out->s2.insert(out->s2.end(), b, b + lb);
         out->o1.push_back(out->s1.size());
         out->o2.push_back(out->s2.size());
-        out->cnt2.push_back(sb <= size1 ? 1 : 0);  // quirk Q4: mate 2 counted only while its line starts at <= size(fq1)
+        out->flags.push_back((uint8_t)(PAIR_COUNT1 | PAIR_VOTE | (sb <= size1 ? PAIR_COUNT2 : 0)));  // quirk Q4: mate 2 counted only while its line starts at <= size(fq1)
     }
 }
 
@@ -251,8 +250,10 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
     double t0 = now_s();
     ChunkPlan p1 = plan_chunks(m1, chunk_bytes, threads), p2 = plan_chunks(m2, chunk_bytes, threads);
     double t_plan = now_s() - t0, t_parse = 0, t_consume = 0;
-    if (p2.line0.back() < p1.line0.back()) LHGT_FAIL(LHGT_E_FORMAT, "%s has fewer lines than %s", fq2, fq1);
-    if (p2.line0.back() > p1.line0.back()) LHGT_FAIL(LHGT_E_FORMAT, "%s has more lines than %s", fq2, fq1);
+    // fq2 shorter than fq1: the reference pairs the surplus sequence lines of fq1 with a stale line of fq2 (E:356-367) -- refused.
+    // Tolerated like the reference: surplus lines of fq1 that are no sequence lines (a trailing blank line)
+    for (long g = p2.line0.back(); g < p1.line0.back(); g++)
+        if (g % 4 == 1 || g - p2.line0.back() >= 4) LHGT_FAIL(LHGT_E_FORMAT, "%s has fewer records than %s", fq2, fq1);
     const long nc = (long)p1.start.size() - 1;
     for (long base = 0; base < nc; base += threads) {
         long n = nc - base < threads ? nc - base : threads;
@@ -268,6 +269,33 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
         }
         t_parse += t2 - t1;
         t_consume += now_s() - t2;
+    }
+    // fq2 longer than fq1: phase C stops with fq1 (E:356), but phase A counts every record of fq2 whose sequence line starts
+    // at a byte offset <= size(fq1) (E:1419-1445, quirk Q4) -- surplus records become mate-2-only entries
+    if (p2.line0.back() > p1.line0.back()) {
+        ParsedChunk tail;
+        tail.o1.assign(1, 0);
+        tail.o2.assign(1, 0);
+        const long g0 = p1.line0.back();
+        long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g0) - p2.line0.begin()) - 1;
+        LineCursor k2(m2);
+        k2.cur = p2.start[c2];
+        const uint8_t* b;
+        size_t lb, sb;
+        for (long skip = g0 - p2.line0[c2]; skip > 0; skip--) k2.next(&b, &lb, &sb);
+        for (long g = g0; k2.next(&b, &lb, &sb); g++) {
+            if (sb > m1.n) break;
+            if (g % 4 != 1) continue;
+            const long n = g / 4;
+            const bool keep = ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio;
+            if (!keep || (n / shard_block) % shard_world != shard_rank) continue;
+            if (lb > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read %ld longer than %d bases (the reference's buffers, E:1004)", n, LHGT_MAX_READ_LEN);
+            tail.s2.insert(tail.s2.end(), b, b + lb);
+            tail.o1.push_back(0);
+            tail.o2.push_back(tail.s2.size());
+            tail.flags.push_back(PAIR_COUNT2);
+        }
+        if (tail.o1.size() > 1) LHGT_TRY(consume(tail));
     }
     if (ingest_trace())
         fprintf(stderr, "[lhgt ingest] %d threads, %ld chunks: line count %.3fs, parse %.3fs, consume(+upload) %.3fs\n", threads, nc,
@@ -289,7 +317,7 @@ extern "C" {
 
 int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, int shard_rank,
                           int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !fq1 || !fq2) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world || shard_block < 1)
         LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d block %ld", shard_rank, shard_world, shard_block);
@@ -303,7 +331,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     LHGT_TRY(ws_reserve(ctx, BATCH_BYTES + 4 * CHUNK, 0));
     std::vector<uint64_t> st1, st2;
     std::vector<uint16_t> ln1, ln2;
-    std::vector<uint8_t> cnt2;
+    std::vector<uint8_t> pflags;
     size_t fill = 0;
     long kept = 0;
     auto flush = [&]() -> int {
@@ -311,8 +339,8 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
         if (n == 0) return LHGT_OK;
         st1.insert(st1.end(), st2.begin(), st2.end());
         ln1.insert(ln1.end(), ln2.begin(), ln2.end());
-        int rc = install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, st1.data(), ln1.data(), n, cnt2.data());
-        st1.clear(); st2.clear(); ln1.clear(); ln2.clear(); cnt2.clear();
+        int rc = install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, st1.data(), ln1.data(), n, pflags.data());
+        st1.clear(); st2.clear(); ln1.clear(); ln2.clear(); pflags.clear();
         fill = 0;
         return rc;
     };
@@ -332,7 +360,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
                                  ln1.push_back((uint16_t)(ch.o1[i + 1] - ch.o1[i]));
                                  ln2.push_back((uint16_t)(ch.o2[i + 1] - ch.o2[i]));
                              }
-                             cnt2.insert(cnt2.end(), ch.cnt2.begin(), ch.cnt2.end());
+                             pflags.insert(pflags.end(), ch.flags.begin(), ch.flags.end());
                              if ((long)st1.size() >= BATCH_PAIRS || fill >= BATCH_BYTES) return flush();
                              return LHGT_OK;
                          });
@@ -360,7 +388,7 @@ int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_perce
                                  mix(ch.s1.data() + ch.o1[i], l1);
                                  mix((const uint8_t*)&l2, 8);
                                  mix(ch.s2.data() + ch.o2[i], l2);
-                                 mix(&ch.cnt2[i], 1);
+                                 { const uint8_t c2 = (ch.flags[i] & PAIR_COUNT2) ? 1 : 0; mix(&c2, 1); if (!(ch.flags[i] & PAIR_VOTE)) { const uint8_t f = ch.flags[i]; mix(&f, 1); } }
                              }
                              kept += n;
                              return LHGT_OK;
@@ -375,7 +403,7 @@ int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_perce
 // writes 4 bytes from a short array), then per contig [len][hashes]; genome.len.txt beside it.
 int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_path, const char* genome_len_path,
                      long* n_contigs, long* n_bases) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !fasta_path || !index_path || !genome_len_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: call lhgt_coder_generate or lhgt_coder_set first");
     FILE* idx = fopen(index_path, "wb");
@@ -387,29 +415,51 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
         fwrite(&w, 4, 1, idx);
     }
     long contigs = 0, bases = 0;
+    // Contigs are collected into spans of ~64 Mbase; a span is uploaded, packed and hashed by ONE launch, straight into the file's
+    // layout ([u32 len][(len-k+1)*e u32] per contig), and comes back as one copy and one write (a catalogue like UHGG has
+    // hundreds of thousands of contigs: two launches, a copy and two writes per contig is what the first version did).
+    const size_t SPAN = (size_t)64 << 20;
+    std::vector<uint8_t> span;
+    std::vector<uint64_t> coff(1, 0), ow;
     std::vector<uint32_t> host;
+    uint64_t out_words = 0;
     uint32_t* d_out = nullptr;
     size_t d_cap = 0;
     const int k = ctx->k, e = ctx->e;
-    int rc = for_each_contig(fasta_path, k, [&](const std::string& name, long ref_index, const uint8_t* seq, long len, long cum) -> int {
-        fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", name.c_str(), ref_index, len, cum);
-        size_t need = (size_t)(len - k + 1) * e;
-        if (need > d_cap) {
+    auto flush = [&]() -> int {
+        if (ow.empty()) return LHGT_OK;
+        if (out_words > d_cap) {
             if (d_out) hipFree(d_out);
-            d_cap = need + need / 4;
+            d_out = nullptr;
+            d_cap = out_words + out_words / 4;
             LHGT_HIP(hipMalloc(&d_out, d_cap * 4));
         }
-        LHGT_TRY(hash_contig_to_device(ctx, seq, len, d_out, nullptr));
-        host.resize(need);
-        LHGT_HIP(hipMemcpyAsync(host.data(), d_out, need * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_TRY(ws_reserve(ctx, span.size() + 32, 0));
+        LHGT_TRY(stage_ascii(ctx, 0, span.data(), span.size()));
+        LHGT_TRY(hash_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span.size(), coff.data(), ow.data(), (long)ow.size(), d_out));
+        host.resize(out_words);
+        LHGT_HIP(hipMemcpyAsync(host.data(), d_out, out_words * 4, hipMemcpyDeviceToHost, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
-        uint32_t u = (uint32_t)len;
-        if (fwrite(&u, 4, 1, idx) != 1 || fwrite(host.data(), 4, need, idx) != need)
-            LHGT_FAIL(LHGT_E_IO, "short write to %s", index_path);
+        for (size_t c = 0; c < ow.size(); c++) host[ow[c] - 1] = (uint32_t)(coff[c + 1] - coff[c]);
+        if (fwrite(host.data(), 4, out_words, idx) != out_words) LHGT_FAIL(LHGT_E_IO, "short write to %s", index_path);
+        span.clear();
+        coff.assign(1, 0);
+        ow.clear();
+        out_words = 0;
+        return LHGT_OK;
+    };
+    int rc = for_each_contig(fasta_path, k, [&](const std::string& name, long ref_index, const uint8_t* seq, long len, long cum) -> int {
+        fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", name.c_str(), ref_index, len, cum);
+        if (!span.empty() && span.size() + (size_t)len > SPAN) LHGT_TRY(flush());
+        span.insert(span.end(), seq, seq + len);
+        coff.push_back(span.size());
+        ow.push_back(out_words + 1);
+        out_words += 1 + (uint64_t)(len - k + 1) * e;
         contigs++;
         bases += len;
         return LHGT_OK;
     });
+    if (rc == LHGT_OK) rc = flush();
     if (d_out) hipFree(d_out);
     fclose(idx);
     fclose(lenf);
@@ -423,7 +473,7 @@ int lhgt_index_load(lhgt_ctx* ctx, const char* index_path, long* n_contigs, long
 }
 
 int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank, int shard_world, long* n_contigs, long* n_bases) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !index_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     Mapped m;
     LHGT_TRY(m.open(index_path));

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams h
     for (long r = wave; r < n_reads; r += n_waves) {
         const int m = (int)(r & 1);
         const long p = r >> 1;
-        if (m == 1 && b.count2 && !b.count2[p]) continue;  // quirk Q4
+        if (b.flags && !((b.flags[p] >> m) & 1)) continue;  // quirk Q4, thread-chunk emulation
         const int len = b.len[m][p];
         const int nk = len - hp.k + 1;
         if (nk <= 0) continue;
@@ -93,7 +93,7 @@ using namespace lhgt;
 extern "C" {
 
 int lhgt_count_kmers(lhgt_ctx* ctx) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: load or build the index first");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -125,14 +125,14 @@ int lhgt_set_count_mode(lhgt_ctx* ctx, int mode) {
 }
 
 int lhgt_counts_clear(lhgt_ctx* ctx) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     LHGT_HIP(hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * 4, ctx->stream));
     return LHGT_OK;
 }
 
 int lhgt_counts_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !dev_ptr || !bytes) LHGT_FAIL(LHGT_E_ARG, "null argument");
     *dev_ptr = ctx->d_counts;
     *bytes = ctx->counts_words * 4;
@@ -140,7 +140,7 @@ int lhgt_counts_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
 }
 
 int lhgt_counts_merge(lhgt_ctx* ctx, const void* dev_other, size_t byte_offset, size_t bytes) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !dev_other) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (byte_offset % 4 || bytes % 4 || byte_offset + bytes > ctx->counts_words * 4)
         LHGT_FAIL(LHGT_E_ARG, "merge range [%zu,+%zu) outside the table or not word aligned", byte_offset, bytes);
@@ -156,7 +156,7 @@ int lhgt_counts_merge(lhgt_ctx* ctx, const void* dev_other, size_t byte_offset, 
 }
 
 int lhgt_counts_export_u8(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint8_t* out) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     uint64_t total = 1ull << ctx->k;
     if (first_slot + n_slots > total) LHGT_FAIL(LHGT_E_ARG, "slot range outside the table");
@@ -176,7 +176,7 @@ int lhgt_counts_export_u8(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, 
 }
 
 int lhgt_counts_histogram(lhgt_ctx* ctx, uint64_t out[4]) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     unsigned long long* d_h;
     LHGT_HIP(hipMalloc(&d_h, 32));

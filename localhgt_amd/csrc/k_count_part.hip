@@ -77,7 +77,7 @@ __host__ __device__ inline uint32_t part_region(const PartCap& c, uint32_t q) {
 // load into its 64-word LDS area `stage`, and every lane cuts its windows out of LDS (instead of 6 global loads per offset).
 template <class F>
 __device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashParams& hp, long p, int m, int lane, uint32_t* stage, F f) {
-    if (m == 1 && b.count2 && !b.count2[p]) return;  // quirk Q4
+    if (b.flags && !((b.flags[p] >> m) & 1)) return;  // quirk Q4, thread-chunk emulation
     const int len = b.len[m][p];
     const int nk = len - hp.k + 1;
     if (nk <= 0) return;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
             if (r >= r1) continue;
             const long p = pair0 + (r >> 1);
             const int m = (int)(r & 1);
-            if (m == 1 && b.count2 && !b.count2[p]) continue;   // quirk Q4
+            if (b.flags && !((b.flags[p] >> m) & 1)) continue;   // quirk Q4, thread-chunk emulation
             const int len = b.len[m][p];
             const int nk = len - k + 1;
             const int wpr = ((len + 31) >> 5) + 1;

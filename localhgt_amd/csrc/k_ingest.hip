@@ -63,6 +63,36 @@ __global__ void __launch_bounds__(256) hash_positions(const uint32_t* __restrict
     if (out_valid) out_valid[j] = valid;
 }
 
+// ---------------------------------------------------------------- hash every position of MANY sequences in one launch
+// The sequences lie back to back in one packed span (planes of span_len bases, wps words each).  Thread = span position x;
+// its sequence c is found by binary search in coff[0..n_c] (offsets inside the span), j = x - coff[c].  Sequences whose
+// out_word is ~0 (length <= k: not indexed, E:772) are skipped; a window never crosses into the next sequence because
+// j <= len - k.  One launch per span instead of two per contig: a catalogue like UHGG has hundreds of thousands of contigs.
+__global__ void __launch_bounds__(256) hash_span_positions(const uint32_t* __restrict__ planes, long span_len, int wps,
+                                                           const uint64_t* __restrict__ coff, int n_c,
+                                                           const uint64_t* __restrict__ out_word, HashParams hp,
+                                                           uint32_t* __restrict__ out) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= span_len) return;
+    int lo = 0, hi = n_c;                 // last c with coff[c] <= x
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long)coff[mid] <= x) lo = mid; else hi = mid; }
+    const long j = x - (long)coff[lo], len = (long)(coff[lo + 1] - coff[lo]);
+    const uint64_t ow = out_word[lo];
+    if (ow == ~0ull || j + hp.k > len) return;
+    const uint32_t* hiw = planes + (x >> 5);
+    const int r = (int)(x & 31);
+    const uint32_t whi = plane_window(hiw, r, hp.k), wlo = plane_window(hiw + wps, r, hp.k), wnb = plane_window(hiw + 2 * wps, r, hp.k);
+    const uint32_t rhi = brev_k(whi, hp.k), rlo = brev_k(wlo, hp.k);
+    uint32_t* o = out + ow + (uint64_t)j * hp.e;
+    for (int i = 0; i < hp.e; i++) o[i] = wnb == 0 ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;   // quirk Q6
+}
+
+// the length word in front of every contig's hashes in the resident index ([u32 len][(len-k+1)*e u32], E:785, 847)
+__global__ void __launch_bounds__(256) write_contig_lens(const ContigDev* __restrict__ contigs, long n, uint32_t* __restrict__ index) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) index[contigs[c].hash_word - 1] = contigs[c].len;
+}
+
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words) {
     if (ascii_bytes > ctx->ws_ascii_cap) {
         if (ctx->d_ws_ascii) hipFree(ctx->d_ws_ascii);
@@ -96,6 +126,38 @@ int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint3
     return LHGT_OK;
 }
 
+// Pack a span of back-to-back sequences that sits in device memory (d_ascii[0 .. span_len)) and hash all their positions:
+// sequence c of the span covers [coff[c], coff[c+1]) and its hashes go to d_out[out_word[c] ...] (out_word ~0 = skip).
+int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const uint64_t* out_word,
+                        long n_c, uint32_t* d_out) {
+    if (span_len <= 0 || n_c <= 0) return LHGT_OK;
+    const int wps = (int)((span_len + 31) / 32) + 1;
+    const size_t meta_words = 2 * ((size_t)2 * n_c + 4);
+    LHGT_TRY(ws_reserve(ctx, 0, (size_t)3 * wps + 8 + meta_words));
+    uint64_t* d_meta = (uint64_t*)(ctx->d_ws_words + (((size_t)3 * wps + 3) & ~(size_t)1));
+    uint64_t* d_coff = d_meta + 2;
+    uint64_t* d_ow = d_coff + n_c + 1;
+    const uint64_t offs[2] = {0, 0};
+    LHGT_HIP(hipMemcpyAsync(d_meta, offs, sizeof offs, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_coff, coff, (size_t)(n_c + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LHGT_HIP(hipMemcpyAsync(d_ow, out_word, (size_t)n_c * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pack_bases, dim3((unsigned)((wps + 255) / 256)), dim3(256), 0, ctx->stream, d_ascii, d_meta,
+                       (const uint16_t*)nullptr, span_len, d_meta + 1, 1L, wps, ctx->d_ws_words);
+    hipLaunchKernelGGL(hash_span_positions, dim3((unsigned)((span_len + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ws_words,
+                       span_len, wps, d_coff, (int)n_c, d_ow, ctx->hp, d_out);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays and the workspace are reused by the next span
+    return LHGT_OK;
+}
+
+int write_index_lens(lhgt_ctx* ctx) {
+    const long n = (long)ctx->contigs.size();
+    if (n == 0) return LHGT_OK;
+    hipLaunchKernelGGL(write_contig_lens, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_contigs, n, ctx->d_index);
+    LHGT_HIP(hipGetLastError());
+    return LHGT_OK;
+}
+
 int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid) {
     if (len < ctx->k) return LHGT_OK;
     LHGT_TRY(ws_reserve(ctx, (size_t)len + 32, 0));
@@ -121,7 +183,7 @@ static void free_batch(ReadBatch& b) {
 // Install n pairs whose ASCII bases already sit in device memory: sequence r (r < n: mate 1 of pair r, else
 // mate 2 of pair r-n) is d_ascii[start[r] .. start[r]+len[r]).
 int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
-                            const uint8_t* count_mate2) {
+                            const uint8_t* pair_flags) {
     const int k = ctx->k;
     std::vector<uint64_t> word_off(2 * n);
     uint64_t words = 0, nkm = 0;
@@ -149,10 +211,10 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
     b.alloc[1] = d_off32;
     LHGT_HIP(hipMalloc(&d_len, (size_t)2 * n * 2));
     b.alloc[2] = d_len;
-    if (count_mate2) {
+    if (pair_flags) {
         LHGT_HIP(hipMalloc(&d_cnt, (size_t)n));
         b.alloc[3] = d_cnt;
-        LHGT_HIP(hipMemcpyAsync(d_cnt, count_mate2, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        LHGT_HIP(hipMemcpyAsync(d_cnt, pair_flags, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     }
     LHGT_HIP(hipMalloc(&d_start, (size_t)2 * n * 8));
     b.alloc[4] = d_start;
@@ -177,7 +239,7 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
     b.d.off[1] = d_off32 + n;
     b.d.len[0] = d_len;
     b.d.len[1] = d_len + n;
-    b.d.count2 = d_cnt;
+    b.d.flags = d_cnt;
     b.d.n_pairs = n;
     ctx->batches.push_back(b);
     ctx->n_pairs += n;
@@ -196,7 +258,7 @@ int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes)
 }
 
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
-                 long n, const uint8_t* count_mate2) {
+                 long n, const uint8_t* pair_flags) {
     if (n <= 0) return LHGT_OK;
     size_t bytes1 = off1[n] - off1[0], bytes2 = off2[n] - off2[0];
     std::vector<uint64_t> start(2 * n);
@@ -214,7 +276,7 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
     // registering costs ~25 ms/GiB (tools/h2d_rates.hip): stage_ascii pins each source range for its copy
     LHGT_TRY(stage_ascii(ctx, 0, seq1 + off1[0], bytes1));
     LHGT_TRY(stage_ascii(ctx, bytes1, seq2 + off2[0], bytes2));
-    return install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, start.data(), lens.data(), n, count_mate2);
+    return install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, start.data(), lens.data(), n, pair_flags);
 }
 
 // ---------------------------------------------------------------- index layout / install
@@ -306,16 +368,24 @@ using namespace lhgt;
 
 extern "C" {
 
-int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
-                      const uint64_t* off2, long n_pairs, const uint8_t* count_mate2) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+int lhgt_pairs_append_flags(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
+                            const uint64_t* off2, long n_pairs, const uint8_t* pair_flags) {
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !seq1 || !off1 || !seq2 || !off2 || n_pairs < 0) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     const long CH = 4L << 20;  // pairs per device batch (keeps 32-bit word offsets inside a batch)
     for (long p = 0; p < n_pairs; p += CH) {
         long n = n_pairs - p < CH ? n_pairs - p : CH;
-        LHGT_TRY(upload_pairs(ctx, seq1, off1 + p, seq2, off2 + p, n, count_mate2 ? count_mate2 + p : nullptr));
+        LHGT_TRY(upload_pairs(ctx, seq1, off1 + p, seq2, off2 + p, n, pair_flags ? pair_flags + p : nullptr));
     }
     return LHGT_OK;
+}
+
+int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
+                      const uint64_t* off2, long n_pairs, const uint8_t* count_mate2) {
+    if (!count_mate2 || n_pairs <= 0) return lhgt_pairs_append_flags(ctx, seq1, off1, seq2, off2, n_pairs, nullptr);
+    std::vector<uint8_t> fl((size_t)n_pairs);
+    for (long p = 0; p < n_pairs; p++) fl[p] = (uint8_t)(PAIR_COUNT1 | PAIR_VOTE | (count_mate2[p] ? PAIR_COUNT2 : 0));
+    return lhgt_pairs_append_flags(ctx, seq1, off1, seq2, off2, n_pairs, fl.data());
 }
 
 int lhgt_pairs_clear(lhgt_ctx* ctx) {
@@ -333,7 +403,7 @@ int lhgt_pairs_count(lhgt_ctx* ctx, long* n_pairs) {
 }
 
 int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* out_hash, uint8_t* out_valid) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !ascii || !out_hash) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
     long nk = len - ctx->k + 1;
@@ -353,7 +423,7 @@ int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* 
 }
 
 int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* off, long n_contigs) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !ascii || !off || n_contigs < 0) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
     std::vector<uint32_t> lens;
@@ -363,10 +433,23 @@ int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* 
         if ((long)len > ctx->k) { lens.push_back((uint32_t)len); src.push_back(c); }  // E:772: shorter contigs are not indexed
     }
     LHGT_TRY(index_layout(ctx, lens));
-    for (size_t i = 0; i < lens.size(); i++) {
-        const ContigDev& c = ctx->contigs[i];
-        LHGT_HIP(hipMemcpyAsync(ctx->d_index + c.hash_word - 1, &lens[i], 4, hipMemcpyHostToDevice, ctx->stream));
-        LHGT_TRY(hash_contig_to_device(ctx, ascii + off[src[i]], (long)lens[i], ctx->d_index + c.hash_word, nullptr));
+    LHGT_TRY(write_index_lens(ctx));
+    // spans of consecutive source contigs (short ones included and skipped), ~256 MB of bases per upload and launch
+    const uint64_t SPAN = 256ull << 20;
+    size_t ci = 0;
+    for (long p = 0; p < n_contigs;) {
+        long q = p;
+        while (q < n_contigs && (q == p || off[q + 1] - off[p] <= SPAN)) q++;
+        const uint64_t span_len = off[q] - off[p];
+        std::vector<uint64_t> coff((size_t)(q - p) + 1), ow((size_t)(q - p));
+        for (long r = p; r <= q; r++) coff[r - p] = off[r] - off[p];
+        for (long r = p; r < q; r++) ow[r - p] = (long)(off[r + 1] - off[r]) > ctx->k ? ctx->contigs[ci++].hash_word : ~0ull;
+        if (span_len) {
+            LHGT_TRY(ws_reserve(ctx, (size_t)span_len + 32, 0));
+            LHGT_TRY(stage_ascii(ctx, 0, ascii + off[p], (size_t)span_len));
+            LHGT_TRY(hash_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span_len, coff.data(), ow.data(), q - p, ctx->d_index));
+        }
+        p = q;
     }
     return LHGT_OK;
 }

@@ -903,7 +903,7 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
 extern "C" {
 
 int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (!ctx->index_resident) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load first");
     if (max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "max_peak must be positive");
@@ -936,7 +936,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
 //   4. ranks all-gather both record sets; lhgt_peaks_install replays them into the local peak_kmer
 // after which lhgt_vote runs unchanged on this rank's read shard.
 int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long* n_new_local, long* n_selected_local) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !n_new_local || !n_selected_local) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->index_resident) LHGT_FAIL(LHGT_E_STATE, "no index resident: call lhgt_index_load_shard first");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -955,7 +955,7 @@ int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long*
 }
 
 int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs, long* n_regs) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !d_loci || !d_regs || !n_regs) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (ctx->local_new < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan_local must precede lhgt_ref_scan_emit");
     if (id_base < 0 || id_base + ctx->local_new > 0xffffffffL) LHGT_FAIL(LHGT_E_ARG, "peak ids overflow 32 bits");
@@ -991,7 +991,7 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
 
 int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total, long max_peak, const void* d_loci_all,
                        const void* d_regs_all, long n_regs_all) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || n_peaks_total < 0 || n_regs_all < 0 || max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if ((n_peaks_total && !d_loci_all) || (n_regs_all && !d_regs_all)) LHGT_FAIL(LHGT_E_ARG, "null record buffer");
     if (n_peaks_total > 0xffffffffL) LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "more than 2^32 peaks");
@@ -1018,7 +1018,7 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
 }
 
 int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t* out) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (first_pos + n_pos > ctx->n_pos) LHGT_FAIL(LHGT_E_ARG, "position range outside the reference");
     LHGT_HIP(hipMemcpy(out, ctx->d_flags + first_pos, n_pos, hipMemcpyDeviceToHost));
@@ -1026,7 +1026,7 @@ int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t
 }
 
 int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint32_t* out) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->d_peak_kmer) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     if (first_slot + n_slots > (1ull << ctx->k)) LHGT_FAIL(LHGT_E_ARG, "slot range outside the table");

@@ -25,6 +25,9 @@ struct SynthSpec {
     uint32_t read_len;      // 150
     uint32_t frag_min, frag_max;  // 300..500
     uint32_t n_permille;    // reads carrying one N, per thousand (20)
+    uint32_t snp_permille;  // positions of a sample genome that differ from the reference, per thousand (0; 10 = the "snp0.01" of the
+                            // reference's test data, test/run_BKP_detection.sh)
+    uint32_t n_sample;      // contigs the sample is made of (even; default: half of the reference)
 };
 
 // donor cut position / recipient insert position of sample pair i
@@ -36,7 +39,17 @@ __host__ __device__ __forceinline__ void transfer_sites(const SynthSpec& s, uint
 }
 
 // base x of sample genome g (even g = recipient with the insert, odd g = donor with the deletion)
+__device__ __forceinline__ uint32_t sample_code_nosnp(const SynthSpec& s, uint32_t g, uint64_t x);
+// a SNP belongs to the sample genome, not to a read: every read over the position shows it
 __device__ __forceinline__ uint32_t sample_code(const SynthSpec& s, uint32_t g, uint64_t x) {
+    uint32_t c = sample_code_nosnp(s, g, x);
+    if (s.snp_permille) {
+        const uint64_t h = mix64(s.ref_seed * 0x2545F491ull ^ mix64(((uint64_t)g << 40) ^ x));
+        if (h % 1000 < s.snp_permille) c = (c + 1u + (uint32_t)((h >> 32) % 3)) & 3u;
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t sample_code_nosnp(const SynthSpec& s, uint32_t g, uint64_t x) {
     uint64_t r0, d0;
     transfer_sites(s, g >> 1, &r0, &d0);
     uint32_t rec = g & ~1u, don = g | 1u;
@@ -48,10 +61,12 @@ __device__ __forceinline__ uint32_t sample_code(const SynthSpec& s, uint32_t g, 
     return ref_code(s.ref_seed, don, x < d0 ? x : x + s.transfer_len);
 }
 
-__global__ void __launch_bounds__(256) synth_contig_ascii(SynthSpec s, uint32_t contig, uint8_t* __restrict__ out) {
-    uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= s.contig_len) return;
-    out[pos] = "ACGT"[ref_code(s.ref_seed, contig, pos)];
+// bases [flat0, flat0 + n) of the reference laid out as one stream (contig c = stream positions [c*contig_len, (c+1)*contig_len))
+__global__ void __launch_bounds__(256) synth_flat_ascii(SynthSpec s, uint64_t flat0, uint64_t n, uint8_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = flat0 + i;
+    out[i] = "ACGT"[ref_code(s.ref_seed, (uint32_t)(x / s.contig_len), x % s.contig_len)];
 }
 
 // thread = one base of one mate; out1/out2 are [n][read_len] ASCII
@@ -64,8 +79,7 @@ __global__ void __launch_bounds__(256) synth_pairs_ascii(SynthSpec s, uint64_t f
     uint32_t b = (uint32_t)(t % L);
     uint64_t p = first_pair + pi;
     uint64_t h = mix64(s.reads_seed ^ mix64(p));
-    uint32_t n_sample = (s.n_contigs / 2) & ~1u;
-    uint32_t g = (uint32_t)(h % n_sample);
+    uint32_t g = (uint32_t)(h % s.n_sample);
     uint64_t h2 = mix64(h);
     uint64_t glen = (g & 1) ? s.contig_len - s.transfer_len : s.contig_len + s.transfer_len;
     uint64_t flen = s.frag_min + h2 % (s.frag_max - s.frag_min + 1);
@@ -85,11 +99,13 @@ __global__ void __launch_bounds__(256) synth_pairs_ascii(SynthSpec s, uint64_t f
     out2[pi * L + b] = c2;
 }
 
-static SynthSpec make_spec(uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len, int read_len) {
+static SynthSpec make_spec(const lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len, int read_len) {
     SynthSpec s;
+    s.snp_permille = (uint32_t)ctx->synth_snp_permille;
+    s.n_sample = ctx->synth_sample_contigs > 0 && ctx->synth_sample_contigs <= n_contigs ? (uint32_t)ctx->synth_sample_contigs & ~1u : ((uint32_t)n_contigs / 2) & ~1u;
     s.ref_seed = ref_seed; s.reads_seed = reads_seed;
     s.n_contigs = (uint32_t)n_contigs; s.contig_len = (uint64_t)contig_len;
-    s.transfer_len = 3000; s.read_len = (uint32_t)read_len; s.frag_min = 300; s.frag_max = 500; s.n_permille = 20;
+    s.transfer_len = 3000; s.read_len = (uint32_t)read_len; s.frag_min = 300; s.frag_max = 500; s.n_permille = (uint32_t)ctx->synth_n_permille;
     return s;
 }
 
@@ -105,26 +121,82 @@ int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long 
     return lhgt_synth_reference_shard(ctx, ref_seed, n_contigs, contig_len, 0, 1, host_ascii);
 }
 
+// The same base stream cut into contigs at cuts[0] = 0 < cuts[1] < ... < cuts[n_cuts-1] = n_contigs*contig_len: a reference
+// with a ragged length distribution (a real catalogue has hundreds of thousands of contigs from a few hundred bases to
+// megabases) over which the SAME synthetic reads can be scanned -- reads that straddle a cut simply match on either side of it.
+// Pieces of length <= k are not indexed (E:772).  Only pieces [piece0, piece1) become resident; contig numbers are global.
+static int synth_reference_pieces(lhgt_ctx* ctx, const SynthSpec& s, const uint64_t* cuts, long n_cuts, long piece0, long piece1,
+                                  uint8_t* host_ascii) {
+    const int k = ctx->k, e = ctx->e;
+    std::vector<uint32_t> lens;
+    uint32_t first_ref_index = 1;
+    for (long p = 0; p < piece1; p++) {
+        const uint64_t len = cuts[p + 1] - cuts[p];
+        if (len >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "contig of %llu bases", (unsigned long long)len);
+        if ((long)len <= k) continue;
+        if (p < piece0) first_ref_index++;
+        else lens.push_back((uint32_t)len);
+    }
+    LHGT_TRY(index_layout(ctx, lens, first_ref_index));
+    LHGT_TRY(write_index_lens(ctx));
+    // spans of whole pieces, at most ~256 Mbase each (one huge piece is its own span)
+    const uint64_t SPAN = 256ull << 20;
+    long ci = 0;   // next resident contig
+    for (long p = piece0; p < piece1;) {
+        long q = p;
+        while (q < piece1 && (q == p || cuts[q + 1] - cuts[p] <= SPAN)) q++;
+        const uint64_t span0 = cuts[p], span_len = cuts[q] - cuts[p];
+        std::vector<uint64_t> coff((size_t)(q - p) + 1), ow((size_t)(q - p));
+        for (long r = p; r <= q; r++) coff[r - p] = cuts[r] - span0;
+        for (long r = p; r < q; r++) {
+            const uint64_t len = cuts[r + 1] - cuts[r];
+            ow[r - p] = (long)len <= k ? ~0ull : ctx->contigs[ci++].hash_word;
+        }
+        LHGT_TRY(ws_reserve(ctx, (size_t)span_len + 32, 0));
+        hipLaunchKernelGGL(synth_flat_ascii, dim3((unsigned)((span_len + 255) / 256)), dim3(256), 0, ctx->stream, s, span0, span_len, ctx->d_ws_ascii);
+        LHGT_HIP(hipGetLastError());
+        if (host_ascii) LHGT_HIP(hipMemcpyAsync(host_ascii + (span0 - cuts[piece0]), ctx->d_ws_ascii, (size_t)span_len, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_TRY(hash_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span_len, coff.data(), ow.data(), q - p, ctx->d_index));
+        p = q;
+    }
+    (void)e;
+    return LHGT_OK;
+}
+
 // Same reference, but only contigs [rank*n/world, (rank+1)*n/world) become resident (reference-sharded phase B).
 int lhgt_synth_reference_shard(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, int shard_rank, int shard_world,
                                uint8_t* host_ascii) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d", shard_rank, shard_world);
-    if (ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
     if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32)) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
-    SynthSpec s = make_spec(ref_seed, 0, n_contigs, contig_len, 150);
+    SynthSpec s = make_spec(ctx, ref_seed, 0, n_contigs, contig_len, 150);
+    std::vector<uint64_t> cuts((size_t)n_contigs + 1);
+    for (long c = 0; c <= n_contigs; c++) cuts[c] = (uint64_t)c * (uint64_t)contig_len;
     const long c0 = n_contigs * shard_rank / shard_world, c1 = n_contigs * (shard_rank + 1) / shard_world;
-    std::vector<uint32_t> lens((size_t)(c1 - c0), (uint32_t)contig_len);
-    LHGT_TRY(index_layout(ctx, lens, (uint32_t)c0 + 1));
-    LHGT_TRY(ws_reserve(ctx, (size_t)contig_len + 32, 0));
-    for (long c = c0; c < c1; c++) {
-        const ContigDev& cd = ctx->contigs[c - c0];
-        hipLaunchKernelGGL(synth_contig_ascii, dim3((unsigned)((contig_len + 255) / 256)), dim3(256), 0, ctx->stream, s, (uint32_t)c, ctx->d_ws_ascii);
-        if (host_ascii) LHGT_HIP(hipMemcpyAsync(host_ascii + (size_t)(c - c0) * contig_len, ctx->d_ws_ascii, (size_t)contig_len, hipMemcpyDeviceToHost, ctx->stream));
-        LHGT_HIP(hipMemcpyAsync(ctx->d_index + cd.hash_word - 1, &lens[c - c0], 4, hipMemcpyHostToDevice, ctx->stream));
-        LHGT_TRY(hash_contig_dev_ascii(ctx, ctx->d_ws_ascii, contig_len, ctx->d_index + cd.hash_word, nullptr));
-    }
+    return synth_reference_pieces(ctx, s, cuts.data(), n_contigs + 1, c0, c1, host_ascii);
+}
+
+int lhgt_synth_reference_cuts(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, const uint64_t* cuts, long n_cuts,
+                              uint8_t* host_ascii) {
+    if (!ctx || !cuts) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
+    if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32)) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
+    if (n_cuts < 2 || cuts[0] != 0 || cuts[n_cuts - 1] != (uint64_t)n_contigs * (uint64_t)contig_len) LHGT_FAIL(LHGT_E_ARG, "cuts must run from 0 to n_contigs*contig_len");
+    for (long i = 1; i < n_cuts; i++) if (cuts[i] <= cuts[i - 1]) LHGT_FAIL(LHGT_E_ARG, "cuts must ascend strictly");
+    SynthSpec s = make_spec(ctx, ref_seed, 0, n_contigs, contig_len, 150);
+    return synth_reference_pieces(ctx, s, cuts, n_cuts, 0, n_cuts - 1, host_ascii);
+}
+
+// Knobs of the synthetic sample (defaults: no SNPs, 20 reads per thousand carry one N, the sample is half of the contigs).
+int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sample_contigs) {
+    if (!ctx || snp_permille < 0 || snp_permille > 1000 || n_permille < 0 || n_permille > 1000 || sample_contigs < 0 || sample_contigs == 1)
+        LHGT_FAIL(LHGT_E_ARG, "bad synthetic options");
+    ctx->synth_snp_permille = snp_permille;
+    ctx->synth_n_permille = n_permille;
+    ctx->synth_sample_contigs = sample_contigs;
     return LHGT_OK;
 }
 
@@ -133,9 +205,9 @@ int lhgt_synth_reference_shard(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs,
 int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
                      long first_pair, long n_pairs, int read_len, uint8_t* host_seq1, uint8_t* host_seq2) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
-    if (ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context");
+    LHGT_DEVICE_ENTRY(ctx);
     if (n_contigs < 4 || contig_len < 16000 || read_len < 1 || read_len > 300 || n_pairs < 0) LHGT_FAIL(LHGT_E_ARG, "bad synthetic spec");
-    SynthSpec s = make_spec(ref_seed, reads_seed, n_contigs, contig_len, read_len);
+    SynthSpec s = make_spec(ctx, ref_seed, reads_seed, n_contigs, contig_len, read_len);
     const long CH = 16L << 20;  // pairs per resident batch (one scan launch each)
     for (long o = 0; o < n_pairs; o += CH) {
         long n = n_pairs - o < CH ? n_pairs - o : CH;

@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
     for (long p = wave; p < b.n_pairs; p += n_waves) {
+        if (b.flags && !(b.flags[p] & PAIR_VOTE)) continue;   // counted only (surplus fq2 record, thread-chunk emulation)
         int n_ev = 0;
         for (int m = 0; m < 2; m++) {
             const int len = b.len[m][p];
@@ -237,6 +238,7 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
             pp[u] = p0 + (long)u * n_waves;
             live[u] = pp[u] < b.n_pairs;
             if (!live[u]) pp[u] = p0;          // a duplicate keeps every load unconditional; its result is dropped
+            if (b.flags && !(b.flags[pp[u]] & PAIR_VOTE)) live[u] = false;
         }
         int nk[NP][2], wpr[NP][2];
         const uint32_t* rec[NP][2];
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
     for (long p = wave;; p += n_waves, it++) {
         const bool live = p < b.n_pairs;   // one more round after the last pair drains the queue
         int T = 0;
-        if (live) {
+        if (live && !(b.flags && !(b.flags[p] & PAIR_VOTE))) {
             // two round trips: the four descriptors together, then both records (lane index clamped instead of a lane-masked
             // load, which the compiler would wait for on its own)
             const int len0 = b.len[0][p], len1 = b.len[1][p];
@@ -640,7 +642,7 @@ using namespace lhgt;
 extern "C" {
 
 int lhgt_vote(lhgt_ctx* ctx) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan must precede lhgt_vote");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -655,10 +657,16 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (wpb < 1) wpb = 1;
         long blocks = (b.d.n_pairs + wpb - 1) / wpb;
         if (blocks > 256L * 16) blocks = 256L * 16;
+        // long reads with many hashes need more than the default 64 KiB of dynamic LDS for one wave's event list (500 bases, e = 9:
+        // 67.5 KiB); gfx950 has 160 KiB per workgroup
 #define LHGT_VOTE(TR_, PF_, NT_, THREADS_, LDS_)                                                                           \
-    hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
-                       ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                       ctx->debug, ctx->pf_mask, ctx->pf2)
+    do {                                                                                                                   \
+        if ((size_t)(LDS_) > 65536)                                                                                        \
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, PF_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
+                           ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
+                           ctx->debug, ctx->pf_mask, ctx->pf2);                                                             \
+    } while (0)
         const bool nt = ctx->k >= 28;
         // sparse peak sets on a folded (k > PF_BITS) bitmap: 16-wave workgroups that keep a 64 KiB fold of it in LDS
         const size_t lds2 = (size_t)LF_WORDS * 4 + 16 * per_wave_sp;
@@ -673,11 +681,8 @@ int lhgt_vote(lhgt_ctx* ctx) {
             wpb = 16;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256) blocks = 256;     // one resident workgroup per CU
-            static bool attr_set = false;
-            if (!attr_set) {
-                LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
+            // per device, not per process: the attribute belongs to the kernel's code object on the device that is current
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold);
             LHGT_VOTE_SPARSE(2, 1024, lds2);
         } else if (sparse_ok) {
@@ -710,7 +715,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
 }
 
 int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !dev_ptr || !bytes) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     *dev_ptr = ctx->d_filter;
@@ -719,7 +724,7 @@ int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
 }
 
 int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     if (n > ctx->n_peaks) LHGT_FAIL(LHGT_E_ARG, "asked for %ld peaks, have %ld", n, ctx->n_peaks);
@@ -736,7 +741,7 @@ int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
 // count_filtered_peak (E:515-548), single thread range: leading sentinel "1 1 1", merge while the
 // contig is the same and the gap to the running end is < 500.  Only the voted peaks leave the GPU.
 int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
-    if (ctx && ctx->device < 0) LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");
+    LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     const long n = ctx->n_peaks;

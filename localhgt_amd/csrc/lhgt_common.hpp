@@ -30,6 +30,15 @@ void set_error(const char* fmt, ...);
         lhgt::set_error(__VA_ARGS__); \
         return (code);            \
     } while (0)
+// top of every entry point that touches the GPU: a host-only context fails loudly (there is no CPU fallback), and the calling
+// thread is bound to the context's device, so lazily allocated buffers and launches land on the right GPU whatever the caller
+// (or another engine in the same process) made current in between
+#define LHGT_DEVICE_ENTRY(ctx)                                                                                        \
+    do {                                                                                                              \
+        if ((ctx) && (ctx)->device < 0)                                                                               \
+            LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");                 \
+        if (ctx) LHGT_HIP(hipSetDevice((ctx)->device));                                                               \
+    } while (0)
 
 // ---------------------------------------------------------------- hash parameters (by value to kernels)
 // mask[i][m] has bit (k-1-z) set iff choose_coder[z*e+i] == m  
@@ -47,9 +56,13 @@ struct ReadBatchDev {
     const uint32_t* words;
     const uint32_t* off[2];
     const uint16_t* len[2];
-    const uint8_t* count2;  // nullable: 0 = mate 2 not counted in phase A (quirk Q4)
+    // nullable (= every bit set).  Per pair: bit 0 / bit 1 = mate 1 / mate 2 is counted in phase A, bit 2 = the pair is re-scanned
+    // and voted in phase C.  Quirk Q4 (mate 2 past size(fq1) is not counted) clears bit 1; surplus records of a longer fq2 are
+    // mate-2-only entries (bit 1 alone); the -t N emulation (host_threads.cpp) clears whatever a thread chunk boundary loses.
+    const uint8_t* flags;
     long n_pairs;
 };
+constexpr uint8_t PAIR_COUNT1 = 1, PAIR_COUNT2 = 2, PAIR_VOTE = 4, PAIR_ALL = 7;
 struct ReadBatch {
     ReadBatchDev d{};
     void* alloc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -137,6 +150,8 @@ struct lhgt_ctx {
     uint32_t* d_part_keys[2] = {nullptr, nullptr};
     size_t part_keys_cap = 0;  // keys per buffer
     uint32_t* d_part_meta = nullptr;
+    int synth_snp_permille = 0, synth_n_permille = 20;   // k_synth.hip: lhgt_synth_options
+    long synth_sample_contigs = 0;
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)
@@ -153,14 +168,17 @@ namespace lhgt {
 int build_hash_params(const int16_t* cc, int k, int e, HashParams* hp);
 int rng_next(lhgt_ctx* ctx);  // one rand() draw from the private glibc stream
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
-                 long n_pairs, const uint8_t* count_mate2);
+                 long n_pairs, const uint8_t* pair_flags);
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index = 1);  // allocates d_index, tiles, flags
 int index_install(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, bool words_on_device);
 int index_install_shard(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, int rank, int world);
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words);
 int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint32_t* d_out, uint8_t* d_valid);
+int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const uint64_t* out_word,
+                        long n_c, uint32_t* d_out);
+int write_index_lens(lhgt_ctx* ctx);
 int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
-                            const uint8_t* count_mate2);
+                            const uint8_t* pair_flags);
 int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes);
 }  // namespace lhgt

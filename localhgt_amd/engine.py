@@ -110,12 +110,20 @@ class Engine:
         return seen.value, kept.value
 
     def pairs_append(self, seq1: np.ndarray, off1: np.ndarray, seq2: np.ndarray, off2: np.ndarray,
-                     count_mate2: Optional[np.ndarray] = None):
+                     count_mate2: Optional[np.ndarray] = None, flags: Optional[np.ndarray] = None):
+        """flags (one byte per pair: 1 = mate 1 counted in phase A, 2 = mate 2 counted, 4 = pair voted in phase C) overrides
+        count_mate2 (0 = mate 2 not counted, the fq2-cut of E:1438-1445)"""
         s1 = np.ascontiguousarray(seq1, dtype=np.uint8)
         s2 = np.ascontiguousarray(seq2, dtype=np.uint8)
         o1 = np.ascontiguousarray(off1, dtype=np.uint64)
         o2 = np.ascontiguousarray(off2, dtype=np.uint64)
         assert o1.size == o2.size
+        if flags is not None:
+            fl = np.ascontiguousarray(flags, dtype=np.uint8)
+            assert fl.size == o1.size - 1
+            _lib.check(self.lib.lhgt_pairs_append_flags(self.h, _ptr(s1, C.c_uint8), _ptr(o1, C.c_uint64), _ptr(s2, C.c_uint8),
+                                                        _ptr(o2, C.c_uint64), o1.size - 1, _ptr(fl, C.c_uint8)))
+            return
         c2 = None if count_mate2 is None else np.ascontiguousarray(count_mate2, dtype=np.uint8)
         _lib.check(self.lib.lhgt_pairs_append(self.h, _ptr(s1, C.c_uint8), _ptr(o1, C.c_uint64), _ptr(s2, C.c_uint8),
                                               _ptr(o2, C.c_uint64), o1.size - 1,
@@ -138,6 +146,17 @@ class Engine:
 
     def synth_reference_shard(self, ref_seed: int, n_contigs: int, contig_len: int, rank: int, world: int):
         _lib.check(self.lib.lhgt_synth_reference_shard(self.h, ref_seed, n_contigs, contig_len, rank, world, None))
+
+    def synth_reference_cuts(self, ref_seed: int, n_contigs: int, contig_len: int, cuts: np.ndarray, want_host: bool = False):
+        """the same base stream as synth_reference, cut into contigs at `cuts` (ascending, 0 .. n_contigs*contig_len)"""
+        cu = np.ascontiguousarray(cuts, dtype=np.uint64)
+        host = np.zeros(n_contigs * contig_len, dtype=np.uint8) if want_host else None
+        _lib.check(self.lib.lhgt_synth_reference_cuts(self.h, ref_seed, n_contigs, contig_len, _ptr(cu, C.c_uint64), cu.size,
+                                                      None if host is None else _ptr(host, C.c_uint8)))
+        return host
+
+    def synth_options(self, snp_permille: int = 0, n_permille: int = 20, sample_contigs: int = 0):
+        _lib.check(self.lib.lhgt_synth_options(self.h, snp_permille, n_permille, sample_contigs))
 
     def synth_pairs(self, ref_seed: int, reads_seed: int, n_contigs: int, contig_len: int, first_pair: int,
                     n_pairs: int, read_len: int = 150, want_host: bool = False):

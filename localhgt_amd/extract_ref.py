@@ -51,6 +51,20 @@ def index_name(fasta: str, k: int, e: int) -> str:
     return f"{fasta}.k{k}.h{e}.index.dat"  # E:1401
 
 
+def _warn_if_ids_desynchronise(genome_len_path: str, k: int, log) -> None:
+    """SURVEY.md quirk Q7, told BEFORE any GPU work: read_ref numbers every FASTA record (E:825) while read_index numbers the
+    indexed contigs sequentially (E:905, 963), so a contig of <= k bases in front of an indexed one makes the ids of the interval
+    file point at the wrong line of genome.len.txt.  The interval file is still the reference's; get_bed_file will refuse it."""
+    try:
+        with open(genome_len_path) as f:
+            ids = [int(line.split("\t")[1]) for line in f if line.strip()]
+    except (OSError, ValueError, IndexError):
+        return
+    if ids != list(range(ids[0] if ids else 0, (ids[0] if ids else 0) + len(ids))) or (ids and ids[0] != 1):
+        log(f"warning: {genome_len_path} skips contig numbers (a contig of <= {k} bases precedes an indexed one): the contig ids of "
+            f"the interval file follow the reference's sequential numbering (E:905) and will not match; get_bed_file refuses them")
+
+
 def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
     """The whole path A->D. `dist` is a localhgt_amd.dist.Exchange (or None for one GPU)."""
     rank, world = (dist.rank, dist.world) if dist else (0, 1)
@@ -83,6 +97,7 @@ def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
         n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
     else:
         n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
+    _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
     eng.sampling_init(ratio)                                   # E:1422
     seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
     t1 = time.time()

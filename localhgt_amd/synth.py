@@ -170,12 +170,19 @@ def write_fastq(mate: np.ndarray, path: str, suffix: str, header_pad: int = 0,
 
 
 def write_case(outdir: str, ref: SynthRef, reads: SynthReads, fq2_header_pad: int = 0,
-               lowercase_every: int = 0) -> Tuple[str, str, str]:
+               lowercase_every: int = 0, fq1_header_pad: int = 0, fq1_drop_tail: int = 0,
+               fq1_trailing_blank: bool = False) -> Tuple[str, str, str]:
+    """fq1_drop_tail: fq1 loses its last records, so fq2 holds surplus ones (counted in phase A while they start inside
+    size(fq1), E:1438-1445; never voted, E:356); fq1_trailing_blank: one empty line after fq1's last record"""
     os.makedirs(outdir, exist_ok=True)
     fa = os.path.join(outdir, "ref.fa")
     f1 = os.path.join(outdir, "s.1.fq")
     f2 = os.path.join(outdir, "s.2.fq")
     write_fasta(ref, fa)
-    write_fastq(reads.mate1, f1, "1", lowercase_every=lowercase_every)
+    m1 = reads.mate1[:len(reads.mate1) - fq1_drop_tail] if fq1_drop_tail else reads.mate1
+    write_fastq(m1, f1, "1", header_pad=fq1_header_pad, lowercase_every=lowercase_every)
+    if fq1_trailing_blank:
+        with open(f1, "ab") as f:
+            f.write(b"\n")
     write_fastq(reads.mate2, f2, "2", header_pad=fq2_header_pad)
     return fa, f1, f2

@@ -37,6 +37,10 @@ class Case:
     snp_rate: float = 0.0
     n_read_frac: float = 0.02
     fq2_header_pad: int = 0
+    fq1_header_pad: int = 0
+    fq1_drop_tail: int = 0                      # fq1 has that many records fewer than fq2
+    fq1_trailing_blank: bool = False
+    threads: int = 1                            # -t of the run (parity contract of t > 1: oracle/_ref run on ONE core)
     lowercase_every: int = 0
     preexisting_index: bool = False             # run twice, keep outputs of the 2nd run (quirk Q3)
     bed_defined: bool = True                    # False when a short contig sits mid-file (quirk Q7)
@@ -56,6 +60,10 @@ CASES: Dict[str, Case] = {c.name: c for c in [
     Case("k22_e5", k=22, e=5, ref_seed=41, reads_seed=42, match_ratio=0.04, notes="five hashes: two rand() rows per position"),
     Case("k24_nrun_lower", n_run_at=(1, 9000, 40), lowercase_every=7, snp_rate=0.005, ref_seed=51, reads_seed=52,
          notes="N run in the reference (Q6), lower-case read bases, SNPs"),
+    Case("k24_fq2_surplus", fq1_header_pad=30, fq1_drop_tail=300, fq1_trailing_blank=True, ref_seed=71, reads_seed=72, n_contigs=5,
+         min_len=12000, max_len=20000, short_contig_at=None, depth=10,
+         notes="fq2 holds 300 records more than fq1 and shorter headers: surplus mate-2 reads are counted in phase A, never voted; "
+               "fq1 ends with a blank line"),
     Case("k24_seed7", seed=7, ref_seed=61, reads_seed=62, n_contigs=5, min_len=12000, max_len=20000,
          short_contig_at=None, depth=10, notes="tiny; inputs also committed gz-compressed"),
 ]}
@@ -76,14 +84,15 @@ def materialise(case: Case, outdir: str):
     reads = synth.make_sample(ref, case.reads_seed, depth=case.depth, snp_rate=case.snp_rate,
                               n_read_frac=case.n_read_frac)
     return synth.write_case(outdir, ref, reads, fq2_header_pad=case.fq2_header_pad,
-                            lowercase_every=case.lowercase_every)
+                            lowercase_every=case.lowercase_every, fq1_header_pad=case.fq1_header_pad,
+                            fq1_drop_tail=case.fq1_drop_tail, fq1_trailing_blank=case.fq1_trailing_blank)
 
 
 def extract_ref_argv(case: Case, fq1: str, fq2: str, fa: str, interval: str):
     """argv[1:] of extract_ref for the case, threads fixed at 1 (parity contract = -t 1)."""
     def num(x):
         return str(int(x)) if float(x) == int(x) else repr(float(x))
-    return [fq1, fq2, fa, interval, repr(case.hit_ratio), repr(case.match_ratio), "1", str(case.k),
+    return [fq1, fq2, fa, interval, repr(case.hit_ratio), repr(case.match_ratio), str(case.threads), str(case.k),
             str(case.max_peak), str(case.e), str(case.seed), num(case.sample)]
 
 

@@ -214,11 +214,29 @@ def test_parallel_fastq_parser_is_split_invariant(lib, oracle, case_inputs, tmp_
         assert one[0] == 0, name
         for threads, chunk in ((4, 500), (5, 97)):
             assert _digest(lib, p1, p2, threads=threads, chunk=chunk) == one, (name, threads, chunk)
-    # unequal line counts are refused, whatever the split
+    # a second file with fewer records is refused, whatever the split (the reference would pair stale lines, E:356-367) ...
     p2s = str(tmp_path / "short.2.fq")
     open(p2s, "wb").write(b"\n".join(raw2.split(b"\n")[:400]) + b"\n")
     assert _digest(lib, f1, p2s, threads=4, chunk=1000)[0] == 4
-    assert _digest(lib, p2s, f2, threads=4, chunk=1000)[0] == 4
+    # ... one with more records is read like the reference reads it: phase C stops with fq1, phase A counts the surplus
+    # records of fq2 that start inside size(fq1) (none here: the files share their first 400 lines)
+    rc, seen, kept, _ = _digest(lib, p2s, f2, threads=4, chunk=1000)
+    assert (rc, seen, kept) == (0, 100, 100)
+
+
+def test_surplus_records_of_fq2_are_counted_not_voted(lib, oracle, case_inputs):
+    """fq2 with 300 records more than fq1 and shorter headers, fq1 with a trailing blank line: entries = fq1's pairs + the
+    surplus mate-2 reads whose sequence line starts at <= size(fq1) -- what the reference's phase A visits (E:1438-1445)"""
+    fa, f1, f2, _ = case_inputs("k24_fq2_surplus")
+    n1 = sum(1 for _ in open(f1)) // 4
+    table = np.zeros(1 << 12, dtype=np.uint8)
+    cc = oracle.random_coder(12, 3)
+    counted2 = oracle.count(f2, os.path.getsize(f1), 12, 3, cc, 100.0, None, table)
+    assert counted2 > n1
+    base = _digest(lib, f1, f2)
+    assert base[:3] == (0, n1, counted2)
+    for threads, chunk in ((4, 1000), (7, 333)):
+        assert _digest(lib, f1, f2, threads=threads, chunk=chunk) == base
 
 
 def test_parser_counts_match_the_oracle_reader(lib, oracle, case_inputs):

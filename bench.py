@@ -8,10 +8,28 @@ configs[2], the configuration the metric is quoted on ("UHGG-scale ref") and the
 GPU: 13 Gbase reference (13000 x 1 Mbp, 156 GB of index resident in HBM), 100 M 150 bp pairs PER GPU
 (weak scaling: read shards are independent), k=32 e=3, every read kept (--sample 1).
 `--workload 1g` = configs[1] (1 Gbase, 10 M pairs).  Prints ONE JSON line on rank 0.
+
+`python3 bench.py --gpus N` is self-contained: without WORLD_SIZE in the environment it starts its N ranks itself (child
+processes, before this process touches a GPU); under `torch.distributed.run` it is one of the ranks.
+
+What the line holds besides the contract's fields (N = 1; all of it measured inside this run):
+  roofline    dominant kernel: measured HBM bytes per launch (rocprofv3 --pmc passes of this same command, collected by child
+              processes before the timed run) / launch duration by HIP events / 8 TB/s -- a fraction <= 1 by construction;
+              the request rate against the microbenchmarked ceiling; SURVEY 8d's sector-model bytes as `model_speedup`
+  compulsory  bytes a step cannot avoid reading (reads twice, index, tables) as a fraction of peak
+  secondary   configs[1] (the workload where votes, judge and the dense vote kernel do real work), the UHGG reference under a
+              sample of 1000 genomes, and the CLI's default --sample 2e9 mode
+  e2e         pairs/s from FASTQ files in the page cache through the drop-in entry point (parse, H2D, pack, A-D)
+  cpu_baseline  the CPU restatement on the host cores, bounded sample
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -21,36 +39,186 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PAIR = lambda L, k, e: 2 * (L - k + 1) * e * 64 + (2 * L + 3) // 4   # one 64 B sector per probe + packed bases
 HBM_PEAK_GBS = 8000.0                                                               # MI355X_MICROARCH.md: 8 TB/s spec
+METRIC = "M paired-reads/s k-mer sketch->peak, UHGG-scale ref; %HBM roofline @1/2/4/8 GPU"
+# request-rate ceilings of the memory system, measured by tools/probe_rates.hip (profiles/r01_probe_rates_microbench.txt,
+# profiles/r02_probe_shapes.txt): random 4-byte loads that miss to HBM / that hit in L2
+CEIL_HBM_GREQ, CEIL_L2_GREQ = 55.0, 254.0
+KERNEL_SOURCES = {   # which sources a kernel's measured traffic depends on (stamp of profiles/traffic_per_launch.json)
+    "count_A": ("k_count_part.hip", "k_count.hip"), "ref_flags": ("k_scan.hip",), "vote_kernel": ("k_vote.hip",),
+}
+COMMON_SOURCES = ("lhgt_hash.hpp", "lhgt_common.hpp", "k_ingest.hip", "k_synth.hip")
+RANDOM_PROBE_KERNELS = ("vote_kernel", "ref_flags", "register_peaks", "count_direct")   # FETCH_SIZE exact (one 64 B request per probe); others: x2 (guide, HBM section)
+PHASE_KERNELS = {
+    "count_A": ("part_scatter_reads", "part_scatter_keys", "part_apply", "count_direct"),
+    "ref_flags": ("ref_flags=", "ref_flags_lite="),      # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
+    "vote_kernel": ("vote_kernel",),
+}
 
 
-def cpu_baseline(k, e, n_contigs, contig_len, n_pairs, seed_ref, seed_reads, eng_factory):
+def _kernel_in(kname, names):
+    return any(kname == n[:-1] if n.endswith("=") else kname.startswith(n) for n in names)
+
+
+def source_stamp(names):
+    h = hashlib.sha256()
+    for n in sorted(set(names) | set(COMMON_SOURCES)):
+        with open(os.path.join(ROOT, "localhgt_amd", "csrc", n), "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------- launcher
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N ranks as children (nothing here has touched a GPU yet)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------- PMC (child processes)
+def collect_pmc(args, passes, timeout_s=420):
+    """Run this same command (1 step, no extras) under `rocprofv3 --pmc`, one child per counter group, and return
+    {kernel base name: {counter: sum over the step's dispatches, 'dispatches': n}}.  Must run before this process touches
+    the GPU.  Counters only (no trace domains besides the kernel dispatch records the CSV needs)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    agg, notes = {}, []
+    base = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.abspath(__file__),
+            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-verify",
+            "--workload", args.workload, "--pairs", str(args.pairs), "--contigs", str(args.contigs),
+            "--contig-len", str(args.contig_len), "-k", str(args.k), "-e", str(args.e), "--count-mode", str(args.count_mode),
+            "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs)]
+    for counters in passes:
+        d = tempfile.mkdtemp(prefix="lhgt_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            res = subprocess.run([exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--"] + base, cwd="/tmp", env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not files:
+                notes.append(f"pass {'+'.join(counters)}: rc {res.returncode}, {len(files)} csv")
+                continue
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        kname = r["Kernel_Name"].replace("void ", "").replace("lhgt::", "").split("(")[0].split("<")[0]
+                        ent = agg.setdefault(kname, {"_n": {}})
+                        c = r["Counter_Name"]
+                        ent[c] = ent.get(c, 0.0) + float(r["Counter_Value"])
+                        ent["_n"][c] = ent["_n"].get(c, 0) + 1
+        except subprocess.TimeoutExpired:
+            notes.append(f"pass {'+'.join(counters)}: timeout")
+        except Exception as ex:   # the profiler must never sink the measurement
+            notes.append(f"pass {'+'.join(counters)}: {ex}")
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for ent in agg.values():
+        ent["dispatches"] = max(ent.pop("_n").values())
+    return (agg or None), "; ".join(notes)
+
+
+def pmc_traffic(agg):
+    """HBM bytes per bench step per phase/kernel family from a collect_pmc() summary (FETCH_SIZE / WRITE_SIZE count KiB;
+    streaming kernels' FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, random-probe kernels' not)."""
+    out = {}
+    for ph, names in PHASE_KERNELS.items():
+        tot, req_l2, req_ea, seen = 0.0, 0.0, 0.0, False
+        for kname, ent in agg.items():
+            if not _kernel_in(kname, names) or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
+                continue
+            seen = True
+            mult = 1 if any(kname.startswith(r) for r in RANDOM_PROBE_KERNELS) else 2
+            tot += (ent["FETCH_SIZE"] * mult + ent["WRITE_SIZE"]) * 1024
+            req_l2 += ent.get("TCP_TCC_READ_REQ_sum", 0.0)
+            req_ea += ent.get("TCC_EA0_RDREQ_sum", 0.0)
+        if seen:
+            out[ph] = {"bytes": int(tot), "l2_read_requests": int(req_l2) or None, "hbm_read_requests": int(req_ea) or None}
+    return out
+
+
+def committed_traffic(tag):
+    """profiles/traffic_per_launch.json, per kernel only while the sources it was measured on are unchanged"""
+    path = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+    try:
+        ent = json.load(open(path)).get(tag, {})
+    except Exception:
+        return {}, {}
+    fresh, stale = {}, {}
+    for ph, srcs in KERNEL_SOURCES.items():
+        if ph not in ent:
+            continue
+        rec = ent[ph] if isinstance(ent[ph], dict) else {"bytes": ent[ph]}
+        (fresh if ent.get("_stamp", {}).get(ph) == source_stamp(srcs) else stale)[ph] = rec
+    return fresh, stale
+
+
+# ---------------------------------------------------------------------------------------------- files for e2e / cpu legs
+def write_fasta(path, ref, n_contigs, contig_len):
+    with open(path, "wb") as f:
+        for c in range(n_contigs):
+            f.write(b">g%d\n" % (c + 1))
+            f.write(ref[c * contig_len:(c + 1) * contig_len].tobytes())
+            f.write(b"\n")
+
+
+def write_fastq(path, mate, n, L, suffix):
+    """4-line records `@r<9 digits>/<suffix>`, vectorised (4 M records in a second or two)"""
+    import numpy as np
+    a = mate.reshape(n, L)
+    ids = np.char.zfill(np.arange(n).astype("U9"), 9)
+    head = np.char.add(np.char.add("@r", ids), "/" + suffix)
+    hb = np.frombuffer("".join(head.tolist()).encode(), dtype=np.uint8).reshape(n, -1)
+    hl = hb.shape[1]
+    rec = np.empty((n, hl + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
+    rec[:, :hl] = hb
+    rec[:, hl] = 10
+    rec[:, hl + 1: hl + 1 + L] = a
+    rec[:, hl + 1 + L] = 10
+    rec[:, hl + 2 + L] = ord("+")
+    rec[:, hl + 3 + L] = 10
+    rec[:, hl + 4 + L: hl + 4 + 2 * L] = ord("I")
+    rec[:, hl + 4 + 2 * L] = 10
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())
+
+
+def synth_files(tmp, k, e, n_contigs, contig_len, n_pairs, device, seed_ref=1, seed_reads=2):
+    from localhgt_amd.engine import Engine
+    with Engine(k, e, device=device) as eng:
+        eng.rng_seed(1)
+        eng.coder_generate()
+        ref = eng.synth_reference(seed_ref, n_contigs, contig_len, want_host=True)
+        m1, m2 = eng.synth_pairs(seed_ref, seed_reads, n_contigs, contig_len, 0, n_pairs, 150, want_host=True)
+    fa, f1, f2 = (os.path.join(tmp, x) for x in ("ref.fa", "s.1.fq", "s.2.fq"))
+    write_fasta(fa, ref, n_contigs, contig_len)
+    write_fastq(f1, m1, n_pairs, 150, "1")
+    write_fastq(f2, m2, n_pairs, 150, "2")
+    return fa, f1, f2
+
+
+def cpu_baseline(k, e, n_contigs, contig_len, n_pairs, device):
     """Time the CPU oracle (oracle/lhgt_oracle.c, all host cores) on a bounded sample of the same
     synthetic workload.  The oracle is the checker/baseline here, never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_api
     from conftest import build_oracle
     orc = oracle_api.Oracle(build_oracle())
-    orc.set_pretouch(True)     # table page faults before the phase timers, like the reference's memsets (E:1416, 1458)
+    orc.set_pretouch(True)     # table page faults before the phase timers, like the reference's memsets do (E:1416, 1458)
     cores = os.cpu_count() or 1
     with tempfile.TemporaryDirectory(prefix="lhgt_cpu_") as tmp:
-        with eng_factory() as eng:
-            eng.rng_seed(1)
-            eng.coder_generate()
-            ref = eng.synth_reference(seed_ref, n_contigs, contig_len, want_host=True)
-            m1, m2 = eng.synth_pairs(seed_ref, seed_reads, n_contigs, contig_len, 0, n_pairs, 150, want_host=True)
-        fa, f1, f2 = (os.path.join(tmp, x) for x in ("ref.fa", "s.1.fq", "s.2.fq"))
-        with open(fa, "wb") as f:
-            for c in range(n_contigs):
-                f.write(b">g%d\n" % (c + 1))
-                f.write(ref[c * contig_len:(c + 1) * contig_len].tobytes())
-                f.write(b"\n")
-        for path, m, suf in ((f1, m1, b"1"), (f2, m2, b"2")):
-            a = m.reshape(n_pairs, 150)
-            qual = b"I" * 150
-            with open(path, "wb") as f:
-                for i in range(n_pairs):
-                    f.write(b"@r%09d/%s\n" % (i, suf) + a[i].tobytes() + b"\n+\n" + qual + b"\n")
+        fa, f1, f2 = synth_files(tmp, k, e, n_contigs, contig_len, n_pairs, device)
         rc, rep = orc.run(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, cores, k, 3000000, e, 1, 1.0)
         if rc != 0:
             return None
@@ -60,6 +228,131 @@ def cpu_baseline(k, e, n_contigs, contig_len, n_pairs, seed_ref, seed_reads, eng
                           f"phases A+B+C of oracle/lhgt_oracle.c (index build excluded): "
                           f"A {rep.t_count:.2f}s B {rep.t_scan:.2f}s C {rep.t_vote:.2f}s",
                 "raw_peaks": int(rep.n_peaks)}
+
+
+def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_000_000):
+    """from FASTQ files in the page cache through the drop-in entry point (localhgt_amd.extract_ref.run: what bin/extract_ref
+    calls): sampling pass, index (built in the first run, loaded in the second), parse + H2D + pack, phases A-D, interval file"""
+    from localhgt_amd import extract_ref
+    with tempfile.TemporaryDirectory(prefix="lhgt_e2e_") as tmp:
+        fa, f1, f2 = synth_files(tmp, k, e, n_contigs, contig_len, n_pairs, device)
+        a = extract_ref.Args(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, 10, k, 300_000_000, e, 1, 1.0)
+        reps = [extract_ref.run(a, device=device, log=lambda *x: None) for _ in range(3)]
+        built, cached = reps[0], min(reps[1:], key=lambda r: r["total_s"])
+        fq_bytes = os.path.getsize(f1) + os.path.getsize(f2)
+        return {"value": round(n_pairs / cached["total_s"] / 1e6, 3), "unit": "M paired-reads/s",
+                "what": f"extract_ref on {n_pairs} pairs ({fq_bytes / 1e9:.2f} GB of FASTQ, page cache) vs {n_contigs} x {contig_len} bp, "
+                        f"k={k} e={e}, cached index; whole call incl. context set-up, index load, parse, H2D, packing, A-D, interval file",
+                "total_s": round(cached["total_s"], 3), "ingest_s": round(cached["ingest_s"], 3),
+                "index_load_s": round(cached.get("index_s", 0.0), 3), "reads_s": round(cached.get("reads_s", 0.0), 3),
+                "kernels_ms": round(cached["count_kernel_ms"] + cached["scan_kernel_ms"] + cached["vote_kernel_ms"], 1),
+                "fastq_GB_per_s": round(fq_bytes / cached["total_s"] / 1e9, 2),
+                "with_index_build": {"value": round(n_pairs / built["total_s"] / 1e6, 3), "total_s": round(built["total_s"], 3)},
+                "raw_peaks": cached["n_peaks"], "filtered_peaks": cached["n_filtered"]}
+
+
+# ---------------------------------------------------------------------------------------------- the timed loop
+class Workload:
+    def __init__(self, eng, dist, rank, world, shard_index, out_path):
+        self.eng, self.dist, self.rank, self.world, self.shard_index, self.out_path = eng, dist, rank, world, shard_index, out_path
+        self.xch = {"merge_counts": 0.0, "sharded_scan": 0.0, "sum_votes": 0.0}
+
+    def _timed(self, name, fn, *a):
+        t0 = time.perf_counter()
+        r = fn(*a)
+        self.xch[name] += time.perf_counter() - t0
+        return r
+
+    def step(self):
+        eng, dist = self.eng, self.dist
+        eng.counts_clear()
+        eng.count_kmers()
+        if dist:
+            self._timed("merge_counts", dist.merge_counts, eng)
+        if self.shard_index:
+            n_peaks = self._timed("sharded_scan", dist.sharded_scan, eng, 0.1, 0.08, 300_000_000)
+        else:
+            n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
+        eng.vote()
+        if dist:
+            self._timed("sum_votes", dist.sum_votes, eng)
+        nf = eng.write_intervals(self.out_path) if self.rank == 0 else -1
+        return n_peaks, nf
+
+    def fence(self):
+        import torch
+        self.eng.synchronize()
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        """W untimed steps, then exactly K timed ones between fences; every step must reproduce the same peaks"""
+        import torch
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        for key in self.xch:
+            self.xch[key] = 0.0
+        t0 = time.time()
+        ms = [0.0, 0.0, 0.0, 0.0]
+        seen = set()
+        for _ in range(steps):
+            seen.add(self.step())
+            for ph in range(4):
+                ms[ph] += self.eng.phase_ms(ph)
+        self.fence()
+        dt = time.time() - t0
+        if self.dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{self.eng.device}")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        if len(seen) != 1:
+            raise SystemExit(f"bench: steps disagree on (raw peaks, filtered peaks): {sorted(seen)}")
+        n_peaks, nf = seen.pop()
+        return dt, [m / steps for m in ms], n_peaks, nf
+
+
+def verify_forms(eng):
+    """one untimed check that the shortcuts of the timed path change nothing: the form of phase B the engine picks (lite on a
+    nearly full table) against the exact form, and the vote kernel it picks against the generic kernel without any prefilter --
+    whole tables compared through device-side checksums"""
+    res = {}
+    for name, dbg in (("picked", 0), ("exact", 8192 | 4)):
+        eng.set_debug(dbg)
+        n = eng.ref_scan(0.1, 0.08, 300_000_000)
+        eng.vote()
+        res[name] = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_FLAGS, 0b1111101),
+                     eng.digest(eng.DIGEST_VOTES))
+    eng.set_debug(0)
+    if res["picked"] != res["exact"]:
+        raise SystemExit(f"bench --verify: the timed forms disagree with the exact ones: {res}")
+    return {"ok": True, "raw_peaks": res["exact"][0], "votes_nonzero": res["exact"][4][1],
+            "compared": "peak loci, peak_kmer[2^k], flags of every reference position, votes: picked forms vs exact scan + unfiltered generic vote"}
+
+
+def roofline_entry(desc, ms_step, launches, algo_bytes, traffic_rec, source, ceiling):
+    """one kernel: measured HBM bytes / time / 8 TB/s (<= 1 by construction), the request rate against its measured ceiling,
+    and SURVEY 8d's sector-model bytes as a ratio to what the kernel really moves"""
+    ent = {"kernel": desc, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(ms_step, 3),
+           "launches_per_step": launches, "launch_ms": round(ms_step / launches, 3) if launches else None,
+           "algorithmic_bytes_per_step": algo_bytes,
+           "sector_model_GBps": round(algo_bytes / (ms_step * 1e-3) / 1e9, 1) if ms_step > 0 else None}
+    if traffic_rec and ms_step > 0:
+        b = traffic_rec["bytes"]
+        ach = b / (ms_step * 1e-3) / 1e9
+        ent.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": b // max(1, launches or 1),
+                    "traffic_per_step": b, "traffic_source": source, "model_speedup": round(algo_bytes / b, 2) if b else None})
+        req = traffic_rec.get(ceiling[0])
+        if req:
+            g = req / (ms_step * 1e-3) / 1e9
+            ent["request_rate"] = {"value": round(g, 1), "unit": "G requests/s", "counter": ceiling[1], "ceiling": ceiling[2],
+                                   "frac_of_ceiling": round(g / ceiling[2], 3), "ceiling_source": ceiling[3]}
+    else:
+        ent.update({"achieved": None, "frac": None, "traffic": None, "stale": True,
+                    "traffic_source": "none: the rocprofv3 --pmc passes failed and profiles/traffic_per_launch.json was measured on other sources"})
+    return ent
 
 
 def main():
@@ -72,6 +365,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (overrides the workload's)")
     ap.add_argument("--contigs", type=int, default=None, help="contigs of the synthetic reference (overrides the workload's)")
     ap.add_argument("--contig-len", type=int, default=1_000_000)
+    ap.add_argument("--sample-contigs", type=int, default=0, help="contigs the synthetic sample is drawn from (0 = half of the reference)")
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-e", type=int, default=3)
     ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index (the default at N > 1)")
@@ -79,20 +373,50 @@ def main():
     ap.add_argument("--count-mode", type=int, default=-1, help="-1 = engine default (adaptive), 0 = direct CAS kernel, 1 = radix partition")
     ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + process group + exchanges on host tensors, no GPU and no measurement (CPU self-test of the N>1 plumbing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=400_000)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads and the from-FASTQ leg")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect HBM traffic with rocprofv3 --pmc child runs")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed picked-forms-vs-exact-forms check")
+    ap.add_argument("--pmc-out", default=None, help="also write the PMC summary of this run to this JSON file")
     args = ap.parse_args()
     wl_contigs, wl_pairs = (13000, 100_000_000) if args.workload == "uhgg" else (1000, 10_000_000)
     args.contigs = args.contigs or wl_contigs
     args.pairs = args.pairs or wl_pairs
-
-    import torch
-    from localhgt_amd.engine import Engine
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world, local)
+
+    k, e, L = args.k, args.e, 150
+    workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}" + (f"_s{args.sample_contigs}" if args.sample_contigs else "")
+    # ---- measured HBM traffic: child runs of this command under rocprofv3 --pmc, before this process touches the GPU
+    pmc, pmc_note, traffic, traffic_src = None, "", {}, None
+    if world == 1 and not args.no_pmc and not args.force_dist:
+        t0 = time.time()
+        pmc, pmc_note = collect_pmc(args, [["FETCH_SIZE", "TCP_TCC_READ_REQ_sum"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum"]])
+        if pmc:
+            traffic = pmc_traffic(pmc)
+            traffic_src = f"rocprofv3 --pmc passes of this run ({time.time() - t0:.0f} s, 1 step each; FETCH_SIZE+TCP_TCC_READ_REQ, WRITE_SIZE+TCC_EA0_RDREQ)"
+            if args.pmc_out:
+                json.dump({"tag": workload_tag, "kernels": pmc, "per_step": traffic,
+                           "_stamp": {ph: source_stamp(s) for ph, s in KERNEL_SOURCES.items()}}, open(args.pmc_out, "w"), indent=1, sort_keys=True)
+    if world == 1:
+        fresh, stale = committed_traffic(workload_tag)
+        for ph, rec in fresh.items():
+            if ph not in traffic:
+                traffic[ph] = rec
+                traffic_src = traffic_src or "profiles/traffic_per_launch.json (measured on these sources)"
+
+    import torch
+    from localhgt_amd.engine import Engine
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_dist:
@@ -101,7 +425,6 @@ def main():
             os.environ.setdefault(key, val)
         dist = Exchange.from_env(backend="nccl")
 
-    k, e, L = args.k, args.e, 150
     eng = Engine(k, e, device=local)
     eng.rng_seed(1)
     eng.coder_generate()
@@ -116,135 +439,193 @@ def main():
         eng.synth_reference_shard(1, args.contigs, args.contig_len, rank, world)  # this rank's contig range only
     else:
         eng.synth_reference(1, args.contigs, args.contig_len)                   # whole index resident in HBM
+    eng.synth_options(0, 20, args.sample_contigs)
     eng.synth_pairs(1, 2, args.contigs, args.contig_len, rank * args.pairs, args.pairs, L)   # this rank's shard, packed, resident
     eng.synchronize()
     setup_s = time.time() - t0
     out_path = os.path.join(tempfile.gettempdir(), f"lhgt_bench_interval_{os.getpid()}.txt")
+    wl = Workload(eng, dist, rank, world, shard_index, out_path)
 
-    def step():
+    verify = None
+    if world == 1 and not args.no_verify and not args.debug:
         eng.counts_clear()
         eng.count_kmers()
+        verify = verify_forms(eng)
+    dt, per_ms, n_peaks, nf = wl.run(args.steps, args.warmup)
+    if rank != 0:
+        eng.close()
         if dist:
-            dist.merge_counts(eng)
-        if shard_index:
-            n_peaks = dist.sharded_scan(eng, 0.1, 0.08, 300_000_000)
-        else:
-            n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
-        eng.vote()
-        if dist:
-            dist.sum_votes(eng)
-        nf = eng.write_intervals(out_path) if rank == 0 else -1
-        return n_peaks, nf
-
-    def fence():
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.time()
-    ms = [0.0, 0.0, 0.0, 0.0]
-    for _ in range(args.steps):
-        n_peaks, nf = step()
-        for ph in range(4):
-            ms[ph] += eng.phase_ms(ph)
-    fence()
-    dt = time.time() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        total_pairs = args.pairs * world * args.steps
-        algo = ALGO_BYTES_PER_PAIR(L, k, e) * args.pairs    # algorithmic bytes of one scan launch over this GPU's pairs
-        per = {"count_A": ms[0] / args.steps, "scan_B": ms[1] / args.steps, "vote_C": ms[2] / args.steps}   # HIP events on the engine stream
-
-        def roof(ms_launch, bytes_launch):
-            ach = bytes_launch / (ms_launch * 1e-3) / 1e9
-            return round(ach, 2), round(ach / HBM_PEAK_GBS, 4)
-
-        # measured HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
-        # FETCH_SIZE of random 4-byte probes = TCC_EA0_RDREQ x 64 B, the streaming kernels' FETCH_SIZE doubled per
-        # MI355X_MICROARCH.md section HBM); committed with the profile it came from
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")   # {workload tag: {phase: bytes}}
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))
-            except Exception:
-                traffic = {}
-        ref_bytes = args.contigs * args.contig_len * (4 * e + 64 * e)     # 204 B per reference base
-        if shard_index:
-            ref_bytes = (args.contigs * (rank + 1) // world - args.contigs * rank // world) * args.contig_len * (4 * e + 64 * e)   # this rank's contig range
-        # candidates for "the dominant kernel": single kernels timed by their own HIP events (ref_flags: one launch per step;
-        # vote_kernel: one launch per resident batch of <= 16 Mi pairs, phase C holds nothing else), and phase A's kernel family
-        n_batches = -(-args.pairs // (16 << 20))
-        scan = eng.scan_info()
-        kern = {"count_A": per["count_A"], "ref_flags": ms[3] / args.steps, "vote_C": per["vote_C"]}
-        phases = {
-            "count_A": ("phase A kernel family (part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
-                        "count_direct below k = 26): 714 table updates per pair", algo, None),
-            "ref_flags": (("ref_flags_lite (phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base; "
-                           "algorithmic bytes as for the exact form)" if scan["lite"] else
-                           "ref_flags (phase B: e random 2-bit table probes + e index words per reference base)") + ", 1 launch per step", ref_bytes, 1),
-            "vote_C": (f"vote_kernel (phase C read re-scan: 714 probes per pair into peak_kmer), {n_batches} launches per step", algo, n_batches),
-        }
-        # the dominant KERNEL: of the two that are one kernel each (phase A is a family of three kernels per chunk, reported below)
-        dominant = max(("ref_flags", "vote_C"), key=kern.get)
-        dom_ach, dom_frac = roof(kern[dominant], phases[dominant][1])
-        tkey = {"count_A": "count_A", "ref_flags": "ref_flags", "vote_C": "vote_kernel"}
-        workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}"
-        tr = traffic.get(workload_tag, {}) if not (shard_index and world > 1) else {}   # measured on the single-GPU, whole-index run
-        line = {
-            "metric": "M paired-reads/s k-mer sketch->peak, UHGG-scale ref; %HBM roofline @1/2/4/8 GPU",
-            "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{2 if (args.contigs, args.pairs) == (13000, 100_000_000) else 1 if (args.contigs, args.pairs) == (1000, 10_000_000) else '-'}]: "
-                                   f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
-                                   f"index resident), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
-                       "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
-                       "parallelism": f"reads sharded x{world}" + (", index sharded" if shard_index else ", phase B replicated" if world > 1 else "")},
-            "phase_ms": {kk: round(v, 3) for kk, v in per.items()},
-            "scan_B_form": scan,
-            "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
-            "roofline": {"bound": "hbm", "kernel": phases[dominant][0] + " -- the dominant kernel of this workload",
-                         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_frac,
-                         "traffic": tr.get(tkey[dominant]), "algorithmic_bytes_per_step": phases[dominant][1],
-                         "ms_per_step": round(kern[dominant], 3), "launches_per_step": phases[dominant][2],
-                         "launch_ms": round(kern[dominant] / phases[dominant][2], 3) if phases[dominant][2] else None},
-            "roofline_other": {ph: {"kernel": phases[ph][0], "achieved": roof(kern[ph], phases[ph][1])[0], "frac": roof(kern[ph], phases[ph][1])[1],
-                                    "algorithmic_bytes_per_step": phases[ph][1], "ms_per_step": round(kern[ph], 3),
-                                    "launches_per_step": phases[ph][2], "traffic": tr.get(tkey[ph])}
-                               for ph in kern if ph != dominant},
-            "note": "fractions use SURVEY 8d's sector model (one 64 B HBM sector per probe); the radix-partitioned count, the L2-resident vote "
-                    "prefilter and the lite reference scan do the same work with far fewer HBM bytes (roofline.traffic is the measured figure), so "
-                    "their fractions can exceed 1. The limits they actually run against are request rates measured by microbenchmark "
-                    "(profiles/r01_probe_*): ~55 G random requests/s from HBM (ref_flags: 96 % of it), ~254 G/s from L2 (sparse vote: 80 % of it); DESIGN.md 4",
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            eng.pairs_clear()
-            try:
-                line["cpu_baseline"] = cpu_baseline(k, e, 20, 1_000_000, args.cpu_pairs, 1, 2, lambda: Engine(k, e, device=local))
-            except Exception as ex:  # the baseline must never sink the measurement
-                line["cpu_baseline"] = {"error": str(ex)}
-        # RCCL writes its version banner through C stdio, which on a pipe is flushed at exit, i.e. after Python's output:
-        # flush it now so that the JSON line is the last thing on stdout
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(line), flush=True)
+            dist.close()
+        return
+    total_pairs = args.pairs * world * args.steps
+    algo = ALGO_BYTES_PER_PAIR(L, k, e) * args.pairs    # algorithmic bytes of one scan over this GPU's pairs
+    per = {"count_A": per_ms[0], "scan_B": per_ms[1], "vote_C": per_ms[2]}   # HIP events on the engine stream
+    ref_bases = args.contigs * args.contig_len
+    if shard_index:
+        ref_bases = (args.contigs * (rank + 1) // world - args.contigs * rank // world) * args.contig_len   # this rank's contig range
+    ref_bytes = ref_bases * (4 * e + 64 * e)              # 204 B per reference base
+    n_batches = -(-args.pairs // (16 << 20))
+    scan = eng.scan_info()
+    kern = {"count_A": per["count_A"], "ref_flags": per_ms[3], "vote_kernel": per["vote_C"]}
+    hbm_ceiling = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_rates.hip: random 4-byte loads from a table far beyond the caches")
+    l2_ceiling = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table")
+    sparse_vote = scan["tiles"] > 0 and n_peaks > 0 and per["vote_C"] > 0 and traffic.get("vote_kernel", {}).get("bytes", algo) < algo / 4
+    desc = {
+        "count_A": ("phase A kernel family (part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
+                    "count_direct below k = 26): 714 table updates per pair", algo, None, hbm_ceiling),
+        "ref_flags": (("ref_flags_lite (phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base)"
+                       if scan["lite"] else "ref_flags (phase B: e random 2-bit table probes + e index words per reference base)")
+                      + ", 1 launch per step", ref_bytes, 1, hbm_ceiling),
+        "vote_kernel": (f"vote_kernel (phase C read re-scan: 714 probes per pair, "
+                        f"{'answered by the L2-resident bitmap except for its survivors' if sparse_vote else 'into peak_kmer'}), "
+                        f"{n_batches} launches per step", algo, n_batches, l2_ceiling if sparse_vote else hbm_ceiling),
+    }
+    dominant = max(("ref_flags", "vote_kernel"), key=kern.get)   # of the two that are ONE kernel each; phase A is a family of three
+    src = traffic_src if not (shard_index and world > 1) else None
+    roof = {ph: roofline_entry(desc[ph][0], kern[ph], desc[ph][2], desc[ph][1], traffic.get(ph) if src else None, src, desc[ph][3]) for ph in kern}
+    # bytes a step cannot avoid: the packed reads twice (A and C), the resident index once, count table written and read,
+    # peak_kmer cleared (E:1458) -- everything else is the price of random access
+    read_store = args.pairs * 2 * 3 * ((L + 31) // 32 + 1) * 4
+    compulsory = 2 * read_store + ref_bases * 4 * e + 2 * ((1 << k) // 4) + (1 << k) * 4
+    step_s = dt / args.steps
+    line = {
+        "metric": METRIC, "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{2 if (args.contigs, args.pairs, args.sample_contigs) == (13000, 100_000_000, 0) else 1 if (args.contigs, args.pairs, args.sample_contigs) == (1000, 10_000_000, 0) else '-'}]: "
+                               f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
+                               f"index resident), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
+                   "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
+                   "parallelism": f"reads sharded x{world}" + (", index sharded" if shard_index else ", phase B replicated" if world > 1 else "")},
+        "world_size": torch.distributed.get_world_size() if dist else 1,
+        "phase_ms": {kk: round(v, 3) for kk, v in per.items()},
+        "exchange_ms": {kk: round(v / args.steps * 1e3, 3) for kk, v in wl.xch.items()} if dist else None,
+        "scan_B_form": scan,
+        "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
+        "verify": verify,
+        "roofline": dict(roof[dominant], kernel=roof[dominant]["kernel"] + " -- the dominant kernel of this workload"),
+        "roofline_other": {ph: roof[ph] for ph in roof if ph != dominant},
+        "compulsory": {"bytes_per_step": compulsory, "frac_of_peak": round(compulsory / step_s / (HBM_PEAK_GBS * 1e9), 4),
+                       "what": "packed reads twice + resident index once + count table written and read + peak_kmer cleared; a step at HBM peak would take "
+                               f"{compulsory / (HBM_PEAK_GBS * 1e9) * 1e3:.0f} ms"},
+        "note": "roofline.frac = measured HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) / kernel time / 8 TB/s. "
+                "These kernels are bound by the RATE of random requests, not by bytes: request_rate gives that rate against the ceiling "
+                "measured by microbenchmark (~55 G/s from HBM, ~254 G/s from L2). sector_model_GBps is SURVEY 8d's one-64-B-sector-per-probe figure "
+                "(it exceeds the peak where partitioning, the L2 bitmap or the lite scan avoid the sectors: see model_speedup); DESIGN.md 4-5"
+                + (f"; pmc: {pmc_note}" if pmc_note else ""),
+    }
+    eng.pairs_clear()
+    if world == 1 and not args.no_extras and not args.debug:
+        line["secondary"] = secondary_workloads(eng, args, wl, local)
     eng.close()
     if dist:
         dist.close()
+    if world == 1 and not args.no_extras and not args.debug:
+        try:
+            line["e2e"] = e2e_from_files(k, e, local)
+        except Exception as ex:
+            line["e2e"] = {"error": str(ex)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(k, e, 20, 1_000_000, args.cpu_pairs, local)
+        except Exception as ex:  # the baseline must never sink the measurement
+            line["cpu_baseline"] = {"error": str(ex)}
+    # RCCL writes its version banner through C stdio, which on a pipe is flushed at exit, i.e. after Python's output:
+    # flush it now so that the JSON line is the last thing on stdout
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
     try:
         os.remove(out_path)
     except OSError:
         pass
+
+
+def secondary_workloads(eng, args, wl, local):
+    """the other regimes of the same path, a few steps each (N = 1): results a reader needs next to the headline, whose
+    synthetic sample (half of a 13 Gbase reference) saturates the 2^32-slot table and yields no voted peak"""
+    from localhgt_amd.engine import Engine
+    out = {}
+    k, e, L = args.k, args.e, 150
+
+    def leg(engine, pairs, steps=3):
+        w = Workload(engine, None, 0, 1, False, wl.out_path)
+        dt, per_ms, n_peaks, nf = w.run(steps, 1)
+        return {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
+                "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
+                "scan_B_form": engine.scan_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs}
+
+    try:
+        if (args.contigs, args.pairs) == (13000, 100_000_000):
+            # the same reference under a sample of 1000 genomes (1 Gbase at 30x): the table stays a quarter full, transfers are found
+            eng.synth_options(0, 20, 1000)
+            eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, args.pairs, L)
+            out["uhgg_focused_sample"] = dict(leg(eng, args.pairs), workload="13000x1000000 bp ref, 100 M pairs drawn from 1000 of its contigs (a metagenome holds few of a catalogue's genomes), sample=1")
+            eng.pairs_clear()
+            # the CLI's default --sample 2000000000 (E:1392-1398): 2e9 / (2 * 100 M * 150) = 6.67 % of the pairs survive the
+            # sampling array; any subset of iid pairs is iid, so the kept pairs are generated directly
+            kept = int(2e9 / (2 * 150))
+            eng.synth_options(0, 20, 0)
+            eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, kept, L)
+            d = leg(eng, kept)
+            d.update(workload=f"configs[2] under the pipeline's default --sample 2000000000: {kept} of 100 M pairs kept (resident; a real run is bound by parsing the other 93 %)",
+                     input_pairs=args.pairs, input_pairs_per_s_M=round(args.pairs / (d["ms_per_step"] * 1e-3) / 1e6, 1))
+            out["uhgg_default_sample"] = d
+            eng.pairs_clear()
+    except Exception as ex:
+        out["uhgg_error"] = str(ex)
+    eng.close()
+    try:
+        if (args.contigs, args.pairs) != (1000, 10_000_000):
+            with Engine(k, e, device=local) as e1:
+                e1.rng_seed(1)
+                e1.coder_generate()
+                e1.synth_reference(1, 1000, 1_000_000)
+                e1.synth_pairs(1, 2, 1000, 1_000_000, 0, 10_000_000, L)
+                d = leg(e1, 10_000_000, steps=5)
+                algo = ALGO_BYTES_PER_PAIR(L, k, e) * 10_000_000
+                fresh, _ = committed_traffic(f"1000x1000000_10000000_k{k}_e{e}")
+                hbm = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_rates.hip")
+                d["roofline"] = roofline_entry("vote_kernel (dense peak set: every one of the 714 probes per pair goes to the 16 GiB peak_kmer), 1 launch per step",
+                                               d["phase_ms"]["vote_C"], 1, algo, fresh.get("vote_kernel"), "profiles/traffic_per_launch.json (measured on these sources)", hbm)
+                d["workload"] = "BASELINE configs[1]: 1000x1000000 bp ref, 10 M pairs, k=32 e=3, sample=1"
+                out["configs1_1g"] = d
+    except Exception as ex:
+        out["configs1_error"] = str(ex)
+    return out
+
+
+def dry_run(args, rank, world, local):
+    """CPU self-test of the N > 1 plumbing: the launcher, the process group (gloo) and every exchange of localhgt_amd/dist.py
+    on host tensors through the test adapter.  Measures nothing."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_dist_cpu import FakeEngine, NumpyAdapter, unpack
+    from localhgt_amd.dist import Exchange
+    for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+        os.environ.setdefault(key, val)
+    ex = Exchange.from_env(backend="gloo", adapter=NumpyAdapter())
+    rng = np.random.default_rng(100 + rank)
+    table = rng.choice(4, size=(1 << 16) * 4, p=[.6, .2, .1, .1]).astype(np.uint8)
+    eng = FakeEngine(table, rng.integers(0, 300, size=1000))
+    t0 = time.time()
+    ex.merge_counts(eng)
+    ex.sum_votes(eng)
+    eng.rank, eng.n_new = rank, 3 + rank
+    total = ex.sharded_scan(eng, 0.1, 0.08, 1000)
+    mine = torch.tensor([int(unpack(eng.table.numpy()).sum()), int(eng.votes.sum())], dtype=torch.int64)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(allv, mine)
+    ok = all(bool((v == allv[0]).all()) for v in allv) and total == sum(3 + r for r in range(world))
+    ex.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "n_gpus": world, "world_size": torch.distributed.get_world_size(),
+                          "backend": "gloo", "exchanges_consistent": ok, "seconds": round(time.time() - t0, 3)}), flush=True)
+    ex.close()
+    if not ok:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

@@ -142,6 +142,11 @@ int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t
 int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci /*[2*n]*/, uint8_t* filter /*[n]*/, long n);
 int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint32_t* out);
 
+/* position-sensitive checksum of a whole device table (parity at sizes whose tables cannot travel through the host):
+ * out[0] = sum_i mix(i, v[i] & mask) mod 2^64, out[1] = number of i with v[i] & mask != 0.
+ * what: 0 = count table (packed words), 1 = flags per reference position, 2 = peak_kmer, 3 = peak_loci, 4 = votes (u32) */
+int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]);
+
 /* ---- synthetic workload generated on the device (bench.py / tests; no reference counterpart).
  * Bases are a pure function of (seed, contig, position); see localhgt_amd/csrc/k_synth.hip. */
 int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long contig_len, uint8_t* host_ascii_or_null);

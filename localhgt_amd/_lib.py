@@ -67,6 +67,7 @@ SIGNATURES = {
     "lhgt_flags_export": [_vp, C.c_uint64, C.c_uint64, _u8p],
     "lhgt_peaks_export": [_vp, _i32p, _u8p, _l],
     "lhgt_peak_kmer_export": [_vp, C.c_uint64, C.c_uint64, _u32p],
+    "lhgt_digest": [_vp, _i, C.c_uint64, _u64p],
     "lhgt_synth_reference": [_vp, C.c_uint64, _l, _l, _u8p],
     "lhgt_synth_reference_shard": [_vp, C.c_uint64, _l, _l, _i, _i, _u8p],
     "lhgt_synth_reference_cuts": [_vp, C.c_uint64, _l, _l, _u64p, _l, _u8p],

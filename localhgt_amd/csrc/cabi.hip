@@ -4,7 +4,63 @@
 
 using namespace lhgt;
 
+namespace lhgt {
+// Position-sensitive checksum of a device array for parity tests at sizes whose tables cannot go through the host:
+// sum over i of mix(i, v[i] & mask) mod 2^64 (order of summation free, so one pass of atomics).  BYTES = element size.
+__device__ __forceinline__ uint64_t digest_mix(uint64_t i, uint64_t v) {
+    uint64_t x = i * 0x9E3779B97F4A7C15ull + v * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <class T>
+__global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, uint64_t n, uint64_t mask, unsigned long long* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t acc = 0, nz = 0;
+    for (; i < n; i += stride) {
+        const uint64_t x = (uint64_t)v[i] & mask;
+        acc += digest_mix(i, x);
+        nz += x != 0;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); nz += __shfl_xor(nz, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)acc); atomicAdd(out + 1, (unsigned long long)nz); }
+}
+}  // namespace lhgt
+
 extern "C" {
+
+int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    const void* p = nullptr;
+    uint64_t n = 0;
+    int bytes = 4;
+    switch (what) {
+        case 0: p = ctx->d_counts; n = ctx->counts_words; break;                                   // packed 2-bit table, as words
+        case 1: p = ctx->d_flags; n = ctx->n_pos; bytes = 1; break;                                // per reference position
+        case 2: p = ctx->d_peak_kmer; n = ctx->d_peak_kmer ? (1ull << ctx->k) : 0; break;
+        case 3: p = ctx->d_loci; n = ctx->n_peaks > 0 ? 2ull * (uint64_t)ctx->id_end : 0; break;
+        case 4: p = ctx->d_filter; n = ctx->n_peaks > 0 ? (uint64_t)ctx->id_end : 0; break;         // votes (u32, unclamped)
+        default: LHGT_FAIL(LHGT_E_ARG, "digest of what?");
+    }
+    out[0] = out[1] = 0;
+    if (!p || !n) return LHGT_OK;
+    unsigned long long* d_out;
+    LHGT_HIP(hipMalloc(&d_out, 16));
+    LHGT_HIP(hipMemsetAsync(d_out, 0, 16, ctx->stream));
+    if (bytes == 1) hipLaunchKernelGGL((digest_kernel<uint8_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint8_t*)p, n, mask, d_out);
+    else hipLaunchKernelGGL((digest_kernel<uint32_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint32_t*)p, n, mask, d_out);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e1 = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(d_out);
+    if (e1 != hipSuccess || e2 != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "digest copy failed");
+    out[0] = h[0];
+    out[1] = h[1];
+    return LHGT_OK;
+}
 
 int lhgt_device_count(int* n) {
     if (!n) LHGT_FAIL(LHGT_E_ARG, "null argument");

@@ -922,6 +922,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
     LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[1], ctx->ev0, ctx->ev1));
     ctx->n_peaks = total;
+    ctx->id_end = total;
     ctx->max_peak = max_peak;
     ctx->voted = false;
     if (n_peaks) *n_peaks = total;
@@ -1012,6 +1013,7 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
     LHGT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->phase_ms[1] += ms;
     ctx->n_peaks = n_peaks_total;
+    ctx->id_end = n_peaks_total;
     ctx->max_peak = max_peak;
     ctx->voted = false;
     return LHGT_OK;

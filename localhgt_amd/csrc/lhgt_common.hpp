@@ -131,6 +131,7 @@ struct lhgt_ctx {
     uint32_t* d_filter = nullptr;
     uint32_t* d_tile_count = nullptr;
     long n_peaks = -1, max_peak = 0;
+    long id_end = 0;   // one past the largest peak id in use (= n_peaks unless thread ranges are emulated: ids start at j * (max_peak / t))
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
     uint32_t* d_prefilter_fold = nullptr;  // 64 KiB fold of it, copied into LDS by the sparse-path vote kernel
     bool prefilter_on = false;

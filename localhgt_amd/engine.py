@@ -240,6 +240,14 @@ class Engine:
         return p.value, n.value
 
     # ---- introspection (parity tests)
+    DIGEST_COUNTS, DIGEST_FLAGS, DIGEST_PEAK_KMER, DIGEST_LOCI, DIGEST_VOTES = range(5)
+
+    def digest(self, what: int, mask: int = 0xFFFFFFFFFFFFFFFF) -> Tuple[int, int]:
+        """(position-sensitive checksum, non-zero entries) of a whole device table"""
+        out = np.zeros(2, dtype=np.uint64)
+        _lib.check(self.lib.lhgt_digest(self.h, what, C.c_uint64(mask), _ptr(out, C.c_uint64)))
+        return int(out[0]), int(out[1])
+
     def counts_export(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
         n = (1 << self.k) - first if n is None else n
         out = np.zeros(n, dtype=np.uint8)

@@ -93,12 +93,15 @@ def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
     if dist:
         mode = os.environ.get("LHGT_SHARD_INDEX", "auto")
         shard_index = mode == "1" or (mode == "auto" and os.path.getsize(idx) > 180e9)
+    t_i0 = time.time()
     if shard_index:
         n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
     else:
         n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
+    t_i1 = time.time()
     _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
     eng.sampling_init(ratio)                                   # E:1422
+    t_r0 = time.time()
     seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
     t1 = time.time()
     eng.count_kmers()                                          # phase A, E:1426-1448
@@ -124,7 +127,7 @@ def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
     t5 = time.time()
     log(f"Finish with time:\t{t5 - t0:.2f}")
     rep = dict(pairs_seen=seen, pairs_kept=kept, n_contigs=n_contigs, n_bases=n_bases, n_peaks=n_peaks,
-               n_filtered=n_filtered, ratio=ratio, index_built=built, ingest_s=t1 - t0, count_s=t2 - t1, scan_s=t3 - t2,
+               n_filtered=n_filtered, ratio=ratio, index_built=built, ingest_s=t1 - t0, index_s=t_i1 - t_i0, reads_s=t1 - t_r0, count_s=t2 - t1, scan_s=t3 - t2,
                vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
                vote_kernel_ms=eng.phase_ms(2))
     eng.close()

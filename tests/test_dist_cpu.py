@@ -105,6 +105,27 @@ def test_exchange_world2_gloo(tmp_path):
         assert (np.load(tmp_path / f"votes_out_{r}.npy") == want_v).all()
 
 
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself; --dry-run drives the launcher, the process
+    group and every exchange on host tensors (gloo) and prints the one JSON line on rank 0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["world_size"] == 2 and d["exchanges_consistent"]
+    # under a launcher (WORLD_SIZE set) it is one of the ranks and must not start more
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
+
+
 def test_saturating_sum_identity():
     """min(3, sum_r min(3, c_r)) == min(3, sum_r c_r): why per-rank saturated tables can be merged"""
     rng = np.random.default_rng(0)

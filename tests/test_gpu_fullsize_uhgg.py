@@ -1,0 +1,161 @@
+"""Parity at the size the headline number is quoted on (BASELINE.json configs[2]: 13000 x 1 Mbp reference, 156 GB of index
+resident, up to 100 M pairs, k=32 e=3).  The CPU oracle cannot run here, so the code paths that only switch on at this scale
+are pinned against the forms the oracle checks at small sizes (tests/test_gpu_parity.py, test_gpu_fuzz.py), on whole tables
+through device-side checksums (lhgt_digest: position-sensitive, every entry counted):
+
+  phase A   radix partition (24 chunks, overflow regions)          == direct compare-and-swap kernel
+  phase B   lite form / the form the trial picks / chunked id scan == exact form (E:550-725), tiles settled or not
+  phase C   queued sparse kernel (folded two-bit Bloom bitmap)     == generic kernel == no prefilter at all (E:313-506)
+
+at three sample depths -- 25 M pairs (table 59 % full: exact form), 35 M (the trial's range), 100 M (lite form) -- and once
+more on a RAGGED reference (117 k contigs from 10 bases to 2 Mbp, many shorter than one 2000-position tile, some <= k)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NC, CL, K, E = 13000, 1_000_000, 32, 3
+FLAG_BITS = 0b1111101          # the trio bit is a lower bound after the lite form and bit 7 says whether it is exact
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from localhgt_amd.engine import Engine
+    e = Engine(K, E)
+    e.rng_seed(1)
+    e.coder_generate()
+    e.synth_reference(1, NC, CL)
+    yield e
+    e.close()
+
+
+def _scan(eng, debug):
+    eng.set_debug(debug)
+    n = eng.ref_scan(0.1, 0.08, 300_000_000)
+    info = eng.scan_info()
+    res = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_FLAGS, FLAG_BITS))
+    eng.set_debug(0)
+    return res, info
+
+
+def _vote(eng, debug):
+    """votes of the resident pairs with the peak registry of a fresh scan under `debug` (the prefilter is decided there)"""
+    eng.set_debug(debug)
+    eng.ref_scan(0.1, 0.08, 300_000_000)
+    eng.vote()
+    d = eng.digest(eng.DIGEST_VOTES)
+    eng.set_debug(0)
+    return d
+
+
+def _check_scans_and_votes(eng, expect_lite, tag):
+    exact, info_x = _scan(eng, 8192)
+    assert not info_x["lite"]
+    assert exact[0] > 1000, (tag, exact[0])
+    lite, info_l = _scan(eng, 4096)
+    assert info_l["lite"]
+    trial, info_t = _scan(eng, 0)
+    chunked, _ = _scan(eng, 128)                       # ids through the chunked tile scan (on by itself above 65536 tiles) ...
+    unsettled, _ = _scan(eng, 8192 | 256)              # ... and no tile settled by window_good alone
+    for name, other in (("lite", lite), ("trial", trial), ("chunked", chunked), ("unsettled", unsettled)):
+        assert other == exact, (tag, name, other, exact)
+    if expect_lite is not None:
+        assert info_t["lite"] == expect_lite, (tag, info_t)
+    queued = _vote(eng, 0)
+    generic = _vote(eng, 32)                           # generic kernel behind the same bitmap
+    direct = _vote(eng, 2048)                          # queued kernel, pairs with > 8 bitmap survivors voted at once
+    nofilter = _vote(eng, 4)                           # every probe goes to peak_kmer
+    assert queued == generic == direct == nofilter, (tag, queued, generic, direct, nofilter)
+    return exact, info_t, queued
+
+
+def _count_both_ways(eng):
+    got = []
+    for mode in (1, 0):
+        eng.set_count_mode(mode)
+        eng.counts_clear()
+        eng.count_kmers()
+        got.append((eng.digest(eng.DIGEST_COUNTS), tuple(int(x) for x in eng.counts_histogram())))
+    eng.set_count_mode(-1)
+    assert got[0] == got[1]
+    assert sum(got[0][1]) == 1 << 32
+    return got[0]
+
+
+# (pairs, contigs the sample is drawn from, lite form expected, votes expected).  With the default sample -- half of the
+# reference, 6.5 Gbase -- three hashes of 6.5 G k-mers fill the 2^32 slots by collisions alone and nothing is ever voted (the
+# reference would find nothing either: this is why it down-samples, E:1392-1398); a sample of 1000 contigs at 7.5x is the
+# regime of configs[1] on the big reference: transfers are found and voted.
+@pytest.mark.parametrize("pairs,sample_contigs,expect_lite,expect_votes",
+                         [(25_000_000, 0, False, False), (35_000_000, 0, None, False), (100_000_000, 0, True, False),
+                          (25_000_000, 1000, None, True)])
+def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_votes):
+    eng.pairs_clear()
+    eng.synth_options(0, 20, sample_contigs)
+    eng.synth_pairs(1, 2, NC, CL, 0, pairs)
+    eng.synth_options(0, 20, 0)
+    digest, hist = _count_both_ways(eng)               # leaves the direct kernel's table: same bits
+    frac3 = hist[3] / float(1 << 32)
+    exact, info, votes = _check_scans_and_votes(eng, expect_lite, f"{pairs} pairs")
+    assert abs(info["frac_slots_at_3"] - frac3) < 0.01
+    assert info["tiles"] == NC * CL // 2000
+    if expect_votes:
+        assert votes[1] >= 1, votes
+        n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
+        eng.vote()
+        loci, filt = eng.peaks_export(n_peaks)
+        assert filt.max() >= 1
+        contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
+        assert (np.diff(contig * (1 << 32) + pos) > 0).all()      # ids ascend in (contig, position), E:232-275
+        assert 1 <= contig.min() and contig.max() <= NC
+
+
+def _ragged_cuts(total, seed=5):
+    """contig boundaries of a catalogue-like length distribution: 3 of 4 contigs log-uniform in 300 b .. 20 kb, the others
+    20 kb .. 2 Mb, and one piece in a hundred of 10 .. 32 bases (not indexed at k = 32, E:772)"""
+    rng = np.random.default_rng(seed)
+    lens = []
+    have = 0
+    while have < total:
+        n = 4096
+        u = rng.random(n)
+        kind = rng.random(n)
+        ln = np.where(kind < 0.75, np.exp(np.log(300) + u * np.log(20000 / 300)), np.exp(np.log(20000) + u * np.log(2_000_000 / 20000)))
+        ln = np.where(rng.random(n) < 0.01, 10 + (u * 23), ln).astype(np.int64)
+        lens.append(ln)
+        have += int(ln.sum())
+    lens = np.concatenate(lens)
+    cuts = np.concatenate([[0], np.cumsum(lens)])
+    cuts = cuts[cuts < total]
+    return np.concatenate([cuts, [total]]).astype(np.uint64)
+
+
+def test_ragged_reference_forms_agree(eng):
+    """the same base stream cut into ~117 k ragged contigs, under the 100 M pairs of the headline workload (the count table
+    does not depend on the reference): per-contig tiles mostly shorter than 2000 positions, windows and contrast halos that
+    hang over contig ends everywhere"""
+    eng.pairs_clear()
+    eng.synth_pairs(1, 2, NC, CL, 0, 100_000_000)
+    eng.counts_clear()
+    eng.count_kmers()
+    cuts = _ragged_cuts(NC * CL)
+    lens = np.diff(cuts.astype(np.int64))
+    assert lens.size >= 100_000 and (lens <= K).sum() > 100 and lens.max() > 1_500_000
+    eng.synth_reference_cuts(1, NC, CL, cuts)
+    exact, info, votes = _check_scans_and_votes(eng, None, "ragged")
+    assert info["tiles"] == int(np.ceil(lens[lens > K] / 2000).sum())
+    n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
+    loci, _ = eng.peaks_export(n_peaks)
+    contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
+    assert (np.diff(contig * (1 << 32) + pos) > 0).all()
+    indexed = lens[lens > K]
+    assert contig.max() <= indexed.size and (pos < indexed[contig - 1]).all()          # sequential ids of indexed contigs (quirk Q7)
+    # a lighter sample on the same ragged reference: the exact form's territory
+    eng.pairs_clear()
+    eng.synth_options(0, 20, 1000)
+    eng.synth_pairs(1, 2, NC, CL, 0, 25_000_000)
+    eng.synth_options(0, 20, 0)
+    eng.counts_clear()
+    eng.count_kmers()
+    _, _, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
+    assert votes[1] >= 1

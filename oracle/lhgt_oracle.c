@@ -631,6 +631,233 @@ int orc_run(const char* fq1, const char* fq2, const char* fasta, const char* int
     return 0;
 }
 
+/* ================================================================ `-t N` as the reference executes it WITHOUT its races
+ * (SURVEY.md 8f rank 4).  Contract = the reference binary with its N threads run one after the other in creation order
+ * (oracle/seq_threads.c preloaded into oracle/_ref/extract_ref_z): per-thread byte chunks of the FASTQs found by
+ * get_fq_start's forward scan (E:44-89), lines consumed while the byte cursor before the line is <= the chunk end
+ * (E:1019-1026), sampling ordinals counted per chunk (E:1037), contig groups of split_ref (E:1280-1330) with peak ids
+ * starting at j * (max_peak / N) (E:229-237), one sentinel line per thread in the interval file (E:515-548). */
+
+/* get_fq_start (E:44-89), literally: the newline counter x and the flag persist across restarts of the outer loop.
+ * Returns -1 where the reference's ifstream would run into EOF (its behaviour there is garbage-in): chunk starts must lie
+ * more than 1000 bytes before the end of the file. */
+long orc_get_fq_start(const unsigned char* p, long n, long start) {
+    long pos = 0;
+    int flag = 0, done = 0, x = 0;
+    for (long i = start; i > 0; i--) {
+        for (long j = i; j < i + 1000; j++) {
+            if (j + 1 >= n) return -1;
+            const char chr1 = (char)p[j], chr2 = (char)p[j + 1];
+            if (chr1 == '\n' && chr2 == '+') { flag = 1; x = 0; }             /* third field */
+            if (flag) {
+                if (chr1 == '\n') x += 1;                                     /* forth field */
+                if (chr1 == '\n' && chr2 == '@' && x == 3) { pos = j + 1; done = 1; break; }
+            } else if (chr1 == '\n') x += 1;
+            if (x == 3) break;
+        }
+        if (done) break;
+    }
+    return pos;
+}
+
+/* phase A over one thread chunk [start, end] of one file (read_fastq, E:981-1107) */
+static long orc_count_chunk(const orc_buf* b, long start, long end, int k, int e, const short* cc, double ratio,
+                            const float* rnd, uint8_t* table) {
+    long pos = orc_get_fq_start(b->p, b->n, start);
+    if (pos < 0) return -1;
+    long cur = pos, add_size = pos, lines = 0, len, kept = 0;
+    const unsigned char* s;
+    uint32_t h[16];
+    while (orc_next_line(b, &cur, &s, &len)) {
+        if (add_size > end) break;                                            /* E:1022-1026 */
+        add_size += len + 1;
+        if (lines % 4 == 1 && orc_keep(lines / 4, rnd, ratio)) {               /* ordinal inside the chunk, E:1037 */
+            if (len > ORC_MAX_READ) return -3;
+            kept++;
+            for (int q = 0; q + k <= len; q++) {
+                if (!orc_hash_kmer(s + q, k, e, cc, h)) continue;
+                for (int i = 0; i < e; i++) if (table[h[i]] < 3) table[h[i]]++;
+            }
+        }
+        lines++;
+    }
+    return kept;
+}
+
+/* phase C over one thread chunk (slide_reads, E:313-506): fq2 is entered at the same byte offset and re-synchronised on the
+ * read ID of fq1's first line (E:368-402) */
+static long orc_vote_chunk(const orc_buf* b1, const orc_buf* b2, long start, long end, const orc_vote_job* j) {
+    long pos = orc_get_fq_start(b1->p, b1->n, start);
+    if (pos < 0 || pos > b2->n) return -1;
+    long cur1 = pos, cur2 = pos, add_size = pos, lines = 0, len1, len2 = 0, kept = 0;
+    const unsigned char *s1, *s2 = (const unsigned char*)"";
+    orc_vote_state* S = (orc_vote_state*)malloc(sizeof(orc_vote_state));
+    while (orc_next_line(b1, &cur1, &s1, &len1)) {
+        if (!orc_next_line(b2, &cur2, &s2, &len2)) { s2 = (const unsigned char*)""; len2 = 0; }
+        if (add_size > end) break;
+        add_size += len1 + 1;
+        if (lines == 0) {
+            long i1 = orc_read_id_len(s1, len1), i2 = orc_read_id_len(s2, len2);
+            if (i1 != i2 || memcmp(s1, s2, (size_t)i1)) {
+                cur2 = pos - 1000000000L;
+                if (cur2 < 1) cur2 = 1;
+                for (;;) {
+                    if (!orc_next_line(b2, &cur2, &s2, &len2)) { free(S); return -2; }   /* the reference spins 1e9 times, then reads garbage */
+                    i2 = orc_read_id_len(s2, len2);
+                    if (i1 == i2 && !memcmp(s1, s2, (size_t)i1)) break;
+                }
+            }
+        }
+        if (lines % 4 == 1 && orc_keep(lines / 4, j->rnd, j->ratio)) {
+            if (len1 > ORC_MAX_READ || len2 > ORC_MAX_READ) { free(S); return -3; }
+            kept++;
+            S->n = 0; S->base_hits = 0;
+            orc_seq q1 = {s1, (int)len1}, q2 = {s2, (int)len2};
+            orc_vote_mate(S, &q1, j);
+            orc_vote_mate(S, &q2, j);
+            if (S->base_hits >= 6) orc_check_split(S, j->peak_filter);
+        }
+        lines++;
+    }
+    free(S);
+    return kept;
+}
+
+/* split_ref (E:1280-1330): contig groups from genome.len.txt; cut[3*i] = start byte, [3*i+1] = end byte, [3*i+2] = first ref_index */
+static int orc_split_ref(const char* index_path, const char* len_path, int k, int e, int threads, long* cut /*[300]*/) {
+    memset(cut, 0, sizeof(long) * 300);
+    FILE* f = fopen(len_path, "r");
+    if (!f) return -1;
+    long index_size = orc_file_size(index_path), each = index_size / threads + 1;
+    long pos = 300 * 4, start_byte = pos, end_byte, start_ref_index = 1, count_ref_index = 0, slide;
+    int cut_index = 0, ref_len, ref_index;
+    char name[4096];
+    while (fscanf(f, "%4095s %d %d %ld", name, &ref_index, &ref_len, &slide) == 4) {
+        count_ref_index += 1;
+        long add = 4L * ((long)(ref_len - k + 1) * e + 1);
+        if (pos - start_byte > each) {
+            end_byte = pos + add;
+            cut[3 * cut_index] = start_byte; cut[3 * cut_index + 1] = end_byte; cut[3 * cut_index + 2] = start_ref_index;
+            cut_index += 1;
+            start_byte = end_byte;
+            start_ref_index = count_ref_index + 1;
+        }
+        pos += add;
+        if (pos >= index_size) break;
+    }
+    if (start_byte != index_size) {
+        cut[3 * cut_index] = start_byte; cut[3 * cut_index + 1] = index_size; cut[3 * cut_index + 2] = start_ref_index;
+        cut[3 * cut_index + 3] = 0;
+    }
+    fclose(f);
+    return 0;
+}
+
+/* The 12-argument contract with `threads` = the reference's -t (> 1), executed without its races.  Unsupported inputs (a chunk
+ * start within 1000 bytes of EOF, fq2 without the read ID of a chunk's first record, a thread's peaks overflowing its id
+ * range) return an error instead of the reference's undefined behaviour. */
+int orc_run_threads(const char* fq1, const char* fq2, const char* fasta, const char* interval_path,
+                    double hit_ratio_d, double match_ratio_d, int threads, int k, long max_peak, int e,
+                    unsigned seed, double sample, orc_report* rep) {
+    if (threads < 1 || threads > 99) return -9;
+    size_t slots = (size_t)1 << k;
+    uint8_t* table = (uint8_t*)calloc(slots, 1);
+    short cc[ORC_CODER_SLOTS], cc_file[ORC_CODER_SLOTS];
+    if (!table) return -1;
+    srand(seed);
+    double ratio = orc_sam_ratio(fq1, sample);
+    char index_path[4096], len_path[4096];
+    snprintf(index_path, sizeof index_path, "%s.k%d.h%d.index.dat", fasta, k, e);
+    snprintf(len_path, sizeof len_path, "%s.genome.len.txt", fasta);
+    FILE* probe = fopen(index_path, "rb");
+    if (probe) fclose(probe);
+    else {
+        orc_random_coder(k, e, cc);
+        if (orc_index_build(fasta, index_path, len_path, k, e, cc) < 0) return -2;
+    }
+    if (orc_index_header(index_path, cc_file)) return -3;
+    float* rnd = ratio >= 100.0 ? NULL : orc_sampling_array(ORC_MAX_RANDOM);
+    orc_buf b1 = orc_slurp(fq1), b2 = orc_slurp(fq2);
+    if (b1.n < 0 || b2.n < 0) return -4;
+    const long size = b1.n, each_size = size / threads;                                  /* E:1419-1420 */
+    long c1 = 0, c2 = 0;
+    for (int pass = 0; pass < 2; pass++)                                                  /* fq1 by all threads, then fq2 (E:1426-1448) */
+        for (int i = 0; i < threads; i++) {
+            long start = i * each_size, end = i == threads - 1 ? size : (i + 1) * each_size;
+            long got = orc_count_chunk(pass ? &b2 : &b1, start, end, k, e, cc_file, ratio, rnd, table);
+            if (got < 0) return -4;
+            if (pass) c2 += got; else c1 += got;
+        }
+    int32_t* loci = (int32_t*)calloc((size_t)max_peak * 2 + 2, 4);
+    uint8_t* peak_filter = (uint8_t*)calloc((size_t)max_peak + 1, 1);
+    uint32_t* peak_kmer = (uint32_t*)calloc(slots, 4);
+    if (!loci || !peak_filter || !peak_kmer) return -1;
+    /* phase B: one thread per contig group (E:1468-1489), ids from j * (max_peak / threads) (E:229-237) */
+    long cut[300], peak_index[100], each_peaks = max_peak / threads, total_peaks = 0;
+    for (int j = 0; j < threads; j++) peak_index[j] = each_peaks * j;
+    if (orc_split_ref(index_path, len_path, k, e, threads, cut)) return -5;
+    FILE* f = fopen(index_path, "rb");
+    if (!f) return -5;
+    for (int i = 0; i < threads; i++) {
+        long start = cut[3 * i], end = cut[3 * i + 1];
+        if (start == 0) break;
+        int ref_index = (int)cut[3 * i + 2];
+        orc_peaks P = {loci, peak_kmer, peak_index[i], max_peak, 0, 0, 0};
+        fseek(f, start, SEEK_SET);
+        long start_point = start;
+        uint32_t ref_len_u;
+        while (fread(&ref_len_u, 4, 1, f) == 1) {                                         /* read_index, E:921-972 */
+            int ref_len = (int)ref_len_u;
+            long nk = (long)ref_len - k + 1;
+            uint32_t* hidx = (uint32_t*)calloc((size_t)ref_len * e, 4);
+            uint8_t* hit = (uint8_t*)calloc((size_t)ref_len * e, 1);
+            if (fread(hidx, 4, (size_t)nk * e, f) != (size_t)nk * e) { fclose(f); return -5; }
+            for (long q = 0; q < nk * e; q++) hit[q] = hidx[q] ? table[hidx[q]] : 0;
+            orc_slide_window(&P, hit, hidx, ref_len, ref_index, k, e, (float)hit_ratio_d, (float)match_ratio_d, NULL);
+            free(hidx); free(hit);
+            start_point += 4 + nk * e * 4;
+            ref_index += 1;
+            if (start_point >= end) break;
+        }
+        if (P.too_many || P.n_peaks - each_peaks * i > each_peaks) { fclose(f); return -7; }   /* the reference runs into the next thread's ids */
+        total_peaks += P.n_peaks - peak_index[i];
+        peak_index[i] = P.n_peaks;
+    }
+    fclose(f);
+    /* phase C */
+    orc_vote_job jb = {NULL, NULL, 0, 0, k, e, cc_file, rnd, ratio, peak_kmer, loci, peak_filter, 0};
+    long voted = 0;
+    for (int i = 0; i < threads; i++) {
+        long start = i * each_size, end = i == threads - 1 ? size : (i + 1) * each_size;
+        long got = orc_vote_chunk(&b1, &b2, start, end, &jb);
+        if (got < 0) return -6;
+        voted += got;
+    }
+    /* phase D (E:515-548): every thread's id range with its own sentinel state */
+    FILE* out = fopen(interval_path, "w");
+    if (!out) return -8;
+    long nf = 0;
+    for (int j = 0; j < threads; j++) {
+        int start = 1, end = 1, chr = 1;
+        for (long i = each_peaks * j; i < peak_index[j]; i++) {
+            if (peak_filter[i] < 1) continue;
+            nf++;
+            int c = loci[2 * i], pos = loci[2 * i + 1];
+            if (chr == c && pos - 500 - end < 500) end = pos + 500;
+            else { fprintf(out, "%d\t%d\t%d\n", chr, start, end); chr = c; start = pos - 500; end = pos + 500; }
+        }
+        fprintf(out, "%d\t%d\t%d\n", chr, start, end);
+    }
+    fclose(out);
+    if (rep) {
+        memset(rep, 0, sizeof *rep);
+        rep->pairs_counted = c1; rep->pairs_voted = voted; rep->n_peaks = total_peaks; rep->n_filtered = nf;
+        rep->t_count = (double)c2;   /* mate-2 reads counted, for the partition tests */
+    }
+    free(table); free(loci); free(peak_filter); free(peak_kmer); free(rnd); free(b1.p); free(b2.p);
+    return 0;
+}
+
 #ifdef ORC_MAIN
 int main(int argc, char** argv) {
     if (argc < 13) {
@@ -638,8 +865,10 @@ int main(int argc, char** argv) {
         return 2;
     }
     orc_report rep;
-    int rc = orc_run(argv[1], argv[2], argv[3], argv[4], atof(argv[5]), atof(argv[6]), (int)atof(argv[7]),
-                     (int)atof(argv[8]), (long)atof(argv[9]), (int)atof(argv[10]), (unsigned)atof(argv[11]),
+    /* ORC_EMULATE_THREADS=1: argv[7] is the reference's -t, executed without its races (orc_run_threads); otherwise it only
+     * shards the reads over worker threads and the result is the -t 1 one */
+    int rc = (getenv("ORC_EMULATE_THREADS") ? orc_run_threads : orc_run)(argv[1], argv[2], argv[3], argv[4], atof(argv[5]), atof(argv[6]),
+                     (int)atof(argv[7]), (int)atof(argv[8]), (long)atof(argv[9]), (int)atof(argv[10]), (unsigned)atof(argv[11]),
                      atof(argv[12]), &rep);
     if (rc) { fprintf(stderr, "oracle failed: %d\n", rc); return 1; }
     printf("{\"index_s\": %.3f, \"count_s\": %.3f, \"scan_s\": %.3f, \"vote_s\": %.3f, \"total_s\": %.3f, "

@@ -64,6 +64,11 @@ CASES: Dict[str, Case] = {c.name: c for c in [
          min_len=12000, max_len=20000, short_contig_at=None, depth=10,
          notes="fq2 holds 300 records more than fq1 and shorter headers: surplus mate-2 reads are counted in phase A, never voted; "
                "fq1 ends with a blank line"),
+    # -t N: goldens from the reference with its threads run in creation order (oracle/seq_threads.c)
+    Case("k24_t4", threads=4, notes="-t 4: thread chunks of the FASTQs, 2 contig groups, 4 sentinel lines"),
+    Case("k24_t8_sample_half", threads=8, sample=0.5, notes="-t 8 with sampling: ordinals restart in every chunk (E:1037)"),
+    Case("k24_t3_fq2_longer", threads=3, fq2_header_pad=20, notes="-t 3, fq2 laid out differently: phase C re-synchronises on read IDs (E:368-402), phase A cuts fq2 by fq1's size"),
+    Case("k24_t10_sample_bases", threads=10, sample=700000.0, ref_seed=81, reads_seed=82, notes="-t 10 (the CLI default) with --sample > 1"),
     Case("k24_seed7", seed=7, ref_seed=61, reads_seed=62, n_contigs=5, min_len=12000, max_len=20000,
          short_contig_at=None, depth=10, notes="tiny; inputs also committed gz-compressed"),
 ]}

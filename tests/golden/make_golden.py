@@ -39,8 +39,11 @@ def run_case(case, keep_inputs=False):
         interval = os.path.join(tmp, "interval.txt")
         argv = [BIN] + extract_ref_argv(case, f1, f2, fa, interval)
         runs = 2 if case.preexisting_index else 1
+        env = dict(os.environ)
+        if case.threads > 1:    # -t N contract: the reference's threads one after the other in creation order (oracle/seq_threads.c)
+            env["LD_PRELOAD"] = os.path.join(ROOT, "oracle", "_ref", "libseqthreads.so")
         for _ in range(runs):
-            res = subprocess.run(argv, capture_output=True, text=True, check=True)
+            res = subprocess.run(argv, capture_output=True, text=True, check=True, env=env)
         raw = int(re.findall(r"No\. of raw BKPs: (\d+)", res.stdout)[-1])
         index = f"{fa}.k{case.k}.h{case.e}.index.dat"
         meta = {
@@ -51,6 +54,8 @@ def run_case(case, keep_inputs=False):
             "index_bytes": os.path.getsize(index),
             "raw_peaks": raw,
             "index_preexisting": bool(case.preexisting_index),
+            "threads": case.threads,
+            "thread_log": re.findall(r">>> Thread: final read.*", res.stdout),
         }
         shutil.copy(interval, os.path.join(out, "interval.txt"))
         shutil.copy(fa + ".genome.len.txt", os.path.join(out, "genome.len.txt"))

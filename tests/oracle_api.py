@@ -42,6 +42,10 @@ class Oracle:
                                C.POINTER(C.c_uint8), C.c_int]
         L.orc_write_intervals.restype = C.c_long
         L.orc_write_intervals.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_long]
+        L.orc_get_fq_start.restype = C.c_long
+        L.orc_get_fq_start.argtypes = [C.c_char_p, C.c_long, C.c_long]
+        L.orc_run_threads.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                      C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(Report)]
         L.orc_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int,
                               C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(Report)]
 
@@ -105,6 +109,16 @@ class Oracle:
 
     def write_intervals(self, path, loci, pf, n_peaks):
         return self.L.orc_write_intervals(path.encode(), _p(loci, C.c_int32), _p(pf, C.c_uint8), n_peaks)
+
+    def get_fq_start(self, data: bytes, start: int) -> int:
+        return self.L.orc_get_fq_start(data, len(data), start)
+
+    def run_threads(self, fq1, fq2, fasta, interval, hit_ratio, match_ratio, threads, k, max_peak, e, seed, sample):
+        """the reference's -t N without its races (threads one after the other in creation order)"""
+        rep = Report()
+        rc = self.L.orc_run_threads(fq1.encode(), fq2.encode(), fasta.encode(), interval.encode(), hit_ratio, match_ratio,
+                                    threads, k, max_peak, e, seed, sample, C.byref(rep))
+        return rc, rep
 
     # ---- whole run with the 12-argument contract
     def run(self, fq1, fq2, fasta, interval, hit_ratio, match_ratio, threads, k, max_peak, e, seed, sample):

@@ -43,3 +43,32 @@ def test_oracle_equals_reference_binary(oracle, tmp_path, idx):
     assert open(r / "ref.fa.genome.len.txt").read() == open(c / "ref.fa.genome.len.txt").read()
     a, b = open(r / f"ref.fa.k{k}.h{e}.index.dat", "rb").read(), open(c / f"ref.fa.k{k}.h{e}.index.dat", "rb").read()
     assert len(a) == len(b) and a[:1198] == b[:1198] and a[1200:] == b[1200:]   # bytes 1198-1199: past-the-array read in the reference
+
+
+SHIM = os.path.join(ROOT, "oracle", "_ref", "libseqthreads.so")
+
+
+@pytest.mark.skipif(not os.path.exists(SHIM), reason="oracle/_ref/libseqthreads.so not built")
+@pytest.mark.parametrize("idx", range(16))
+def test_oracle_thread_emulation_equals_reference_binary(oracle, tmp_path, idx):
+    """-t N: the restatement's thread chunks, per-chunk sampling ordinals, contig groups, id ranges and
+    per-thread sentinel lines against the reference run with its threads in creation order (oracle/seq_threads.c)"""
+    r, c = tmp_path / "ref", tmp_path / "cpu"
+    r.mkdir()
+    k, e, seed, sample, hit, match, max_peak = _make_case(100 + idx, str(r), k_max=24)
+    threads = 2 + idx % 9
+    max_peak = 100000 * threads
+    if hit == 0.0 or match == 0.0:
+        hit, match = max(hit, 0.05), max(match, 0.02)
+    shutil.copytree(r, c, dirs_exist_ok=True)
+    rc, orep = oracle.run_threads(str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(hit)),
+                                  float(np.float32(match)), threads, k, max_peak, e, seed, sample)
+    if rc in (-4, -6):
+        pytest.skip("a thread chunk starts within 1000 bytes of EOF / fq2 cannot be re-synchronised: the reference reads garbage there")
+    assert rc == 0
+    res = subprocess.run([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt", repr(hit), repr(match), str(threads), str(k), str(max_peak), str(e),
+                          str(seed), repr(sample)], cwd=r, capture_output=True, text=True, timeout=300, env=dict(os.environ, LD_PRELOAD=SHIM))
+    assert res.returncode == 0, res.stderr[-500:]
+    assert open(r / "i.txt").read() == open(c / "i.txt").read(), (threads, k, e, seed, sample, hit, match)
+    mates = [int(x) for x in re.findall(r">>> Thread: final read .* read num: (\d+)", res.stdout)]
+    assert sum(mates[:threads]) == orep.pairs_counted and sum(mates[threads:]) == int(orep.t_count)   # reads each chunk kept, mate 1 / mate 2

@@ -77,6 +77,23 @@ int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, 
  * default min(32, cores)): the reference's pairing is purely line-indexed, so any line start is a split point. */
 int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent,
                           int shard_rank, int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept);
+/* The reference's -t N as it runs WITHOUT its races (contract = the reference binary with its threads run
+ * one after the other in creation order).  threads > 1 makes the calls below restate: the per-thread byte chunks of the
+ * FASTQs (get_fq_start E:44-89; lines consumed while the cursor before the line is <= the chunk end, E:1019-1026; a record cut
+ * by a boundary is lost as there), sampling ordinals counted per chunk (E:1037) -- lhgt_pairs_load_fastq; the contig groups of
+ * split_ref with peak ids from j * (max_peak / threads) (E:1280-1330, 229-237) -- lhgt_ref_scan; one sentinel line per thread
+ * (E:515-548) -- lhgt_write_intervals.  Default 1: every read, one id range (the -t 1 result whatever -t says).
+ * Not combined with the reference-sharded scan.  Inputs on which the reference's behaviour is undefined (a chunk entered within
+ * 1000 bytes of EOF, overlapping chunks, a thread's peaks overflowing its id range) are refused with an error. */
+int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads);
+/* where thread i of `threads` enters a FASTQ (byte), the global index of its first line and the lines it consumes;
+ * size_for_chunks = size of fq1 (also for fq2, E:1419), < 0 = this file's */
+int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, long* entry_byte, long* first_line, long* n_lines);
+int lhgt_fastq_parse_digest_threads(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null,
+                                    int shard_rank, int shard_world, long shard_block, int threads, long chunk_bytes,
+                                    int emulate_threads, long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest,
+                                    long* counts_or_null /*[3]: mate 1 counted, mate 2 counted, voted*/);
+
 /* host-only probe of the same parser (tests): FNV-1a digest of every kept pair in order; threads/chunk_bytes explicit */
 int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null,
                             int shard_rank, int shard_world, long shard_block, int threads, long chunk_bytes,

@@ -44,6 +44,9 @@ SIGNATURES = {
     "lhgt_fastq_sam_ratio": [_cs, _d, _dp, _lp],
     "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
     "lhgt_fastq_parse_digest": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _lp, _lp, _u64p],
+    "lhgt_set_thread_emulation": [_vp, _i],
+    "lhgt_fastq_thread_chunks": [_cs, _l, _i, _lp, _lp, _lp],
+    "lhgt_fastq_parse_digest_threads": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _i, _lp, _lp, _u64p, _lp],
     "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
     "lhgt_pairs_append_flags": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
     "lhgt_pairs_clear": [_vp],

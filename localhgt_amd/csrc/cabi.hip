@@ -123,7 +123,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_peak_kmer, (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],
-                    (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_emit_loci, (void*)c->d_emit_regs})
+                    (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_contig_id_adj})
         if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -132,6 +132,12 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     if (c->stream) hipStreamDestroy(c->stream);
     free(c->rng);
     delete c;
+    return LHGT_OK;
+}
+
+int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads) {
+    if (!ctx || threads < 1 || threads > 99) LHGT_FAIL(LHGT_E_ARG, "thread emulation: 1 (off) .. 99 threads (split_ref holds 100 groups, E:1284)");
+    ctx->emu_threads = threads;
     return LHGT_OK;
 }
 

@@ -199,9 +199,86 @@ static ChunkPlan plan_chunks(const Mapped& m, size_t chunk_bytes, int threads) {
     return pl;
 }
 
+// ---------------------------------------------------------------- the reference's -t N read partition
+// Thread i of N reads the byte chunk [i*(size/N), (i+1)*(size/N)] (the last one to `size`; E:1426-1434) -- `size` being fq1's
+// for BOTH files (E:1419, quirk Q4).  It enters the file at get_fq_start(start) and consumes lines while the byte offset of the
+// line's start is <= end (E:1022-1026); sampling ordinals count sequence lines from the chunk's first line (E:1037).  A record
+// cut by a boundary is lost or half-read exactly as there.  One ThreadPart per file: the global line ranges the chunks consume.
+
+// get_fq_start (E:44-89): scan forward from `start` for a "\n+" line and take the "\n@" two newlines later; when three newlines
+// pass without it the scan restarts one byte EARLIER with its newline counter and flag kept (the reference's loop, literally).
+// -1 where the reference's ifstream would hit EOF (from there on it reads stale bytes).
+static long get_fq_start(const uint8_t* p, long n, long start) {
+    long pos = 0;
+    bool flag = false, done = false;
+    int x = 0;
+    for (long i = start; i > 0; i--) {
+        for (long j = i; j < i + 1000; j++) {
+            if (j + 1 >= n) return -1;
+            const uint8_t c1 = p[j], c2 = p[j + 1];
+            if (c1 == '\n' && c2 == '+') { flag = true; x = 0; }
+            if (flag) {
+                if (c1 == '\n') x++;
+                if (c1 == '\n' && c2 == '@' && x == 3) { pos = j + 1; done = true; break; }
+            } else if (c1 == '\n') x++;
+            if (x == 3) break;
+        }
+        if (done) break;
+    }
+    return pos;
+}
+
+struct ThreadPart {
+    std::vector<long> first, count;   // per thread chunk: global index of its first line, lines it consumes
+    // sequence line g: in which chunk, and is it kept there?  (-1 = no chunk consumes it)
+    int keep(long g, double ratio, const float* random_array) const {
+        size_t i = (size_t)(std::upper_bound(first.begin(), first.end(), g) - first.begin());
+        while (i > 0) {   // chunks are in file order; a later chunk never starts before an earlier one
+            i--;
+            if (g < first[i]) continue;
+            if (g >= first[i] + count[i]) return -1;
+            const long local = g - first[i];
+            if (local % 4 != 1) return -1;
+            return (ratio >= 100.0 || (double)random_array[(local / 4) % LHGT_MAX_RANDOM] < ratio) ? 1 : 0;
+        }
+        return -1;
+    }
+};
+
+static long line_index_of(const Mapped& m, const ChunkPlan& pl, size_t byte_pos) {
+    if (byte_pos >= m.n) return pl.line0.back();
+    size_t c = (size_t)(std::upper_bound(pl.start.begin(), pl.start.end(), byte_pos) - pl.start.begin()) - 1;
+    return pl.line0[c] + count_lines(m.p, pl.start[c], byte_pos, m.n + 1);   // newlines in [chunk start, byte_pos)
+}
+
+static int thread_part(const Mapped& m, const ChunkPlan& pl, long size_for_chunks, int threads, const char* path, ThreadPart* out,
+                       std::vector<long>* pos_out = nullptr) {
+    const long each = size_for_chunks / threads;
+    for (int i = 0; i < threads; i++) {
+        const long start = (long)i * each, end = i == threads - 1 ? size_for_chunks : (long)(i + 1) * each;
+        const long pos = get_fq_start(m.p, (long)m.n, start);
+        if (pos < 0) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: thread %d would enter %s within 1000 bytes of its end (the reference reads stale bytes there)", threads, i, path);
+        const long first = line_index_of(m, pl, (size_t)pos);
+        if (first % 4) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: thread %d enters %s at line %ld, not at a record (the reference would take quality lines for reads)", threads, i, path, first);
+        const size_t next = line_start_at_or_after(m.p, m.n, (size_t)end + 1);    // first line the chunk does NOT consume
+        const long stop = (size_t)end + 1 >= m.n ? pl.line0.back() : line_index_of(m, pl, next);
+        out->first.push_back(first);
+        out->count.push_back(stop > first ? stop - first : 0);
+        if (pos_out) pos_out->push_back(pos);
+    }
+    for (int i = 0; i + 1 < threads; i++)   // the reference would count such reads twice; only files of a few records per thread get here
+        if (out->first[i + 1] < out->first[i] + out->count[i])
+            LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: the chunks of threads %d and %d of %s overlap (file too small for that many threads)", threads, i, i + 1, path);
+    return LHGT_OK;
+}
+
+struct ThreadEmu {
+    ThreadPart f1, f2;
+};
+
 // Parse fq1 chunk c (all lines starting in it) against the same global lines of fq2.
 static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, const ChunkPlan& p2, long c, double ratio,
-                        const float* random_array, int shard_rank, int shard_world, long shard_block, ParsedChunk* out) {
+                        const float* random_array, int shard_rank, int shard_world, long shard_block, const ThreadEmu* emu, ParsedChunk* out) {
     out->o1.assign(1, 0);
     out->o2.assign(1, 0);
     const long g0 = p1.line0[c], g1 = p1.line0[c + 1];
@@ -224,8 +301,15 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
         }
         if (g % 4 != 1) continue;
         const long n = g / 4;
-        const bool keep = ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio;
-        if (!keep || (n / shard_block) % shard_world != shard_rank) continue;
+        uint8_t fl;
+        if (emu) {   // each mate by its own file's thread chunks; phase C follows fq1's (E:350-359)
+            fl = (uint8_t)((emu->f1.keep(g, ratio, random_array) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
+                           (emu->f2.keep(g, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
+        } else {
+            const bool keep = ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio;
+            fl = keep ? (uint8_t)(PAIR_COUNT1 | PAIR_VOTE | (sb <= size1 ? PAIR_COUNT2 : 0)) : 0;   // quirk Q4: mate 2 counted only while its line starts at <= size(fq1)
+        }
+        if (!fl || (n / shard_block) % shard_world != shard_rank) continue;
         if (la > LHGT_MAX_READ_LEN || lb > LHGT_MAX_READ_LEN) {
             out->rc = LHGT_E_FORMAT;
             out->err = "read " + std::to_string(n) + " longer than " + std::to_string(LHGT_MAX_READ_LEN) + " bases (the reference's buffers, E:1004)";
@@ -235,14 +319,14 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
         out->s2.insert(out->s2.end(), b, b + lb);
         out->o1.push_back(out->s1.size());
         out->o2.push_back(out->s2.size());
-        out->flags.push_back((uint8_t)(PAIR_COUNT1 | PAIR_VOTE | (sb <= size1 ? PAIR_COUNT2 : 0)));  // quirk Q4: mate 2 counted only while its line starts at <= size(fq1)
+        out->flags.push_back(fl);
     }
 }
 
 // consume(chunk) is called on the calling thread, in file order.
 template <class Consume>
 static int parse_pairs(const char* fq1, const char* fq2, double ratio, const float* random_array, int shard_rank, int shard_world,
-                       long shard_block, int threads, size_t chunk_bytes, long* n_pairs_seen, Consume consume) {
+                       long shard_block, int threads, size_t chunk_bytes, int emulate_threads, long* n_pairs_seen, Consume consume) {
     Mapped m1, m2;
     LHGT_TRY(m1.open(fq1));
     LHGT_TRY(m2.open(fq2));
@@ -254,13 +338,38 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
     // Tolerated like the reference: surplus lines of fq1 that are no sequence lines (a trailing blank line)
     for (long g = p2.line0.back(); g < p1.line0.back(); g++)
         if (g % 4 == 1 || g - p2.line0.back() >= 4) LHGT_FAIL(LHGT_E_FORMAT, "%s has fewer records than %s", fq2, fq1);
+    ThreadEmu emu_store;
+    const ThreadEmu* emu = nullptr;
+    if (emulate_threads > 1) {
+        LHGT_TRY(thread_part(m1, p1, (long)m1.n, emulate_threads, fq1, &emu_store.f1));
+        LHGT_TRY(thread_part(m2, p2, (long)m1.n, emulate_threads, fq2, &emu_store.f2));
+        // phase C enters fq2 at the record whose read ID equals that of the chunk's first record of fq1 (E:368-402): with
+        // record-aligned files that is the same line number -- anything else is refused
+        for (int i = 0; i < emulate_threads; i++) {
+            const long g = emu_store.f1.first[i];
+            if (g >= p1.line0.back() || emu_store.f1.count[i] == 0) continue;
+            if (g >= p2.line0.back()) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: %s ends before thread %d's first record", emulate_threads, fq2, i);
+            LineCursor k1(m1), k2(m2);
+            const uint8_t *a, *b;
+            size_t la, lb, sa, sb;
+            long c1 = (long)(std::upper_bound(p1.line0.begin(), p1.line0.end(), g) - p1.line0.begin()) - 1;
+            long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g) - p2.line0.begin()) - 1;
+            k1.cur = p1.start[c1];
+            k2.cur = p2.start[c2];
+            for (long s = g - p1.line0[c1]; s >= 0; s--) k1.next(&a, &la, &sa);
+            for (long s = g - p2.line0[c2]; s >= 0; s--) k2.next(&b, &lb, &sb);
+            const size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
+            if (ia != ib || memcmp(a, b, ia)) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: thread %d's first record has different read IDs in the two files", emulate_threads, i);
+        }
+        emu = &emu_store;
+    }
     const long nc = (long)p1.start.size() - 1;
     for (long base = 0; base < nc; base += threads) {
         long n = nc - base < threads ? nc - base : threads;
         std::vector<ParsedChunk> out((size_t)n);
         double t1 = now_s();
         parallel_for(n, threads, [&](long i) {
-            parse_chunk(m1, m2, p1, p2, base + i, ratio, random_array, shard_rank, shard_world, shard_block, &out[i]);
+            parse_chunk(m1, m2, p1, p2, base + i, ratio, random_array, shard_rank, shard_world, shard_block, emu, &out[i]);
         });
         double t2 = now_s();
         for (long i = 0; i < n; i++) {
@@ -287,7 +396,7 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
             if (sb > m1.n) break;
             if (g % 4 != 1) continue;
             const long n = g / 4;
-            const bool keep = ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio;
+            const bool keep = emu ? emu->f2.keep(g, ratio, random_array) == 1 : (ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio);
             if (!keep || (n / shard_block) % shard_world != shard_rank) continue;
             if (lb > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read %ld longer than %d bases (the reference's buffers, E:1004)", n, LHGT_MAX_READ_LEN);
             tail.s2.insert(tail.s2.end(), b, b + lb);
@@ -345,7 +454,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
         return rc;
     };
     int rc = parse_pairs(fq1, fq2, ratio_percent, ctx->random_array.data(), shard_rank, shard_world, shard_block, default_threads(),
-                         CHUNK, n_pairs_seen, [&](ParsedChunk& ch) -> int {
+                         CHUNK, ctx->emu_threads, n_pairs_seen, [&](ParsedChunk& ch) -> int {
                              long n = (long)ch.o1.size() - 1;
                              if (n == 0) return LHGT_OK;
                              if (fill + ch.s1.size() + ch.s2.size() > ctx->ws_ascii_cap) LHGT_TRY(flush());
@@ -374,15 +483,26 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
 int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
                             int shard_world, long shard_block, int threads, long chunk_bytes, long* n_pairs_seen, long* n_pairs_kept,
                             uint64_t* digest) {
+    return lhgt_fastq_parse_digest_threads(fq1, fq2, ratio_percent, random_array_or_null, shard_rank, shard_world, shard_block, threads,
+                                           chunk_bytes, 1, n_pairs_seen, n_pairs_kept, digest, nullptr);
+}
+
+// the same with the reference's -t N read partition (emulate_threads > 1); counts[3] (optional) = entries with mate 1 counted
+// in phase A, with mate 2 counted, voted in phase C
+int lhgt_fastq_parse_digest_threads(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
+                                    int shard_world, long shard_block, int threads, long chunk_bytes, int emulate_threads,
+                                    long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest, long* counts) {
     if (!fq1 || !fq2 || !digest || chunk_bytes < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if (ratio_percent < 100.0 && !random_array_or_null) LHGT_FAIL(LHGT_E_ARG, "sampling needs the random array");
     uint64_t h = 1469598103934665603ull;
     long kept = 0;
     auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
+    long cnt[3] = {0, 0, 0};
     int rc = parse_pairs(fq1, fq2, ratio_percent, random_array_or_null, shard_rank, shard_world, shard_block, threads, (size_t)chunk_bytes,
-                         n_pairs_seen, [&](ParsedChunk& ch) -> int {
+                         emulate_threads, n_pairs_seen, [&](ParsedChunk& ch) -> int {
                              long n = (long)ch.o1.size() - 1;
                              for (long i = 0; i < n; i++) {
+                                 for (int q = 0; q < 3; q++) cnt[q] += (ch.flags[i] >> q) & 1;
                                  uint64_t l1 = ch.o1[i + 1] - ch.o1[i], l2 = ch.o2[i + 1] - ch.o2[i];
                                  mix((const uint8_t*)&l1, 8);
                                  mix(ch.s1.data() + ch.o1[i], l1);
@@ -396,6 +516,20 @@ int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_perce
     if (rc != LHGT_OK) return rc;
     *digest = h;
     if (n_pairs_kept) *n_pairs_kept = kept;
+    if (counts) for (int q = 0; q < 3; q++) counts[q] = cnt[q];
+    return LHGT_OK;
+}
+
+// where the reference's thread i of `threads` enters a FASTQ and which lines it consumes (tests; E:44-89, 1019-1026)
+int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, long* entry_byte, long* first_line, long* n_lines) {
+    if (!fq || threads < 1 || !entry_byte || !first_line || !n_lines) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    Mapped m;
+    LHGT_TRY(m.open(fq));
+    ChunkPlan pl = plan_chunks(m, (size_t)1 << 20, default_threads());
+    ThreadPart tp;
+    std::vector<long> pos;
+    LHGT_TRY(thread_part(m, pl, size_for_chunks < 0 ? (long)m.n : size_for_chunks, threads, fq, &tp, &pos));
+    for (int i = 0; i < threads; i++) { entry_byte[i] = pos[i]; first_line[i] = tp.first[i]; n_lines[i] = tp.count[i]; }
     return LHGT_OK;
 }
 

@@ -286,6 +286,8 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
         if (p) hipFree(p);
     ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr;
     ctx->contigs.clear();
+    ctx->contig_first_tile.clear();
+    if (ctx->d_contig_id_adj) { hipFree(ctx->d_contig_id_adj); ctx->d_contig_id_adj = nullptr; }
     std::vector<TileDev> tiles;
     uint64_t word = 0, flat = 0;
     uint32_t ref_index = first_ref_index;   // contig numbers stay the global ones when only a shard is resident
@@ -297,6 +299,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
         c.len = len;
         c.ref_index = ref_index++;
         ctx->contigs.push_back(c);
+        ctx->contig_first_tile.push_back((long)tiles.size());
         for (uint32_t j0 = 0; j0 < len; j0 += TILE) tiles.push_back(TileDev{(uint32_t)(ctx->contigs.size() - 1), j0});
         word += 1 + (uint64_t)(len - k + 1) * e;
         flat += len;

@@ -616,14 +616,16 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                                                      const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
-                                                     uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2) {
+                                                     uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2,
+                                                     const uint32_t* __restrict__ id_adj /* nullable: per contig, -t N id ranges */) {
     __shared__ int incl[TILE], part[BT];
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, nk = len - k + 1;
     const uint8_t* F = flags + c.flat_base;
-    const uint32_t base = tile_base[blockIdx.x];
+    uint32_t base = tile_base[blockIdx.x];
     if (tile_base[blockIdx.x + 1] == base) return;  // no peak in this tile (uniform exit)
+    if (id_adj) base += id_adj[t.contig];           // thread j's ids start at j * (max_peak / N) (E:229-237)
     constexpr int CH = (TILE + BT - 1) / BT;
     const int b = threadIdx.x * CH, en = b + CH < TILE ? b + CH : TILE;
     int s = 0;
@@ -860,6 +862,55 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     return LHGT_OK;
 }
 
+// -t N emulation: the contig groups of split_ref (E:1280-1330) and their id ranges.  Thread j scans group j
+// and numbers its peaks from j * (max_peak / N) (E:229-237); the tile scan numbered all peaks sequentially, so a contig of group j
+// gets the adjustment base_j - (peaks of all earlier groups).  A later thread's id wins in peak_kmer as before (atomicMax: ids
+// grow with the thread number, and the contract runs the threads in creation order).
+static int thread_id_ranges(lhgt_ctx* ctx, long max_peak, uint32_t total, long* id_end) {
+    const int k = ctx->k, e = ctx->e, N = ctx->emu_threads;
+    const long nc = (long)ctx->contigs.size();
+    const long each_peaks = max_peak / N;
+    ctx->emu_each_peaks = each_peaks;
+    ctx->emu_range_end.assign((size_t)N, 0);
+    for (int j = 0; j < N; j++) ctx->emu_range_end[j] = each_peaks * j;
+    *id_end = 0;
+    if (nc == 0) return LHGT_OK;
+    if (ctx->contigs[0].ref_index != 1) LHGT_FAIL(LHGT_E_STATE, "-t N emulation needs the whole index on this GPU (not a reference shard)");
+    // split_ref over the resident contigs: a group closes with the contig at which the bytes before it exceed index_size / N + 1
+    const long index_size = 1200 + 4 * (long)ctx->index_words, each = index_size / N + 1;
+    std::vector<long> group_first;   // first contig of each group
+    long pos = 1200, start_byte = 1200;
+    group_first.push_back(0);
+    for (long c = 0; c < nc; c++) {
+        const long add = 4 * ((long)(ctx->contigs[c].len - k + 1) * e + 1);
+        if (pos - start_byte > each) {
+            start_byte = pos + add;
+            if (c + 1 < nc) group_first.push_back(c + 1);
+        }
+        pos += add;
+    }
+    if ((long)group_first.size() > N) LHGT_FAIL(LHGT_E_STATE, "split_ref made %zu groups for %d threads", group_first.size(), N);
+    // peaks before each group = the exclusive tile scan at the group's first tile
+    std::vector<uint32_t> before(group_first.size() + 1, 0);
+    for (size_t g = 0; g < group_first.size(); g++)
+        LHGT_HIP(hipMemcpyAsync(&before[g], ctx->d_tile_count + ctx->contig_first_tile[group_first[g]], 4, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    before[group_first.size()] = total;
+    std::vector<uint32_t> adj((size_t)nc);
+    for (size_t g = 0; g < group_first.size(); g++) {
+        const long count = (long)before[g + 1] - (long)before[g], base = each_peaks * (long)g;
+        if (count > each_peaks)
+            LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! thread %zu of %d found %ld, its id range holds %ld (the reference runs into the next thread's ids): appoint a larger max_peak_num (see --max_peak).", g, N, count, each_peaks);
+        ctx->emu_range_end[g] = base + count;
+        if (base + count > *id_end) *id_end = base + count;
+        const long c1 = g + 1 < group_first.size() ? group_first[g + 1] : nc;
+        for (long c = group_first[g]; c < c1; c++) adj[c] = (uint32_t)(base - (long)before[g]);
+    }
+    if (!ctx->d_contig_id_adj) LHGT_HIP(hipMalloc(&ctx->d_contig_id_adj, (size_t)nc * 4));
+    LHGT_HIP(hipMemcpy(ctx->d_contig_id_adj, adj.data(), (size_t)nc * 4, hipMemcpyHostToDevice));
+    return LHGT_OK;
+}
+
 // peak tables sized for `total` peaks; peak_kmer cleared; prefilter decided from the global selected count
 static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_selected, long max_peak) {
     const size_t slots = (size_t)1 << ctx->k;
@@ -912,17 +963,23 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     uint32_t total = 0;
     unsigned long long n_sel = 0;
     LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));   // no contig longer than k: zero tiles, zero peaks
-    LHGT_TRY(peaks_prepare(ctx, total, n_sel, max_peak));
+    const bool emu = ctx->emu_threads > 1;
+    long id_end = total;
+    ctx->emu_range_end.clear();
+    if (emu) LHGT_TRY(thread_id_ranges(ctx, max_peak, total, &id_end));
+    if ((long)total > max_peak)
+        LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
+    LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, id_end > max_peak ? id_end : max_peak));
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, emu ? ctx->d_contig_id_adj : nullptr);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
     LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[1], ctx->ev0, ctx->ev1));
     ctx->n_peaks = total;
-    ctx->id_end = total;
+    ctx->id_end = emu ? id_end : (long)total;
     ctx->max_peak = max_peak;
     ctx->voted = false;
     if (n_peaks) *n_peaks = total;

@@ -719,7 +719,7 @@ int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
     if (!ctx || !dev_ptr || !bytes) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     *dev_ptr = ctx->d_filter;
-    *bytes = (size_t)ctx->n_peaks * 4;
+    *bytes = (size_t)ctx->id_end * 4;
     return LHGT_OK;
 }
 
@@ -727,7 +727,7 @@ int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
-    if (n > ctx->n_peaks) LHGT_FAIL(LHGT_E_ARG, "asked for %ld peaks, have %ld", n, ctx->n_peaks);
+    if (n > ctx->id_end) LHGT_FAIL(LHGT_E_ARG, "asked for %ld peak ids, have %ld", n, ctx->id_end);
     if (n == 0) return LHGT_OK;
     if (loci) LHGT_HIP(hipMemcpy(loci, ctx->d_loci, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (filter) {
@@ -744,7 +744,7 @@ int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
-    const long n = ctx->n_peaks;
+    const long n = ctx->id_end;
     std::vector<int32_t> rec;
     long nf = 0;
     if (n > 0) {
@@ -776,16 +776,23 @@ int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
     std::sort(order.begin(), order.end(), [&](long a, long b) { return rec[3 * a] < rec[3 * b]; });
     FILE* f = fopen(path, "w");
     if (!f) LHGT_FAIL(LHGT_E_IO, "cannot write %s", path);
-    int start = 1, end = 1, chr = 1;
-    for (long q = 0; q < nf; q++) {
-        const int c = rec[3 * order[q] + 1], pos = rec[3 * order[q] + 2];
-        if (chr == c && pos - 500 - end < 500) end = pos + 500;
-        else {
-            fprintf(f, "%d\t%d\t%d\n", chr, start, end);
-            chr = c; start = pos - 500; end = pos + 500;
+    // one pass per thread id range (E:520-543): a single one normally; under -t N emulation thread j owns
+    // [j * (max_peak / N), its last id), starts from the sentinel state again and writes its own last line
+    const int n_ranges = ctx->emu_threads > 1 && !ctx->emu_range_end.empty() ? ctx->emu_threads : 1;
+    long q = 0;
+    for (int j = 0; j < n_ranges; j++) {
+        const long id_hi = n_ranges > 1 ? ctx->emu_range_end[j] : n;
+        int start = 1, end = 1, chr = 1;
+        for (; q < nf && rec[3 * order[q]] < id_hi; q++) {
+            const int c = rec[3 * order[q] + 1], pos = rec[3 * order[q] + 2];
+            if (chr == c && pos - 500 - end < 500) end = pos + 500;
+            else {
+                fprintf(f, "%d\t%d\t%d\n", chr, start, end);
+                chr = c; start = pos - 500; end = pos + 500;
+            }
         }
+        fprintf(f, "%d\t%d\t%d\n", chr, start, end);
     }
-    fprintf(f, "%d\t%d\t%d\n", chr, start, end);
     fclose(f);
     if (n_filtered) *n_filtered = nf;
     return LHGT_OK;

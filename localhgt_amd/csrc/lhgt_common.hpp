@@ -153,6 +153,13 @@ struct lhgt_ctx {
     uint32_t* d_part_meta = nullptr;
     int synth_snp_permille = 0, synth_n_permille = 20;   // k_synth.hip: lhgt_synth_options
     long synth_sample_contigs = 0;
+    // the reference's -t N, race-free (lhgt_set_thread_emulation): read partition in host_fastx.cpp, contig groups with their own
+    // id ranges in k_scan.hip, one sentinel line per thread in lhgt_write_intervals
+    int emu_threads = 1;
+    long emu_each_peaks = 0;                 // max_peak / N of the last scan
+    std::vector<long> emu_range_end;         // per thread: one past its last peak id
+    uint32_t* d_contig_id_adj = nullptr;     // per resident contig: its group's id base minus the peaks of all earlier groups
+    std::vector<long> contig_first_tile;     // tile index of every resident contig's first tile
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)

@@ -208,6 +208,10 @@ class Engine:
         _lib.check(self.lib.lhgt_write_intervals(self.h, path.encode(), C.byref(n)))
         return n.value
 
+    def set_thread_emulation(self, threads: int):
+        """the reference's -t N without its races (include/localhgt_hip.h: lhgt_set_thread_emulation); 1 = off"""
+        _lib.check(self.lib.lhgt_set_thread_emulation(self.h, int(threads)))
+
     def set_debug(self, flags: int):
         _lib.check(self.lib.lhgt_set_debug(self.h, flags))
 

@@ -65,11 +65,19 @@ def _warn_if_ids_desynchronise(genome_len_path: str, k: int, log) -> None:
             f"the interval file follow the reference's sequential numbering (E:905) and will not match; get_bed_file refuses them")
 
 
-def run(a: Args, device: int = 0, dist=None, log=print) -> dict:
-    """The whole path A->D. `dist` is a localhgt_amd.dist.Exchange (or None for one GPU)."""
+def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) -> dict:
+    """The whole path A->D. `dist` is a localhgt_amd.dist.Exchange (or None for one GPU).
+    emulate_threads (default: LHGT_EMULATE_THREADS=1 in the environment): give the result of the reference's `-t threads` run
+    without its races -- its per-thread read partition, id ranges and sentinel lines -- instead of the
+    `-t 1` result.  `localhgt bkp` passes -t 10 by default, so that is what a user's reference run produced."""
     rank, world = (dist.rank, dist.world) if dist else (0, 1)
     t0 = time.time()
     eng = Engine(a.k, a.e, device)
+    if emulate_threads is None:
+        emulate_threads = os.environ.get("LHGT_EMULATE_THREADS", "0") == "1"
+    if emulate_threads and a.threads > 1:
+        eng.set_thread_emulation(a.threads)
+        log(f"reproducing the reference's -t {a.threads} read partition and peak id ranges")
     log(f"kmer length is {a.k}\nseed is {a.seed}\nnum of hash functions is {a.e}")
     eng.rng_seed(a.seed)                                       # E:1386
     ratio = eng.sam_ratio(a.fq1, a.sample)                     # E:1392-1398

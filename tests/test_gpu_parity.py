@@ -140,7 +140,7 @@ def test_extract_ref_matches_reference_golden(case_inputs, name, tmp_path):
     interval = str(tmp_path / "interval.txt")
     argv = cases.extract_ref_argv(case, f1, f2, fa2, interval)
     for _ in range(2 if case.preexisting_index else 1):
-        rep = extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None)
+        rep = extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None, emulate_threads=case.threads > 1)
     gold = os.path.join(cases.GOLDEN_DIR, name)
     assert rep["n_peaks"] == meta["raw_peaks"]
     assert open(interval).read() == open(os.path.join(gold, "interval.txt")).read()

@@ -246,3 +246,85 @@ def test_parser_counts_match_the_oracle_reader(lib, oracle, case_inputs):
     table = np.zeros(1 << 12, dtype=np.uint8)
     cc = oracle.random_coder(12, 3)
     assert rc == 0 and seen == kept == oracle.count(f1, 1 << 40, 12, 3, cc, 100.0, None, table)
+
+
+# ------------------------------------------------------------------ -t N read partition
+def _thread_chunks(lib, path, size, threads):
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    arr = [(C.c_long * threads)() for _ in range(3)]
+    rc = h.lhgt_fastq_thread_chunks(path.encode(), size, threads, *arr)
+    return rc, [list(a) for a in arr]
+
+
+@pytest.mark.parametrize("name", ["k24_t4", "k24_t3_fq2_longer", "k24_t8_sample_half", "k24_t10_sample_bases"])
+def test_thread_partition_matches_the_reference_log(lib, oracle, case_inputs, name):
+    """entry byte, last record and read count of every thread chunk against the `>>> Thread: final read` lines the reference
+    printed when the golden was made (E:1105), and get_fq_start against the oracle's literal restatement"""
+    import re
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    t = case.threads
+    size1 = os.path.getsize(f1)
+    log = [re.match(r">>> Thread: final read (\d+) : (\S+).* read num: (\d+)", ln).groups() for ln in meta["thread_log"]]
+    assert len(log) == 2 * t
+    sampling = float(case.sample) != 1.0
+    for path, rows in ((f1, log[:t]), (f2, log[t:])):
+        rc, (entry, first, count) = _thread_chunks(lib, path, size1, t)
+        assert rc == 0
+        data = open(path, "rb").read()
+        lines = data.split(b"\n")
+        for i in range(t):
+            start = i * (size1 // t)
+            assert int(rows[i][0]) == start                              # the log prints the chunk's start byte
+            assert entry[i] == oracle.get_fq_start(data, start)
+            assert first[i] % 4 == 0 and data[entry[i]:entry[i] + 1] == b"@"
+            seqs = (count[i] + 2) // 4                                    # lines with local index % 4 == 1 among the consumed ones
+            if not sampling:
+                assert seqs == int(rows[i][2])
+            # the last header the thread saw (read_first_line, E:1105) is the header of its last consumed record
+            last_header = first[i] + 4 * ((count[i] - 1) // 4)
+            assert lines[last_header].split(b" ")[0].decode() == rows[i][1]
+
+
+def test_thread_partition_flags_and_refusals(lib, oracle, case_inputs, tmp_path):
+    """pairs_counted / mate-2 counts / voted pairs of the partitioned parse equal the oracle's -t N run; one thread = the plain
+    parse; files too small for the thread count are refused like every input on which the reference reads stale bytes"""
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    for name in ("k24_t4", "k24_t3_fq2_longer", "k24_t8_sample_half"):
+        case = cases.CASES[name]
+        fa, f1, f2, meta = case_inputs(name)
+        work = tmp_path / name
+        work.mkdir()
+        fa2 = str(work / "ref.fa")
+        shutil.copy(fa, fa2)
+        rc, rep = oracle.run_threads(f1, f2, fa2, str(work / "i.txt"), case.hit_ratio, case.match_ratio, case.threads, case.k, case.max_peak,
+                                     case.e, case.seed, float(case.sample))
+        assert rc == 0
+        ratio = 100.0 * float(case.sample) if case.sample <= 1 else None
+        rnd = None
+        if ratio is not None and ratio < 100:
+            oracle.srand(case.seed)
+            oracle.random_coder(case.k, case.e)          # index built in-run: the coder draws come first (quirk Q3)
+            rnd = oracle.sampling_array(50_000_000)
+        seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+        cnt = (C.c_long * 3)()
+        rc = h.lhgt_fastq_parse_digest_threads(f1.encode(), f2.encode(), ratio if ratio is not None else 100.0,
+                                               rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None, 0, 1, 4096, 4, 20000,
+                                               case.threads, C.byref(seen), C.byref(kept), C.byref(dig), cnt)
+        assert rc == 0
+        assert (cnt[0], cnt[1], cnt[2]) == (rep.pairs_counted, int(rep.t_count), rep.pairs_voted), name
+    # emulate_threads = 1 is the plain parse
+    fa, f1, f2, _ = case_inputs("k24_t4")
+    a = _digest(lib, f1, f2, threads=3, chunk=5000)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+    assert h.lhgt_fastq_parse_digest_threads(f1.encode(), f2.encode(), 100.0, None, 0, 1, 4096, 3, 5000, 1, C.byref(seen), C.byref(kept),
+                                             C.byref(dig), None) == 0
+    assert (0, seen.value, kept.value, dig.value) == a
+    # 40 threads on a file of 6 records: chunks near EOF / overlapping
+    tiny1, tiny2 = str(tmp_path / "t.1.fq"), str(tmp_path / "t.2.fq")
+    open(tiny1, "wb").write(b"\n".join(open(f1, "rb").read().split(b"\n")[:24]) + b"\n")
+    open(tiny2, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:24]) + b"\n")
+    assert h.lhgt_fastq_parse_digest_threads(tiny1.encode(), tiny2.encode(), 100.0, None, 0, 1, 4096, 2, 5000, 40, C.byref(seen),
+                                             C.byref(kept), C.byref(dig), None) == 4

@@ -1,0 +1,123 @@
+// probe_shapes.hip -- does ANY access shape beat the random-probe rate the phase B / phase C kernels sit on?
+// (VERDICT r1 #4b.)  Random reads from a 16 GiB table (peak_kmer's size at k = 32) and a 1 GiB one (the count table), as:
+//   ld4 / ld8 / ld16     one aligned 4-, 8-, 16-byte load per probe, global_load
+//   buf4                 the same 4-byte probe through a raw buffer descriptor (buffer_load_dword)
+//   nt4                  4-byte nontemporal
+//   pair64 / pair128     TWO 4-byte probes in the same random 64-B sector / 128-B line (counted as 2 probes)
+//   quad128              FOUR probes in the same 128-B line
+//   row2k                the 64 lanes of a wave probe inside one random 2 KiB span (DRAM-row locality without line locality)
+//   page4k-wave          all 12 probes of a lane's iteration inside one 4 KiB page
+// and with 1, 2, 4, 8 waves per SIMD x 4 / 12 loads in flight per lane.  Each variant is its own kernel, so
+// `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum` gives its fabric requests per probe.
+// Build: hipcc -O3 --offload-arch=gfx950 -o probe_shapes probe_shapes.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+
+enum { LD4, LD8, LD16, BUF4, NT4, PAIR64, PAIR128, QUAD128, ROW2K, PAGE4K };
+
+// raw buffer descriptor over [base, base + bytes): stride 0, flags 0x00020000 (the untyped-dword format the compiler's own
+// buffer code uses on gfx9)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+
+template <int MODE, int ILP>
+__global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ table, uint64_t words, int iters, uint32_t* sink, uint32_t salt) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t wmask = words - 1;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        uint64_t h[ILP];
+#pragma unroll
+        for (int u = 0; u < ILP; u++) h[u] = mix64(((uint64_t)gid << 20) ^ (uint64_t)(it * ILP + u) ^ ((uint64_t)salt << 50));
+        if (MODE == LD4) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) acc += table[h[u] & wmask];
+        } else if (MODE == NT4) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) acc += __builtin_nontemporal_load(table + (h[u] & wmask));
+        } else if (MODE == LD8) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) { uint2 v = ((const uint2*)table)[(h[u] & wmask) >> 1]; acc += v.x ^ v.y; }
+        } else if (MODE == LD16) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) { uint4 v = ((const uint4*)table)[(h[u] & wmask) >> 2]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+        } else if (MODE == BUF4) {
+            // 4 GiB windows: a raw buffer offset is 32 bits
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(table, 0xffffffffu);
+#pragma unroll
+            for (int u = 0; u < ILP; u++) acc += (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((uint32_t)(h[u] & wmask & 0x3fffffffull) * 4u), 0, 0);
+        } else if (MODE == PAIR64 || MODE == PAIR128 || MODE == QUAD128) {
+            constexpr int LINE_WORDS = MODE == PAIR64 ? 16 : 32, PER = MODE == QUAD128 ? 4 : 2;
+#pragma unroll
+            for (int u = 0; u < ILP / PER; u++) {
+                const uint64_t line = (h[u] & wmask) & ~(uint64_t)(LINE_WORDS - 1);
+#pragma unroll
+                for (int q = 0; q < PER; q++) acc += table[line + ((h[u] >> (40 + 5 * q)) & (LINE_WORDS - 1))];
+            }
+        } else if (MODE == ROW2K) {
+            // the wave's 64 lanes stay inside one random 2 KiB span per load slot
+#pragma unroll
+            for (int u = 0; u < ILP; u++) {
+                const uint64_t wv = mix64(((uint64_t)(gid >> 6) << 20) ^ (uint64_t)(it * ILP + u) ^ ((uint64_t)salt << 50));
+                acc += table[((wv & wmask) & ~511ull) + (h[u] & 511ull)];
+            }
+        } else if (MODE == PAGE4K) {
+            const uint64_t page = (h[0] & wmask) & ~1023ull;
+#pragma unroll
+            for (int u = 0; u < ILP; u++) acc += table[page + (h[u] >> 30 & 1023ull)];
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int MODE, int ILP>
+void run(const char* name, const uint32_t* table, uint64_t bytes, uint32_t* sink, int waves_per_simd) {
+    const int threads = 256, blocks = 256 * waves_per_simd;   // 4 waves per block, one SIMD each -> blocks per CU = waves per SIMD
+    const int iters = 512 / waves_per_simd / (ILP >= 12 ? 1 : 1);
+    const double probes = (double)blocks * threads * iters * ILP;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((probe<MODE, ILP>), dim3(blocks), dim3(threads), 0, 0, table, bytes / 4, iters, sink, 17u * rep + 1u);
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+    }
+    printf("%-9s ILP=%2d waves/SIMD=%d table=%6.0f MiB  %8.3f ms  %7.2f Gprobe/s\n", name, ILP, waves_per_simd, bytes / 1048576.0, best, probes / best / 1e6);
+    fflush(stdout);
+}
+
+int main() {
+    const uint64_t max_bytes = 16ull << 30;
+    uint32_t *table, *sink;
+    CK(hipMalloc(&table, max_bytes)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(table, 1, max_bytes));
+    for (uint64_t s : {16ull << 30, 1ull << 30}) {
+        for (int w : {1, 2, 4, 8}) {
+            run<LD4, 4>("ld4", table, s, sink, w);
+            run<LD4, 12>("ld4", table, s, sink, w);
+        }
+        run<LD4, 24>("ld4", table, s, sink, 4);
+        run<NT4, 12>("nt4", table, s, sink, 8);
+        run<BUF4, 12>("buf4", table, s, sink, 8);
+        run<LD8, 12>("ld8", table, s, sink, 8);
+        run<LD16, 12>("ld16", table, s, sink, 8);
+        run<PAIR64, 12>("pair64", table, s, sink, 8);
+        run<PAIR128, 12>("pair128", table, s, sink, 8);
+        run<QUAD128, 12>("quad128", table, s, sink, 8);
+        run<ROW2K, 12>("row2k", table, s, sink, 8);
+        run<PAGE4K, 12>("page4k", table, s, sink, 8);
+    }
+    return 0;
+}

@@ -42,12 +42,16 @@ HBM_PEAK_GBS = 8000.0                                                           
 METRIC = "M paired-reads/s k-mer sketch->peak, UHGG-scale ref; %HBM roofline @1/2/4/8 GPU"
 # request-rate ceilings of the memory system, measured by tools/probe_rates.hip (profiles/r01_probe_rates_microbench.txt,
 # profiles/r02_probe_shapes.txt): random 4-byte loads that miss to HBM / that hit in L2
-CEIL_HBM_GREQ, CEIL_L2_GREQ = 55.0, 254.0
+CEIL_HBM_GREQ, CEIL_L2_GREQ = 56.0, 254.0
 KERNEL_SOURCES = {   # which sources a kernel's measured traffic depends on (stamp of profiles/traffic_per_launch.json)
     "count_A": ("k_count_part.hip", "k_count.hip"), "ref_flags": ("k_scan.hip",), "vote_kernel": ("k_vote.hip",),
 }
 COMMON_SOURCES = ("lhgt_hash.hpp", "lhgt_common.hpp", "k_ingest.hip", "k_synth.hip")
-RANDOM_PROBE_KERNELS = ("vote_kernel", "ref_flags", "register_peaks", "count_direct")   # FETCH_SIZE exact (one 64 B request per probe); others: x2 (guide, HBM section)
+# FETCH_SIZE tallies 64 B per fabric read request (TCC_EA0_RDREQ), but on gfx950 EVERY request of these kernels is a 128-B line
+# fill: the guide says so for wide streaming reads, and tools/probe_shapes.hip calibrates it for random 4-byte probes (two probes
+# in the two 64-B halves of one line cost ONE request: split128, 1.07 requests per pair; a 16 B/lane stream shows 128.0 B per
+# request; TCC_BUBBLE and the 32-B request counter are zero) -- profiles/r02/probe_shapes_pmc.txt.  So read bytes = FETCH_SIZE x 2.
+FETCH_SIZE_SCALE = 2
 PHASE_KERNELS = {
     "count_A": ("part_scatter_reads", "part_scatter_keys", "part_apply", "count_direct"),
     "ref_flags": ("ref_flags=", "ref_flags_lite="),      # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
@@ -131,7 +135,7 @@ def collect_pmc(args, passes, timeout_s=420):
 
 def pmc_traffic(agg):
     """HBM bytes per bench step per phase/kernel family from a collect_pmc() summary (FETCH_SIZE / WRITE_SIZE count KiB;
-    streaming kernels' FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, random-probe kernels' not)."""
+    FETCH_SIZE doubled: see FETCH_SIZE_SCALE)"""
     out = {}
     for ph, names in PHASE_KERNELS.items():
         tot, req_l2, req_ea, seen = 0.0, 0.0, 0.0, False
@@ -139,8 +143,7 @@ def pmc_traffic(agg):
             if not _kernel_in(kname, names) or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
                 continue
             seen = True
-            mult = 1 if any(kname.startswith(r) for r in RANDOM_PROBE_KERNELS) else 2
-            tot += (ent["FETCH_SIZE"] * mult + ent["WRITE_SIZE"]) * 1024
+            tot += (ent["FETCH_SIZE"] * FETCH_SIZE_SCALE + ent["WRITE_SIZE"]) * 1024
             req_l2 += ent.get("TCP_TCC_READ_REQ_sum", 0.0)
             req_ea += ent.get("TCC_EA0_RDREQ_sum", 0.0)
         if seen:
@@ -408,6 +411,13 @@ def main():
             if args.pmc_out:
                 json.dump({"tag": workload_tag, "kernels": pmc, "per_step": traffic,
                            "_stamp": {ph: source_stamp(s) for ph, s in KERNEL_SOURCES.items()}}, open(args.pmc_out, "w"), indent=1, sort_keys=True)
+    traffic_1g = {}
+    if world == 1 and not args.no_pmc and not args.no_extras and not args.force_dist and not args.debug and (args.contigs, args.pairs) != (1000, 10_000_000):
+        a1 = argparse.Namespace(**dict(vars(args), workload="1g", contigs=1000, pairs=10_000_000, sample_contigs=0))
+        pmc1, note1 = collect_pmc(a1, [["FETCH_SIZE", "TCP_TCC_READ_REQ_sum"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum"]])
+        if pmc1:
+            traffic_1g = pmc_traffic(pmc1)
+        pmc_note = "; ".join(x for x in (pmc_note, note1) if x)
     if world == 1:
         fresh, stale = committed_traffic(workload_tag)
         for ph, rec in fresh.items():
@@ -467,8 +477,8 @@ def main():
     n_batches = -(-args.pairs // (16 << 20))
     scan = eng.scan_info()
     kern = {"count_A": per["count_A"], "ref_flags": per_ms[3], "vote_kernel": per["vote_C"]}
-    hbm_ceiling = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_rates.hip: random 4-byte loads from a table far beyond the caches")
-    l2_ceiling = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table")
+    hbm_ceiling = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 1 GiB table, 128-B line fills per second (profiles/r02/probe_shapes_microbench.txt)")
+    l2_ceiling = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table (profiles/r01_probe_rates_microbench.txt)")
     sparse_vote = scan["tiles"] > 0 and n_peaks > 0 and per["vote_C"] > 0 and traffic.get("vote_kernel", {}).get("bytes", algo) < algo / 4
     desc = {
         "count_A": ("phase A kernel family (part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
@@ -508,15 +518,16 @@ def main():
         "compulsory": {"bytes_per_step": compulsory, "frac_of_peak": round(compulsory / step_s / (HBM_PEAK_GBS * 1e9), 4),
                        "what": "packed reads twice + resident index once + count table written and read + peak_kmer cleared; a step at HBM peak would take "
                                f"{compulsory / (HBM_PEAK_GBS * 1e9) * 1e3:.0f} ms"},
-        "note": "roofline.frac = measured HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) / kernel time / 8 TB/s. "
-                "These kernels are bound by the RATE of random requests, not by bytes: request_rate gives that rate against the ceiling "
-                "measured by microbenchmark (~55 G/s from HBM, ~254 G/s from L2). sector_model_GBps is SURVEY 8d's one-64-B-sector-per-probe figure "
-                "(it exceeds the peak where partitioning, the L2 bitmap or the lite scan avoid the sectors: see model_speedup); DESIGN.md 4-5"
+        "note": "roofline.frac = measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE: every fabric read request on gfx950 is a 128-B line fill tallied "
+                "at 64 B, calibrated by tools/probe_shapes.hip, profiles/r02/) / kernel time / 8 TB/s. A random 4-byte probe therefore costs a whole "
+                "128-B line: the probe kernels are bound by HBM bandwidth in lines (49-56 G lines/s = 6.3-7.2 TB/s, more than a streaming read reaches), "
+                "request_rate gives their line rate against that measured ceiling (254 G/s for L2-resident tables). sector_model_GBps is SURVEY 8d's "
+                "one-64-B-sector-per-probe figure (it exceeds the peak where partitioning, the L2 bitmap or the lite scan avoid the probes: see model_speedup); DESIGN.md 4-5"
                 + (f"; pmc: {pmc_note}" if pmc_note else ""),
     }
     eng.pairs_clear()
     if world == 1 and not args.no_extras and not args.debug:
-        line["secondary"] = secondary_workloads(eng, args, wl, local)
+        line["secondary"] = secondary_workloads(eng, args, wl, local, traffic_1g)
     eng.close()
     if dist:
         dist.close()
@@ -542,7 +553,7 @@ def main():
         pass
 
 
-def secondary_workloads(eng, args, wl, local):
+def secondary_workloads(eng, args, wl, local, traffic_1g):
     """the other regimes of the same path, a few steps each (N = 1): results a reader needs next to the headline, whose
     synthetic sample (half of a 13 Gbase reference) saturates the 2^32-slot table and yields no voted peak"""
     from localhgt_amd.engine import Engine
@@ -586,9 +597,11 @@ def secondary_workloads(eng, args, wl, local):
                 d = leg(e1, 10_000_000, steps=5)
                 algo = ALGO_BYTES_PER_PAIR(L, k, e) * 10_000_000
                 fresh, _ = committed_traffic(f"1000x1000000_10000000_k{k}_e{e}")
-                hbm = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_rates.hip")
+                rec = traffic_1g.get("vote_kernel") or fresh.get("vote_kernel")
+                src1 = "rocprofv3 --pmc passes of this run on this workload" if traffic_1g.get("vote_kernel") else "profiles/traffic_per_launch.json (measured on these sources)"
+                hbm = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 16 GiB table, 128-B line fills per second")
                 d["roofline"] = roofline_entry("vote_kernel (dense peak set: every one of the 714 probes per pair goes to the 16 GiB peak_kmer), 1 launch per step",
-                                               d["phase_ms"]["vote_C"], 1, algo, fresh.get("vote_kernel"), "profiles/traffic_per_launch.json (measured on these sources)", hbm)
+                                               d["phase_ms"]["vote_C"], 1, algo, rec, src1, hbm)
                 d["workload"] = "BASELINE configs[1]: 1000x1000000 bp ref, 10 M pairs, k=32 e=3, sample=1"
                 out["configs1_1g"] = d
     except Exception as ex:

@@ -7,6 +7,8 @@
 //   quad128              FOUR probes in the same 128-B line
 //   row2k                the 64 lanes of a wave probe inside one random 2 KiB span (DRAM-row locality without line locality)
 //   page4k-wave          all 12 probes of a lane's iteration inside one 4 KiB page
+//   split128             two probes in the same 128-B line, always in DIFFERENT 64-B halves
+//   stream16             coalesced 16-byte-per-lane streaming read of the same table (TB/s)
 // and with 1, 2, 4, 8 waves per SIMD x 4 / 12 loads in flight per lane.  Each variant is its own kernel, so
 // `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum` gives its fabric requests per probe.
 // Build: hipcc -O3 --offload-arch=gfx950 -o probe_shapes probe_shapes.hip
@@ -23,7 +25,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
 }
 
-enum { LD4, LD8, LD16, BUF4, NT4, PAIR64, PAIR128, QUAD128, ROW2K, PAGE4K };
+enum { LD4, LD8, LD16, BUF4, NT4, PAIR64, PAIR128, QUAD128, ROW2K, PAGE4K, SPLIT128, STREAM16 };
 
 // raw buffer descriptor over [base, base + bytes): stride 0, flags 0x00020000 (the untyped-dword format the compiler's own
 // buffer code uses on gfx9)
@@ -65,6 +67,23 @@ __global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ table,
 #pragma unroll
                 for (int q = 0; q < PER; q++) acc += table[line + ((h[u] >> (40 + 5 * q)) & (LINE_WORDS - 1))];
             }
+        } else if (MODE == SPLIT128) {
+            // two probes in the same random 128-B line, ALWAYS in different 64-B halves: one fabric request per pair means a
+            // request returns the whole line
+#pragma unroll
+            for (int u = 0; u < ILP / 2; u++) {
+                const uint64_t line = (h[u] & wmask) & ~31ull;
+                acc += table[line + ((h[u] >> 40) & 15)];
+                acc += table[line + 16 + ((h[u] >> 45) & 15)];
+            }
+        } else if (MODE == STREAM16) {
+            // plain streaming read, 16 bytes per lane, for the byte rate the same memory system reaches on full lines
+#pragma unroll
+            for (int u = 0; u < ILP; u++) {
+                const uint64_t i4 = ((uint64_t)(it * ILP + u) * gridDim.x * blockDim.x + gid) & (wmask >> 2);
+                uint4 v = ((const uint4*)table)[i4];
+                acc += v.x ^ v.y ^ v.z ^ v.w;
+            }
         } else if (MODE == ROW2K) {
             // the wave's 64 lanes stay inside one random 2 KiB span per load slot
 #pragma unroll
@@ -94,14 +113,37 @@ void run(const char* name, const uint32_t* table, uint64_t bytes, uint32_t* sink
         CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }
-    printf("%-9s ILP=%2d waves/SIMD=%d table=%6.0f MiB  %8.3f ms  %7.2f Gprobe/s\n", name, ILP, waves_per_simd, bytes / 1048576.0, best, probes / best / 1e6);
+    if (MODE == STREAM16) printf("%-9s ILP=%2d waves/SIMD=%d table=%6.0f MiB  %8.3f ms  %7.2f TB/s streamed (16 B per lane-load)\n", name, ILP, waves_per_simd, bytes / 1048576.0, best, probes * 16 / best / 1e9);
+    else printf("%-9s ILP=%2d waves/SIMD=%d table=%6.0f MiB  %8.3f ms  %7.2f Gprobe/s\n", name, ILP, waves_per_simd, bytes / 1048576.0, best, probes / best / 1e6);
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     const uint64_t max_bytes = 16ull << 30;
     uint32_t *table, *sink;
-    CK(hipMalloc(&table, max_bytes)); CK(hipMalloc(&sink, 4));
+    CK(hipMalloc(&sink, 4));
+    if (argc > 1) {
+        // memory-type experiment: the same random 4-byte probes on allocations of other kinds -- does the fabric request become
+        // smaller than a 128-B line fill when the L2 may not cache the data?
+        const uint64_t bytes = 4ull << 30;
+        const struct { const char* name; unsigned flags; } kinds[] = {{"default", hipDeviceMallocDefault}, {"uncached", hipDeviceMallocUncached},
+                                                                      {"finegrained", hipDeviceMallocFinegrained}};
+        for (auto& kd : kinds) {
+            uint32_t* t = nullptr;
+            hipError_t e = hipExtMallocWithFlags((void**)&t, bytes, kd.flags);
+            if (e != hipSuccess) { printf("%s: allocation refused (%s)\n", kd.name, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
+            CK(hipMemset(t, 1, bytes));
+            printf("-- %s\n", kd.name);
+            run<LD4, 12>(kd.name, t, bytes, sink, 8);
+            run<NT4, 12>("  nt4", t, bytes, sink, 8);
+            run<LD16, 12>("  ld16", t, bytes, sink, 8);
+            run<PAIR128, 12>("  pair128", t, bytes, sink, 8);
+            run<QUAD128, 12>("  quad128", t, bytes, sink, 8);
+            CK(hipFree(t));
+        }
+        return 0;
+    }
+    CK(hipMalloc(&table, max_bytes));
     CK(hipMemset(table, 1, max_bytes));
     for (uint64_t s : {16ull << 30, 1ull << 30}) {
         for (int w : {1, 2, 4, 8}) {
@@ -118,6 +160,8 @@ int main() {
         run<QUAD128, 12>("quad128", table, s, sink, 8);
         run<ROW2K, 12>("row2k", table, s, sink, 8);
         run<PAGE4K, 12>("page4k", table, s, sink, 8);
+        run<SPLIT128, 12>("split128", table, s, sink, 8);
+        run<STREAM16, 12>("stream16", table, s, sink, 8);
     }
     return 0;
 }

@@ -118,6 +118,16 @@ int lhgt_count_kmers(lhgt_ctx* ctx);
 int lhgt_set_count_mode(lhgt_ctx* ctx, int mode);
 int lhgt_counts_clear(lhgt_ctx* ctx);
 
+/* ---- count_diff_kmer.cpp ("C"), the stand-alone phase-A tool, as it behaves with time() fixed and its 10 threads in creation
+ * order (--compat of bin/count_diff_kmer).  Its coder is a `bool` array: a non-ACGT base codes 1 in every projection on both
+ * strands and voids nothing (C:155-160, 124) -- lhgt_set_count_compat; one rand() % 6 per k-mer offset (C:226-232) --
+ * lhgt_coder_generate_count_diff; reads come in 10 byte chunks entered at the previous '@', tokenised by `>>`, with a byte
+ * budget that overruns into the next chunk (C:53-153) and per-chunk sampling from srand(seed) -- lhgt_reads_load_count_diff
+ * (kept reads are appended as mate-1-only entries; call once per file, size_for_chunks = size of fq1 for both). */
+int lhgt_set_count_compat(lhgt_ctx* ctx, int on);
+int lhgt_coder_generate_count_diff(lhgt_ctx* ctx);
+int lhgt_reads_load_count_diff(lhgt_ctx* ctx, const char* fq, long size_for_chunks, int ratio_percent, unsigned seed, long* n_reads_kept);
+
 /* ---- multi-GPU plumbing (no reference counterpart).  Device pointers are handed
  * to the host layer (torch.distributed/RCCL); merge = per-slot saturating add of 2-bit fields. */
 int lhgt_counts_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes);

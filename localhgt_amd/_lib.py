@@ -54,6 +54,9 @@ SIGNATURES = {
     "lhgt_count_kmers": [_vp],
     "lhgt_set_count_mode": [_vp, _i],
     "lhgt_counts_clear": [_vp],
+    "lhgt_set_count_compat": [_vp, _i],
+    "lhgt_coder_generate_count_diff": [_vp],
+    "lhgt_reads_load_count_diff": [_vp, _cs, _l, _i, C.c_uint, _lp],
     "lhgt_counts_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "lhgt_counts_merge": [_vp, _vp, C.c_size_t, C.c_size_t],
     "lhgt_filter_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],

@@ -479,6 +479,57 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     return LHGT_OK;
 }
 
+// count_diff_kmer.cpp's reader (C:53-153): the file in 10 thread chunks of `size_for_chunks` bytes (fq1's size for both files,
+// C:328-355).  A chunk is entered at the nearest '@' at or before its start (C:61-69; thread 0 from byte 0), read token by token
+// (`>>`, C:91) while the summed token lengths, counted from `start`, stay below `end` (C:70, 93-96) -- chunks overrun into their
+// successors and those reads are counted twice, as there; sampling restarts from srand(seed) in every chunk, one rand() % 100
+// per sequence token (C:87-89, 107-109).  Kept reads become mate-1-only entries of the pair store.  Reads of a chunk must
+// have one length <= 150 (the tool cuts every read to its chunk's first read's length and overruns its buffers otherwise).
+int lhgt_reads_load_count_diff(lhgt_ctx* ctx, const char* fq, long size_for_chunks, int ratio_percent, unsigned seed, long* n_reads_kept) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || !fq) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    Mapped m;
+    LHGT_TRY(m.open(fq));
+    const long n = (long)m.n, size = size_for_chunks < 0 ? n : size_for_chunks, each = size / 10;
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> off(1, 0);
+    auto ws = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
+    for (int t = 0; t < 10; t++) {
+        const long start = t * each, end = t == 9 ? size : (t + 1) * each;
+        if (start > 0 && start >= n) LHGT_FAIL(LHGT_E_FORMAT, "count_diff_kmer: thread %d would start behind the end of %s", t, fq);
+        long pos = 0;
+        for (long i = start; i > 0; i--) if (m.p[i] == '@') { pos = i; break; }
+        long cur = pos, add_size = start, tok = 0, read_len = 0;
+        LHGT_TRY(lhgt_rng_seed(ctx, seed));
+        for (;;) {
+            while (cur < n && ws(m.p[cur])) cur++;
+            if (cur >= n) break;
+            const long t0 = cur;
+            while (cur < n && !ws(m.p[cur])) cur++;
+            const long len = cur - t0;
+            if (add_size >= end) break;
+            add_size += len;
+            if (tok % 4 == 1) {
+                if (tok == 1) read_len = len;
+                if (len != read_len || len > 150) LHGT_FAIL(LHGT_E_FORMAT, "count_diff_kmer: reads of unequal length or longer than 150 in %s (the reference overruns its buffers, C:75-76, 103-105)", fq);
+                if (rng_next(ctx) % 100 < ratio_percent) {
+                    seq.insert(seq.end(), m.p + t0, m.p + t0 + len);
+                    off.push_back(seq.size());
+                }
+            }
+            tok++;
+        }
+    }
+    const long kept = (long)off.size() - 1;
+    if (kept > 0) {
+        std::vector<uint64_t> off2((size_t)kept + 1, 0);
+        std::vector<uint8_t> fl((size_t)kept, PAIR_COUNT1), none(1, 0);
+        LHGT_TRY(lhgt_pairs_append_flags(ctx, seq.data(), off.data(), none.data(), off2.data(), kept, fl.data()));
+    }
+    if (n_reads_kept) *n_reads_kept = kept;
+    return LHGT_OK;
+}
+
 // Host-only probe of the parser (tests): FNV-1a digest over every kept pair (lengths, bases, mate-2 flag) in order.
 int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
                             int shard_world, long shard_block, int threads, long chunk_bytes, long* n_pairs_seen, long* n_pairs_kept,

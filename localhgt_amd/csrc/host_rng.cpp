@@ -80,6 +80,20 @@ int lhgt_coder_generate(lhgt_ctx* ctx) {
     return lhgt_coder_set(ctx, cc);
 }
 
+// random_coder of count_diff_kmer.cpp (C:216-238): ONE draw of rand() % 6 per k-mer offset, three hashes
+int lhgt_coder_generate_count_diff(lhgt_ctx* ctx) {
+    if (!ctx || !ctx->seeded) LHGT_FAIL(LHGT_E_STATE, "lhgt_rng_seed must be called before lhgt_coder_generate_count_diff");
+    if (ctx->e != 3) LHGT_FAIL(LHGT_E_ARG, "count_diff_kmer has three hashes (C:20)");
+    static const int16_t permu[18] = {0, 1, 2, 0, 2, 1, 1, 2, 0, 1, 0, 2, 2, 0, 1, 2, 1, 0};
+    int16_t cc[LHGT_CODER_SLOTS];
+    for (int i = 0; i < LHGT_CODER_SLOTS; i++) cc[i] = 100;
+    for (int j = 0; j < ctx->k; j++) {
+        const int r = rng_next(ctx) % 6;
+        for (int i = 0; i < 3; i++) cc[j * 3 + i] = permu[r * 3 + i];
+    }
+    return lhgt_coder_set(ctx, cc);
+}
+
 int lhgt_coder_set(lhgt_ctx* ctx, const int16_t* cc) {
     if (!ctx || !cc) LHGT_FAIL(LHGT_E_ARG, "null argument");
     HashParams hp;

@@ -21,7 +21,10 @@ __device__ __forceinline__ void sat_inc(uint32_t* __restrict__ T, uint32_t h) {
 
 // One wave per read; lane l takes k-mer offsets l, l+64, ...  All e probes of a lane's k-mer
 // are independent, so a wave keeps up to 64*e table operations in flight.
-__global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams hp, uint32_t* __restrict__ counts) {
+// n_as_base: count_diff_kmer.cpp's `bool` coder (C:155-160) -- a non-ACGT base is not rejected: it codes 1 in every projection
+// on the forward strand (= A: both code bits 0, as pack_bases stores it) and, its complement being the NUL byte, 1 in every
+// projection on the reverse strand too (= the complement of T: both bits 1)
+__global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams hp, uint32_t* __restrict__ counts, int n_as_base) {
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long n_waves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -36,9 +39,10 @@ __global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams h
         const int wpr = ((len + 31) >> 5) + 1;
         const uint32_t* rec = b.words + b.off[m][p];
         for (int j = lane; j < nk; j += 64) {
-            if (plane_window(rec + 2 * wpr, j, hp.k) != 0) continue;  // a non-ACGT base voids the k-mer (E:1065-1069)
+            const uint32_t wnb = plane_window(rec + 2 * wpr, j, hp.k);
+            if (wnb != 0 && !n_as_base) continue;  // a non-ACGT base voids the k-mer (E:1065-1069)
             uint32_t whi = plane_window(rec, j, hp.k), wlo = plane_window(rec + wpr, j, hp.k);
-            uint32_t rhi = brev_k(whi, hp.k), rlo = brev_k(wlo, hp.k);
+            uint32_t rhi = brev_k(whi | wnb, hp.k), rlo = brev_k(wlo | wnb, hp.k);   // wnb != 0 only under n_as_base
             for (int i = 0; i < hp.e; i++) sat_inc(counts, hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]));
         }
     }
@@ -100,7 +104,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     // Which kernel: the radix partition needs many table slices to spread over the chip (16384 at k = 32) and wins from
     // k = 26 up (bench workload: 102 vs 117 ms at k = 26, 60 vs 301 ms at k = 32); for smaller k the table is cache
     // resident and saturates at once, so the direct kernel's pre-check load makes it read-mostly (45 vs 1021 ms at k = 21).
-    const int mode = ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);
+    const int mode = ctx->count_compat ? 0 : ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);   // the compat coder lives in the direct kernel only
     for (const ReadBatch& b : ctx->batches) {
         if (mode == 1) {
             LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
@@ -109,7 +113,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
         long waves = 2 * b.d.n_pairs;
         long blocks = (waves + 3) / 4;
         if (blocks > 256L * 8 * 4) blocks = 256L * 8 * 4;
-        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts);
+        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0);
     }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -121,6 +125,12 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
 int lhgt_set_count_mode(lhgt_ctx* ctx, int mode) {
     if (!ctx || mode < -1 || mode > 1) LHGT_FAIL(LHGT_E_ARG, "count mode must be -1 (by k), 0 (direct) or 1 (partitioned)");
     ctx->count_mode = mode;
+    return LHGT_OK;
+}
+
+int lhgt_set_count_compat(lhgt_ctx* ctx, int on) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    ctx->count_compat = on != 0;
     return LHGT_OK;
 }
 

@@ -160,6 +160,7 @@ struct lhgt_ctx {
     std::vector<long> emu_range_end;         // per thread: one past its last peak id
     uint32_t* d_contig_id_adj = nullptr;     // per resident contig: its group's id base minus the peaks of all earlier groups
     std::vector<long> contig_first_tile;     // tile index of every resident contig's first tile
+    bool count_compat = false;               // count_diff_kmer.cpp's bool coder (lhgt_set_count_compat)
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)

@@ -174,6 +174,18 @@ class Engine:
     def set_count_mode(self, mode: int):
         _lib.check(self.lib.lhgt_set_count_mode(self.h, mode))
 
+    # ---- count_diff_kmer.cpp compatibility (include/localhgt_hip.h)
+    def set_count_compat(self, on: bool):
+        _lib.check(self.lib.lhgt_set_count_compat(self.h, 1 if on else 0))
+
+    def coder_generate_count_diff(self):
+        _lib.check(self.lib.lhgt_coder_generate_count_diff(self.h))
+
+    def reads_load_count_diff(self, fq: str, size_for_chunks: int, ratio_percent: int, seed: int) -> int:
+        n = C.c_long(0)
+        _lib.check(self.lib.lhgt_reads_load_count_diff(self.h, fq.encode(), size_for_chunks, int(ratio_percent), C.c_uint(seed & 0xFFFFFFFF), C.byref(n)))
+        return n.value
+
     def counts_clear(self):
         _lib.check(self.lib.lhgt_counts_clear(self.h))
 

@@ -858,6 +858,83 @@ int orc_run_threads(const char* fq1, const char* fq2, const char* fasta, const c
     return 0;
 }
 
+/* ================================================================ count_diff_kmer.cpp ("C"), the stand-alone phase-A tool
+ * Citations C:n = /root/reference/src/count_diff_kmer.cpp:n.  The tool seeds its coder and its sampling from time(0)
+ * (C:87-89, 223-225) and runs 10 racing threads, so its contract here is the binary run with time() fixed
+ * (oracle/fixed_time.c) and its threads in creation order (oracle/seq_threads.c).  What differs from extract_ref's phase A:
+ *   - the coder is a `bool` array, so the "invalid" code 5 collapses to 1 (C:155-160): a non-ACGT base is never rejected, it
+ *     codes 1 in every projection, on the forward strand and -- its complement being the NUL byte -- on the reverse strand too;
+ *   - one rand() per k-mer position for the coder (C:226-232; extract_ref draws e/3+1);
+ *   - 10 thread chunks of fq1's size (C:308, 331-343); a chunk is entered at the nearest '@' at or BEFORE its start (C:61-69;
+ *     thread 0's `pos` is uninitialised there and behaves as 0 in the -O2 binary), tokens are read with `>>` (C:91), the byte
+ *     budget counts token lengths only, starts at `start` and stops at `add_size >= end` (C:70, 93-96): chunks overrun into
+ *     their successors and those reads are counted twice;
+ *   - every read of a chunk is cut to the length of the chunk's first read (C:103-105);
+ *   - sampling: srand(time) at the head of every chunk, then r = rand() % 100 < ratio per sequence token (C:87-89, 107-109).
+ * hist[v] = slots holding v.  Returns <0 on inputs where the binary reads out of bounds (reads of unequal length or longer
+ * than 150, a chunk starting at or behind the end of a file). */
+static int orc_cdk_bit(int map, int ch) { int m = orc_proj(map, ch); return m == 5 ? 1 : m; }
+
+int orc_count_diff_kmer(const char* fq1, const char* fq2, int k, int ratio, unsigned time_seed, uint64_t hist[4]) {
+    static const short permu[18] = {0, 1, 2, 0, 2, 1, 1, 2, 0, 1, 0, 2, 2, 0, 1, 2, 1, 0};
+    short cc[100];
+    if (k < 1 || k > 32) return -9;
+    srand(time_seed);                                           /* C:223-225 */
+    for (int j = 0; j < k; j++) {
+        int r = rand() % 6;
+        for (int i = 0; i < 3; i++) cc[j * 3 + i] = permu[r * 3 + i];
+    }
+    size_t slots = (size_t)1 << k;
+    uint8_t* table = (uint8_t*)calloc(slots, 1);
+    orc_buf b[2] = {orc_slurp(fq1), orc_slurp(fq2)};
+    if (!table || b[0].n < 0 || b[1].n < 0) return -1;
+    const long size = b[0].n, each = size / 10;
+    int rc = 0;
+    for (int f = 0; f < 2 && !rc; f++)
+        for (int t = 0; t < 10 && !rc; t++) {
+            const long start = t * each, end = t == 9 ? size : (t + 1) * each;
+            if (start >= b[f].n && start > 0) { rc = -4; break; }
+            long pos = 0;                                       /* C:60-69 */
+            for (long i = start; i > 0; i--) if (b[f].p[i] == '@') { pos = i; break; }
+            long cur = pos, add_size = start, tok = 0;
+            int read_len = 0;
+            srand(time_seed);                                   /* C:87-89 */
+            for (;;) {
+                while (cur < b[f].n && (b[f].p[cur] == ' ' || (b[f].p[cur] >= 9 && b[f].p[cur] <= 13))) cur++;   /* operator>> */
+                if (cur >= b[f].n) break;
+                long t0 = cur;
+                while (cur < b[f].n && !(b[f].p[cur] == ' ' || (b[f].p[cur] >= 9 && b[f].p[cur] <= 13))) cur++;
+                const unsigned char* s = b[f].p + t0;
+                const long len = cur - t0;
+                if (add_size >= end) break;                     /* C:93-95 */
+                add_size += len;
+                if (tok % 4 == 1) {
+                    if (tok == 1) read_len = (int)len;          /* C:103-105 */
+                    if (len != read_len || len > 150) { rc = -3; break; }
+                    int r = rand() % 100;
+                    if (r < ratio)
+                        for (int j = 0; j + k <= read_len; j++)
+                            for (int i = 0; i < 3; i++) {
+                                uint32_t fwd = 0, rcw = 0;
+                                for (int z = 0; z < k; z++) {
+                                    fwd += (uint32_t)orc_cdk_bit(cc[z * 3 + i], s[j + z]) << (k - 1 - z);
+                                    rcw += (uint32_t)orc_cdk_bit(cc[(k - 1 - z) * 3 + i], orc_comp(s[j + z])) << z;
+                                }
+                                uint32_t h = fwd > rcw ? rcw : fwd;
+                                if (table[h] < 3) table[h]++;
+                            }
+                }
+                tok++;
+            }
+        }
+    if (!rc) {
+        hist[0] = hist[1] = hist[2] = hist[3] = 0;
+        for (size_t q = 0; q < slots; q++) hist[table[q]]++;
+    }
+    free(table); free(b[0].p); free(b[1].p);
+    return rc;
+}
+
 #ifdef ORC_MAIN
 int main(int argc, char** argv) {
     if (argc < 13) {

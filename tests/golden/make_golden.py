@@ -114,9 +114,28 @@ print(json.dumps(out))
     print("cmdline.json written")
 
 
+def capture_count_diff():
+    """count_diff_kmer.cpp on the committed k24_seed7 inputs, made reproducible by the two shims (time() fixed, threads in
+    creation order): the two result lines it prints (C:45-48)"""
+    tool = os.path.join(ROOT, "oracle", "_ref", "count_diff_kmer")
+    pre = ":".join(os.path.join(ROOT, "oracle", "_ref", x) for x in ("libseqthreads.so", "libfixedtime.so"))
+    out = []
+    with tempfile.TemporaryDirectory(prefix="lhgt_gold_") as tmp:
+        fa, f1, f2 = materialise(CASES["k24_seed7"], tmp)
+        for k, ratio, t in ((12, 100, 1), (16, 100, 1), (20, 37, 5), (24, 80, 123456), (18, 3, 9)):
+            res = subprocess.run([tool, f1, f2, str(k), str(ratio)], capture_output=True, text=True, check=True,
+                                 env=dict(os.environ, LD_PRELOAD=pre, LHGT_FIXED_TIME=str(t)))
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("####") or re.match(r"^\d+\t\S+\t\S+$", ln) or ln.startswith("###kmer_is")]
+            out.append({"case": "k24_seed7", "k": k, "ratio": ratio, "time": t, "lines": lines})
+    with open(os.path.join(HERE, "count_diff_kmer.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("count_diff_kmer.json written")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     capture_cmdlines()
+    capture_count_diff()
     for name, case in CASES.items():
         if only and name not in only:
             continue

@@ -46,6 +46,7 @@ class Oracle:
         L.orc_get_fq_start.argtypes = [C.c_char_p, C.c_long, C.c_long]
         L.orc_run_threads.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int,
                                       C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(Report)]
+        L.orc_count_diff_kmer.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_uint64)]
         L.orc_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int,
                               C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(Report)]
 
@@ -119,6 +120,12 @@ class Oracle:
         rc = self.L.orc_run_threads(fq1.encode(), fq2.encode(), fasta.encode(), interval.encode(), hit_ratio, match_ratio,
                                     threads, k, max_peak, e, seed, sample, C.byref(rep))
         return rc, rep
+
+    def count_diff_kmer(self, fq1, fq2, k, ratio, time_seed=1):
+        """the reference's stand-alone phase-A tool with time() fixed and its threads in creation order; returns (rc, hist[4])"""
+        hist = np.zeros(4, dtype=np.uint64)
+        rc = self.L.orc_count_diff_kmer(fq1.encode(), fq2.encode(), k, int(ratio), time_seed, _p(hist, C.c_uint64))
+        return rc, hist
 
     # ---- whole run with the 12-argument contract
     def run(self, fq1, fq2, fasta, interval, hit_ratio, match_ratio, threads, k, max_peak, e, seed, sample):

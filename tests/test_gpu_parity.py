@@ -436,3 +436,36 @@ def test_saturated_table_line_summary(Engine, oracle, case_inputs, tmp_path):
             res.append((n, eng.flags_export(0, n_bases) & 0b1111101, eng.peaks_export(n)[0].copy()))   # the trio bit is a lower bound after the lite form
         for other in res[1:]:
             assert res[0][0] == other[0] and (res[0][1] == other[1]).all() and (res[0][2] == other[2]).all()
+
+
+# ------------------------------------------------------------------ count_diff_kmer --compat against the reference tool
+def test_count_diff_kmer_compat_prints_the_reference_lines(oracle, case_inputs):
+    """bin/count_diff_kmer --compat: the three result lines of the reference binary (time() fixed, threads in creation order;
+    tests/golden/count_diff_kmer.json) and the whole table histogram of the oracle's restatement"""
+    import io
+    import json
+    from localhgt_amd import count_diff_kmer
+    fa, f1, f2, _ = case_inputs("k24_seed7")
+    for g in json.load(open(os.path.join(cases.GOLDEN_DIR, "count_diff_kmer.json"))):
+        buf = io.StringIO()
+        hist = count_diff_kmer.run(f1, f2, g["k"], g["ratio"], out=buf, compat=True, compat_time=g["time"])
+        assert buf.getvalue().splitlines() == g["lines"], g
+        rc, want = oracle.count_diff_kmer(f1, f2, g["k"], g["ratio"], g["time"])
+        assert rc == 0 and [int(x) for x in hist] == [int(x) for x in want]
+
+
+def test_count_diff_kmer_compat_n_bases_and_overlap(oracle, tmp_path):
+    """reads with N and other letters (never rejected: they code 1 on both strands, C:155-160), lower case, and a file small
+    enough that every chunk overruns deep into the next one"""
+    from localhgt_amd import count_diff_kmer
+    rng = np.random.default_rng(3)
+    f1, f2 = str(tmp_path / "n.1.fq"), str(tmp_path / "n.2.fq")
+    for path, suf in ((f1, "1"), (f2, "2")):
+        with open(path, "w") as f:
+            for i in range(600):
+                s = "".join(rng.choice(list("ACGTacgtNNRn"), size=90))
+                f.write(f"@q{i}/{suf}\n{s}\n+\n{'I' * 90}\n")
+    for k, ratio, t in ((14, 100, 1), (20, 55, 42)):
+        hist = count_diff_kmer.run(f1, f2, k, ratio, out=open(os.devnull, "w"), compat=True, compat_time=t)
+        rc, want = oracle.count_diff_kmer(f1, f2, k, ratio, t)
+        assert rc == 0 and [int(x) for x in hist] == [int(x) for x in want]

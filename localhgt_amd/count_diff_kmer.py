@@ -13,8 +13,8 @@ skipped as in `extract_ref` (the tool's `bool` coder collapses N to 1, C:155-160
 `--compat` gives the reference tool's own numbers instead: what its binary prints when time() returns `--compat-time`
 (default 1) and its 10 threads run in creation order -- its one-draw-per-position coder, the bool coder that never rejects a
 base, the '@'-scan chunk starts, `>>` token reads, the byte budget that makes chunks overlap, the per-chunk read length and the
-per-chunk rand() % 100 sampling (C:53-153, 155-160, 216-238; pinned against oracle/_ref/count_diff_kmer run under
-oracle/fixed_time.c + oracle/seq_threads.c)."""
+per-chunk rand() % 100 sampling (C:53-153, 155-160, 216-238; the tests pin it against the reference binary run with those
+two determinism shims, tests/golden/count_diff_kmer.json)."""
 from __future__ import annotations
 
 import argparse

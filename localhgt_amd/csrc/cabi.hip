@@ -120,6 +120,8 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     lhgt_pairs_clear(c);
+    lhgt::ingest_free(c);
+    lhgt_ingest_pool_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_peak_kmer, (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],

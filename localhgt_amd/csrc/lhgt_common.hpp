@@ -12,6 +12,7 @@ namespace lhgt {
 
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
+const char* last_error();
 #define LHGT_HIP(expr)                                                                      \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -163,6 +164,15 @@ struct lhgt_ctx {
     bool count_compat = false;               // count_diff_kmer.cpp's bool coder (lhgt_set_count_compat)
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
+    // FASTQ loader (host_fastx.cpp): pinned slabs the parse threads write into, pinned per-pair metadata of the open batch,
+    // events that tell when a slab's copy has left the host
+    void* ingest_pool = nullptr;             // lhgt::SlabPool*
+    uint8_t* h_ingest_slabs = nullptr;       // hipHostMalloc: n_slabs x slab_bytes
+    uint32_t* h_ingest_meta = nullptr;       // hipHostMalloc: start1|start2|woff1|woff2 (u32), len1|len2 (u16), flags (u8) x ingest_meta_cap
+    long ingest_meta_cap = 0;
+    std::vector<hipEvent_t> ingest_events;
+    uint32_t* d_ingest_start = nullptr;      // device copy of the start offsets of the batch being packed
+    long ingest_start_cap = 0;
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)
     uint8_t* d_ws_ascii = nullptr;
     size_t ws_ascii_cap = 0;
@@ -171,6 +181,7 @@ struct lhgt_ctx {
 };
 
 int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
+void lhgt_ingest_pool_free(lhgt_ctx* ctx);   // host_fastx.cpp: the SlabPool object behind ctx->ingest_pool
 
 namespace lhgt {
 // host helpers implemented across the .cpp/.hip files
@@ -189,5 +200,11 @@ int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, co
 int write_index_lens(lhgt_ctx* ctx);
 int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
                             const uint8_t* pair_flags);
+// the loader's form: per-mate arrays in pinned host memory (start offsets into d_ascii and word offsets into the batch, u32),
+// everything copied and packed asynchronously on the context's stream
+int install_pairs_pinned(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint32_t* start1, const uint32_t* start2, const uint32_t* woff1,
+                         const uint32_t* woff2, const uint16_t* len1, const uint16_t* len2, const uint8_t* flags, long n,
+                         uint64_t n_words, int max_len, uint64_t n_kmers);
+void ingest_free(lhgt_ctx* ctx);
 int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes);
 }  // namespace lhgt

@@ -98,6 +98,7 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     memset(c->rng_state, 0, sizeof c->rng_state);
     c->counts_words = ((size_t)1 << k) / 16;
     hipError_t he = hipStreamCreate(&c->stream);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreate(&c->ev0);
     if (he == hipSuccess) he = hipEventCreate(&c->ev1);
     if (he == hipSuccess) he = hipEventCreate(&c->ev2);
@@ -132,6 +133,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     if (c->ev2) hipEventDestroy(c->ev2);
     if (c->ev3) hipEventDestroy(c->ev3);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     free(c->rng);
     delete c;
     return LHGT_OK;

@@ -407,8 +407,9 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     LHGT_HIP(hipMalloc(&ctx->d_tile_good, tiles.size() + 8));
     LHGT_HIP(hipMalloc(&ctx->d_active_tiles, (tiles.size() + 1) * 4));
     LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 16) * 4));  // counts, total, then small counters (selected positions, active tiles, saturated lines)
-    LHGT_HIP(hipMemcpy(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice));
-    LHGT_HIP(hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice, ctx->copy_stream));
+    LHGT_HIP(hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice, ctx->copy_stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->copy_stream));
     return LHGT_OK;
 }
 
@@ -450,7 +451,9 @@ int index_install_shard(lhgt_ctx* ctx, const uint32_t* w_all, size_t n_words_all
     for (size_t o = 0; o < n_words; o += CH) {
         size_t n = n_words - o < CH ? n_words - o : CH;
         HostPin pin(w + o, n * 4);
-        LHGT_HIP(hipMemcpy(ctx->d_index + o, w + o, n * 4, hipMemcpyHostToDevice));
+        // on its own non-blocking stream: a plain hipMemcpy would serialise with the FASTQ loader's stream (legacy default-stream rule)
+        LHGT_HIP(hipMemcpyAsync(ctx->d_index + o, w + o, n * 4, hipMemcpyHostToDevice, ctx->copy_stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->copy_stream));
     }
     return LHGT_OK;
 }

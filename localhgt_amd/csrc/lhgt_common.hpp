@@ -92,6 +92,7 @@ struct TileDev {
 struct lhgt_ctx {
     int device = 0, k = 0, e = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // non-blocking: the index upload, which may run next to the FASTQ loader on another host thread
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     float phase_ms[4] = {0, 0, 0, 0};   // A, B, C (all their kernels), and the ref_flags kernel alone
     // R

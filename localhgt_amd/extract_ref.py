@@ -101,16 +101,33 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) ->
     if dist:
         mode = os.environ.get("LHGT_SHARD_INDEX", "auto")
         shard_index = mode == "1" or (mode == "auto" and os.path.getsize(idx) > 180e9)
+    # The index file goes to the GPU on a second host thread while this one parses the FASTQs (the two share nothing but the
+    # PCIe link: the library calls release the interpreter lock, and the coder the index header carries is first needed by
+    # phase A).  The reference does the same things one after the other (E:1417, 1426).
     t_i0 = time.time()
-    if shard_index:
-        n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
-    else:
-        n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
-    t_i1 = time.time()
+    loaded = {}
+
+    def load_index():
+        try:
+            loaded["dims"] = eng.index_load_shard(idx, rank, world) if shard_index else eng.index_load(idx)   # E:1417 (+ resident copy of the hashes)
+        except BaseException as ex:   # re-raised on the main thread
+            loaded["error"] = ex
+        loaded["t"] = time.time()
+
+    import threading
+    loader = threading.Thread(target=load_index, name="lhgt-index-load")
+    loader.start()
     _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
-    eng.sampling_init(ratio)                                   # E:1422
-    t_r0 = time.time()
-    seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
+    try:
+        eng.sampling_init(ratio)                               # E:1422
+        t_r0 = time.time()
+        seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
+    finally:
+        loader.join()
+    if "error" in loaded:
+        raise loaded["error"]
+    n_contigs, n_bases = loaded["dims"]
+    t_i1 = loaded["t"]
     t1 = time.time()
     eng.count_kmers()                                          # phase A, E:1426-1448
     if dist:

@@ -107,6 +107,10 @@ int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, 
  * fq2 adds (E:1438-1445) is expressed this way by lhgt_pairs_load_fastq. */
 int lhgt_pairs_append_flags(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
                             const uint64_t* off2, long n_pairs, const uint8_t* pair_flags);
+/* with count-on-load lhgt_pairs_load_fastq closes a batch every Mi pairs and runs phase A on it at once, behind the parsing of the
+ * next batch (the coder must be set: load or build the index first); lhgt_count_kmers then only counts what is not counted yet and
+ * reports the whole kernel time.  lhgt_counts_clear makes every batch uncounted again. */
+int lhgt_set_count_on_load(lhgt_ctx* ctx, int on);
 int lhgt_pairs_clear(lhgt_ctx* ctx);
 int lhgt_pairs_count(lhgt_ctx* ctx, long* n_pairs);
 

@@ -571,10 +571,12 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
         LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d block %ld", shard_rank, shard_world, shard_block);
     if (ratio_percent < 100.0 && (long)ctx->random_array.size() != LHGT_MAX_RANDOM)
         LHGT_FAIL(LHGT_E_STATE, "lhgt_sampling_init(ratio) must precede lhgt_pairs_load_fastq when ratio < 100");
-    const long BATCH_PAIRS = 4L << 20, META_CAP = BATCH_PAIRS + (1L << 20);
+    // a batch is closed at 4 Mi pairs (1 Mi with count-on-load, so that phase A of one batch hides behind the parsing of the next;
+    // every batch costs phase A one sweep of the count table, which is why they are not smaller)
+    const long BATCH_PAIRS = ctx->count_on_load ? 1L << 20 : 4L << 20, META_CAP = (4L << 20) + (1L << 18);
     const size_t BATCH_BYTES = (size_t)1 << 30, CHUNK = (size_t)2 << 20, SLAB = 2 * (CHUNK + 1024);
     const int threads = default_threads();
-    const int n_slabs = 2 * threads + 4;
+    const int n_slabs = threads + threads / 3 + 4;
     LHGT_TRY(ws_reserve(ctx, BATCH_BYTES + 2 * SLAB, 0));
     SlabPool* pool = (SlabPool*)ctx->ingest_pool;
     if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs) {
@@ -614,9 +616,27 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
             out_head++;
         }
     };
+    std::vector<hipEvent_t> count_ev;    // count-on-load: an event pair around every batch's phase A
     auto flush = [&]() -> int {
         if (n_open == 0) return LHGT_OK;
         int rc = install_pairs_pinned(ctx, ctx->d_ws_ascii, start1, start2, woff1, woff2, len1, len2, pflags, n_open, words, max_len, nkm);
+        if (rc == LHGT_OK && ctx->count_on_load) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                count_ev.push_back(e0);
+                count_ev.push_back(e1);
+                // the copies and the pack kernel of this batch are ahead of it on the same stream; the wait below is for THEM
+                // (staging and metadata are reused) -- the count of this batch runs on while the next batch is parsed
+                hipEvent_t packed = ctx->ev3;
+                (void)hipEventRecord(packed, ctx->stream);
+                rc = lhgt_count_one_batch_async(ctx, ctx->batches.back(), e0, e1);
+                hipError_t e = hipEventSynchronize(packed);
+                reap(false);
+                fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0;
+                if (rc == LHGT_OK && e != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "ingest: %s", hipGetErrorString(e));
+                return rc;
+            }
+        }
         // the staging area and the pinned metadata are reused by the next batch: wait for the copies and the pack kernel
         hipError_t e = hipStreamSynchronize(ctx->stream);
         reap(false);
@@ -670,6 +690,11 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(ctx->stream);      // whatever happened: no copy may still read a slab
     while (out_head < out_slabs.size()) pool->release(out_slabs[out_head++]);
+    for (size_t i = 0; i + 1 < count_ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, count_ev[i], count_ev[i + 1]) == hipSuccess) ctx->count_on_load_ms += ms;
+    }
+    for (hipEvent_t e : count_ev) hipEventDestroy(e);
     if (rc != LHGT_OK) return rc;
     if (n_pairs_kept) *n_pairs_kept = kept;
     return LHGT_OK;

@@ -105,7 +105,9 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     // k = 26 up (bench workload: 102 vs 117 ms at k = 26, 60 vs 301 ms at k = 32); for smaller k the table is cache
     // resident and saturates at once, so the direct kernel's pre-check load makes it read-mostly (45 vs 1021 ms at k = 21).
     const int mode = ctx->count_compat ? 0 : ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);   // the compat coder lives in the direct kernel only
-    for (const ReadBatch& b : ctx->batches) {
+    for (ReadBatch& b : ctx->batches) {
+        if (b.counted) continue;          // counted while the next batch was being parsed (lhgt_set_count_on_load)
+        b.counted = true;
         if (mode == 1) {
             LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
             continue;
@@ -119,6 +121,36 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
     LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[0], ctx->ev0, ctx->ev1));
+    ctx->phase_ms[0] += ctx->count_on_load_ms;
+    ctx->count_on_load_ms = 0.f;
+    return LHGT_OK;
+}
+
+}  // extern "C"
+
+// phase A of ONE resident batch, asynchronously on the context's stream (the loader's count-on-load); t0 / t1 bracket it
+int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0, hipEvent_t t1) {
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: load or build the index before loading reads with count-on-load");
+    const int mode = ctx->count_compat ? 0 : ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);
+    LHGT_HIP(hipEventRecord(t0, ctx->stream));
+    if (mode == 1) LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
+    else {
+        long waves = 2 * b.d.n_pairs;
+        long blocks = (waves + 3) / 4;
+        if (blocks > 256L * 8 * 4) blocks = 256L * 8 * 4;
+        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0);
+        LHGT_HIP(hipGetLastError());
+    }
+    LHGT_HIP(hipEventRecord(t1, ctx->stream));
+    b.counted = true;
+    return LHGT_OK;
+}
+
+extern "C" {
+
+int lhgt_set_count_on_load(lhgt_ctx* ctx, int on) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    ctx->count_on_load = on != 0;
     return LHGT_OK;
 }
 
@@ -138,6 +170,8 @@ int lhgt_counts_clear(lhgt_ctx* ctx) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     LHGT_HIP(hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * 4, ctx->stream));
+    for (ReadBatch& b : ctx->batches) b.counted = false;
+    ctx->count_on_load_ms = 0.f;
     return LHGT_OK;
 }
 

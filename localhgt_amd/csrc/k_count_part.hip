@@ -34,15 +34,15 @@ __device__ __forceinline__ void part_sat_inc(uint32_t* __restrict__ T, uint32_t 
     }
 }
 
-constexpr int SLICE_BITS = 18;            // slots per final bucket (2-bit fields -> 64 KiB of LDS)
-constexpr int MAX_B1 = 7;                 // 128-way fan-out per scatter pass (B2 = k - 18 - B1 <= 7 for k <= 32)
-constexpr int TILE_KEYS = 16384;          // keys sorted per workgroup tile (64 KiB of LDS)
-constexpr int TILE_KEYS_ = TILE_KEYS;
+constexpr int SLICE_BITS = 16;            // slots per final bucket: its keys fit 16 bits, its slice of the 2-bit table is 16 KiB of LDS
+constexpr int MAX_B1 = 8;                 // 256-way fan-out per scatter pass (B2 = k - 16 - B1 <= 8 for k <= 32)
+constexpr int NBK = 1 << MAX_B1;          // buckets of one tile sort
+constexpr int TILE_KEYS = 16384;          // keys sorted per workgroup tile of the generic read scatter (64 KiB of LDS)
 constexpr int PT = 1024;                  // threads per workgroup in the read-side passes (16 waves hide the per-read load chain)
-constexpr int TILE_KEYS2 = TILE_KEYS;     // keys per tile of the key scatter: two 64 KiB workgroups per CU (one of 128 KiB: +14 ms on configs[2])
-constexpr int PK = 512;                   // threads per workgroup in the key scatter: 32 keys per thread stay in registers
+constexpr int TILE_KEYS2 = 32768;         // keys per tile of the key scatter, held as 16-bit keys: 64 KiB of LDS
+constexpr int PK = 1024;                  // threads per workgroup in the key scatter: 32 keys per thread stay in registers (one workgroup per CU)
 constexpr int KPT = TILE_KEYS2 / PK;
-constexpr int PA = 1024;                  // threads per workgroup in apply
+constexpr int PA = 256;                   // threads per workgroup in apply
 
 struct PartGeom {
     int k, slot_bits, b1, b2;             // b1 + b2 = k - slot_bits
@@ -68,8 +68,9 @@ struct PartCap {
 };
 __host__ __device__ inline uint32_t part_region(const PartCap& c, uint32_t q) {
     const unsigned long long tri = (unsigned long long)q * (2ull * c.nb - q);                 // nb^2 (1 - (1 - q/nb)^2)
-    const unsigned long long share = c.n * tri / ((unsigned long long)c.nb * c.nb);           // n * tri < 2^32 * 2^28
-    return (uint32_t)(share + share / 16 + (unsigned long long)q * 1024ull);
+    const unsigned long long t1 = tri / c.nb, r1 = tri % c.nb;                                // n * tri / nb^2 without leaving 64 bits
+    const unsigned long long share = (c.n * t1 + c.n * r1 / c.nb) / c.nb;
+    return (uint32_t)((share + share / 16 + (unsigned long long)q * 512ull + 7ull) & ~7ull);   // multiples of 8 keys: apply reads 16-byte groups
 }
 
 // keys of read (m, p) at offsets lane, lane+64, ...: calls f(key) for each of the e hashes of valid k-mers.
@@ -94,19 +95,36 @@ __device__ __forceinline__ void for_each_key(const ReadBatchDev& b, const HashPa
     }
 }
 
+// exclusive scan of hist[0 .. nbk), nbk <= 256, by the first 256 threads of the workgroup (wave shuffles + 4 wave totals);
+// EVERY thread of the workgroup calls it (it holds a barrier).  Returns this thread's exclusive prefix (threads >= nbk: unused).
+__device__ __forceinline__ uint32_t bucket_excl_scan(const uint32_t* hist, int nbk, uint32_t* wsum /*[4]*/) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t v = t < nbk ? hist[t] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (t < 256 && lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int q = 0; q < wv && q < 4; q++) off += wsum[q];
+    return off + incl - v;
+}
+
 // Sort the tile's keys (already counted into hist[nbk]) by bucket inside LDS and copy the runs out.
 // Called by the whole workgroup; `place(emit)` must call emit(key) for every key of the tile again.
 // Tile bucket q is the union of the final buckets first + q*step .. first + (q+1)*step - 1 and owns their regions of `out`;
 // cursors[q] counts the keys sent to it so far (it may run past the region: the keys beyond go straight to the table).
 template <int NT, class Place>
 __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase,
-                                                uint32_t* rstart, uint32_t* rcap, int nbk, int shift, uint32_t bmask,
+                                                uint32_t* rstart, uint32_t* rcap, uint32_t* wsum, int nbk, int shift, uint32_t bmask,
                                                 uint32_t* __restrict__ cursors, PartCap pc, uint32_t first, uint32_t step,
                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ counts, Place place) {
-    // exclusive scan of hist (nbk <= 128) and reservation of the global runs
+    // exclusive scan of hist (nbk <= 256) and reservation of the global runs
+    const uint32_t o = bucket_excl_scan(hist, nbk, wsum);
     if ((int)threadIdx.x < nbk) {
-        uint32_t o = 0;
-        for (int q = 0; q < (int)threadIdx.x; q++) o += hist[q];
         lofs[threadIdx.x] = o;
         lcur[threadIdx.x] = o;
         uint32_t c = hist[threadIdx.x];
@@ -137,7 +155,7 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
                                                          int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS];
-    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
+    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
     __shared__ uint32_t stage_all[(PT / 64) * 64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 64;
@@ -147,12 +165,12 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
     const long n_tiles = (n_reads + reads_per_tile - 1) / reads_per_tile;
     for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long r0 = t * reads_per_tile, r1 = r0 + reads_per_tile < n_reads ? r0 + reads_per_tile : n_reads;
-        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
         __syncthreads();
         for (long r = r0 + wib; r < r1; r += PT / 64)
             for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
         __syncthreads();
-        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, rstart, rcap, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
+        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, rstart, rcap, wsum, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
             for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, emit);
         });
     }
@@ -172,7 +190,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
                                                              int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                              uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS1];
-    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
+    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
     __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 32;
@@ -183,7 +201,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
     const long n_tiles = (n_reads + reads_per_tile - 1) / reads_per_tile;
     for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long r0 = t * reads_per_tile, r1 = r0 + reads_per_tile < n_reads ? r0 + reads_per_tile : n_reads;
-        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
         __syncthreads();
         uint32_t key[RW][2][3];
         unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
@@ -218,7 +236,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
             }
         }
         __syncthreads();
-        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, gbase, rstart, rcap, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
+        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, gbase, rstart, rcap, wsum, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
 #pragma unroll
             for (int rr = 0; rr < RW; rr++)
 #pragma unroll
@@ -230,96 +248,144 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
     }
 }
 
-// ---- P2: level-1 segment -> its nb2 final buckets.  Tiles of TILE_KEYS2 keys, never straddling segments.
-// A thread keeps its KPT keys in registers between the histogram and the placement, all loads in flight at once.
-// Segment s holds the keys that fitted its region of `in`; its final buckets own the same coordinates of `out`.
-__global__ void __launch_bounds__(PK) part_scatter_keys(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cur1, PartGeom g,
-                                                        PartCap pc, uint32_t* __restrict__ cur2, uint32_t* __restrict__ out,
-                                                        uint32_t* __restrict__ counts) {
-    __shared__ uint32_t sorted[TILE_KEYS2];
-    __shared__ uint32_t hist[128], lofs[128], lcur[128], gbase[128], rstart[128], rcap[128];
-    __shared__ uint32_t tile_pref[129];   // tiles before segment s
-    __shared__ uint32_t seg_at[128], seg_len[128];
+// ---- P2: level-1 segment -> its nb2 final buckets, as 16-BIT keys.  Inside a final bucket only the low slot_bits = 16 bits of
+// a key still carry information (the rest is the bucket's number), so the tile is sorted and written as uint16: this pass
+// writes, and apply reads, 2 bytes per key instead of 4 -- 12 instead of 16 bytes of HBM traffic per key over the three passes.
+// Tiles of TILE_KEYS2 keys, never straddling segments; a thread keeps its KPT keys in registers between the histogram and the
+// placement, all loads in flight at once.  Runs are copied out bucket by bucket (a wave per bucket: the bucket number, which the
+// 16-bit key no longer holds, is the loop variable); a key that finds its region full is rebuilt from (bucket, low bits) and
+// counted at once.  (A second level exists only for k >= 25, where slot_bits is 16.)
+__global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cur1, PartGeom g,
+                                                          PartCap pc, uint32_t* __restrict__ cur2, uint16_t* __restrict__ out,
+                                                          uint32_t* __restrict__ counts) {
+    __shared__ uint16_t sorted[TILE_KEYS2];
+    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
+    __shared__ uint32_t tile_pref[NBK + 1];   // tiles before segment s
+    __shared__ uint32_t seg_at[NBK], seg_len[NBK];
     if ((int)threadIdx.x < g.nb1) {
         const uint32_t s = threadIdx.x, r0 = part_region(pc, s << g.b2), cap = part_region(pc, (s + 1) << g.b2) - r0;
         seg_at[s] = r0;
         seg_len[s] = cur1[s] < cap ? cur1[s] : cap;
-    }
+        hist[s] = (seg_len[s] + TILE_KEYS2 - 1) / TILE_KEYS2;      // tiles of segment s
+    } else if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t a = 0;
-        for (int s = 0; s < g.nb1; s++) {
-            tile_pref[s] = a;
-            a += (seg_len[s] + TILE_KEYS2 - 1) / TILE_KEYS2;
+    {
+        const uint32_t o = bucket_excl_scan(hist, g.nb1, wsum);
+        if ((int)threadIdx.x < g.nb1) {
+            tile_pref[threadIdx.x] = o;
+            if ((int)threadIdx.x == g.nb1 - 1) tile_pref[g.nb1] = o + hist[threadIdx.x];
         }
-        tile_pref[g.nb1] = a;
     }
     __syncthreads();
     const uint32_t n_tiles = tile_pref[g.nb1];
     const int shift = g.slot_bits;
     const uint32_t bmask = (uint32_t)g.nb2 - 1u;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         int lo = 0, hi = g.nb1;             // segment of tile t: last s with tile_pref[s] <= t
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tile_pref[mid] <= t) lo = mid; else hi = mid; }
         const int s = lo;
         const uint32_t seg0 = seg_at[s], seg1 = seg0 + seg_len[s];
         const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS2, k1 = k0 + TILE_KEYS2 < seg1 ? k0 + TILE_KEYS2 : seg1;
-        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        __syncthreads();                    // the previous tile's copy-out has read hist / lofs / sorted
+        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
         __syncthreads();
         uint32_t key[KPT];
 #pragma unroll
         for (int u = 0; u < KPT; u++) {
-            uint32_t i = k0 + u * PK + threadIdx.x;
+            const uint32_t i = k0 + u * PK + threadIdx.x;
             key[u] = i < k1 ? in[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < KPT; u++)
             if (k0 + u * PK + threadIdx.x < k1) atomicAdd(&hist[(key[u] >> shift) & bmask], 1u);
         __syncthreads();
-        tile_sort_flush<PK>(sorted, hist, lofs, lcur, gbase, rstart, rcap, g.nb2, shift, bmask, cur2 + ((size_t)s << g.b2), pc, (uint32_t)s << g.b2, 1u, out, counts, [&](auto emit) {
+        const uint32_t first = (uint32_t)s << g.b2;
+        const uint32_t o = bucket_excl_scan(hist, g.nb2, wsum);
+        if ((int)threadIdx.x < g.nb2) {
+            lofs[threadIdx.x] = o;
+            lcur[threadIdx.x] = o;
+            const uint32_t c = hist[threadIdx.x];
+            gbase[threadIdx.x] = c ? atomicAdd(&cur2[first + threadIdx.x], c) : 0u;
+            const uint32_t r0 = part_region(pc, first + threadIdx.x);
+            rstart[threadIdx.x] = r0;
+            rcap[threadIdx.x] = part_region(pc, first + threadIdx.x + 1) - r0;
+        }
+        __syncthreads();
 #pragma unroll
-            for (int u = 0; u < KPT; u++)
-                if (k0 + u * PK + threadIdx.x < k1) emit(key[u]);
-        });
+        for (int u = 0; u < KPT; u++)
+            if (k0 + u * PK + threadIdx.x < k1) sorted[atomicAdd(&lcur[(key[u] >> shift) & bmask], 1u)] = (uint16_t)key[u];
+        __syncthreads();
+        for (int bk = wv; bk < g.nb2; bk += PK / 64) {
+            const uint32_t cnt = hist[bk], l0 = lofs[bk], gb = gbase[bk], cap = rcap[bk];
+            uint16_t* dst = out + rstart[bk];
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                const uint16_t low = sorted[l0 + i];
+                const uint32_t pos = gb + i;                 // consecutive lanes -> consecutive addresses
+                if (pos < cap) dst[pos] = low;
+                else part_sat_inc(counts, ((first + (uint32_t)bk) << shift) | low);   // region full: count it now (see the header)
+            }
+        }
     }
 }
 
-// ---- P3: apply one final bucket inside LDS
-__global__ void __launch_bounds__(PA) part_apply(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_keys /*[nb]*/, PartGeom g,
+// ---- P3: apply one final bucket inside LDS.  K16: the bucket's keys are the 16-bit ones of part_scatter_keys16, read eight at
+// a time (regions start at multiples of 8 keys); otherwise (k <= 24: no second level) they are the level-1 keys, masked.
+template <bool K16>
+__global__ void __launch_bounds__(PA) part_apply(const void* __restrict__ keys_v, const uint32_t* __restrict__ n_keys /*[nb]*/, PartGeom g,
                                                  PartCap pc, uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t slice[];   // 2^slot_bits / 16 words
     const uint32_t fb = blockIdx.x;
     const uint32_t k0 = part_region(pc, fb), cap = part_region(pc, fb + 1) - k0;
     const uint32_t k1 = k0 + (n_keys[fb] < cap ? n_keys[fb] : cap);
     if (k0 == k1) return;                 // untouched slice: nothing to read or write
-    const int words = (1 << g.slot_bits) >> 4;
+    const int words = ((1 << g.slot_bits) + 15) >> 4;
     uint32_t* T = counts + (size_t)fb * words;
     for (int i = threadIdx.x; i < words; i += PA) slice[i] = T[i];
     __syncthreads();
     const uint32_t smask = (1u << g.slot_bits) - 1u;
-    constexpr int U = 8;                  // keys in flight per thread
-    for (uint32_t base = k0; base < k1; base += U * PA) {
-        uint32_t s[U], old[U];
-        bool live[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t i = base + u * PA + threadIdx.x;
-            live[u] = i < k1;
-            s[u] = live[u] ? keys[i] & smask : 0u;
+    auto sat_inc_lds = [&](uint32_t s) {          // if (T[h] < 3) T[h]++  (E:1082-1084), race-free
+        uint32_t* w = slice + (s >> 4);
+        const uint32_t sh = (s & 15u) * 2u;
+        uint32_t o = *(volatile uint32_t*)w;
+        while (((o >> sh) & 3u) != 3u) {
+            const uint32_t seen = atomicCAS(w, o, o + (1u << sh));
+            if (seen == o) break;
+            o = seen;
         }
+    };
+    if (K16) {
+        const uint16_t* keys = (const uint16_t*)keys_v;
+        constexpr int U = 2;              // 16-byte groups in flight per thread
+        for (uint32_t base = k0; base < k1; base += U * PA * 8) {
+            uint4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) old[u] = ((volatile uint32_t*)slice)[s[u] >> 4];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (!live[u]) continue;
-            uint32_t* w = slice + (s[u] >> 4);
-            const uint32_t sh = (s[u] & 15u) * 2u;
-            uint32_t o = old[u];
-            while (((o >> sh) & 3u) != 3u) {         // if (T[h] < 3) T[h]++  (E:1082-1084), race-free
-                uint32_t seen = atomicCAS(w, o, o + (1u << sh));
-                if (seen == o) break;
-                o = seen;
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + (u * PA + threadIdx.x) * 8;
+                v[u] = i < k1 ? *(const uint4*)(keys + i) : make_uint4(0, 0, 0, 0);   // the group is inside the region even when k1 cuts it
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + (u * PA + threadIdx.x) * 8;
+                const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i + q < k1) sat_inc_lds((w4[q >> 1] >> ((q & 1) * 16)) & 0xffffu);
+            }
+        }
+    } else {
+        const uint32_t* keys = (const uint32_t*)keys_v;
+        constexpr int U = 8;              // keys in flight per thread
+        for (uint32_t base = k0; base < k1; base += U * PA) {
+            uint32_t sl[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + u * PA + threadIdx.x;
+                sl[u] = i < k1 ? keys[i] & smask : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (sl[u] != 0xffffffffu) sat_inc_lds(sl[u]);
         }
     }
     __syncthreads();
@@ -342,7 +408,7 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     auto cap_of = [&](long np) { return PartCap{(unsigned long long)np * keys_per_pair, (uint32_t)g.nb}; };
     auto need_of = [&](long np) {
         const PartCap c = cap_of(np);
-        return c.n + c.n / 16 + (unsigned long long)g.nb * 1024ull + 64;
+        return c.n + c.n / 16 + (unsigned long long)g.nb * 512ull + 64;
     };
     long want = b.d.n_pairs < (4L << 20) ? b.d.n_pairs : (4L << 20);
     while (want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
@@ -351,19 +417,19 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         for (int i = 0; i < 2; i++) {
             if (ctx->d_part_keys[i]) hipFree(ctx->d_part_keys[i]);
             ctx->d_part_keys[i] = nullptr;
-            LHGT_HIP(hipMalloc(&ctx->d_part_keys[i], need * 4));
+            LHGT_HIP(hipMalloc(&ctx->d_part_keys[i], need * (i == 0 ? 4 : 2) + 64));   // level-1 keys are 32-bit, final keys 16-bit
         }
         ctx->part_keys_cap = need;
     }
     const long chunk_pairs = want;
-    if (!ctx->d_part_meta) LHGT_HIP(hipMalloc(&ctx->d_part_meta, (size_t)(16384 + 128) * 4));
+    if (!ctx->d_part_meta) LHGT_HIP(hipMalloc(&ctx->d_part_meta, (size_t)(65536 + 256) * 4));
     uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket
-    uint32_t* cur1 = cur2 + 16384;         // keys sent to each level-1 segment
+    uint32_t* cur1 = cur2 + 65536;         // keys sent to each level-1 segment
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
     for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
         const PartCap pc = cap_of(np);
-        LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(16384 + 128) * 4, ctx->stream));
+        LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(65536 + 256) * 4, ctx->stream));
         if (max_nk <= 128 && ctx->e <= 3) {
             int rpt = (int)(TILE_KEYS1 / ((long)max_nk * ctx->e));
             if (rpt > (PT1 / 64) * RW) rpt = (PT1 / 64) * RW;
@@ -372,16 +438,15 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         } else
             hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, pc, cur1,
                                ctx->d_part_keys[0], ctx->d_counts);
-        const uint32_t* final_keys = ctx->d_part_keys[0];
-        const uint32_t* final_n = cur1;    // without a second level the level-1 segments are the final buckets
+        const size_t slice_bytes = (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4;
         if (g.b2 > 0) {
-            hipLaunchKernelGGL(part_scatter_keys, dim3(grid), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], cur1, g, pc, cur2,
-                               ctx->d_part_keys[1], ctx->d_counts);
-            final_keys = ctx->d_part_keys[1];
-            final_n = cur2;
-        }
-        hipLaunchKernelGGL(part_apply, dim3(g.nb), dim3(PA), (size_t)((1 << g.slot_bits) >> 4) * 4, ctx->stream, final_keys, final_n, g, pc,
-                           ctx->d_counts);
+            hipLaunchKernelGGL(part_scatter_keys16, dim3(256), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], cur1, g, pc, cur2,
+                               (uint16_t*)ctx->d_part_keys[1], ctx->d_counts);
+            hipLaunchKernelGGL((part_apply<true>), dim3(g.nb), dim3(PA), slice_bytes, ctx->stream, (const void*)ctx->d_part_keys[1], cur2, g, pc,
+                               ctx->d_counts);
+        } else   // without a second level the level-1 segments are the final buckets
+            hipLaunchKernelGGL((part_apply<false>), dim3(g.nb), dim3(PA), slice_bytes, ctx->stream, (const void*)ctx->d_part_keys[0], cur1, g, pc,
+                               ctx->d_counts);
         LHGT_HIP(hipGetLastError());
     }
     return LHGT_OK;

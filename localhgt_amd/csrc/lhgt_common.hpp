@@ -66,6 +66,7 @@ struct ReadBatchDev {
 constexpr uint8_t PAIR_COUNT1 = 1, PAIR_COUNT2 = 2, PAIR_VOTE = 4, PAIR_ALL = 7;
 struct ReadBatch {
     ReadBatchDev d{};
+    bool counted = false;   // phase A already ran on this batch (count-on-load); reset by lhgt_counts_clear
     void* alloc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t n_words = 0;
     int max_len = 0;
@@ -157,6 +158,8 @@ struct lhgt_ctx {
     long synth_sample_contigs = 0;
     // the reference's -t N, race-free (lhgt_set_thread_emulation): read partition in host_fastx.cpp, contig groups with their own
     // id ranges in k_scan.hip, one sentinel line per thread in lhgt_write_intervals
+    bool count_on_load = false;              // lhgt_set_count_on_load: the FASTQ loader counts every batch as soon as it is resident
+    float count_on_load_ms = 0.f;            // kernel time of those counts (added to phase_ms[0] by lhgt_count_kmers)
     int emu_threads = 1;
     long emu_each_peaks = 0;                 // max_peak / N of the last scan
     std::vector<long> emu_range_end;         // per thread: one past its last peak id
@@ -182,6 +185,7 @@ struct lhgt_ctx {
 };
 
 int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
+int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0, hipEvent_t t1);
 void lhgt_ingest_pool_free(lhgt_ctx* ctx);   // host_fastx.cpp: the SlabPool object behind ctx->ingest_pool
 
 namespace lhgt {

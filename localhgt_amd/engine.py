@@ -129,6 +129,10 @@ class Engine:
                                               _ptr(o2, C.c_uint64), o1.size - 1,
                                               None if c2 is None else _ptr(c2, C.c_uint8)))
 
+    def set_count_on_load(self, on: bool):
+        """pairs_load_fastq then runs phase A on every batch while the next one is parsed (needs the coder: index first)"""
+        _lib.check(self.lib.lhgt_set_count_on_load(self.h, 1 if on else 0))
+
     def pairs_clear(self):
         _lib.check(self.lib.lhgt_pairs_clear(self.h))
 

@@ -101,33 +101,19 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) ->
     if dist:
         mode = os.environ.get("LHGT_SHARD_INDEX", "auto")
         shard_index = mode == "1" or (mode == "auto" and os.path.getsize(idx) > 180e9)
-    # The index file goes to the GPU on a second host thread while this one parses the FASTQs (the two share nothing but the
-    # PCIe link: the library calls release the interpreter lock, and the coder the index header carries is first needed by
-    # phase A).  The reference does the same things one after the other (E:1417, 1426).
+    # (Uploading the index on a second host thread next to the FASTQ pipeline was tried and lost: 0.23 s instead of 0.17 s for
+    # 4 M pairs + a 1.2 GB index -- the page faults and the pinning of the index mapping fight the parse threads.)
     t_i0 = time.time()
-    loaded = {}
-
-    def load_index():
-        try:
-            loaded["dims"] = eng.index_load_shard(idx, rank, world) if shard_index else eng.index_load(idx)   # E:1417 (+ resident copy of the hashes)
-        except BaseException as ex:   # re-raised on the main thread
-            loaded["error"] = ex
-        loaded["t"] = time.time()
-
-    import threading
-    loader = threading.Thread(target=load_index, name="lhgt-index-load")
-    loader.start()
+    if shard_index:
+        n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
+    else:
+        n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
+    t_i1 = time.time()
     _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
-    try:
-        eng.sampling_init(ratio)                               # E:1422
-        t_r0 = time.time()
-        seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
-    finally:
-        loader.join()
-    if "error" in loaded:
-        raise loaded["error"]
-    n_contigs, n_bases = loaded["dims"]
-    t_i1 = loaded["t"]
+    eng.sampling_init(ratio)                                   # E:1422
+    t_r0 = time.time()
+    eng.set_count_on_load(True)                                # phase A of a batch runs while the next one is parsed (E:1426-1448)
+    seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
     t1 = time.time()
     eng.count_kmers()                                          # phase A, E:1426-1448
     if dist:

@@ -19,7 +19,13 @@ struct Mapped {
     size_t n = 0;
     int fd = -1;
     ~Mapped() {
-        if (p && n) munmap((void*)p, n);
+        if (p && n) {
+            if (n > ((size_t)64 << 20)) {     // tearing down the page tables of a multi-GB mapping takes ~10 ms per GB: not on the caller's clock
+                const uint8_t* q = p;
+                const size_t m = n;
+                std::thread([q, m] { munmap((void*)q, m); }).detach();
+            } else munmap((void*)p, n);
+        }
         if (fd >= 0) close(fd);
     }
     int open(const char* path) {
@@ -577,6 +583,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     const size_t BATCH_BYTES = (size_t)1 << 30, CHUNK = (size_t)2 << 20, SLAB = 2 * (CHUNK + 1024);
     const int threads = default_threads();
     const int n_slabs = threads + threads / 3 + 4;
+    const double t_a0 = now_s();
     LHGT_TRY(ws_reserve(ctx, BATCH_BYTES + 2 * SLAB, 0));
     SlabPool* pool = (SlabPool*)ctx->ingest_pool;
     if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs) {
@@ -593,6 +600,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
         ctx->ingest_events.resize((size_t)n_slabs);
         for (auto& e : ctx->ingest_events) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    const double t_a1 = now_s();
     uint32_t* start1 = ctx->h_ingest_meta;
     uint32_t* start2 = start1 + META_CAP;
     uint32_t* woff1 = start2 + META_CAP;
@@ -687,8 +695,10 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
                              return LHGT_OK;
                          },
                          [&](bool block) { reap(block); });
+    const double t_f0 = now_s();
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(ctx->stream);      // whatever happened: no copy may still read a slab
+    if (ingest_trace()) fprintf(stderr, "[lhgt ingest] staging + pinned pool %.3fs, last batch + drain %.3fs\n", t_a1 - t_a0, now_s() - t_f0);
     while (out_head < out_slabs.size()) pool->release(out_slabs[out_head++]);
     for (size_t i = 0; i + 1 < count_ev.size(); i += 2) {
         float ms = 0.f;

@@ -106,8 +106,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     // resident and saturates at once, so the direct kernel's pre-check load makes it read-mostly (45 vs 1021 ms at k = 21).
     const int mode = ctx->count_compat ? 0 : ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);   // the compat coder lives in the direct kernel only
     for (ReadBatch& b : ctx->batches) {
-        if (b.counted) continue;          // counted while the next batch was being parsed (lhgt_set_count_on_load)
-        b.counted = true;
+        if (b.counted) { b.counted = false; continue; }   // the loader counted it already (lhgt_set_count_on_load): skipped this once
         if (mode == 1) {
             LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
             continue;

@@ -66,7 +66,7 @@ struct ReadBatchDev {
 constexpr uint8_t PAIR_COUNT1 = 1, PAIR_COUNT2 = 2, PAIR_VOTE = 4, PAIR_ALL = 7;
 struct ReadBatch {
     ReadBatchDev d{};
-    bool counted = false;   // phase A already ran on this batch (count-on-load); reset by lhgt_counts_clear
+    bool counted = false;   // the loader ran phase A on this batch (count-on-load): the next lhgt_count_kmers skips it once; reset by lhgt_counts_clear
     void* alloc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t n_words = 0;
     int max_len = 0;

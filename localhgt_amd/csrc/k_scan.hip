@@ -930,11 +930,12 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
     ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key
-    // On while the bitmap still screens enough: with two bits per key, n_keys = 0.3 x 2^pf_bits leaves 45 % of the bits set and lets
-    // ~20 % of foreign probes through -- about 140 of a pair's 714, which the queued kernel still handles inside its queue, and
-    // bitmap + survivors (330 + 290 ms per 100 M pairs) still beat 714 HBM probes per pair (1430 ms).  Round 1 stopped at 1/8:
-    // a ragged 13 Gbase reference (118 k contigs, 217 k peaks) fell off that cliff, 389 -> 1381 ms of phase C.
-    ctx->prefilter_on = !(ctx->debug & 4) && n_keys * 10 <= 3 * (1ull << pf_bits);
+    // On while the bitmap still screens enough: with two bits per key, n_keys = 0.5 x 2^pf_bits leaves 63 % of the bits set and lets
+    // 40 % of foreign probes through -- 285 of a pair's 714, which the queued kernel still holds in its queue -- and bitmap +
+    // survivors (330 + 0.4 x 1430 ms per 100 M pairs) still beat 714 HBM probes per pair (1430 ms).  Round 1 stopped at 1/8 with a
+    // queue for a dozen survivors: a ragged 13 Gbase reference (118 k contigs, 217 k peaks at their ends, 14 M registered k-mers)
+    // fell off that cliff, 389 -> 1381 ms of phase C.
+    ctx->prefilter_on = !(ctx->debug & 4) && 2 * n_keys <= (1ull << pf_bits);
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] peaks %u, registered positions %llu (%llu k-mers), prefilter 2^%d bits %s\n", total, n_selected, n_keys, pf_bits, ctx->prefilter_on ? "on" : "off");
     if (ctx->prefilter_on) {
         if (!ctx->d_prefilter) {

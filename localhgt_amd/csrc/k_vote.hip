@@ -422,7 +422,10 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
 // voted from scratch in the lane-per-offset form (hits in offset order for the judge); the others are done.  A pair's entries
 // are appended together and never split over two flushes, so no pair is voted twice.  (Straight-line code, one site per step:
 // as lambdas called from several places the steps became real calls with their captures in scratch memory.)
-constexpr int VQ_CAP = 384, VQ_FLUSH = 192;
+// Queue of 1024 entries, flushed at 512: a pair may bring up to 512 survivors.  (Round 1: 384 / 192, sized for the dozen survivors
+// per pair of a 2.3 M-k-mer peak set; a reference of 118 k ragged contigs registers 14 M k-mers, a third of the bitmap probes
+// pass, and 235 survivors per pair sent every pair down the direct path.)
+constexpr int VQ_CAP = 1024, VQ_FLUSH = 512;
 __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                           const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
                                                           uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,

@@ -109,30 +109,6 @@ using namespace lhgt;
 
 extern "C" {
 
-// cal_sam_ratio (E:1244-1270) / E:1392-1398
-int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, long* n_records) {
-    if (!fq1 || !ratio_percent) LHGT_FAIL(LHGT_E_ARG, "null argument");
-    if (sample <= 1) {
-        *ratio_percent = 100 * sample;
-        if (n_records) *n_records = -1;
-        return LHGT_OK;
-    }
-    Mapped m;
-    LHGT_TRY(m.open(fq1));
-    LineCursor lc(m);
-    const uint8_t* s;
-    size_t len, start;
-    long i = 0, bases = 0;
-    while (lc.next(&s, &len, &start)) {
-        if (i % 4 == 1) bases += (long)len;
-        i++;
-    }
-    bases *= 2;
-    *ratio_percent = 100 * sample / (double)bases;
-    if (n_records) *n_records = i / 4;
-    return LHGT_OK;
-}
-
 // ---------------------------------------------------------------- parallel lock-step FASTQ parser
 // The reference pairs line i of fq1 with line i of fq2 and treats lines with i % 4 == 1 as sequences
 // (E:356-367, 403-419): purely line-indexed.  So ANY line start is a valid split point: pass 1 counts the
@@ -566,6 +542,51 @@ static int default_threads() {
 }  // namespace lhgt
 
 extern "C" {
+
+// cal_sam_ratio (E:1244-1270) / E:1392-1398
+int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, long* n_records) {
+    if (!fq1 || !ratio_percent) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (sample <= 1) {
+        *ratio_percent = 100 * sample;
+        if (n_records) *n_records = -1;
+        return LHGT_OK;
+    }
+    Mapped m;
+    LHGT_TRY(m.open(fq1));
+    // the reference's extra getline pass over fq1 (E:1244-1270), on all parse threads: every chunk sums its line lengths by
+    // (local line index mod 4); which residue holds the sequence lines follows from the lines before the chunk
+    long i = 0, bases = 0;
+    {
+        const size_t CH = (size_t)8 << 20;
+        const size_t nchunks = m.n ? (m.n + CH - 1) / CH : 0;
+        std::vector<size_t> st;
+        for (size_t c = 0; c < nchunks; c++) {
+            const size_t b = lhgt::line_start_at_or_after(m.p, m.n, c * CH);
+            if (st.empty() || b > st.back()) st.push_back(b);
+        }
+        if (st.empty() || st.back() != m.n) st.push_back(m.n);
+        const long nc = (long)st.size() - 1;
+        std::vector<long> cnt((size_t)(nc > 0 ? nc : 0)), sums((size_t)(nc > 0 ? nc : 0) * 4, 0);
+        lhgt::parallel_for(nc, lhgt::default_threads(), [&](long c) {
+            lhgt::LineCursor lc(m);
+            lc.cur = st[(size_t)c];
+            const uint8_t* s;
+            size_t len, start;
+            long k = 0;
+            while (lc.cur < st[(size_t)c + 1] && lc.next(&s, &len, &start)) { sums[(size_t)c * 4 + (k & 3)] += (long)len; k++; }
+            cnt[(size_t)c] = k;
+        });
+        for (long c = 0; c < nc; c++) {
+            bases += sums[(size_t)c * 4 + (size_t)(((1 - i) % 4 + 4) % 4)];
+            i += cnt[(size_t)c];
+        }
+    }
+    bases *= 2;
+    *ratio_percent = 100 * sample / (double)bases;
+    if (n_records) *n_records = i / 4;
+    return LHGT_OK;
+}
+
 
 }  // extern "C"
 

@@ -328,3 +328,20 @@ def test_thread_partition_flags_and_refusals(lib, oracle, case_inputs, tmp_path)
     open(tiny2, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:24]) + b"\n")
     assert h.lhgt_fastq_parse_digest_threads(tiny1.encode(), tiny2.encode(), 100.0, None, 0, 1, 4096, 2, 5000, 40, C.byref(seen),
                                              C.byref(kept), C.byref(dig), None) == 4
+
+
+def test_parallel_sam_ratio_equals_the_getline_pass(lib, oracle, case_inputs, tmp_path):
+    """cal_sam_ratio (E:1244-1270) computed chunk-parallel == the oracle's line-by-line pass, whatever the line structure"""
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    fa, f1, f2, _ = case_inputs("k24_fq2_longer")
+    raw = open(f2, "rb").read()
+    variants = {"plain": raw, "nonl": raw[:-1], "crlf": raw[:50000].replace(b"\n", b"\r\n"), "blank_tail": raw + b"\n\n",
+                "ragged": b"".join(ln + b"\n" for i, ln in enumerate(raw.split(b"\n")[:4001]) if i % 7), "empty": b"", "one": b"@x\nACGT"}
+    for name, data in variants.items():
+        p = str(tmp_path / f"{name}.fq")
+        open(p, "wb").write(data)
+        r, n = C.c_double(0), C.c_long(0)
+        assert h.lhgt_fastq_sam_ratio(p.encode(), C.c_double(700000.0), C.byref(r), C.byref(n)) == 0
+        want = oracle.sam_ratio(p, 700000.0)
+        assert (r.value == want) or (np.isinf(r.value) and np.isinf(want)), (name, r.value, want)

@@ -6,6 +6,7 @@
 #   extract_ref_raw : the same source with no shim               (what `make` would build, at -O2)
 #   count_diff_kmer : src/count_diff_kmer.cpp
 #   libseqthreads.so: oracle/seq_threads.c, LD_PRELOADed for -t N runs
+#   libfixedtime.so : oracle/fixed_time.c, LD_PRELOADed for count_diff_kmer
 # Test infrastructure only: nothing in the product path may execute these.
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
@@ -21,4 +22,6 @@ g++ -O2 -std=c++11 -pthread -w -o "$here/_ref/count_diff_kmer" "$ref/src/count_d
 # determinism shims for multi-threaded runs of those binaries (our own files, preloaded; the sources stay untouched):
 #   libseqthreads.so : threads run one after the other in creation order (the -t N contract)
 gcc -O2 -shared -fPIC -o "$here/_ref/libseqthreads.so" "$here/seq_threads.c"
+#   libfixedtime.so  : time() returns LHGT_FIXED_TIME (count_diff_kmer seeds its coder and sampling from it)
+gcc -O2 -shared -fPIC -o "$here/_ref/libfixedtime.so" "$here/fixed_time.c"
 echo "built: $(ls "$here/_ref")"

@@ -1,23 +1,25 @@
 // k_count_part.hip -- phase A as a radix partition: the MI355X-first form of the k-mer count.
 //
-// Measured on MI355X (profiles/r01_probe_rates_microbench.txt): device atomics top out at
-// 18-27 G/s whatever the locality, random 4-byte loads at ~50 G/s, streaming at ~5 TB/s.  714
-// random read-modify-writes per read pair therefore cap the direct kernel (k_count.hip) at
-// ~33 M pairs/s.  Here the hashes are first routed by their top bits so that every final bucket
-// covers 2^18 table slots = one 64 KiB slice of the 2-bit table, which is then updated inside LDS:
-//   P1 part_scatter_r hash every k-mer, route keys by the top B1 bits            (tile sort in LDS, 64 KiB)
-//   P2 part_scatter_k route each level-1 segment by the next B2 bits           (same tile sort)
-//   P3 part_apply     one workgroup per final bucket: slice -> LDS, saturating
-//                     2-bit increments by LDS compare-and-swap, slice -> HBM
-// No histogram pass: every bucket owns a fixed region of the key buffer sized by its EXPECTED load plus 1/16 and 1024 keys, and
+// Measured on MI355X (profiles/r01_probe_rates_microbench.txt, profiles/r02/): device atomics top out at 18-27 G/s whatever
+// the locality, a random load costs a 128-byte line fill (~50 G lines/s), streaming runs at ~5 TB/s.  714 random
+// read-modify-writes per read pair therefore cap the direct kernel (k_count.hip) at ~33 M pairs/s.  Here the hashes are first
+// routed by their top bits so that every final bucket covers 2^16 table slots = one 16 KiB slice of the 2-bit table, which is
+// then updated inside LDS:
+//   P1 part_scatter_reads(_reg)  hash every k-mer, route 32-bit keys by the top B1 <= 8 bits      (tile sort in LDS, 128 KiB)
+//   P2 part_scatter_keys16       route each level-1 segment by the next B2 <= 8 bits, write the
+//                                low 16 bits -- all that still matters inside a bucket             (tile sort in LDS, 128 KiB)
+//   P3 part_apply                one workgroup per final bucket: slice -> LDS, saturating
+//                                2-bit increments by LDS compare-and-swap, slice -> HBM
+// No histogram pass: every bucket owns a fixed region of the key buffer sized by its EXPECTED load plus 1/16 and 512 keys, and
 // runs are placed with one global atomicAdd per tile and bucket.  A hash is min(forward word, reverse-complement word), the
 // minimum of two roughly uniform values, so its density falls linearly (2(1-x)): bucket q of nb expects the share
-// (2(nb-q)-1)/nb^2 of the keys -- twice the mean for the first, next to nothing for the last (part_region below).  A key that finds its bucket full -- heavily repeated k-mers: poly-A, adapters -- is applied to the table at once with
-// the direct kernel's CAS loop; part_apply of the same chunk starts after the scatters and loads its slice from the table, so
-// nothing is lost or counted twice and the result does not depend on how much overflowed.  (The first version counted the keys
-// of every final bucket in a separate pass that hashed all reads once more: 69 ms of 534 on configs[2].)
-// HBM traffic is 16 B per key streamed plus one table sweep per chunk, instead of one random
-// 64-byte sector (and its write-back) per key.  The result is the same table: min(3, count).
+// (2(nb-q)-1)/nb^2 of the keys -- twice the mean for the first, next to nothing for the last (part_region below).  A key that
+// finds its bucket full -- heavily repeated k-mers: poly-A, adapters -- is applied to the table at once with the direct
+// kernel's CAS loop; part_apply of the same chunk starts after the scatters and loads its slice from the table, so nothing is
+// lost or counted twice and the result does not depend on how much overflowed.  (The first version counted the keys of every
+// final bucket in a separate pass that hashed all reads once more: 69 ms of 534 on configs[2].)
+// HBM traffic is 4 + 4 + 2 + 2 = 12 B per key streamed plus one table sweep per chunk, instead of one random 128-byte line
+// (and its write-back) per key.  The result is the same table: min(3, count).
 #include "lhgt_hash.hpp"
 
 namespace lhgt {

@@ -119,34 +119,37 @@ __device__ __forceinline__ uint32_t bucket_excl_scan(const uint32_t* hist, int n
 // Called by the whole workgroup; `place(emit)` must call emit(key) for every key of the tile again.
 // Tile bucket q is the union of the final buckets first + q*step .. first + (q+1)*step - 1 and owns their regions of `out`;
 // cursors[q] counts the keys sent to it so far (it may run past the region: the keys beyond go straight to the table).
+// dl[bk] = (delta, limit): sorted position i of bucket bk goes to out[i + delta] while i < limit, beyond that its region is full.
 template <int NT, class Place>
-__device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint32_t* gbase,
-                                                uint32_t* rstart, uint32_t* rcap, uint32_t* wsum, int nbk, int shift, uint32_t bmask,
+__device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint2* dl,
+                                                uint32_t* wsum, int nbk, int shift, uint32_t bmask,
                                                 uint32_t* __restrict__ cursors, PartCap pc, uint32_t first, uint32_t step,
                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ counts, Place place) {
-    // exclusive scan of hist (nbk <= 256) and reservation of the global runs
+    // exclusive scan of hist (nbk <= 256) and reservation of the global runs: the atomicAdd's answer is first needed by the
+    // copy-out, so its round trip to the L2 hides behind the placement
     const uint32_t o = bucket_excl_scan(hist, nbk, wsum);
-    if ((int)threadIdx.x < nbk) {
+    const bool mine = (int)threadIdx.x < nbk;
+    uint32_t gb = 0, r0 = 0, cap = 0;
+    if (mine) {
         lofs[threadIdx.x] = o;
         lcur[threadIdx.x] = o;
-        uint32_t c = hist[threadIdx.x];
-        gbase[threadIdx.x] = c ? atomicAdd(&cursors[threadIdx.x], c) : 0u;
-        const uint32_t r0 = part_region(pc, first + threadIdx.x * step);
-        rstart[threadIdx.x] = r0;
-        rcap[threadIdx.x] = part_region(pc, first + (threadIdx.x + 1) * step) - r0;
+        const uint32_t c = hist[threadIdx.x];
+        if (c) gb = atomicAdd(&cursors[threadIdx.x], c);
+        r0 = part_region(pc, first + threadIdx.x * step);
+        cap = part_region(pc, first + (threadIdx.x + 1) * step) - r0;
     }
     __syncthreads();
     place([&](uint32_t key) {
         uint32_t bk = (key >> shift) & bmask;
         sorted[atomicAdd(&lcur[bk], 1u)] = key;
     });
+    if (mine) dl[threadIdx.x] = make_uint2(r0 + gb - o, o + (cap > gb ? cap - gb : 0u));
     __syncthreads();
     const uint32_t total = lofs[nbk - 1] + hist[nbk - 1];
     for (uint32_t i = threadIdx.x; i < total; i += NT) {
-        uint32_t key = sorted[i];
-        uint32_t bk = (key >> shift) & bmask;
-        const uint32_t pos = gbase[bk] + (i - lofs[bk]);   // consecutive i of one bucket -> consecutive addresses
-        if (pos < rcap[bk]) out[rstart[bk] + pos] = key;
+        const uint32_t key = sorted[i];
+        const uint2 d = dl[(key >> shift) & bmask];
+        if (i < d.y) out[i + d.x] = key;                    // consecutive i of one bucket -> consecutive addresses
         else part_sat_inc(counts, key);                     // region full: count it now (see the header)
     }
     __syncthreads();
@@ -157,7 +160,8 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
                                                          int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS];
-    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
+    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], wsum[4];
+    __shared__ uint2 dl[NBK];
     __shared__ uint32_t stage_all[(PT / 64) * 64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 64;
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
         for (long r = r0 + wib; r < r1; r += PT / 64)
             for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, [&](uint32_t key) { atomicAdd(&hist[g.b1 ? (key >> shift) & bmask : 0], 1u); });
         __syncthreads();
-        tile_sort_flush<PT>(sorted, hist, lofs, lcur, gbase, rstart, rcap, wsum, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
+        tile_sort_flush<PT>(sorted, hist, lofs, lcur, dl, wsum, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
             for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, emit);
         });
     }
@@ -192,7 +196,8 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
                                                              int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                              uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS1];
-    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
+    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], wsum[4];
+    __shared__ uint2 dl[NBK];
     __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     uint32_t* stage = stage_all + wib * 32;
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
             }
         }
         __syncthreads();
-        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, gbase, rstart, rcap, wsum, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
+        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, dl, wsum, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
 #pragma unroll
             for (int rr = 0; rr < RW; rr++)
 #pragma unroll
@@ -261,7 +266,8 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
                                                           PartCap pc, uint32_t* __restrict__ cur2, uint16_t* __restrict__ out,
                                                           uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS2];   // (bucket << 16) | low 16 bits: the copy-out below needs no search for the bucket
-    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], gbase[NBK], rstart[NBK], rcap[NBK], wsum[4];
+    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], wsum[4];
+    __shared__ uint2 dl[NBK];                 // (delta, limit) per bucket: sorted position i -> out[i + delta] while i < limit
     __shared__ uint32_t tile_pref[NBK + 1];   // tiles before segment s
     __shared__ uint32_t seg_at[NBK], seg_len[NBK];
     if ((int)threadIdx.x < g.nb1) {
@@ -303,14 +309,15 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
         __syncthreads();
         const uint32_t first = (uint32_t)s << g.b2;
         const uint32_t o = bucket_excl_scan(hist, g.nb2, wsum);
-        if ((int)threadIdx.x < g.nb2) {
+        const bool mine = (int)threadIdx.x < g.nb2;
+        uint32_t gb = 0, r0 = 0, cap = 0;
+        if (mine) {
             lofs[threadIdx.x] = o;
             lcur[threadIdx.x] = o;
             const uint32_t c = hist[threadIdx.x];
-            gbase[threadIdx.x] = c ? atomicAdd(&cur2[first + threadIdx.x], c) : 0u;
-            const uint32_t r0 = part_region(pc, first + threadIdx.x);
-            rstart[threadIdx.x] = r0;
-            rcap[threadIdx.x] = part_region(pc, first + threadIdx.x + 1) - r0;
+            if (c) gb = atomicAdd(&cur2[first + threadIdx.x], c);   // answer needed by the copy-out only: in flight during the placement
+            r0 = part_region(pc, first + threadIdx.x);
+            cap = part_region(pc, first + threadIdx.x + 1) - r0;
         }
         __syncthreads();
 #pragma unroll
@@ -319,12 +326,13 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
                 const uint32_t bk = (key[u] >> shift) & bmask;
                 sorted[atomicAdd(&lcur[bk], 1u)] = (bk << 16) | (key[u] & 0xffffu);
             }
+        if (mine) dl[threadIdx.x] = make_uint2(r0 + gb - o, o + (cap > gb ? cap - gb : 0u));
         __syncthreads();
         const uint32_t total = lofs[g.nb2 - 1] + hist[g.nb2 - 1];
         for (uint32_t i = threadIdx.x; i < total; i += PK) {
             const uint32_t v = sorted[i], bk = v >> 16;
-            const uint32_t pos = gbase[bk] + (i - lofs[bk]);   // consecutive i of one bucket -> consecutive addresses
-            if (pos < rcap[bk]) out[rstart[bk] + pos] = (uint16_t)v;
+            const uint2 d = dl[bk];
+            if (i < d.y) out[i + d.x] = (uint16_t)v;           // consecutive i of one bucket -> consecutive addresses
             else part_sat_inc(counts, ((first + bk) << shift) | (v & 0xffffu));   // region full: count it now (see the header)
         }
     }

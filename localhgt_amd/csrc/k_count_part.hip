@@ -212,19 +212,34 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
         __syncthreads();
         uint32_t key[RW][2][3];
         unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
+        // two round trips to memory for the wave's RW reads instead of two per read: all descriptors first (unconditional loads on
+        // clamped indices -- a load under a lane- or wave-dependent branch is waited for on its own), then all records
+        int lens[RW];
+        uint32_t offs[RW], recw[RW];
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const long r = r0 + wib + rr * (PT1 / 64);
-            if (r >= r1) continue;
-            const long p = pair0 + (r >> 1);
-            const int m = (int)(r & 1);
-            if (b.flags && !((b.flags[p] >> m) & 1)) continue;   // quirk Q4, thread-chunk emulation
+            const long rc = r < r1 ? r : r1 - 1;
+            const long p = pair0 + (rc >> 1);
+            const int m = (int)(rc & 1);
             const int len = b.len[m][p];
+            offs[rr] = b.off[m][p];
+            const bool counted = !b.flags || ((b.flags[p] >> m) & 1);   // quirk Q4, thread-chunk emulation
+            lens[rr] = r < r1 && counted ? len : 0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) {
+            const int wpr = ((lens[rr] + 31) >> 5) + 1;
+            recw[rr] = b.words[offs[rr] + (lane < 3 * wpr ? lane : 0)];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) {
+            const int len = lens[rr];
             const int nk = len - k + 1;
+            if (nk <= 0) continue;
             const int wpr = ((len + 31) >> 5) + 1;
-            const uint32_t* rec = b.words + b.off[m][p];
             __builtin_amdgcn_wave_barrier();             // the previous read's windows have been cut
-            if (lane < 3 * wpr) stage[lane] = rec[lane];  // one coalesced load per read, windows cut out of LDS
+            if (lane < 3 * wpr) stage[lane] = recw[rr];   // the read's record, windows cut out of LDS
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 2; it++) {

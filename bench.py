@@ -54,7 +54,7 @@ COMMON_SOURCES = ("lhgt_hash.hpp", "lhgt_common.hpp", "k_ingest.hip", "k_synth.h
 FETCH_SIZE_SCALE = 2
 PHASE_KERNELS = {
     "count_A": ("part_scatter_reads", "part_scatter_keys", "part_apply", "count_direct"),
-    "ref_flags": ("ref_flags=", "ref_flags_lite="),      # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
+    "ref_flags": ("ref_flags=", "ref_flags_lite=", "ref_flags_trio="),      # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
     "vote_kernel": ("vote_kernel",),
 }
 
@@ -363,7 +363,7 @@ def verify_forms(eng):
         eng.set_debug(dbg)
         n = eng.ref_scan(0.1, 0.08, 300_000_000)
         eng.vote()
-        res[name] = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_FLAGS, 0b1111101),
+        res[name] = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_FLAGS, 0b1111100),
                      eng.digest(eng.DIGEST_VOTES))
     eng.set_debug(0)
     if res["picked"] != res["exact"]:
@@ -521,7 +521,8 @@ def main():
         "count_A": ("phase A kernel family (part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
                     "count_direct below k = 26): 714 table updates per pair", algo, None, hbm_ceiling),
         "ref_flags": (("ref_flags_lite (phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base)"
-                       if scan["lite"] else "ref_flags (phase B: e random 2-bit table probes + e index words per reference base)")
+                       if scan["lite"] else "ref_flags_trio (phase B on a sparse table: probes per base until a hash does not read 3)" if scan["form"] == "trio-first"
+                       else "ref_flags (phase B: e random 2-bit table probes + e index words per reference base)")
                       + ", 1 launch per step", ref_bytes, 1, hbm_ceiling),
         "vote_kernel": (f"vote_kernel (phase C read re-scan: 714 probes per pair, "
                         f"{'answered by the L2-resident bitmap except for its survivors' if sparse_vote else 'into peak_kmer'}), "

@@ -200,15 +200,18 @@ int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sam
  * sparse path; bit6: ref_flags never uses the saturated-line summary; bit7: chunked tile scan at any size; bit8: no tile is
  * settled by window_good alone (bits 2-8: outputs unchanged); bit9 / bit10: the sparse vote kernel stops after its first /
  * second filter level (stage timing, outputs wrong); bit11: the queued sparse vote kernel votes every pair with more than 8 bitmap
- * survivors directly (exercises that branch; outputs unchanged); bit12 / bit13: lhgt_ref_scan takes the lite / the exact form of its
- * first two steps whatever the table looks like (default for e <= 3: by how full the table is and, in between, by a trial on a few runs of tiles; outputs unchanged).
+ * survivors directly (exercises that branch; outputs unchanged); bit12 / bit13 / bit14: lhgt_ref_scan takes the single-first (lite) / the exact /
+ * the trio-first form of its first two steps whatever the table looks like (default for e <= 3: trio-first below 45 % of the slots at 3, lite from 90 %,
+ * in between exact unless a trial on a few runs of tiles favours lite; outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the phase), 3 = the ref_flags kernel alone*/, float* ms);
-/* ---- which form the last lhgt_ref_scan took (k_scan.hip: lite = one probe per position until a hash reads 3, complete probes at
- *      every 8th position and in the tiles that cannot be settled from that; exact = all e probes everywhere) */
+/* ---- which form the last lhgt_ref_scan took (k_scan.hip): *lite = 0 exact (all e probes everywhere); 1 single-first, for a nearly
+ *      full table (one probe per position until a hash reads 3, complete probes at every 8th position and in the tiles that cannot
+ *      be settled from that); 2 trio-first, for a sparse table (probes until a hash does not read 3; complete probes only near
+ *      windows that reach the trio threshold).  n_tiles_exact = tiles that got the exact treatment. */
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact);
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream);
 int lhgt_synchronize(lhgt_ctx* ctx);

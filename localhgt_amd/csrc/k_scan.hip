@@ -142,6 +142,49 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
     }
 }
 
+// ---- B1 for a SPARSE table ("trio-first").  A window is good only if `three` -- positions whose e hashes ALL read 3 -- reaches
+// its threshold (E:610-615), and on a table that is mostly empty (the default down-sampled run: 15 % of the slots at 3; a sample
+// of a few hundred genomes: 20 %) almost no position outside the sampled genomes is such a position.  So the hashes of a position
+// are probed one after the other until one does NOT read 3: 1 + f + f^2 probes instead of 3 (1.24 at f = 0.2), and `trio` is
+// exact everywhere.  Tiles with no window reaching the `three` threshold, nor within three tiles of one, are done: no good
+// window, no interval, nothing of them is ever read again.  The others get their remaining probes (ref_flags_fill) and the exact
+// window_good, like the unsettled tiles of the single-first form.  flags bit 7 = "single and trio are exact" (some probed hash
+// read 3, or all were probed); pstate as above.  Same peaks, ids and votes as the exact form.
+__global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                     int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate) {
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    const uint32_t full = (1u << e) - 1u;
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        long j = (long)t.j0 + jj;
+        if (j >= c.len) break;
+        uint8_t f = 0x80, ps = 0x70;   // the last k-1 positions have no k-mer: exact zeros (quirk Q1 contract)
+        if (j < nk) {
+            const uint32_t* hp = index + c.hash_word + j * e;
+            uint32_t h[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) h[i] = i < e ? hp[i] : 0u;
+            uint32_t known = 0, is3 = 0;
+            bool all3 = true;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if (i < e && all3) {
+                    const uint32_t cnt = h[i] != 0 ? count_of(counts, h[i]) : 0u;   // hash 0 = invalid (E:936-941)
+                    known |= 1u << i;
+                    if (cnt == 3u) is3 |= 1u << i;                                    // least_depth 3 (E:580)
+                    else all3 = false;
+                }
+            const bool exact = known == full || is3 != 0u;
+            f = (uint8_t)((is3 != 0u) | ((is3 == full) << 1) | (exact ? 0x80 : 0));
+            ps = (uint8_t)(is3 | (known << 4));
+        }
+        flags[c.flat_base + j] = f;
+        pstate[c.flat_base + j] = ps;
+    }
+}
+
 // the remaining probes of the listed tiles and of the HL2 positions their window sums look back on
 __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ index,
@@ -190,6 +233,53 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
     for (int q = 0; q < wv; q++) off += sh[q];
     __syncthreads();
     return off + incl - v;
+}
+
+// does any window of the tile reach the `three` threshold?  (exact trio sums; `one` is not looked at: it is a lower bound here)
+__global__ void __launch_bounds__(BT) window_trio(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, int three_min,
+                                                  const uint8_t* __restrict__ flags, uint32_t* __restrict__ cand) {
+    __shared__ int P3[N2], part[BT];
+    __shared__ int any;
+    const TileDev t = tiles[blockIdx.x];
+    const ContigDev c = contigs[t.contig];
+    const long len = c.len, lo = (long)t.j0 - HL2;
+    const uint8_t* F = flags + c.flat_base;
+    constexpr int NW = TILE + HL2;
+    constexpr int CH = (NW + BT - 1) / BT;
+    const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
+    if (threadIdx.x == 0) any = 0;
+    int s3 = 0;
+    for (int i = b; i < en; i++) {
+        const long pos = lo + i;
+        s3 += (pos >= 0 && pos < len) ? (F[pos] >> 1) & 1 : 0;
+        P3[i] = s3;
+    }
+    const int o3 = block_excl_sum(s3, part);
+    for (int i = b; i < en; i++) P3[i] += o3;
+    __syncthreads();
+    bool mine = false;
+    if (P3[NW - 1] >= three_min) {
+        const long rest = len - (long)t.j0;
+        const int n_here = rest < TILE ? (int)rest : TILE;
+        for (int jj = threadIdx.x; jj < n_here; jj += BT) mine |= P3[jj + HL2] - P3[jj + HL2 - WINDOW] >= three_min;
+    }
+    if (__ballot(mine) && (threadIdx.x & 63) == 0) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) cand[blockIdx.x] = (uint32_t)any;
+}
+
+// tiles that need exact flags: within three tiles (the 2560-position reach of the interval rules plus the contrast halo) of a
+// tile with a candidate window, inside the same contig; every other tile holds no good window (tile_good = 0) and is done
+__global__ void __launch_bounds__(256) mark_need_tiles(const TileDev* __restrict__ tiles, const uint32_t* __restrict__ cand, long n_tiles,
+                                                       uint8_t* __restrict__ tile_good, uint32_t* __restrict__ need, unsigned int* __restrict__ n_need) {
+    const long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q0 >= n_tiles) return;
+    const uint32_t contig = tiles[q0].contig;
+    bool reach = false;
+    for (long q = q0 - 3; q <= q0 + 3; q++)
+        if (q >= 0 && q < n_tiles && tiles[q].contig == contig && cand[q]) reach = true;
+    if (reach) need[atomicAdd(n_need, 1u)] = (uint32_t)q0;
+    else tile_good[q0] = 0;
 }
 
 // ---- B2: good-window bit per position (E:597-615).  A good position lies inside a merged interval whatever its neighbours do
@@ -768,8 +858,15 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     ctx->scan_n_need = 0;
     // In between the clear cases a trial decides: the lite kernels on 64 runs of 65 consecutive tiles spread over the reference
     // (the first tile of a run only supplies the look-back of the second); lite if they settle at least 40 % of the others.
+    // Three forms of B1/B2 (e <= 3): exact (every hash of every position); single-first ("lite": a nearly full table -- probe until a
+    // hash reads 3); trio-first (a sparse table -- probe until a hash does NOT read 3).  Below 45 % of the slots at 3 the sparse
+    // form asks 1 + f + f^2 <= 1.65 probes per position instead of 3 and random positions almost never make a candidate window;
+    // above, the old rule: lite from 90 %, exact in between unless a trial of the lite kernels settles 40 % of its tiles.
+    // bit 12 / 13 / 14 force single-first / exact / trio-first.
+    const bool force_any = (ctx->debug & (4096 | 8192 | 16384)) != 0;
+    const bool sparse_form = e <= 3 && ((ctx->debug & 16384) || (!force_any && frac3 < 0.45 && n_lines >= 64 && !(ctx->debug & 64)));
     double pilot_settled = -1.0;
-    if (e <= 3 && !(ctx->debug & (4096 | 8192)) && frac3 >= 0.2 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
+    if (e <= 3 && !force_any && !sparse_form && frac3 >= 0.2 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
         std::vector<uint32_t> pl, pw;
         for (int r = 0; r < 64; r++) {
             const long t0 = (ctx->n_tiles - 65) * r / 63;
@@ -794,10 +891,31 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     }
     // measured (13 Gbase; slots at 3 / tiles the trial settles: phase B exact -> lite, ms): 81.8 % / 99.9 % (100 M pairs) 791 -> 368;
     // 74.2 % / 92.7 % (50 M) 878 -> 494; 67.4 % / 32.3 % (35 M) 946 -> 890; 58.6 % / 0.5 % (25 M) 1067 -> 1169; 24.5 % / 25.1 % (configs[1]) 97 -> 105
-    ctx->scan_lite = e <= 3 && !(ctx->debug & 8192) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.4 : frac3 >= 0.65));
-    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, ctx->scan_lite ? "lite" : "exact");
+    ctx->scan_lite = sparse_form || (e <= 3 && !(ctx->debug & (8192 | 16384)) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.4 : frac3 >= 0.65)));
+    ctx->scan_form = sparse_form ? 2 : ctx->scan_lite ? 1 : 0;
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
-    if (ctx->scan_lite) {
+    if (sparse_form) {
+        hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+                           ctx->d_nzmask);
+        LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
+        unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
+        LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(window_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count);   // tile_count: free until the id scan
+        hipLaunchKernelGGL(mark_need_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_tile_count,
+                           ctx->n_tiles, ctx->d_tile_good, ctx->d_active_tiles, d_nneed);
+        unsigned int n_need = 0;
+        LHGT_HIP(hipMemcpyAsync(&n_need, d_nneed, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, near a window that reaches the trio threshold %u\n", ctx->n_tiles, n_need);
+        ctx->scan_n_need = n_need;
+        if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
+            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_index,
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
+            hipLaunchKernelGGL(window_good, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
+                               ctx->d_flags, ctx->d_tile_good);
+        }
+    } else if (ctx->scan_lite) {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);

@@ -124,6 +124,7 @@ struct lhgt_ctx {
     uint8_t* d_nzmask = nullptr;  // per position: bit i = hash i has a non-zero count (E:250's `record_ref_hit > 0`)
     double scan_frac3 = 0.0;      // fraction of the table's slots holding 3 at the last scan
     long scan_n_need = 0;         // tiles the lite form had to treat exactly
+    int scan_form = 0;            // 0 exact, 1 single-first (lite), 2 trio-first
     bool scan_lite = false;       // the last scan took the lite form of B1/B2: d_nzmask then holds the per-hash probe state, not nz bits
     // reads
     std::vector<lhgt::ReadBatch> batches;

@@ -240,7 +240,8 @@ class Engine:
         """form of the last ref_scan: {'lite': bool, 'frac_slots_at_3': float, 'tiles': int, 'tiles_exact': int}"""
         lite, frac, nt, ne = C.c_int(0), C.c_double(0), C.c_long(0), C.c_long(0)
         _lib.check(self.lib.lhgt_scan_info(self.h, C.byref(lite), C.byref(frac), C.byref(nt), C.byref(ne)))
-        return {"lite": bool(lite.value), "frac_slots_at_3": round(frac.value, 4), "tiles": nt.value, "tiles_exact": ne.value}
+        return {"lite": lite.value == 1, "form": ("exact", "single-first", "trio-first")[lite.value], "frac_slots_at_3": round(frac.value, 4),
+                "tiles": nt.value, "tiles_exact": ne.value}
 
     def synchronize(self):
         _lib.check(self.lib.lhgt_synchronize(self.h))

@@ -100,10 +100,10 @@ def test_settled_tiles_change_nothing_on_a_saturated_table(eng):
     hist = eng.counts_histogram()
     assert hist[3] > 0.2 * (1 << 32) and hist[1] == hist[2] == 0, hist
     res = []
-    for flags in (8192, 8192 | 256, 4096, 0):    # exact scan with / without settled tiles, lite scan, the form the trial picks
+    for flags in (8192, 8192 | 256, 4096, 16384, 0):    # exact scan with / without settled tiles, single-first, trio-first, the form the engine picks
         eng.set_debug(flags)
         n = eng.ref_scan(0.1, 0.08, 300_000_000)
-        res.append((n, eng.peaks_export(n)[0].copy(), eng.flags_export(0, NC * CL) & 0b1111101))   # the trio bit is a lower bound after the lite form
+        res.append((n, eng.peaks_export(n)[0].copy(), eng.flags_export(0, NC * CL) & 0b1111100))   # single / trio are bounds outside the tiles a lite form treats exactly
     info = eng.scan_info()
     assert 0.2 < info["frac_slots_at_3"] < 0.9 and info["tiles"] == NC * CL // 2000   # in the range where the trial decides
     eng.set_debug(0)

@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 NC, CL, K, E = 13000, 1_000_000, 32, 3
-FLAG_BITS = 0b1111101          # the trio bit is a lower bound after the lite form and bit 7 says whether it is exact
+FLAG_BITS = 0b1111100          # good window, peak, inside, selected, new: single / trio are bounds where a lite form did not need them exact
 
 
 @pytest.fixture(scope="module")
@@ -55,9 +55,11 @@ def _check_scans_and_votes(eng, expect_lite, tag):
     lite, info_l = _scan(eng, 4096)
     assert info_l["lite"]
     trial, info_t = _scan(eng, 0)
+    sparse, info_s = _scan(eng, 16384)                 # trio-first form (what a sparse table gets by itself)
+    assert info_s["form"] == "trio-first"
     chunked, _ = _scan(eng, 128)                       # ids through the chunked tile scan (on by itself above 65536 tiles) ...
     unsettled, _ = _scan(eng, 8192 | 256)              # ... and no tile settled by window_good alone
-    for name, other in (("lite", lite), ("trial", trial), ("chunked", chunked), ("unsettled", unsettled)):
+    for name, other in (("lite", lite), ("trial", trial), ("trio-first", sparse), ("chunked", chunked), ("unsettled", unsettled)):
         assert other == exact, (tag, name, other, exact)
     if expect_lite is not None:
         assert info_t["lite"] == expect_lite, (tag, info_t)

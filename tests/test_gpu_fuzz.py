@@ -85,8 +85,8 @@ def _make_case(idx, d, k_max=32):
 def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     from localhgt_amd import _lib, extract_ref
     import shutil
-    if idx % 2:                               # every other case through the lite form of the reference scan (when e <= 3)
-        monkeypatch.setenv("LHGT_DEBUG", "4096")
+    if idx % 3:                               # a third of the cases each: the form the engine picks, single-first, trio-first (when e <= 3)
+        monkeypatch.setenv("LHGT_DEBUG", "4096" if idx % 3 == 1 else "16384")
     g, c = tmp_path / "gpu", tmp_path / "cpu"
     g.mkdir()
     k, e, seed, sample, hit, match, max_peak = _make_case(idx, str(g))

@@ -94,7 +94,10 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         pk_o = np.zeros(1 << k, dtype=np.uint32)
         n_o, loci_o, _ = oracle.ref_scan(index, table, k, e, np.float32(case.hit_ratio), np.float32(case.match_ratio),
                                          case.max_peak, pk_o, flags_o)
+        eng.set_debug(8192)                               # the exact form: every hash of every position probed
         n_g = eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak)
+        assert eng.scan_info()["form"] == "exact"
+        eng.set_debug(0)
         flags_g = eng.flags_export(0, n_bases)
         assert ((flags_g & 0b0011) == (flags_o & 0b0011)).all(), "single/trio flags differ"
         inside_o = (flags_o >> 2) & 1
@@ -110,18 +113,31 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         _, pf_o = oracle.vote(f1, f2, k, e, cc, ratio, None, pk_o, loci_o, n_o)
         _, pf_g = eng.peaks_export(n_g)
         assert (pf_g == pf_o[:n_g]).all()
-        for flags in (2048, 32, 4, 4096, 4096 | 256):   # every vote kernel (queued with its direct branch forced, generic with / without the
-            eng.set_debug(flags)                          # bitmap); the lite form of the scan, also with no tile settled early
+        # every vote kernel (queued with its direct branch forced, generic with / without the bitmap); the form of the scan the
+        # engine picks by itself (0), the single-first ("lite") form, also with no tile settled early, and the trio-first form
+        for flags in (0, 2048, 32, 4, 4096, 4096 | 256, 16384, 16384 | 256):
+            eng.set_debug(flags)
             assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
             eng.vote()
             assert (eng.peaks_export(n_g)[1] == pf_o[:n_g]).all(), f"votes differ with debug flags {flags}"
-            if flags & 4096:
-                fl = eng.flags_export(0, n_bases)
-                assert (((fl ^ flags_g) & 0b1111101) == 0).all(), "lite scan: single / good / peak / inside / selected / new flags differ"
-                exact = (fl & 0x80) != 0
-                assert (((fl ^ flags_g) & 0b10)[exact] == 0).all(), "lite scan: trio flag differs where it claims to be exact"
-                assert (((fl & ~flags_g) & 0b10) == 0).all(), "lite scan: trio flag is not a lower bound"
-                assert (eng.peaks_export(n_g)[0] == loci_o[:2 * n_o]).all() and (eng.peak_kmer_export() == pk_o).all()
+            assert (eng.peaks_export(n_g)[0] == loci_o[:2 * n_o]).all() and (eng.peak_kmer_export() == pk_o).all(), flags
+            form = eng.scan_info()["form"]
+            fl = eng.flags_export(0, n_bases)
+            assert (((fl ^ flags_g) & 0b1111100) == 0).all(), f"{form}: good / peak / inside / selected / new flags differ"
+            exact = (fl & 0x80) != 0
+            if form == "single-first":
+                assert flags & 4096
+                assert (((fl ^ flags_g) & 1) == 0).all(), "single-first: the single flag is exact everywhere"
+                assert (((fl ^ flags_g) & 0b10)[exact] == 0).all(), "single-first: trio flag differs where it claims to be exact"
+                assert (((fl & ~flags_g) & 0b10) == 0).all(), "single-first: trio flag is not a lower bound"
+            elif form == "trio-first":
+                assert (((fl ^ flags_g) & 0b10) == 0).all(), "trio-first: the trio flag is exact everywhere"
+                assert (((fl ^ flags_g) & 1)[exact] == 0).all(), "trio-first: single flag differs where it claims to be exact"
+                assert (((fl & ~flags_g) & 1) == 0).all(), "trio-first: single flag is not a lower bound"
+                if flags & 16384:
+                    assert eng.scan_info()["tiles_exact"] <= eng.scan_info()["tiles"]
+            else:
+                assert (((fl ^ flags_g) & 0b11) == 0).all()
         eng.set_debug(0)
         # D
         out = str(tmp_path / "interval.txt")

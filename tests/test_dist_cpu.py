@@ -131,3 +131,38 @@ def test_saturating_sum_identity():
     rng = np.random.default_rng(0)
     c = rng.integers(0, 9, size=(8, 10000))
     assert (np.minimum(3, np.minimum(3, c).sum(0)) == np.minimum(3, c.sum(0))).all()
+
+
+def test_bench_helpers_planted_transfers_and_traffic_stamps(tmp_path):
+    """bench.py's host-side helpers: the breakpoints the synthetic sample carries (the same hash as k_synth.hip: transfer_sites),
+    interval recall as the reference's evaluation defines it, and the rule that a committed traffic figure is only used while the
+    kernel sources it was measured on are unchanged"""
+    import importlib
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    bp = bench.planted_breakpoints(1000, 1_000_000)
+    assert len(bp) == 750 and bp[:3] == [(1, 953947), (2, 109604), (2, 112604)]          # values of the device generator (seed 1)
+    assert all(1 <= c <= 500 and 3000 <= p < 1_000_000 for c, p in bp)
+    assert len(bench.planted_breakpoints(13000, 1_000_000, 300)) == 450
+    iv = tmp_path / "iv.txt"
+    iv.write_text("1\t1\t1\n1\t953000\t954000\n2\t-100\t900\n2\t109000\t110000\n")
+    rec = bench.interval_recall(str(iv), bp)
+    assert rec["inside_an_interval"] == 2 and rec["breakpoints"] == 750 and rec["interval_lines"] == 4
+    # traffic fallback: entries whose stamp matches the sources are fresh, the others are ignored
+    stamps = {ph: bench.source_stamp(srcs) for ph, srcs in bench.KERNEL_SOURCES.items()}
+    fake = {"tagA": {"count_A": {"bytes": 1}, "ref_flags": {"bytes": 2}, "vote_kernel": {"bytes": 3},
+                     "_stamp": dict(stamps, ref_flags="0000000000000000")}}
+    path = os.path.join(root, "profiles", "traffic_per_launch.json")
+    real = open(path).read()
+    try:
+        open(path, "w").write(json.dumps(fake))
+        fresh, stale = bench.committed_traffic("tagA")
+        assert set(fresh) == {"count_A", "vote_kernel"} and set(stale) == {"ref_flags"}
+        assert bench.committed_traffic("other") == ({}, {})
+    finally:
+        open(path, "w").write(real)
+    committed = json.loads(real)
+    assert all("_stamp" in v for v in committed.values())

@@ -113,3 +113,37 @@ def test_settled_tiles_change_nothing_on_a_saturated_table(eng):
         assert (res[0][2] == other[2]).all()
     inside = (res[0][2] >> 4) & 1
     assert 0.3 < inside.mean() < 0.7             # the sampled contigs lie inside good intervals, the others do not
+
+
+def test_count_on_load_equals_count_after_load(eng, tmp_path):
+    """the FASTQ pipeline with phase A running behind the parser (1 Mi-pair batches counted as they become resident) gives the table
+    of load-everything-then-count, and lhgt_count_kmers neither counts those batches again nor skips them the next time"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = 2_300_000                                   # three batches with count-on-load, one without
+    eng.pairs_clear()
+    m1, m2 = eng.synth_pairs(1, 7, NC, CL, 0, n, 150, want_host=True)
+    eng.pairs_clear()
+    f1, f2 = str(tmp_path / "c.1.fq"), str(tmp_path / "c.2.fq")
+    bench.write_fastq(f1, m1, n, 150, "1")
+    bench.write_fastq(f2, m2, n, 150, "2")
+    del m1, m2
+    got = []
+    for on in (True, False):
+        eng.counts_clear()
+        eng.set_count_on_load(on)
+        seen, kept = eng.pairs_load_fastq(f1, f2, 100.0)
+        assert seen == kept == n == eng.pairs_count()
+        eng.count_kmers()
+        got.append((eng.digest(eng.DIGEST_COUNTS), tuple(int(x) for x in eng.counts_histogram())))
+        if on:                                      # a second count of the same resident pairs really counts them again
+            before = eng.counts_histogram()
+            eng.count_kmers()
+            after = eng.counts_histogram()
+            assert after[3] > before[3] and after[0] == before[0]
+        eng.pairs_clear()
+    eng.set_count_on_load(False)
+    assert got[0] == got[1]
+    assert got[0][1][0] < (1 << 32) and got[0][1][1] > 0

@@ -395,6 +395,34 @@ def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
     assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]
 
 
+def test_extract_ref_executable_honours_t_when_asked(case_inputs, tmp_path):
+    """`localhgt bkp` passes -t 10 by default: with LHGT_EMULATE_THREADS=1 bin/extract_ref gives the reference's -t 10 file (golden
+    from the reference run with its threads in creation order), without it the -t 1 file whatever -t says"""
+    import subprocess
+    name = "k24_t10_sample_bases"
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("emulated", {"LHGT_EMULATE_THREADS": "1"}), ("plain", {})):
+        d = tmp_path / tag
+        d.mkdir()
+        fa2 = str(d / "ref.fa")
+        shutil.copy(fa, fa2)
+        interval = str(d / "S.interval.txt")
+        env = dict(os.environ, PATH=os.path.join(root, "bin") + os.pathsep + os.environ["PATH"], **extra)
+        env.pop("LHGT_EMULATE_THREADS", None) if not extra else None
+        num = str(int(case.sample)) if float(case.sample) == int(case.sample) else repr(float(case.sample))
+        res = subprocess.run(["extract_ref", f1, f2, fa2, interval, repr(case.hit_ratio), repr(case.match_ratio), str(case.threads), str(case.k),
+                              str(case.max_peak), str(case.e), str(case.seed), num], env=env, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[tag] = open(interval).read()
+    gold = open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+    assert outs["emulated"] == gold
+    assert outs["plain"] != gold and outs["plain"].count("1\t1\t1\n") == 1      # one thread range, one sentinel line
+    assert gold.count("1\t1\t1\n") >= 8                                           # ten ranges, most of them empty
+
+
 @pytest.mark.parametrize("k,e", [(20, 9), (33 - 1, 1), (16, 4)])
 def test_whole_run_matches_oracle_for_unusual_e(oracle, case_inputs, tmp_path, k, e):
     """e = 9 (four rand() rows per position, 9th hash outside the 8-bit nzmask), e = 1 and e = 4: GPU run vs oracle run"""

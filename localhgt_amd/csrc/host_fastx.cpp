@@ -624,6 +624,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     uint16_t *len1 = nullptr, *len2 = nullptr;
     uint8_t* pflags = nullptr;
     double t_alloc = 0;
+    std::vector<uint32_t> meta_pageable;     // only when the host refuses page-locked memory
     auto prepare = [&](SlabPool** pool_out) -> int {
         const double t_a0 = now_s();
         LHGT_TRY(ws_reserve(ctx, BATCH_BYTES + 2 * SLAB, 0));
@@ -631,8 +632,22 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
         if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != META_CAP) {
             lhgt_ingest_pool_free(ctx);
             ingest_free(ctx);
-            LHGT_HIP(hipHostMalloc(&ctx->h_ingest_slabs, (size_t)n_slabs * SLAB, hipHostMallocDefault));
-            LHGT_HIP(hipHostMalloc(&ctx->h_ingest_meta, (size_t)META_CAP * 21 + 64, hipHostMallocDefault));
+            pool = nullptr;
+            if (getenv("LHGT_NO_PINNED") ||     // test hook for the fallback below
+                hipHostMalloc(&ctx->h_ingest_slabs, (size_t)n_slabs * SLAB, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(&ctx->h_ingest_meta, (size_t)META_CAP * 21 + 64, hipHostMallocDefault) != hipSuccess) {
+                // no page-locked memory to be had (a locked-memory limit): the same pipeline on pageable buffers -- chunks in
+                // vectors, copied synchronously; slower, same result
+                (void)hipGetLastError();
+                ingest_free(ctx);
+                meta_pageable.assign((size_t)(META_CAP * 21 + 64 + 3) / 4, 0u);
+                uint32_t* base = meta_pageable.data();
+                start1 = base; start2 = start1 + META_CAP; woff1 = start2 + META_CAP; woff2 = woff1 + META_CAP;
+                len1 = (uint16_t*)(woff2 + META_CAP); len2 = len1 + META_CAP; pflags = (uint8_t*)(len2 + META_CAP);
+                *pool_out = nullptr;
+                t_alloc = now_s() - t_a0;
+                return LHGT_OK;
+            }
             ctx->ingest_meta_cap = META_CAP;
             pool = new SlabPool();
             pool->base = ctx->h_ingest_slabs;

@@ -395,6 +395,24 @@ def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
     assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]
 
 
+def test_loader_without_page_locked_memory(case_inputs, tmp_path, monkeypatch):
+    """the FASTQ pipeline's fallback when the host refuses pinned memory (LHGT_NO_PINNED forces it): pageable buffers, same files"""
+    from localhgt_amd import extract_ref
+    monkeypatch.setenv("LHGT_NO_PINNED", "1")
+    for name in ("k24_sample_half_fresh", "k24_t4"):
+        case = cases.CASES[name]
+        fa, f1, f2, meta = case_inputs(name)
+        d = tmp_path / name
+        d.mkdir()
+        fa2 = str(d / "ref.fa")
+        shutil.copy(fa, fa2)
+        interval = str(d / "interval.txt")
+        rep = extract_ref.run(extract_ref.parse_argv(cases.extract_ref_argv(case, f1, f2, fa2, interval)), log=lambda *a: None,
+                              emulate_threads=case.threads > 1)
+        assert rep["n_peaks"] == meta["raw_peaks"]
+        assert open(interval).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+
+
 def test_extract_ref_executable_honours_t_when_asked(case_inputs, tmp_path):
     """`localhgt bkp` passes -t 10 by default: with LHGT_EMULATE_THREADS=1 bin/extract_ref gives the reference's -t 10 file (golden
     from the reference run with its threads in creation order), without it the -t 1 file whatever -t says"""

@@ -345,3 +345,37 @@ def test_parallel_sam_ratio_equals_the_getline_pass(lib, oracle, case_inputs, tm
         assert h.lhgt_fastq_sam_ratio(p.encode(), C.c_double(700000.0), C.byref(r), C.byref(n)) == 0
         want = oracle.sam_ratio(p, 700000.0)
         assert (r.value == want) or (np.isinf(r.value) and np.isinf(want)), (name, r.value, want)
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_thread_partition_fuzz_against_the_oracle(lib, oracle, tmp_path, idx):
+    """random small inputs (ragged reads, padded fq2 headers, sampling) at -t 2..8: mate-1 / mate-2 / voted counts of the product's
+    partitioned parse equal the oracle's -t N run wherever the product accepts the input (it refuses what the reference reads as garbage)"""
+    import ctypes as C
+    from test_gpu_fuzz import _make_case
+    h = lib.load(require_gpu=False)
+    d = tmp_path / "c"
+    d.mkdir()
+    k, e, seed, sample, hit, match, max_peak = _make_case(300 + idx, str(d), k_max=16)
+    threads = 2 + idx % 7
+    f1, f2, fa = str(d / "s.1.fq"), str(d / "s.2.fq"), str(d / "ref.fa")
+    rc, rep = oracle.run_threads(f1, f2, fa, str(d / "i.txt"), 0.1, 0.08, threads, k, 100000 * threads, e, seed, sample)
+    ratio = 100.0 * sample if sample <= 1 else oracle.sam_ratio(f1, sample)
+    rnd = None
+    if ratio < 100:
+        oracle.srand(seed)
+        oracle.random_coder(k, e)                 # the index was built in the oracle's run: the coder draws come first (quirk Q3)
+        rnd = oracle.sampling_array(50_000_000)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+    cnt = (C.c_long * 3)()
+    rc2 = h.lhgt_fastq_parse_digest_threads(f1.encode(), f2.encode(), ratio, rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None,
+                                            0, 1, 4096, 3, 3000, threads, C.byref(seen), C.byref(kept), C.byref(dig), cnt)
+    if rc in (-4, -6):
+        assert rc2 == 4                            # chunk start near EOF / no re-synchronisation: refused by both
+        return
+    assert rc in (0, -5, -7)                       # -5 / -7: too many peaks for the id ranges -- the read partition is still defined
+    if rc2 == 4:
+        return                                     # overlapping chunks or a chunk entered off a record boundary: the product refuses
+    assert rc2 == 0
+    if rc == 0:
+        assert (cnt[0], cnt[1], cnt[2]) == (rep.pairs_counted, int(rep.t_count), rep.pairs_voted), (threads, k, e, sample)

@@ -759,7 +759,11 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(ctx->stream);      // whatever happened: no copy may still read a slab
     if (ingest_trace()) fprintf(stderr, "[lhgt ingest] staging + pinned pool %.3fs (behind the line count), last batch + drain %.3fs\n", t_alloc, now_s() - t_f0);
-    while (out_head < out_slabs.size()) pool->release(out_slabs[out_head++]);
+    if (pool) {                                    // ... so every slab is free again, also one a failed chunk still held
+        std::lock_guard<std::mutex> lk(pool->mu);
+        pool->free_ids.clear();
+        for (int i = 0; i < n_slabs; i++) pool->free_ids.push_back(i);
+    }
     for (size_t i = 0; i + 1 < count_ev.size(); i += 2) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, count_ev[i], count_ev[i + 1]) == hipSuccess) ctx->count_on_load_ms += ms;

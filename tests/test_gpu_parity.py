@@ -395,6 +395,37 @@ def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
     assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]
 
 
+def test_loader_survives_bad_input(Engine, case_inputs, tmp_path):
+    """a load that fails half-way (a read of 600 bases in the middle of the file; a second file with fewer records) returns its
+    error, leaves nothing resident, and the same engine then loads good files as if nothing had happened"""
+    from localhgt_amd import _lib
+    fa, f1, f2, _ = case_inputs("k24_base")
+    raw1 = open(f1, "rb").read().split(b"\n")
+    bad1 = str(tmp_path / "long.1.fq")
+    mid = (len(raw1) // 8) * 4 + 1
+    open(bad1, "wb").write(b"\n".join(raw1[:mid] + [b"A" * 600] + raw1[mid + 1:]))
+    short2 = str(tmp_path / "short.2.fq")
+    open(short2, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:400]) + b"\n")
+    with Engine(24, 3) as eng:
+        eng.rng_seed(1)
+        eng.coder_generate()
+        want = None
+        for attempt in range(2):
+            for a, b in ((bad1, f2), (f1, short2)):
+                with pytest.raises(_lib.LocalHGTError) as ei:
+                    eng.pairs_load_fastq(a, b, 100.0)
+                assert ei.value.code == 4
+                eng.pairs_clear()
+            eng.counts_clear()
+            seen, kept = eng.pairs_load_fastq(f1, f2, 100.0)
+            assert seen == kept == eng.pairs_count() > 1000
+            eng.count_kmers()
+            got = eng.counts_export().tobytes()
+            want = want or got
+            assert got == want
+            eng.pairs_clear()
+
+
 def test_loader_without_page_locked_memory(case_inputs, tmp_path, monkeypatch):
     """the FASTQ pipeline's fallback when the host refuses pinned memory (LHGT_NO_PINNED forces it): pageable buffers, same files"""
     from localhgt_amd import extract_ref

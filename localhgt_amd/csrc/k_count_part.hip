@@ -120,11 +120,12 @@ __device__ __forceinline__ uint32_t bucket_excl_scan(const uint32_t* hist, int n
 // Tile bucket q is the union of the final buckets first + q*step .. first + (q+1)*step - 1 and owns their regions of `out`;
 // cursors[q] counts the keys sent to it so far (it may run past the region: the keys beyond go straight to the table).
 // dl[bk] = (delta, limit): sorted position i of bucket bk goes to out[i + delta] while i < limit, beyond that its region is full.
-template <int NT, class Place>
+// `prefetch()` runs between the placement and the copy-out: loads issued there (the next tile's input) fly during the stores.
+template <int NT, class Place, class Prefetch>
 __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist, uint32_t* lofs, uint32_t* lcur, uint2* dl,
                                                 uint32_t* wsum, int nbk, int shift, uint32_t bmask,
                                                 uint32_t* __restrict__ cursors, PartCap pc, uint32_t first, uint32_t step,
-                                                uint32_t* __restrict__ out, uint32_t* __restrict__ counts, Place place) {
+                                                uint32_t* __restrict__ out, uint32_t* __restrict__ counts, Place place, Prefetch prefetch) {
     // exclusive scan of hist (nbk <= 256) and reservation of the global runs: the atomicAdd's answer is first needed by the
     // copy-out, so its round trip to the L2 hides behind the placement
     const uint32_t o = bucket_excl_scan(hist, nbk, wsum);
@@ -144,6 +145,7 @@ __device__ __forceinline__ void tile_sort_flush(uint32_t* sorted, uint32_t* hist
         sorted[atomicAdd(&lcur[bk], 1u)] = key;
     });
     if (mine) dl[threadIdx.x] = make_uint2(r0 + gb - o, o + (cap > gb ? cap - gb : 0u));
+    prefetch();
     __syncthreads();
     const uint32_t total = lofs[nbk - 1] + hist[nbk - 1];
     for (uint32_t i = threadIdx.x; i < total; i += NT) {
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
         __syncthreads();
         tile_sort_flush<PT>(sorted, hist, lofs, lcur, dl, wsum, g.nb1, g.b1 ? shift : 0, g.b1 ? bmask : 0u, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
             for (long r = r0 + wib; r < r1; r += PT / 64) for_each_key(b, hp, pair0 + (r >> 1), (int)(r & 1), lane, stage, emit);
-        });
+        }, [] {});
     }
 }
 
@@ -198,28 +200,25 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
     __shared__ uint32_t sorted[TILE_KEYS1];
     __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], wsum[4];
     __shared__ uint2 dl[NBK];
-    __shared__ uint32_t stage_all[(PT1 / 64) * 32];   // <= 18 record words per read on this path (<= 159 bases)
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    uint32_t* stage = stage_all + wib * 32;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;   // <= 18 record words per read on this path (<= 159 bases)
     const int shift = g.b1 ? g.k - g.b1 : 0;
     const uint32_t bmask = g.b1 ? (uint32_t)g.nb1 - 1u : 0u;
     const int k = hp.k, e = hp.e;
     const long n_reads = 2 * npairs;
     const long n_tiles = (n_reads + reads_per_tile - 1) / reads_per_tile;
-    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    if (n_reads <= 0) return;
+    // The wave's RW reads arrive in two round trips to memory: all descriptors (unconditional loads on clamped indices -- a load
+    // under a lane- or wave-dependent branch is waited for on its own), then all records.  With one workgroup per CU nothing else
+    // hides them, so they are software-pipelined: the next tile's descriptors fly during this tile's placement, its records
+    // during the copy-out.
+    int lens[RW];
+    uint32_t offs[RW], recw[RW];
+    auto load_descriptors = [&](long t) {        // t >= n_tiles: every length 0
         const long r0 = t * reads_per_tile, r1 = r0 + reads_per_tile < n_reads ? r0 + reads_per_tile : n_reads;
-        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
-        __syncthreads();
-        uint32_t key[RW][2][3];
-        unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
-        // two round trips to memory for the wave's RW reads instead of two per read: all descriptors first (unconditional loads on
-        // clamped indices -- a load under a lane- or wave-dependent branch is waited for on its own), then all records
-        int lens[RW];
-        uint32_t offs[RW], recw[RW];
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const long r = r0 + wib + rr * (PT1 / 64);
-            const long rc = r < r1 ? r : r1 - 1;
+            const long rc = r < r1 ? r : n_reads - 1;
             const long p = pair0 + (rc >> 1);
             const int m = (int)(rc & 1);
             const int len = b.len[m][p];
@@ -227,25 +226,43 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
             const bool counted = !b.flags || ((b.flags[p] >> m) & 1);   // quirk Q4, thread-chunk emulation
             lens[rr] = r < r1 && counted ? len : 0;
         }
+    };
+    auto load_records = [&] {
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const int wpr = ((lens[rr] + 31) >> 5) + 1;
             recw[rr] = b.words[offs[rr] + (lane < 3 * wpr ? lane : 0)];
         }
+    };
+    load_descriptors(blockIdx.x);
+    load_records();
+    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t key[RW][2][3];
+        unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const int len = lens[rr];
             const int nk = len - k + 1;
             if (nk <= 0) continue;
             const int wpr = ((len + 31) >> 5) + 1;
-            __builtin_amdgcn_wave_barrier();             // the previous read's windows have been cut
-            if (lane < 3 * wpr) stage[lane] = recw[rr];   // the read's record, windows cut out of LDS
-            __builtin_amdgcn_wave_barrier();
+            // The read's record sits in the wave's registers, word w of plane p in lane p * wpr + w.  The 64 offsets of one
+            // iteration need only three consecutive words of a plane (lanes 0-31: words 2it, 2it+1; lanes 32-63: 2it+1, 2it+2), so
+            // they are broadcast with readlane -- no LDS staging, no LDS reads for the windows (a third of this kernel's LDS traffic).
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int j = it * 64 + lane;
-                if (j >= nk || plane_window(stage + 2 * wpr, j, k) != 0) continue;
-                const uint32_t whi = plane_window(stage, j, k), wlo = plane_window(stage + wpr, j, k);
+                const bool upper = lane >= 32;
+                auto window = [&](int plane) {
+                    const int base = plane * wpr + 2 * it;
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)recw[rr], base);
+                    const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)recw[rr], base + 1);
+                    const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)recw[rr], base + 2);
+                    return window32(upper ? w1 : w0, upper ? w2 : w1, lane & 31) >> (32 - k);
+                };
+                if (j >= nk || window(2) != 0) continue;
+                const uint32_t whi = window(0), wlo = window(1);
                 const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
 #pragma unroll
                 for (int i = 0; i < 3; i++)
@@ -257,6 +274,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
                     }
             }
         }
+        load_descriptors(t + gridDim.x);
         __syncthreads();
         tile_sort_flush<PT1>(sorted, hist, lofs, lcur, dl, wsum, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
 #pragma unroll
@@ -266,7 +284,7 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
 #pragma unroll
                     for (int i = 0; i < 3; i++)
                         if (live & (1ull << (rr * 6 + it * 3 + i))) emit(key[rr][it][i]);
-        });
+        }, load_records);
     }
 }
 
@@ -303,21 +321,33 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
     const uint32_t n_tiles = tile_pref[g.nb1];
     const int shift = g.slot_bits;
     const uint32_t bmask = (uint32_t)g.nb2 - 1u;
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        int lo = 0, hi = g.nb1;             // segment of tile t: last s with tile_pref[s] <= t
+    // tile t: its segment s (last s with tile_pref[s] <= t) and key range [k0, k1); t >= n_tiles: empty
+    auto tile_bounds = [&](uint32_t t, int& s, uint32_t& k0, uint32_t& k1) {
+        if (t >= n_tiles) { s = 0; k0 = k1 = 0; return; }
+        int lo = 0, hi = g.nb1;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tile_pref[mid] <= t) lo = mid; else hi = mid; }
-        const int s = lo;
+        s = lo;
         const uint32_t seg0 = seg_at[s], seg1 = seg0 + seg_len[s];
-        const uint32_t k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS2, k1 = k0 + TILE_KEYS2 < seg1 ? k0 + TILE_KEYS2 : seg1;
-        __syncthreads();                    // the previous tile's copy-out has read hist / lofs / sorted
-        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
-        __syncthreads();
-        uint32_t key[KPT];
+        k0 = seg0 + (t - tile_pref[s]) * TILE_KEYS2;
+        k1 = k0 + TILE_KEYS2 < seg1 ? k0 + TILE_KEYS2 : seg1;
+    };
+    // a thread's KPT keys of a tile, all loads in flight at once.  The next tile's are issued before the copy-out of this one
+    // (the registers are free by then): with one workgroup per CU nothing else would hide their latency.
+    uint32_t key[KPT];
+    auto load_keys = [&](uint32_t k0, uint32_t k1) {
 #pragma unroll
         for (int u = 0; u < KPT; u++) {
             const uint32_t i = k0 + u * PK + threadIdx.x;
             key[u] = i < k1 ? in[i] : 0u;
         }
+    };
+    int s; uint32_t k0, k1;
+    tile_bounds(blockIdx.x, s, k0, k1);
+    load_keys(k0, k1);
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        __syncthreads();                    // the previous tile's copy-out has read hist / lofs / sorted
+        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < KPT; u++)
             if (k0 + u * PK + threadIdx.x < k1) atomicAdd(&hist[(key[u] >> shift) & bmask], 1u);
@@ -342,6 +372,8 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
                 sorted[atomicAdd(&lcur[bk], 1u)] = (bk << 16) | (key[u] & 0xffffu);
             }
         if (mine) dl[threadIdx.x] = make_uint2(r0 + gb - o, o + (cap > gb ? cap - gb : 0u));
+        tile_bounds(t + gridDim.x, s, k0, k1);
+        load_keys(k0, k1);
         __syncthreads();
         const uint32_t total = lofs[g.nb2 - 1] + hist[g.nb2 - 1];
         for (uint32_t i = threadIdx.x; i < total; i += PK) {

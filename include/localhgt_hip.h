@@ -67,6 +67,19 @@ int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank,
 /* resident index straight from sequences already in host memory (bench / tests): contig c is
  * ascii[off[c] .. off[c+1]) */
 int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* off, long n_contigs);
+/* ---- The resident form of the reference.  form 0 (default): the index file's layout, e stored hashes
+ * per position (4e bytes per base: 156 GB for a 13 Gbase catalogue), read by phase B as read_index does (E:933-945).  form 1:
+ * the BASES, as three bit-planes over the indexed contigs (3/8 byte per base: 4.9 GB), and phase B recomputes the hashes read_ref
+ * would have stored (E:786-813; an invalid k-mer is hash 0, E:808-810) -- same flags, peaks, ids and votes, no index file read.
+ * The packed form is filled from bases only: lhgt_reference_load_fasta, lhgt_index_from_memory, lhgt_synth_reference*;
+ * lhgt_index_load refuses it.  Changing the form drops a resident reference of the other form. */
+int lhgt_set_reference_form(lhgt_ctx* ctx, int form);
+int lhgt_reference_info(lhgt_ctx* ctx, int* form, unsigned long long* resident_bytes);
+/* the coder of an existing index file (saved_random_coder E:1224-1242) without its hashes */
+int lhgt_index_read_coder(lhgt_ctx* ctx, const char* index_path);
+/* read_ref (E:727-886) + read_index (E:888-979) without the file in between: the FASTA's contigs longer than k become resident
+ * in the context's form, numbered as the index numbers them; genome_len_path (nullable) also writes genome.len.txt (E:773, 878) */
+int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char* genome_len_path, long* n_contigs, long* n_bases);
 
 /* ---- reads: sampling ratio (cal_sam_ratio E:1244-1270) and the resident pair store */
 int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, long* n_records);

@@ -123,7 +123,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt_pairs_clear(c);
     lhgt::ingest_free(c);
     lhgt_ingest_pool_free(c);
-    for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
+    for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_peak_kmer, (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],
                     (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_contig_id_adj})
@@ -142,6 +142,27 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
 int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads) {
     if (!ctx || threads < 1 || threads > 99) LHGT_FAIL(LHGT_E_ARG, "thread emulation: 1 (off) .. 99 threads (split_ref holds 100 groups, E:1284)");
     ctx->emu_threads = threads;
+    return LHGT_OK;
+}
+
+// 0 = the index file's hashes resident (4e bytes per base), 1 = packed bases resident (3/8 byte per base), hashes recomputed by
+// phase B.  Takes effect for the next reference made resident; a resident reference of the other form is dropped.
+int lhgt_set_reference_form(lhgt_ctx* ctx, int form) {
+    if (!ctx || form < 0 || form > 1) LHGT_FAIL(LHGT_E_ARG, "reference form: 0 (index) or 1 (packed)");
+    if ((form == 1) == ctx->ref_packed) return LHGT_OK;
+    if (ctx->index_resident) {
+        LHGT_DEVICE_ENTRY(ctx);
+        LHGT_TRY(lhgt::index_layout(ctx, std::vector<uint32_t>()));
+        ctx->index_resident = false;
+    }
+    ctx->ref_packed = form == 1;
+    return LHGT_OK;
+}
+
+int lhgt_reference_info(lhgt_ctx* ctx, int* form, unsigned long long* resident_bytes) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (form) *form = ctx->ref_packed ? 1 : 0;
+    if (resident_bytes) *resident_bytes = !ctx->index_resident ? 0ull : ctx->ref_packed ? 12ull * ctx->ref_plane_words : 4ull * ctx->index_words;
     return LHGT_OK;
 }
 

@@ -953,6 +953,70 @@ int lhgt_index_load(lhgt_ctx* ctx, const char* index_path, long* n_contigs, long
     return lhgt_index_load_shard(ctx, index_path, 0, 1, n_contigs, n_bases);
 }
 
+// saved_random_coder (E:1224-1242) alone: the coder of an existing index file, none of its hashes
+int lhgt_index_read_coder(lhgt_ctx* ctx, const char* index_path) {
+    if (!ctx || !index_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    FILE* f = fopen(index_path, "rb");
+    if (!f) LHGT_FAIL(LHGT_E_IO, "cannot open %s", index_path);
+    uint32_t w[LHGT_CODER_SLOTS];
+    const size_t got = fread(w, 4, LHGT_CODER_SLOTS, f);
+    fclose(f);
+    if (got != (size_t)LHGT_CODER_SLOTS) LHGT_FAIL(LHGT_E_FORMAT, "%s: not an index file (no coder header)", index_path);
+    int16_t cc[LHGT_CODER_SLOTS];
+    for (int i = 0; i < LHGT_CODER_SLOTS; i++) cc[i] = (int16_t)w[i];
+    return lhgt_coder_set(ctx, cc);
+}
+
+// The reference made resident straight from the FASTA, in the context's form (lhgt_set_reference_form): what read_ref
+// (E:727-886) would put into the index file and read_index (E:888-979) would read back -- the same contigs (length > k), the same
+// sequential numbering, the same hashes -- without the file in between.  In the packed form only the bases become resident
+// (3/8 byte per base instead of 4e) and phase B recomputes the hashes.  genome_len_path (nullable): also write genome.len.txt.
+int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char* genome_len_path, long* n_contigs, long* n_bases) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || !fasta_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: call lhgt_coder_generate, lhgt_coder_set or lhgt_index_read_coder first");
+    const int k = ctx->k;
+    FILE* lenf = nullptr;
+    if (genome_len_path && !(lenf = fopen(genome_len_path, "w"))) LHGT_FAIL(LHGT_E_IO, "cannot write %s", genome_len_path);
+    std::vector<uint32_t> lens;
+    int rc = for_each_contig(fasta_path, k, [&](const std::string& name, long ref_index, const uint8_t*, long len, long cum) -> int {
+        if (lenf) fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", name.c_str(), ref_index, len, cum);
+        if (len >= (1L << 32)) LHGT_FAIL(LHGT_E_FORMAT, "contig %s has %ld bases", name.c_str(), len);
+        lens.push_back((uint32_t)len);
+        return LHGT_OK;
+    });
+    if (lenf) fclose(lenf);
+    LHGT_TRY(rc);
+    LHGT_TRY(index_layout(ctx, lens));
+    LHGT_TRY(write_index_lens(ctx));
+    const size_t SPAN = (size_t)256 << 20;
+    std::vector<uint8_t> span;
+    std::vector<uint64_t> coff(1, 0);
+    std::vector<long> contig_of;
+    long ci = 0;
+    auto flush = [&]() -> int {
+        if (contig_of.empty()) return LHGT_OK;
+        LHGT_TRY(ws_reserve(ctx, span.size() + 32, 0));
+        LHGT_TRY(stage_ascii(ctx, 0, span.data(), span.size()));
+        LHGT_TRY(install_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span.size(), coff.data(), contig_of.data(), (long)contig_of.size()));
+        span.clear();
+        coff.assign(1, 0);
+        contig_of.clear();
+        return LHGT_OK;
+    };
+    rc = for_each_contig(fasta_path, k, [&](const std::string&, long, const uint8_t* seq, long len, long) -> int {
+        if (!span.empty() && span.size() + (size_t)len > SPAN) LHGT_TRY(flush());
+        span.insert(span.end(), seq, seq + len);
+        coff.push_back(span.size());
+        contig_of.push_back(ci++);
+        return LHGT_OK;
+    });
+    if (rc == LHGT_OK) rc = flush();
+    if (n_contigs) *n_contigs = (long)ctx->contigs.size();
+    if (n_bases) *n_bases = (long)ctx->n_pos;
+    return rc;
+}
+
 int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank, int shard_world, long* n_contigs, long* n_bases) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !index_path) LHGT_FAIL(LHGT_E_ARG, "null argument");

@@ -117,6 +117,39 @@ __global__ void __launch_bounds__(256) hash_span_positions(const uint32_t* __res
     for (int i = 0; i < hp.e; i++) o[i] = wnb == 0 ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;   // quirk Q6
 }
 
+// ---------------------------------------------------------------- the packed form of the resident reference
+// A span of back-to-back sequences (ASCII, device) -> the flat bit-planes.  The span's indexed contigs occupy the flat positions
+// [fb[0], fb[n]); contig c starts at flat position fb[c] and at span offset src[c] (sequences that are not indexed lie between
+// them in the span and are skipped).  Thread = one word of the planes; words at the ends of the range are shared with the
+// neighbouring spans, hence atomicOr into planes that were cleared when the layout was made.
+__global__ void __launch_bounds__(256) pack_span_flat(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ fb,
+                                                      const uint64_t* __restrict__ src, int n, uint32_t* __restrict__ planes,
+                                                      uint64_t plane_words) {
+    const uint64_t F0 = fb[0], F1 = fb[n];
+    const uint64_t w = (F0 >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (F1 == F0 || w > ((F1 - 1) >> 5)) return;
+    const uint64_t x0 = w * 32 > F0 ? w * 32 : F0, x1 = w * 32 + 32 < F1 ? w * 32 + 32 : F1;
+    int lo = 0, hi = n;                   // last c with fb[c] <= x0
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fb[mid] <= x0) lo = mid; else hi = mid; }
+    int c = lo;
+    uint64_t c_end = fb[c + 1];
+    uint64_t c_src = src[c], c_fb = fb[c];       // flat position x of contig c is ascii[c_src + (x - c_fb)]
+    uint32_t whi = 0, wlo = 0, wnb = 0;
+    for (uint64_t x = x0; x < x1; x++) {
+        while (x >= c_end) { c++; c_end = fb[c + 1]; c_src = src[c]; c_fb = fb[c]; }
+        const uint32_t code = base_code(ascii[c_src + (x - c_fb)]);
+        const uint32_t bit = 0x80000000u >> (x & 31);
+        if (code == 4) wnb |= bit;
+        else {
+            if (code & 2) whi |= bit;
+            if (code & 1) wlo |= bit;
+        }
+    }
+    if (whi) atomicOr(planes + w, whi);
+    if (wlo) atomicOr(planes + plane_words + w, wlo);
+    if (wnb) atomicOr(planes + 2 * plane_words + w, wnb);
+}
+
 // the length word in front of every contig's hashes in the resident index ([u32 len][(len-k+1)*e u32], E:785, 847)
 __global__ void __launch_bounds__(256) write_contig_lens(const ContigDev* __restrict__ contigs, long n, uint32_t* __restrict__ index) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,9 +213,41 @@ int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, co
     return LHGT_OK;
 }
 
+int install_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const long* contig_of, long n_c) {
+    if (span_len <= 0 || n_c <= 0) return LHGT_OK;
+    if (!ctx->ref_packed) {
+        std::vector<uint64_t> ow((size_t)n_c);
+        for (long c = 0; c < n_c; c++) ow[c] = contig_of[c] < 0 ? ~0ull : ctx->contigs[(size_t)contig_of[c]].hash_word;
+        return hash_span_dev_ascii(ctx, d_ascii, span_len, coff, ow.data(), n_c, ctx->d_index);
+    }
+    std::vector<uint64_t> meta;           // fb[0..n] then src[0..n)
+    std::vector<uint64_t> src;
+    for (long c = 0; c < n_c; c++)
+        if (contig_of[c] >= 0) {
+            const ContigDev& cd = ctx->contigs[(size_t)contig_of[c]];
+            if (!meta.empty() && meta.back() != cd.flat_base) LHGT_FAIL(LHGT_E_STATE, "span contigs are not consecutive in the flat layout");
+            if (meta.empty()) meta.push_back(cd.flat_base);
+            meta.push_back(cd.flat_base + cd.len);
+            src.push_back(coff[c]);
+        }
+    const long n = (long)src.size();
+    if (n == 0) return LHGT_OK;
+    const uint64_t F0 = meta.front(), F1 = meta.back();
+    meta.insert(meta.end(), src.begin(), src.end());
+    LHGT_TRY(ws_reserve(ctx, 0, meta.size() * 2 + 8));
+    uint64_t* d_meta = (uint64_t*)ctx->d_ws_words;
+    LHGT_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t n_w = ((F1 - 1) >> 5) - (F0 >> 5) + 1;
+    hipLaunchKernelGGL(pack_span_flat, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, ctx->stream, d_ascii, d_meta, d_meta + n + 1, (int)n,
+                       ctx->d_ref_planes, (uint64_t)ctx->ref_plane_words);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays and the workspace are reused by the next span
+    return LHGT_OK;
+}
+
 int write_index_lens(lhgt_ctx* ctx) {
     const long n = (long)ctx->contigs.size();
-    if (n == 0) return LHGT_OK;
+    if (n == 0 || ctx->ref_packed) return LHGT_OK;
     hipLaunchKernelGGL(write_contig_lens, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_contigs, n, ctx->d_index);
     LHGT_HIP(hipGetLastError());
     return LHGT_OK;
@@ -372,8 +437,9 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
 // ---------------------------------------------------------------- index layout / install
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index) {
     const int k = ctx->k, e = ctx->e;
-    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count})
+    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_ref_planes, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count})
         if (p) hipFree(p);
+    ctx->d_ref_planes = nullptr; ctx->ref_plane_words = 0;
     ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr;
     ctx->contigs.clear();
     ctx->contig_first_tile.clear();
@@ -399,7 +465,14 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     ctx->n_tiles = (long)tiles.size();
     ctx->index_resident = true;
     if (ctx->contigs.empty()) return LHGT_OK;
-    LHGT_HIP(hipMalloc(&ctx->d_index, word * 4));
+    if (ctx->ref_packed) {
+        ctx->ref_plane_words = (size_t)((flat + 31) / 32) + 2;    // a window is cut from two consecutive words
+        LHGT_HIP(hipMalloc(&ctx->d_ref_planes, 3 * ctx->ref_plane_words * 4));
+        LHGT_HIP(hipMemsetAsync(ctx->d_ref_planes, 0, 3 * ctx->ref_plane_words * 4, ctx->stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        LHGT_HIP(hipMalloc(&ctx->d_index, word * 4));
+    }
     LHGT_HIP(hipMalloc(&ctx->d_contigs, ctx->contigs.size() * sizeof(ContigDev)));
     LHGT_HIP(hipMalloc(&ctx->d_tiles, tiles.size() * sizeof(TileDev)));
     LHGT_HIP(hipMalloc(&ctx->d_flags, flat));
@@ -421,6 +494,8 @@ int index_install(lhgt_ctx* ctx, const uint32_t* w, size_t n_words, bool /*words
 // split_ref, E:1280-1330, but balanced exactly).  Contig numbers (ref_index) remain global.
 int index_install_shard(lhgt_ctx* ctx, const uint32_t* w_all, size_t n_words_all, int rank, int world) {
     const int k = ctx->k, e = ctx->e;
+    if (ctx->ref_packed)
+        LHGT_FAIL(LHGT_E_STATE, "the packed reference form is filled from the bases (lhgt_reference_load_fasta), not from the hashes of an index file");
     std::vector<uint32_t> lens_all;
     std::vector<size_t> starts;
     size_t pos = 0;
@@ -537,13 +612,14 @@ int lhgt_index_from_memory(lhgt_ctx* ctx, const uint8_t* ascii, const uint64_t* 
         long q = p;
         while (q < n_contigs && (q == p || off[q + 1] - off[p] <= SPAN)) q++;
         const uint64_t span_len = off[q] - off[p];
-        std::vector<uint64_t> coff((size_t)(q - p) + 1), ow((size_t)(q - p));
+        std::vector<uint64_t> coff((size_t)(q - p) + 1);
+        std::vector<long> contig_of((size_t)(q - p));
         for (long r = p; r <= q; r++) coff[r - p] = off[r] - off[p];
-        for (long r = p; r < q; r++) ow[r - p] = (long)(off[r + 1] - off[r]) > ctx->k ? ctx->contigs[ci++].hash_word : ~0ull;
+        for (long r = p; r < q; r++) contig_of[r - p] = (long)(off[r + 1] - off[r]) > ctx->k ? (long)ci++ : -1L;
         if (span_len) {
             LHGT_TRY(ws_reserve(ctx, (size_t)span_len + 32, 0));
             LHGT_TRY(stage_ascii(ctx, 0, ascii + off[p], (size_t)span_len));
-            LHGT_TRY(hash_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span_len, coff.data(), ow.data(), q - p, ctx->d_index));
+            LHGT_TRY(install_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span_len, coff.data(), contig_of.data(), q - p));
         }
         p = q;
     }

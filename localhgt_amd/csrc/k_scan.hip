@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __rest
 // ---- B1
 template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                const RefSource rs, const uint32_t* __restrict__ counts,
                                                 int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ nzmask,
                                                 const uint32_t* __restrict__ satline) {
     const TileDev t = tiles[blockIdx.x];
@@ -72,10 +72,10 @@ __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tile
         if (j >= c.len) break;
         uint8_t f = 0, nz = 0;
         if (j < nk) {  // the last k-1 positions have no k-mer: zero (quirk Q1 contract)
-            const uint32_t* hp = index + c.hash_word + j * e;
+            const RefKmer km = ref_kmer(rs, c, j, k, e);
             int hc = 0;
             for (int i = 0; i < e; i++) {
-                uint32_t h = hp[i];
+                uint32_t h = ref_hash(rs, km, i);
                 uint32_t cnt = 0u;                                 // hash 0 = invalid (E:936-941)
                 if (h != 0) {
                     if (SAT && ((satline[h >> 13] >> ((h >> 8) & 31u)) & 1u)) cnt = 3u;   // the whole 256-slot line is saturated
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tile
 // tiles stays a lower bound, nothing reads it.  e <= 3.
 template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                     const RefSource rs, const uint32_t* __restrict__ counts,
                                                      int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
                                                      const uint32_t* __restrict__ satline, const uint32_t* __restrict__ list /* nullable */) {
     const TileDev t = tiles[list ? list[blockIdx.x] : blockIdx.x];
@@ -116,10 +116,10 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
         if (j >= c.len) break;
         uint8_t f = 0x80, ps = 0x70;   // the last k-1 positions have no k-mer: exact zeros (quirk Q1 contract)
         if (j < nk) {
-            const uint32_t* hp = index + c.hash_word + j * e;
+            const RefKmer km = ref_kmer(rs, c, j, k, e);
             uint32_t h[3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) h[i] = i < e ? hp[i] : 0u;
+            for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
             const bool sample = (j & 7) == 0;
             uint32_t known = 0, is3 = 0;
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
 // window_good, like the unsettled tiles of the single-first form.  flags bit 7 = "single and trio are exact" (some probed hash
 // read 3, or all were probed); pstate as above.  Same peaks, ids and votes as the exact form.
 __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                     const RefSource rs, const uint32_t* __restrict__ counts,
                                                      int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate) {
     const TileDev t = tiles[blockIdx.x];
     const ContigDev c = contigs[t.contig];
@@ -162,10 +162,10 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
         if (j >= c.len) break;
         uint8_t f = 0x80, ps = 0x70;   // the last k-1 positions have no k-mer: exact zeros (quirk Q1 contract)
         if (j < nk) {
-            const uint32_t* hp = index + c.hash_word + j * e;
+            const RefKmer km = ref_kmer(rs, c, j, k, e);
             uint32_t h[3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) h[i] = i < e ? hp[i] : 0u;
+            for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
             uint32_t known = 0, is3 = 0;
             bool all3 = true;
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
 
 // the remaining probes of the listed tiles and of the HL2 positions their window sums look back on
 __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ index,
+                                                     const uint32_t* __restrict__ list, const RefSource rs,
                                                      const uint32_t* __restrict__ counts, int k, int e, uint8_t* __restrict__ flags,
                                                      uint8_t* __restrict__ pstate) {
     const TileDev t = tiles[list[blockIdx.x]];
@@ -202,11 +202,11 @@ __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__
         const uint8_t ps = pstate[c.flat_base + j];
         uint32_t known = ps >> 4, is3 = ps & 7u;
         if (j < nk) {
-            const uint32_t* hp = index + c.hash_word + j * e;
+            const RefKmer km = ref_kmer(rs, c, j, k, e);
 #pragma unroll
             for (int i = 0; i < 3; i++)
                 if (i < e && !((known >> i) & 1u)) {
-                    const uint32_t h = hp[i];
+                    const uint32_t h = ref_hash(rs, km, i);
                     const uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;
                     if (cnt == 3u) is3 |= 1u << i;
                 }
@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(1024) tile_chunk_scan(uint32_t* __restrict__ v
 
 // ---- B5
 __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                     const RefSource rs, const uint32_t* __restrict__ counts,
                                                      const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
@@ -738,10 +738,10 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
             loci[2 * (long)id + 1] = (int32_t)j;
         }
         if (j < nk) {  // E:247,262; beyond nk the hit array is zero anyway
-            const uint32_t* hp = index + c.hash_word + j * e;
+            const RefKmer km = ref_kmer(rs, c, j, k, e);
             const uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u;
             for (int i = 0; i < e; i++) {
-                uint32_t h = hp[i];
+                uint32_t h = ref_hash(rs, km, i);
                 // hit > 0 for this hash: the bit ref_flags recorded (hashes 8.., and all of them after the lite form, are probed again)
                 if (nzmask && i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
 // one (hash, id) registration per peak position and hash with count > 0.  Order of registrations is irrelevant
 // (they are replayed with atomicMax).
 __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                 const uint32_t* __restrict__ index, const uint32_t* __restrict__ counts,
+                                                 const RefSource rs, const uint32_t* __restrict__ counts,
                                                  const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                  const uint32_t* __restrict__ tile_base,
                                                  int k, int e, uint32_t id_base, int32_t* __restrict__ loci_out,
@@ -794,10 +794,10 @@ __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ til
             loci_out[2 * (long)lid + 1] = (int32_t)j;
         }
         if (j < nk) {
-            const uint32_t* hp = index + c.hash_word + j * e;
+            const RefKmer km = ref_kmer(rs, c, j, k, e);
             const uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u;
             for (int i = 0; i < e; i++) {
-                uint32_t h = hp[i];
+                uint32_t h = ref_hash(rs, km, i);
                 if (nzmask && i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     unsigned long long slot = atomicAdd(n_regs, 1ull);
                     regs_out[2 * slot] = h;
@@ -826,6 +826,15 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
 }  // namespace lhgt
 
 using namespace lhgt;
+
+static RefSource ref_source(const lhgt_ctx* ctx) {
+    RefSource rs{};
+    rs.index = ctx->ref_packed ? nullptr : ctx->d_index;
+    rs.planes = ctx->d_ref_planes;
+    rs.plane_words = ctx->ref_plane_words;
+    rs.hp = ctx->hp;
+    return rs;
+}
 
 // B1-B4 on the resident contigs: flags, and tile_count turned into exclusive local ids.
 static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_t* total_new, unsigned long long* n_selected) {
@@ -880,7 +889,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
         LHGT_HIP(hipMemcpyAsync(d_list, pl.data(), pl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LHGT_HIP(hipMemcpyAsync(d_list + pl.size(), pw.data(), pw.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(ref_flags_lite<false>, dim3((unsigned)pl.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts,
+        hipLaunchKernelGGL(ref_flags_lite<false>, dim3((unsigned)pl.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts,
                            k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list);
         hipLaunchKernelGGL(window_lite, dim3((unsigned)pw.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags,
                            ctx->d_tile_good, (uint32_t*)nullptr, d_cnt, d_list + pl.size());
@@ -896,7 +905,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (sparse_form) {
-        hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+        hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                            ctx->d_nzmask);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
@@ -910,17 +919,17 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, near a window that reaches the trio threshold %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
-            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_index,
+            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
                                ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
             hipLaunchKernelGGL(window_good, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good);
         }
     } else if (ctx->scan_lite) {
         if (use_sat)
-            hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+            hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);
         else
-            hipLaunchKernelGGL(ref_flags_lite<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+            hipLaunchKernelGGL(ref_flags_lite<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
@@ -933,17 +942,17 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, not settled by the lower bound %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
-            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_index,
+            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
                                ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
             hipLaunchKernelGGL(window_good, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good);
         }
     } else {
         if (use_sat)
-            hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+            hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline);
         else
-            hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index, ctx->d_counts, k, e, ctx->d_flags,
+            hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         hipLaunchKernelGGL(window_good, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, (const uint32_t*)nullptr, 0, one_min, three_min,
@@ -1094,7 +1103,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, id_end > max_peak ? id_end : max_peak));
     if (ctx->n_tiles > 0)
-        hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
+        hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
                        ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, emu ? ctx->d_contig_id_adj : nullptr);
     LHGT_HIP(hipGetLastError());
@@ -1157,7 +1166,7 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
     LHGT_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     unsigned long long cnt = 0;
     if (ctx->n_tiles > 0 && ctx->local_new > 0) {
-        hipLaunchKernelGGL(emit_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_index,
+        hipLaunchKernelGGL(emit_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                            ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
                            ctx->d_emit_regs, d_cnt);
         LHGT_HIP(hipGetLastError());

@@ -146,17 +146,18 @@ static int synth_reference_pieces(lhgt_ctx* ctx, const SynthSpec& s, const uint6
         long q = p;
         while (q < piece1 && (q == p || cuts[q + 1] - cuts[p] <= SPAN)) q++;
         const uint64_t span0 = cuts[p], span_len = cuts[q] - cuts[p];
-        std::vector<uint64_t> coff((size_t)(q - p) + 1), ow((size_t)(q - p));
+        std::vector<uint64_t> coff((size_t)(q - p) + 1);
+        std::vector<long> contig_of((size_t)(q - p));
         for (long r = p; r <= q; r++) coff[r - p] = cuts[r] - span0;
         for (long r = p; r < q; r++) {
             const uint64_t len = cuts[r + 1] - cuts[r];
-            ow[r - p] = (long)len <= k ? ~0ull : ctx->contigs[ci++].hash_word;
+            contig_of[r - p] = (long)len <= k ? -1L : ci++;
         }
         LHGT_TRY(ws_reserve(ctx, (size_t)span_len + 32, 0));
         hipLaunchKernelGGL(synth_flat_ascii, dim3((unsigned)((span_len + 255) / 256)), dim3(256), 0, ctx->stream, s, span0, span_len, ctx->d_ws_ascii);
         LHGT_HIP(hipGetLastError());
         if (host_ascii) LHGT_HIP(hipMemcpyAsync(host_ascii + (span0 - cuts[piece0]), ctx->d_ws_ascii, (size_t)span_len, hipMemcpyDeviceToHost, ctx->stream));
-        LHGT_TRY(hash_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span_len, coff.data(), ow.data(), q - p, ctx->d_index));
+        LHGT_TRY(install_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span_len, coff.data(), contig_of.data(), q - p));
         p = q;
     }
     (void)e;

@@ -111,6 +111,11 @@ struct lhgt_ctx {
     // I
     uint32_t* d_index = nullptr;
     size_t index_words = 0;
+    // the packed form of the resident reference (lhgt_set_reference_form): three bit-planes over the flat positions instead of
+    // the e stored hashes per position; phase B recomputes the hashes (lhgt_hash.hpp: RefSource)
+    bool ref_packed = false;
+    uint32_t* d_ref_planes = nullptr;
+    size_t ref_plane_words = 0;
     std::vector<lhgt::ContigDev> contigs;
     lhgt::ContigDev* d_contigs = nullptr;
     lhgt::TileDev* d_tiles = nullptr;
@@ -204,6 +209,9 @@ int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint3
 int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const uint64_t* out_word,
                         long n_c, uint32_t* d_out);
 int write_index_lens(lhgt_ctx* ctx);
+// one span of back-to-back sequences in device memory becomes resident in the context's reference form: hashed into d_index
+// (hash_span_dev_ascii) or packed into the flat planes.  contig_of[c] = resident contig of span sequence c, or -1 (not indexed).
+int install_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const long* contig_of, long n_c);
 int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
                             const uint8_t* pair_flags);
 // the loader's form: per-mate arrays in pinned host memory (start offsets into d_ascii and word offsets into the batch, u32),

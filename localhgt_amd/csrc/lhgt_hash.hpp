@@ -32,6 +32,43 @@ __device__ __forceinline__ uint32_t hash_from_windows(uint32_t whi, uint32_t wlo
     return fwd < rc ? fwd : rc;
 }
 
+// Where phase B takes the e hashes of reference position (contig c, offset j) from.  Two resident forms of the reference:
+//   index  : the index file's own layout, [u32 len][(len-k+1)*e u32] per contig (E:785-813) -- 4e bytes per base, read as stored;
+//   packed : three bit-planes (hi bit, lo bit, not-a-base) over the flat positions of the indexed contigs -- 3/8 byte per base,
+//            the hashes recomputed where they are needed (156 GB -> 4.9 GB for a 13 Gbase catalogue).
+//            An invalid k-mer hashes to 0 exactly as the index stores it (E:808-810, quirk Q6).
+struct RefSource {
+    const uint32_t* index;    // non-null: index form
+    const uint32_t* planes;   // packed form: plane m starts at planes + m * plane_words, position x at bit 31 - (x & 31) of word x >> 5
+    uint64_t plane_words;
+    HashParams hp;
+};
+struct RefKmer {
+    const uint32_t* stored;   // index form: the e hashes
+    uint32_t whi, wlo, rhi, rlo;
+    bool valid;
+};
+__device__ __forceinline__ RefKmer ref_kmer(const RefSource& rs, const ContigDev& c, long j, int k, int e) {
+    RefKmer km{};
+    if (rs.index) {
+        km.stored = rs.index + c.hash_word + j * e;
+    } else {
+        const uint64_t x = c.flat_base + (uint64_t)j;
+        const uint32_t* w = rs.planes + (x >> 5);
+        const int r = (int)(x & 31);
+        km.whi = window32(w[0], w[1], r) >> (32 - k);
+        km.wlo = window32(w[rs.plane_words], w[rs.plane_words + 1], r) >> (32 - k);
+        km.valid = (window32(w[2 * rs.plane_words], w[2 * rs.plane_words + 1], r) >> (32 - k)) == 0u;
+        km.rhi = brev_k(km.whi, k);
+        km.rlo = brev_k(km.wlo, k);
+    }
+    return km;
+}
+__device__ __forceinline__ uint32_t ref_hash(const RefSource& rs, const RefKmer& km, int i) {
+    if (rs.index) return km.stored[i];
+    return km.valid ? hash_from_windows(km.whi, km.wlo, km.rhi, km.rlo, rs.hp.mask[i]) : 0u;
+}
+
 // ASCII -> 2-bit code, 4 = not a base (E:1112-1151: upper and lower case ACGT only)
 __host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
     switch (c | 0x20) {

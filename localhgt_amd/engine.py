@@ -91,6 +91,25 @@ class Engine:
         _lib.check(self.lib.lhgt_index_load_shard(self.h, index_path.encode(), rank, world, C.byref(nc), C.byref(nb)))
         return nc.value, nb.value
 
+    def set_reference_form(self, packed: bool):
+        """False: the index file's hashes resident (4e bytes per base).  True: the bases resident as bit-planes (3/8 byte per
+        base), phase B recomputes the hashes.  A resident reference of the other form is dropped."""
+        _lib.check(self.lib.lhgt_set_reference_form(self.h, 1 if packed else 0))
+
+    def reference_info(self) -> dict:
+        form, nbytes = C.c_int(0), C.c_uint64(0)
+        _lib.check(self.lib.lhgt_reference_info(self.h, C.byref(form), C.byref(nbytes)))
+        return {"form": "packed" if form.value else "index", "resident_bytes": nbytes.value}
+
+    def index_read_coder(self, index_path: str):
+        _lib.check(self.lib.lhgt_index_read_coder(self.h, index_path.encode()))
+
+    def reference_load_fasta(self, fasta: str, genome_len_path: Optional[str] = None) -> Tuple[int, int]:
+        nc, nb = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_reference_load_fasta(self.h, fasta.encode(), genome_len_path.encode() if genome_len_path else None,
+                                                      C.byref(nc), C.byref(nb)))
+        return nc.value, nb.value
+
     def index_from_memory(self, ascii_bases: np.ndarray, offsets: np.ndarray):
         a = np.ascontiguousarray(ascii_bases, dtype=np.uint8)
         o = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -65,8 +65,12 @@ def _warn_if_ids_desynchronise(genome_len_path: str, k: int, log) -> None:
             f"the interval file follow the reference's sequential numbering (E:905) and will not match; get_bed_file refuses them")
 
 
-def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) -> dict:
+def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, ref_form=None) -> dict:
     """The whole path A->D. `dist` is a localhgt_amd.dist.Exchange (or None for one GPU).
+    ref_form (default: LHGT_REF_FORM in the environment, "index"): "packed" keeps the reference's BASES resident (3/8 byte per
+    base, read from the FASTA) instead of the index file's hashes (12 bytes per base at e = 3) and lets phase B recompute the
+    hashes: same interval file, no 12-bytes-per-base file read or written -- only the coder header of an existing index is
+    used; without one the coder is drawn as the index build would draw it and genome.len.txt is written.
     emulate_threads (default: LHGT_EMULATE_THREADS=1 in the environment): give the result of the reference's `-t threads` run
     without its races -- its per-thread read partition, id ranges and sentinel lines -- instead of the
     `-t 1` result.  `localhgt bkp` passes -t 10 by default, so that is what a user's reference run produced."""
@@ -83,6 +87,11 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) ->
     ratio = eng.sam_ratio(a.fq1, a.sample)                     # E:1392-1398
     log(f"down-sampling ratio: {ratio}%.")
     idx = index_name(a.fasta, a.k, a.e)
+    if ref_form is None:
+        ref_form = os.environ.get("LHGT_REF_FORM", "index")
+    if ref_form not in ("index", "packed"):
+        raise SystemExit(f"LHGT_REF_FORM: 'index' or 'packed', not {ref_form!r}")
+    packed = ref_form == "packed"
     # E:1403-1410.  random_coder draws k*(e//3+1) values from the rand() stream before the sampling
     # array is filled (quirk Q3), so every rank draws them when rank 0 has to build the index.
     built = not os.path.exists(idx) if rank == 0 else False
@@ -90,21 +99,29 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) ->
         built = dist.broadcast_flag(built)
     if built:
         eng.coder_generate()
-        if rank == 0:
+        if rank == 0 and not packed:
             log("Reference index not detected, start index...")
             eng.index_build(a.fasta, idx, a.fasta + ".genome.len.txt")
-        if dist:
+        if dist and not packed:
             dist.barrier()
+    elif packed:
+        eng.index_read_coder(idx)                              # E:1413: the coder the index was built with
     # Phase B form: replicated index (default) or reference-sharded (LHGT_SHARD_INDEX=1, or =auto when the index
     # does not fit next to the other tables of one GPU): see localhgt_amd/dist.py
     shard_index = False
-    if dist:
+    if dist and not packed:
         mode = os.environ.get("LHGT_SHARD_INDEX", "auto")
         shard_index = mode == "1" or (mode == "auto" and os.path.getsize(idx) > 180e9)
     # (Uploading the index on a second host thread next to the FASTQ pipeline was tried and lost: 0.23 s instead of 0.17 s for
     # 4 M pairs + a 1.2 GB index -- the page faults and the pinning of the index mapping fight the parse threads.)
     t_i0 = time.time()
-    if shard_index:
+    if packed:
+        eng.set_reference_form(True)
+        log("reference form: packed bases from the FASTA, hashes recomputed in the scan")
+        n_contigs, n_bases = eng.reference_load_fasta(a.fasta, a.fasta + ".genome.len.txt" if built and rank == 0 else None)
+        if dist and built:
+            dist.barrier()
+    elif shard_index:
         n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
     else:
         n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
@@ -138,7 +155,8 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None) ->
     t5 = time.time()
     log(f"Finish with time:\t{t5 - t0:.2f}")
     rep = dict(pairs_seen=seen, pairs_kept=kept, n_contigs=n_contigs, n_bases=n_bases, n_peaks=n_peaks,
-               n_filtered=n_filtered, ratio=ratio, index_built=built, ingest_s=t1 - t0, index_s=t_i1 - t_i0, reads_s=t1 - t_r0, count_s=t2 - t1, scan_s=t3 - t2,
+               n_filtered=n_filtered, ratio=ratio, index_built=built and not packed, ref_form=ref_form,
+               ref_resident_bytes=eng.reference_info()["resident_bytes"], ingest_s=t1 - t0, index_s=t_i1 - t_i0, reads_s=t1 - t_r0, count_s=t2 - t1, scan_s=t3 - t2,
                vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
                vote_kernel_ms=eng.phase_ms(2))
     eng.close()

@@ -161,3 +161,64 @@ def test_ragged_reference_forms_agree(eng):
     eng.count_kmers()
     _, _, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
     assert votes[1] >= 1
+
+
+def test_packed_reference_equals_index_form(eng):
+    """SURVEY.md 8f rank 1 at full size: the 13 Gbase reference resident as bit-planes (4.9 GB) instead of the index file's
+    hashes (156 GB), hashes recomputed inside every form of B1 and in the peak registry -- the same flags, loci, peak_kmer and
+    votes, table by table"""
+    eng.pairs_clear()
+    eng.synth_options(0, 20, 1000)
+    eng.synth_pairs(1, 2, NC, CL, 0, 25_000_000)
+    eng.synth_options(0, 20, 0)
+    eng.counts_clear()
+    eng.count_kmers()
+    info = eng.reference_info()
+    assert info["form"] == "index" and info["resident_bytes"] > 150e9
+    want = {dbg: _scan(eng, dbg)[0] for dbg in (8192, 0, 4096, 16384)}
+    want_votes = _vote(eng, 0)
+    assert want[8192][0] > 1000 and want_votes[1] >= 1
+    try:
+        eng.set_reference_form(True)
+        assert eng.reference_info()["resident_bytes"] == 0           # the index form was dropped
+        eng.synth_reference(1, NC, CL)
+        info = eng.reference_info()
+        assert info["form"] == "packed" and info["resident_bytes"] < 5e9
+        for dbg, expect in want.items():
+            got, sinfo = _scan(eng, dbg)
+            assert got == expect, (dbg, sinfo, got, expect)
+        assert _vote(eng, 0) == want_votes
+        assert _vote(eng, 4) == want_votes
+    finally:
+        eng.set_reference_form(False)
+        eng.synth_reference(1, NC, CL)                               # the module's other tests expect the index form
+
+
+def test_progenomes_scale_reference_on_one_gpu():
+    """BASELINE configs[4] names a reference of more than 50 GB, whose index (12 bytes per base: 600 GB) only fits sharded over
+    eight GPUs.  Packed, 50 Gbase are 19 GB: the whole reference, its per-position flags and the tables fit ONE GPU.  Forms of
+    the scan and of the vote against each other, as at 13 Gbase."""
+    from localhgt_amd.engine import Engine
+    nc = 50_000
+    with Engine(K, E) as e:
+        e.rng_seed(1)
+        e.coder_generate()
+        e.set_reference_form(True)
+        e.synth_reference(1, nc, CL)
+        info = e.reference_info()
+        assert info["form"] == "packed" and 18e9 < info["resident_bytes"] < 20e9
+        e.synth_options(0, 20, 1000)
+        e.synth_pairs(1, 2, nc, CL, 0, 25_000_000)
+        e.synth_options(0, 20, 0)
+        e.count_kmers()
+        exact, info_x = _scan(e, 8192)
+        assert info_x["tiles"] == nc * CL // 2000 and exact[0] > 1000
+        for dbg in (0, 4096, 16384):
+            got, sinfo = _scan(e, dbg)
+            assert got == exact, (dbg, sinfo)
+        votes = _vote(e, 0)
+        assert votes == _vote(e, 32) == _vote(e, 4) and votes[1] >= 1
+        n_peaks = e.ref_scan(0.1, 0.08, 300_000_000)
+        loci, _ = e.peaks_export(n_peaks)
+        contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
+        assert (np.diff(contig * (1 << 32) + pos) > 0).all() and contig.max() <= nc and pos.max() < CL

@@ -143,11 +143,38 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         out = str(tmp_path / "interval.txt")
         eng.write_intervals(out)
         assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+        # the other resident forms of the reference: the bases as bit-planes with the hashes recomputed in the scan (packed), and
+        # the hashes computed straight from the FASTA without the index file -- every form of B1, the same oracle answers
+        index_bytes = eng.reference_info()["resident_bytes"]
+        for packed in (True, False):
+            eng.set_reference_form(packed)
+            assert eng.reference_info()["resident_bytes"] == 0
+            if packed:
+                with pytest.raises(RuntimeError):
+                    eng.index_load(index)                 # hashes cannot be turned back into bases
+            assert eng.reference_load_fasta(fa2) == (n_contigs, n_bases)
+            info = eng.reference_info()
+            assert info["form"] == ("packed" if packed else "index")
+            assert info["resident_bytes"] == (12 * ((n_bases + 31) // 32 + 2) if packed else index_bytes)
+            for flags in (8192, 0, 4096, 4096 | 256, 16384, 16384 | 256):
+                eng.set_debug(flags)
+                assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o
+                eng.vote()
+                loci_p, pf_p = eng.peaks_export(n_g)
+                assert (loci_p == loci_o[:2 * n_o]).all() and (pf_p == pf_o[:n_g]).all() and (eng.peak_kmer_export() == pk_o).all(), (packed, flags)
+                fl = eng.flags_export(0, n_bases)
+                assert (((fl ^ flags_g) & (0b1111111 if flags == 8192 else 0b1111100)) == 0).all(), (packed, flags)
+            eng.set_debug(0)
+            eng.write_intervals(out)
+            assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
 
 
 # ------------------------------------------------------------------ the 12-argument contract against the reference goldens
+@pytest.mark.parametrize("ref_form", ["index", "packed"])
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_extract_ref_matches_reference_golden(case_inputs, name, tmp_path):
+def test_extract_ref_matches_reference_golden(case_inputs, name, ref_form, tmp_path):
+    """ref_form "packed": the bases resident instead of the index file's hashes -- the same files out, and the 12-bytes-per-base
+    index is neither read (beyond its coder header, when the golden was made with the index in place) nor written"""
     from localhgt_amd import extract_ref, get_bed_file
     case = cases.CASES[name]
     fa, f1, f2, meta = case_inputs(name)
@@ -155,13 +182,19 @@ def test_extract_ref_matches_reference_golden(case_inputs, name, tmp_path):
     shutil.copy(fa, fa2)
     interval = str(tmp_path / "interval.txt")
     argv = cases.extract_ref_argv(case, f1, f2, fa2, interval)
-    for _ in range(2 if case.preexisting_index else 1):
-        rep = extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None, emulate_threads=case.threads > 1)
+    index = f"{fa2}.k{case.k}.h{case.e}.index.dat"
+    forms = (["index"] if case.preexisting_index else []) + [ref_form]      # a golden made with the index already in place (quirk Q3)
+    for form in forms:
+        rep = extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: None, emulate_threads=case.threads > 1, ref_form=form)
     gold = os.path.join(cases.GOLDEN_DIR, name)
-    assert rep["n_peaks"] == meta["raw_peaks"]
+    assert rep["n_peaks"] == meta["raw_peaks"] and rep["ref_form"] == ref_form
     assert open(interval).read() == open(os.path.join(gold, "interval.txt")).read()
     assert open(fa2 + ".genome.len.txt").read() == open(os.path.join(gold, "genome.len.txt")).read()
-    assert cases.sha256_file(f"{fa2}.k{case.k}.h{case.e}.index.dat") == meta["sha256"]["index.dat"]
+    if ref_form == "packed" and not case.preexisting_index:
+        assert not os.path.exists(index)
+        assert rep["ref_resident_bytes"] < 0.2 * rep["n_bases"] * 4 * case.e + 64
+    else:
+        assert cases.sha256_file(index) == meta["sha256"]["index.dat"]
     if case.bed_defined:
         n = get_bed_file.write_bed(fa2, interval)
         assert open(interval + ".bed").read() == open(os.path.join(gold, "interval.txt.bed")).read()

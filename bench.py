@@ -103,7 +103,7 @@ def collect_pmc(args, passes, timeout_s=420):
             "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-verify",
             "--workload", args.workload, "--pairs", str(args.pairs), "--contigs", str(args.contigs),
             "--contig-len", str(args.contig_len), "-k", str(args.k), "-e", str(args.e), "--count-mode", str(args.count_mode),
-            "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs)]
+            "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs), "--ref-form", args.ref_form]
     for counters in passes:
         d = tempfile.mkdtemp(prefix="lhgt_pmc_", dir="/tmp")
         try:
@@ -410,6 +410,9 @@ def main():
     ap.add_argument("-e", type=int, default=3)
     ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index (the default at N > 1)")
     ap.add_argument("--replicate-index", action="store_true", help="at N > 1 keep the whole index on every GPU and scan it redundantly (no exchange in phase B)")
+    ap.add_argument("--ref-form", choices=["index", "packed"], default="index",
+                    help="resident form of the reference: the index file's hashes (12 B/base at e=3; what configs[2] names) or the packed bases "
+                         "(3/8 B/base), phase B recomputing the hashes")
     ap.add_argument("--count-mode", type=int, default=-1, help="-1 = engine default (adaptive), 0 = direct CAS kernel, 1 = radix partition")
     ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
@@ -436,7 +439,7 @@ def main():
         return dry_run(args, rank, world, local)
 
     k, e, L = args.k, args.e, 150
-    workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}" + (f"_s{args.sample_contigs}" if args.sample_contigs else "")
+    workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}" + (f"_s{args.sample_contigs}" if args.sample_contigs else "") + ("_packed" if args.ref_form == "packed" else "")
     # ---- measured HBM traffic: child runs of this command under rocprofv3 --pmc, before this process touches the GPU
     pmc, pmc_note, traffic, traffic_src = None, "", {}, None
     if world == 1 and not args.no_pmc and not args.force_dist:
@@ -479,6 +482,8 @@ def main():
         eng.set_count_mode(args.count_mode)
     if args.debug:
         eng.set_debug(args.debug)
+    if args.ref_form == "packed":
+        eng.set_reference_form(True)
     t0 = time.time()
     # phase B shards by contig range -- each rank scans 1/N of the reference and the peaks are exchanged
     shard_index = dist is not None and (args.shard_index or (world > 1 and not args.replicate_index))
@@ -511,6 +516,8 @@ def main():
     if shard_index:
         ref_bases = (args.contigs * (rank + 1) // world - args.contigs * rank // world) * args.contig_len   # this rank's contig range
     ref_bytes = ref_bases * (4 * e + 64 * e)              # 204 B per reference base
+    if args.ref_form == "packed":
+        ref_bytes = ref_bases * 64 * e + ref_bases // 4   # "recomputing hashes from a 2-bit reference: 0.25 + 192 B/base"
     n_batches = -(-args.pairs // (16 << 20))
     scan = eng.scan_info()
     kern = {"count_A": per["count_A"], "ref_flags": per_ms[3], "vote_kernel": per["vote_C"]}
@@ -534,7 +541,7 @@ def main():
     # bytes a step cannot avoid: the packed reads twice (A and C), the resident index once, count table written and read,
     # peak_kmer cleared (E:1458) -- everything else is the price of random access
     read_store = args.pairs * 2 * 3 * ((L + 31) // 32 + 1) * 4
-    compulsory = 2 * read_store + ref_bases * 4 * e + 2 * ((1 << k) // 4) + (1 << k) * 4
+    compulsory = 2 * read_store + (ref_bases * 3 // 8 if args.ref_form == "packed" else ref_bases * 4 * e) + 2 * ((1 << k) // 4) + (1 << k) * 4
     step_s = dt / args.steps
     line = {
         "metric": METRIC, "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
@@ -542,7 +549,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{2 if (args.contigs, args.pairs, args.sample_contigs) == (13000, 100_000_000, 0) else 1 if (args.contigs, args.pairs, args.sample_contigs) == (1000, 10_000_000, 0) else '-'}]: "
                                f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
-                               f"index resident), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
+                               f"{'packed bases resident, hashes recomputed' if args.ref_form == 'packed' else 'index resident'}), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
                    "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
                    "parallelism": f"reads sharded x{world}" + (", index sharded" if shard_index else ", phase B replicated" if world > 1 else "")},
         "world_size": torch.distributed.get_world_size() if dist else 1,
@@ -566,6 +573,7 @@ def main():
     }
     eng.pairs_clear()
     if world == 1 and not args.no_extras and not args.debug:
+        args.headline_peaks = (n_peaks, nf)
         line["secondary"] = secondary_workloads(eng, args, wl, local, traffic_1g)
     eng.close()
     if dist:
@@ -628,6 +636,19 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
                      input_pairs=args.pairs, input_pairs_per_s_M=round(args.pairs / (d["ms_per_step"] * 1e-3) / 1e6, 1))
             out["uhgg_default_sample"] = d
             eng.pairs_clear()
+            if args.ref_form == "index":
+                # the headline workload once more with the reference resident as packed bases (3/8 byte per base instead of the
+                # index file's 12): phase B recomputes the hashes instead of streaming them -- same peaks, 32x less resident
+                index_bytes = eng.reference_info()["resident_bytes"]
+                eng.set_reference_form(True)
+                eng.synth_reference(1, args.contigs, args.contig_len)
+                eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, args.pairs, L)
+                d = leg(eng, args.pairs)
+                d.update(workload="configs[2] with the reference resident as packed bases (lhgt_set_reference_form(1), LHGT_REF_FORM=packed), hashes recomputed in phase B",
+                         resident_reference_bytes=eng.reference_info()["resident_bytes"], resident_index_bytes=index_bytes,
+                         same_peaks_as_headline=(d["raw_peaks"], d["filtered_peaks"]) == tuple(args.headline_peaks))
+                out["uhgg_packed_reference"] = d
+                eng.pairs_clear()
     except Exception as ex:
         out["uhgg_error"] = str(ex)
     eng.close()

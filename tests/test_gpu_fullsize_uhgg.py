@@ -159,8 +159,21 @@ def test_ragged_reference_forms_agree(eng):
     eng.synth_options(0, 20, 0)
     eng.counts_clear()
     eng.count_kmers()
-    _, _, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
+    exact, _, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
     assert votes[1] >= 1
+    # the packed form of the same ragged reference: contigs start anywhere inside a plane word (shared words are OR-ed together by
+    # neighbouring spans), contigs <= k are absent from the planes as they are from the index
+    try:
+        eng.set_reference_form(True)
+        eng.synth_reference_cuts(1, NC, CL, cuts)
+        assert eng.reference_info()["form"] == "packed"
+        for dbg in (8192, 0):
+            got, sinfo = _scan(eng, dbg)
+            assert got == exact, ("ragged packed", dbg, sinfo, got, exact)
+        assert _vote(eng, 0) == votes
+    finally:
+        eng.set_reference_form(False)
+        eng.synth_reference(1, NC, CL)                               # the module's other tests expect the regular reference, index form
 
 
 def test_packed_reference_equals_index_form(eng):
@@ -175,6 +188,7 @@ def test_packed_reference_equals_index_form(eng):
     eng.count_kmers()
     info = eng.reference_info()
     assert info["form"] == "index" and info["resident_bytes"] > 150e9
+    assert eng.scan_info()["tiles"] == NC * CL // 2000, "another test left its own reference resident"
     want = {dbg: _scan(eng, dbg)[0] for dbg in (8192, 0, 4096, 16384)}
     want_votes = _vote(eng, 0)
     assert want[8192][0] > 1000 and want_votes[1] >= 1
@@ -192,33 +206,3 @@ def test_packed_reference_equals_index_form(eng):
     finally:
         eng.set_reference_form(False)
         eng.synth_reference(1, NC, CL)                               # the module's other tests expect the index form
-
-
-def test_progenomes_scale_reference_on_one_gpu():
-    """BASELINE configs[4] names a reference of more than 50 GB, whose index (12 bytes per base: 600 GB) only fits sharded over
-    eight GPUs.  Packed, 50 Gbase are 19 GB: the whole reference, its per-position flags and the tables fit ONE GPU.  Forms of
-    the scan and of the vote against each other, as at 13 Gbase."""
-    from localhgt_amd.engine import Engine
-    nc = 50_000
-    with Engine(K, E) as e:
-        e.rng_seed(1)
-        e.coder_generate()
-        e.set_reference_form(True)
-        e.synth_reference(1, nc, CL)
-        info = e.reference_info()
-        assert info["form"] == "packed" and 18e9 < info["resident_bytes"] < 20e9
-        e.synth_options(0, 20, 1000)
-        e.synth_pairs(1, 2, nc, CL, 0, 25_000_000)
-        e.synth_options(0, 20, 0)
-        e.count_kmers()
-        exact, info_x = _scan(e, 8192)
-        assert info_x["tiles"] == nc * CL // 2000 and exact[0] > 1000
-        for dbg in (0, 4096, 16384):
-            got, sinfo = _scan(e, dbg)
-            assert got == exact, (dbg, sinfo)
-        votes = _vote(e, 0)
-        assert votes == _vote(e, 32) == _vote(e, 4) and votes[1] >= 1
-        n_peaks = e.ref_scan(0.1, 0.08, 300_000_000)
-        loci, _ = e.peaks_export(n_peaks)
-        contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
-        assert (np.diff(contig * (1 << 32) + pos) > 0).all() and contig.max() <= nc and pos.max() < CL

@@ -1,0 +1,61 @@
+"""BASELINE.json configs[4]: a reference of more than 50 Gbase on ONE GPU, possible with the packed resident form (3/8 byte per
+base).  Its own module: the 13 Gbase engine of test_gpu_fullsize_uhgg.py (156 GB of index) must be gone before this one
+allocates its per-position arrays."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CL, E = 1_000_000, 3
+FLAG_BITS = 0b1111100
+
+
+def _scan(eng, debug):
+    eng.set_debug(debug)
+    n = eng.ref_scan(0.1, 0.08, 300_000_000)
+    info = eng.scan_info()
+    res = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_FLAGS, FLAG_BITS))
+    eng.set_debug(0)
+    return res, info
+
+
+def _vote(eng, debug):
+    eng.set_debug(debug)
+    eng.ref_scan(0.1, 0.08, 300_000_000)
+    eng.vote()
+    d = eng.digest(eng.DIGEST_VOTES)
+    eng.set_debug(0)
+    return d
+
+
+@pytest.mark.parametrize("k", [32, 21])
+def test_progenomes_scale_reference_on_one_gpu(k):
+    """BASELINE configs[4] names a reference of more than 50 GB, whose index (12 bytes per base: 600 GB) only fits sharded over
+    eight GPUs.  Packed, 50 Gbase are 19 GB: the whole reference, its per-position flags and the tables fit ONE GPU.  Forms of
+    the scan and of the vote against each other, as at 13 Gbase, for both ends of the config's k = 21 / 32 sweep (at k = 21 the
+    2^21-slot table is full after the first reads: every window is good, the contrast is flat, peaks only at contig ends).
+    The sample: 10 M pairs from 300 of the genomes -- a denser one turns every window of 50 Gbase good and overflows max_peak."""
+    from localhgt_amd.engine import Engine
+    nc = 50_000
+    with Engine(k, E) as e:
+        e.rng_seed(1)
+        e.coder_generate()
+        e.set_reference_form(True)
+        e.synth_reference(1, nc, CL)
+        info = e.reference_info()
+        assert info["form"] == "packed" and 18e9 < info["resident_bytes"] < 20e9
+        e.synth_options(0, 20, 300)
+        e.synth_pairs(1, 2, nc, CL, 0, 10_000_000)
+        e.synth_options(0, 20, 0)
+        e.count_kmers()
+        exact, info_x = _scan(e, 8192)
+        assert info_x["tiles"] == nc * CL // 2000 and exact[0] > 1000, (info_x, exact)
+        for dbg in (0, 4096, 16384):
+            got, sinfo = _scan(e, dbg)
+            assert got == exact, (dbg, sinfo)
+        votes = _vote(e, 0)
+        assert votes == _vote(e, 32) == _vote(e, 4) and (votes[1] >= 1 or k < 32), votes
+        n_peaks = e.ref_scan(0.1, 0.08, 300_000_000)
+        loci, _ = e.peaks_export(n_peaks)
+        contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
+        assert (np.diff(contig * (1 << 32) + pos) > 0).all() and contig.max() <= nc and pos.max() < CL

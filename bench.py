@@ -242,6 +242,7 @@ def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_
         a = extract_ref.Args(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, 10, k, 300_000_000, e, 1, 1.0)
         reps = [extract_ref.run(a, device=device, log=lambda *x: None) for _ in range(3)]
         built, cached = reps[0], min(reps[1:], key=lambda r: r["total_s"])
+        packed = min((extract_ref.run(a, device=device, log=lambda *x: None, ref_form="packed") for _ in range(2)), key=lambda r: r["total_s"])
         fq_bytes = os.path.getsize(f1) + os.path.getsize(f2)
         return {"value": round(n_pairs / cached["total_s"] / 1e6, 3), "unit": "M paired-reads/s",
                 "what": f"extract_ref on {n_pairs} pairs ({fq_bytes / 1e9:.2f} GB of FASTQ, page cache) vs {n_contigs} x {contig_len} bp, "
@@ -251,6 +252,9 @@ def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_
                 "kernels_ms": round(cached["count_kernel_ms"] + cached["scan_kernel_ms"] + cached["vote_kernel_ms"], 1),
                 "fastq_GB_per_s": round(fq_bytes / cached["total_s"] / 1e9, 2),
                 "with_index_build": {"value": round(n_pairs / built["total_s"] / 1e6, 3), "total_s": round(built["total_s"], 3)},
+                "with_packed_reference": {"value": round(n_pairs / packed["total_s"] / 1e6, 3), "total_s": round(packed["total_s"], 3),
+                                          "reference_load_s": round(packed.get("index_s", 0.0), 3), "same_peaks": (packed["n_peaks"], packed["n_filtered"]) == (cached["n_peaks"], cached["n_filtered"]),
+                                          "what": "LHGT_REF_FORM=packed: no index file read; the FASTA text goes to the GPU, is stripped and packed there, phase B recomputes the hashes"},
                 "raw_peaks": cached["n_peaks"], "filtered_peaks": cached["n_filtered"]}
 
 
@@ -458,12 +462,15 @@ def main():
         if pmc1:
             traffic_1g = pmc_traffic(pmc1)
         pmc_note = "; ".join(x for x in (pmc_note, note1) if x)
-    if world == 1:
+    if world == 1 or rank == 0:
+        # N > 1: every rank runs phases A and C on a read shard of the N = 1 size and shape, so the per-GPU traffic of those kernels
+        # is the N = 1 figure (profiles/traffic_per_launch.json, only while its source stamps match); a sharded phase B scans
+        # 1/N of the reference and its bytes are scaled by that share further down
         fresh, stale = committed_traffic(workload_tag)
         for ph, rec in fresh.items():
             if ph not in traffic:
                 traffic[ph] = rec
-                traffic_src = traffic_src or "profiles/traffic_per_launch.json (measured on these sources)"
+                traffic_src = traffic_src or ("profiles/traffic_per_launch.json (measured on these sources" + (", at N = 1: per-GPU work of A and C is the same)" if world > 1 else ")"))
 
     import torch
     from localhgt_amd.engine import Engine
@@ -536,7 +543,10 @@ def main():
                         f"{n_batches} launches per step", algo, n_batches, l2_ceiling if sparse_vote else hbm_ceiling),
     }
     dominant = max(("ref_flags", "vote_kernel"), key=kern.get)   # of the two that are ONE kernel each; phase A is a family of three
-    src = traffic_src if not (shard_index and world > 1) else None
+    src = traffic_src
+    if shard_index and world > 1 and traffic.get("ref_flags"):
+        share = ref_bases / (args.contigs * args.contig_len)
+        traffic["ref_flags"] = {kk: (int(v * share) if isinstance(v, (int, float)) else v) for kk, v in traffic["ref_flags"].items()}
     roof = {ph: roofline_entry(desc[ph][0], kern[ph], desc[ph][2], desc[ph][1], traffic.get(ph) if src else None, src, desc[ph][3]) for ph in kern}
     # bytes a step cannot avoid: the packed reads twice (A and C), the resident index once, count table written and read,
     # peak_kmer cleared (E:1458) -- everything else is the price of random access

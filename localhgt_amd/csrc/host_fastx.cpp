@@ -198,11 +198,9 @@ static size_t line_start_at_or_after(const uint8_t* p, size_t n, size_t from) {
     return nl ? (size_t)(nl - p) + 1 : n;
 }
 
-static long count_lines(const uint8_t* p, size_t b0, size_t b1, size_t n) {
+// newlines in [q, end): 16 bytes at a time (compare, mask, popcount): ~4x a memchr per 60-150-byte line
+static long count_nl(const uint8_t* q, const uint8_t* end) {
     long c = 0;
-    const uint8_t* q = p + b0;
-    const uint8_t* end = p + b1;
-    // newlines 16 bytes at a time (compare, mask, popcount): ~4x a memchr per 60-150-byte FASTQ line
     const __m128i nl16 = _mm_set1_epi8('\n');
     for (; q + 64 <= end; q += 64) {
         const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)q), nl16));
@@ -212,6 +210,11 @@ static long count_lines(const uint8_t* p, size_t b0, size_t b1, size_t n) {
         c += __builtin_popcountll((unsigned long long)m0 | ((unsigned long long)m1 << 16) | ((unsigned long long)m2 << 32) | ((unsigned long long)m3 << 48));
     }
     for (; q < end; q++) c += *q == '\n';
+    return c;
+}
+
+static long count_lines(const uint8_t* p, size_t b0, size_t b1, size_t n) {
+    long c = count_nl(p + b0, p + b1);
     if (b1 == n && n > b0 && p[n - 1] != '\n') c++;   // last line without a newline is still a line (std::getline)
     return c;
 }
@@ -537,6 +540,117 @@ static int default_threads() {
     if (e && atoi(e) > 0) return atoi(e);
     unsigned hc = std::thread::hardware_concurrency();
     return hc == 0 ? 4 : (hc > 48 ? 48 : (int)hc);   // the parse is bound by host memory bandwidth well before that
+}
+
+// ---------------------------------------------------------------- FASTA by line structure, bases never touched on the host
+// read_ref (E:761-880) reads the file with std::getline: a line that starts with '>' opens the next sequence, every other line
+// is appended to the open one (so its bases are the bytes of its lines without the '\n'; a '\r' stays in).  The same sequences
+// fall out of the positions of the '>' lines and the newline counts between them -- found by memchr and SSE2 compares on all
+// cores, block by block -- and the bases themselves go to the GPU as file text (strip_fasta_block, k_ingest.hip).
+struct FastaSeq {
+    uint64_t text_begin = 0, text_end = 0;   // its lines in the file, newlines included
+    uint64_t len = 0;                        // its bases
+    uint64_t name_at = 0;                    // header text after '>' up to get_read_ID's cut (E:303-311); sequence 0 is called "start"
+    uint32_t name_len = 0;
+};
+struct FastaIndex {
+    std::vector<FastaSeq> seqs;              // seqs[i] follows the i-th '>' line; seqs[0] = the lines before the first one
+    std::vector<uint64_t> nl_before;         // newlines before each FASTA_BLK-byte block of the file, and the total at the end
+    uint64_t nl_in(const uint8_t* p, uint64_t a, uint64_t b) const {
+        if (a >= b) return 0;
+        const uint64_t ba = a / FASTA_BLK, bb = b / FASTA_BLK;
+        if (ba == bb) return (uint64_t)count_nl(p + a, p + b);
+        return (uint64_t)count_nl(p + a, p + (ba + 1) * FASTA_BLK) + (nl_before[bb] - nl_before[ba + 1]) + (uint64_t)count_nl(p + bb * FASTA_BLK, p + b);
+    }
+    std::string name(const uint8_t* p, size_t i) const { return i == 0 ? std::string("start") : std::string((const char*)p + seqs[i].name_at, seqs[i].name_len); }
+};
+
+static void fasta_scan(const Mapped& fa, int threads, FastaIndex* fx) {
+    const uint8_t* p = fa.p;
+    const uint64_t n = fa.n;
+    const uint64_t n_blk = (n + FASTA_BLK - 1) / FASTA_BLK;
+    const uint64_t CH = (uint64_t)1024 * FASTA_BLK;   // 4 MiB per task
+    const long n_ch = (long)((n + CH - 1) / CH);
+    std::vector<uint32_t> nl(n_blk);
+    std::vector<std::vector<uint64_t>> hdr((size_t)n_ch);
+    parallel_for(n_ch, threads, [&](long c) {
+        const uint64_t b0 = (uint64_t)c * CH, b1 = b0 + CH < n ? b0 + CH : n;
+        for (uint64_t x = b0; x < b1; x += FASTA_BLK) nl[x / FASTA_BLK] = (uint32_t)count_nl(p + x, p + (x + FASTA_BLK < b1 ? x + FASTA_BLK : b1));
+        for (const uint8_t* q = p + b0; q < p + b1; q++) {   // '>' is rare outside header lines: memchr runs at memory speed
+            q = (const uint8_t*)memchr(q, '>', (size_t)(p + b1 - q));
+            if (!q) break;
+            const uint64_t at = (uint64_t)(q - p);
+            if (at == 0 || p[at - 1] == '\n') hdr[(size_t)c].push_back(at);
+        }
+    });
+    fx->nl_before.assign(n_blk + 1, 0);
+    for (uint64_t b = 0; b < n_blk; b++) fx->nl_before[b + 1] = fx->nl_before[b] + nl[b];
+    fx->seqs.assign(1, FastaSeq());
+    for (const auto& v : hdr)
+        for (uint64_t h : v) {
+            const uint8_t* e = (const uint8_t*)memchr(p + h, '\n', (size_t)(n - h));
+            const uint64_t he = e ? (uint64_t)(e - p) : n;
+            fx->seqs.back().text_end = h;
+            FastaSeq q;
+            q.text_begin = he < n ? he + 1 : n;
+            const size_t idl = read_id_len(p + h, (size_t)(he - h));
+            q.name_at = h + (idl ? 1 : 0);
+            q.name_len = (uint32_t)(idl ? idl - 1 : 0);
+            fx->seqs.push_back(q);
+        }
+    fx->seqs.back().text_end = n;
+    parallel_for((long)fx->seqs.size(), threads, [&](long i) {
+        FastaSeq& q = fx->seqs[(size_t)i];
+        q.len = (q.text_end - q.text_begin) - fx->nl_in(p, q.text_begin, q.text_end);
+    });
+}
+
+// Spans of consecutive sequences, about span_bases bases each (one long sequence is a span of its own): the span's text is
+// copied to the GPU as it is in the file, stripped of header lines and newlines there, and fn sees its bases back to back in
+// device memory: fn(d_bases, n_bases, coff[0..n_c], first sequence, n_c) with sequence first + c at [coff[c], coff[c+1]).
+template <class Fn>
+static int fasta_spans(lhgt_ctx* ctx, const Mapped& fa, const FastaIndex& fx, uint64_t span_bases, Fn fn) {
+    const uint8_t* p = fa.p;
+    const size_t ns = fx.seqs.size();
+    std::vector<uint64_t> kept, seg, coff;
+    for (size_t s0 = 0; s0 < ns;) {
+        size_t s1 = s0;
+        uint64_t bases = 0;
+        while (s1 < ns && (s1 == s0 || bases + fx.seqs[s1].len <= span_bases)) bases += fx.seqs[s1++].len;
+        if (bases) {
+            const uint64_t A = fx.seqs[s0].text_begin & ~(uint64_t)(FASTA_BLK - 1), B = fx.seqs[s1 - 1].text_end;
+            const uint64_t text_len = B - A, n_blocks = (text_len + FASTA_BLK - 1) / FASTA_BLK;
+            kept.assign(n_blocks, 0);
+            seg.assign(2 * (s1 - s0), 0);
+            coff.assign(s1 - s0 + 1, 0);
+            for (size_t s = s0; s < s1; s++) {
+                seg[2 * (s - s0)] = fx.seqs[s].text_begin - A;
+                seg[2 * (s - s0) + 1] = fx.seqs[s].text_end - A;
+                coff[s - s0 + 1] = coff[s - s0] + fx.seqs[s].len;
+            }
+            uint64_t acc = 0;
+            size_t sc = s0;
+            for (uint64_t b = 0; b < n_blocks; b++) {
+                kept[b] = acc;
+                const uint64_t x0 = A + b * FASTA_BLK, x1 = x0 + FASTA_BLK < B ? x0 + FASTA_BLK : B;
+                while (sc < s1 && fx.seqs[sc].text_end <= x0) sc++;
+                for (size_t s = sc; s < s1 && fx.seqs[s].text_begin < x1; s++) {
+                    const uint64_t a = fx.seqs[s].text_begin > x0 ? fx.seqs[s].text_begin : x0, e = fx.seqs[s].text_end < x1 ? fx.seqs[s].text_end : x1;
+                    if (a >= e) continue;
+                    const bool whole = a == x0 && e == x0 + FASTA_BLK;
+                    acc += (e - a) - (whole ? fx.nl_before[x0 / FASTA_BLK + 1] - fx.nl_before[x0 / FASTA_BLK] : (uint64_t)count_nl(p + a, p + e));
+                }
+            }
+            if (acc != bases) LHGT_FAIL(LHGT_E_STATE, "FASTA span: %llu bases by blocks, %llu by sequences", (unsigned long long)acc, (unsigned long long)bases);
+            const size_t toff = ((size_t)bases + 32 + 255) & ~(size_t)255;   // bases at the front of the workspace, the text behind them
+            LHGT_TRY(ws_reserve(ctx, toff + (size_t)text_len + 32, 0));
+            LHGT_TRY(stage_ascii(ctx, toff, p + A, (size_t)text_len));
+            LHGT_TRY(strip_fasta_text(ctx, ctx->d_ws_ascii + toff, text_len, kept.data(), (long)n_blocks, seg.data(), (long)(s1 - s0), ctx->d_ws_ascii));
+            LHGT_TRY(fn((const uint8_t*)ctx->d_ws_ascii, (long)bases, coff.data(), s0, (long)(s1 - s0)));
+        }
+        s0 = s1;
+    }
+    return LHGT_OK;
 }
 
 }  // namespace lhgt
@@ -896,51 +1010,57 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
         fwrite(&w, 4, 1, idx);
     }
     long contigs = 0, bases = 0;
-    // Contigs are collected into spans of ~64 Mbase; a span is uploaded, packed and hashed by ONE launch, straight into the file's
-    // layout ([u32 len][(len-k+1)*e u32] per contig), and comes back as one copy and one write (a catalogue like UHGG has
-    // hundreds of thousands of contigs: two launches, a copy and two writes per contig is what the first version did).
-    const size_t SPAN = (size_t)64 << 20;
-    std::vector<uint8_t> span;
-    std::vector<uint64_t> coff(1, 0), ow;
+    // The file's sequences are taken in spans of ~64 Mbase; a span's text goes to the GPU as it is, is stripped, packed and hashed
+    // there by one launch each, straight into the file's layout ([u32 len][(len-k+1)*e u32] per contig), and comes back as one
+    // copy and one write (a catalogue like UHGG has hundreds of thousands of contigs: two launches, a copy and two writes per
+    // contig is what the first version did; the second still built every span byte by byte on one host thread).
+    const int k = ctx->k, e = ctx->e;
+    Mapped fa;
+    int rc = fa.open(fasta_path);
+    FastaIndex fx;
+    if (rc == LHGT_OK) {
+        fasta_scan(fa, default_threads(), &fx);
+        long cum = 0;
+        for (size_t i = 0; i < fx.seqs.size() && rc == LHGT_OK; i++) {
+            const long len = (long)fx.seqs[i].len;
+            cum += len;
+            if (len <= k) continue;                                        // E:772, 836; it still used up a ref_index (quirk Q7)
+            if (len >= (1L << 32)) { set_error("contig %s has %ld bases", fx.name(fa.p, i).c_str(), len); rc = LHGT_E_FORMAT; break; }
+            fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", fx.name(fa.p, i).c_str(), (long)i, len, cum);
+            contigs++;
+            bases += len;
+        }
+    }
+    std::vector<uint64_t> ow;
     std::vector<uint32_t> host;
-    uint64_t out_words = 0;
     uint32_t* d_out = nullptr;
     size_t d_cap = 0;
-    const int k = ctx->k, e = ctx->e;
-    auto flush = [&]() -> int {
-        if (ow.empty()) return LHGT_OK;
-        if (out_words > d_cap) {
-            if (d_out) hipFree(d_out);
-            d_out = nullptr;
-            d_cap = out_words + out_words / 4;
-            LHGT_HIP(hipMalloc(&d_out, d_cap * 4));
-        }
-        LHGT_TRY(ws_reserve(ctx, span.size() + 32, 0));
-        LHGT_TRY(stage_ascii(ctx, 0, span.data(), span.size()));
-        LHGT_TRY(hash_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span.size(), coff.data(), ow.data(), (long)ow.size(), d_out));
-        host.resize(out_words);
-        LHGT_HIP(hipMemcpyAsync(host.data(), d_out, out_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-        LHGT_HIP(hipStreamSynchronize(ctx->stream));
-        for (size_t c = 0; c < ow.size(); c++) host[ow[c] - 1] = (uint32_t)(coff[c + 1] - coff[c]);
-        if (fwrite(host.data(), 4, out_words, idx) != out_words) LHGT_FAIL(LHGT_E_IO, "short write to %s", index_path);
-        span.clear();
-        coff.assign(1, 0);
-        ow.clear();
-        out_words = 0;
-        return LHGT_OK;
-    };
-    int rc = for_each_contig(fasta_path, k, [&](const std::string& name, long ref_index, const uint8_t* seq, long len, long cum) -> int {
-        fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", name.c_str(), ref_index, len, cum);
-        if (!span.empty() && span.size() + (size_t)len > SPAN) LHGT_TRY(flush());
-        span.insert(span.end(), seq, seq + len);
-        coff.push_back(span.size());
-        ow.push_back(out_words + 1);
-        out_words += 1 + (uint64_t)(len - k + 1) * e;
-        contigs++;
-        bases += len;
-        return LHGT_OK;
-    });
-    if (rc == LHGT_OK) rc = flush();
+    if (rc == LHGT_OK)
+        rc = fasta_spans(ctx, fa, fx, (uint64_t)64 << 20, [&](const uint8_t* d_bases, long n_bases_span, const uint64_t* coff, size_t first, long n_c) -> int {
+            uint64_t out_words = 0;
+            ow.assign((size_t)n_c, ~0ull);
+            for (long c = 0; c < n_c; c++) {
+                const long len = (long)fx.seqs[first + (size_t)c].len;
+                if (len <= k) continue;
+                ow[(size_t)c] = out_words + 1;
+                out_words += 1 + (uint64_t)(len - k + 1) * e;
+            }
+            if (out_words == 0) return LHGT_OK;
+            if (out_words > d_cap) {
+                if (d_out) hipFree(d_out);
+                d_out = nullptr;
+                d_cap = out_words + out_words / 4;
+                LHGT_HIP(hipMalloc(&d_out, d_cap * 4));
+            }
+            LHGT_TRY(hash_span_dev_ascii(ctx, d_bases, n_bases_span, coff, ow.data(), n_c, d_out));
+            host.resize(out_words);
+            LHGT_HIP(hipMemcpyAsync(host.data(), d_out, out_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+            LHGT_HIP(hipStreamSynchronize(ctx->stream));
+            for (long c = 0; c < n_c; c++)
+                if (ow[(size_t)c] != ~0ull) host[ow[(size_t)c] - 1] = (uint32_t)(coff[c + 1] - coff[c]);
+            if (fwrite(host.data(), 4, out_words, idx) != out_words) LHGT_FAIL(LHGT_E_IO, "short write to %s", index_path);
+            return LHGT_OK;
+        });
     if (d_out) hipFree(d_out);
     fclose(idx);
     fclose(lenf);
@@ -976,42 +1096,36 @@ int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char*
     if (!ctx || !fasta_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: call lhgt_coder_generate, lhgt_coder_set or lhgt_index_read_coder first");
     const int k = ctx->k;
+    Mapped fa;
+    LHGT_TRY(fa.open(fasta_path));
+    FastaIndex fx;
+    fasta_scan(fa, default_threads(), &fx);
     FILE* lenf = nullptr;
     if (genome_len_path && !(lenf = fopen(genome_len_path, "w"))) LHGT_FAIL(LHGT_E_IO, "cannot write %s", genome_len_path);
     std::vector<uint32_t> lens;
-    int rc = for_each_contig(fasta_path, k, [&](const std::string& name, long ref_index, const uint8_t*, long len, long cum) -> int {
-        if (lenf) fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", name.c_str(), ref_index, len, cum);
-        if (len >= (1L << 32)) LHGT_FAIL(LHGT_E_FORMAT, "contig %s has %ld bases", name.c_str(), len);
+    long cum = 0;
+    for (size_t i = 0; i < fx.seqs.size(); i++) {
+        const long len = (long)fx.seqs[i].len;
+        cum += len;
+        if (len <= k) continue;                                            // E:772, 836
+        if (len >= (1L << 32)) {
+            if (lenf) fclose(lenf);
+            LHGT_FAIL(LHGT_E_FORMAT, "contig %s has %ld bases", fx.name(fa.p, i).c_str(), len);
+        }
+        if (lenf) fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", fx.name(fa.p, i).c_str(), (long)i, len, cum);
         lens.push_back((uint32_t)len);
-        return LHGT_OK;
-    });
+    }
     if (lenf) fclose(lenf);
-    LHGT_TRY(rc);
     LHGT_TRY(index_layout(ctx, lens));
     LHGT_TRY(write_index_lens(ctx));
-    const size_t SPAN = (size_t)256 << 20;
-    std::vector<uint8_t> span;
-    std::vector<uint64_t> coff(1, 0);
-    std::vector<long> contig_of;
     long ci = 0;
-    auto flush = [&]() -> int {
-        if (contig_of.empty()) return LHGT_OK;
-        LHGT_TRY(ws_reserve(ctx, span.size() + 32, 0));
-        LHGT_TRY(stage_ascii(ctx, 0, span.data(), span.size()));
-        LHGT_TRY(install_span_dev_ascii(ctx, ctx->d_ws_ascii, (long)span.size(), coff.data(), contig_of.data(), (long)contig_of.size()));
-        span.clear();
-        coff.assign(1, 0);
-        contig_of.clear();
-        return LHGT_OK;
-    };
-    rc = for_each_contig(fasta_path, k, [&](const std::string&, long, const uint8_t* seq, long len, long) -> int {
-        if (!span.empty() && span.size() + (size_t)len > SPAN) LHGT_TRY(flush());
-        span.insert(span.end(), seq, seq + len);
-        coff.push_back(span.size());
-        contig_of.push_back(ci++);
-        return LHGT_OK;
+    std::vector<long> contig_of;
+    int rc = fasta_spans(ctx, fa, fx, (uint64_t)256 << 20, [&](const uint8_t* d_bases, long n_bases_span, const uint64_t* coff, size_t first, long n_c) -> int {
+        contig_of.assign((size_t)n_c, -1L);
+        for (long c = 0; c < n_c; c++)
+            if ((long)fx.seqs[first + (size_t)c].len > k) contig_of[(size_t)c] = ci++;
+        return install_span_dev_ascii(ctx, d_bases, n_bases_span, coff, contig_of.data(), n_c);
     });
-    if (rc == LHGT_OK) rc = flush();
     if (n_contigs) *n_contigs = (long)ctx->contigs.size();
     if (n_bases) *n_bases = (long)ctx->n_pos;
     return rc;

@@ -150,6 +150,56 @@ __global__ void __launch_bounds__(256) pack_span_flat(const uint8_t* __restrict_
     if (wnb) atomicOr(planes + 2 * plane_words + w, wnb);
 }
 
+// ---------------------------------------------------------------- FASTA text -> its sequences back to back
+// The text of a stretch of a FASTA file lies in device memory as it is on disk (header lines, newlines and all); the host has
+// found the '>' lines and counted the newlines (host_fastx.cpp: FastaIndex).  seg[2s], seg[2s+1] = the bytes [begin, end) of
+// sequence s's lines inside the text; kept_before[b] = how many bytes of sequences that are not '\n' precede text block b
+// (FASTA_BLK bytes each).  A kept byte goes to out[kept_before + its rank inside the block]: the same stream of bases std::getline
+// and string concatenation build in read_ref (E:761-880; a '\r' stays in, as there), without a host pass over the bases.
+// Thread = 16 consecutive bytes, workgroup = one block.
+__global__ void __launch_bounds__(FASTA_BLK / 16) strip_fasta_block(const uint8_t* __restrict__ text, uint64_t text_len,
+                                                                    const uint64_t* __restrict__ kept_before,
+                                                                    const uint64_t* __restrict__ seg, int n_seg,
+                                                                    uint8_t* __restrict__ out) {
+    __shared__ int wsum[FASTA_BLK / 16 / 64];
+    const uint64_t x0 = (uint64_t)blockIdx.x * FASTA_BLK + (uint64_t)threadIdx.x * 16;
+    uint8_t c[16];
+    uint32_t keep = 0;
+    if (x0 < text_len) {
+        if (x0 + 16 <= text_len) {
+            const uint4 v = *(const uint4*)(text + x0);
+            memcpy(c, &v, 16);
+        } else {
+            for (int i = 0; i < 16; i++) c[i] = x0 + i < text_len ? text[x0 + i] : (uint8_t)'\n';
+        }
+        int lo = -1, hi = n_seg;              // last sequence whose lines begin at or before x0 (-1: none)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg[2 * mid] <= x0) lo = mid; else hi = mid; }
+        int s = lo;
+        uint64_t s_beg = s >= 0 ? seg[2 * s] : 0, s_end = s >= 0 ? seg[2 * s + 1] : 0;
+        uint64_t nxt = s + 1 < n_seg ? seg[2 * (s + 1)] : ~0ull;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint64_t x = x0 + i;
+            while (x >= nxt) { s++; s_beg = nxt; s_end = seg[2 * s + 1]; nxt = s + 1 < n_seg ? seg[2 * (s + 1)] : ~0ull; }
+            if (s >= 0 && x >= s_beg && x < s_end && c[i] != '\n') keep |= 1u << i;
+        }
+    }
+    const int cnt = __popc(keep), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int q = 0; q < wv; q++) off += wsum[q];
+    uint8_t* o = out + kept_before[blockIdx.x] + (uint64_t)(off + incl - cnt);
+    for (int i = 0; i < 16; i++)
+        if ((keep >> i) & 1u) *o++ = c[i];
+}
+
 // the length word in front of every contig's hashes in the resident index ([u32 len][(len-k+1)*e u32], E:785, 847)
 __global__ void __launch_bounds__(256) write_contig_lens(const ContigDev* __restrict__ contigs, long n, uint32_t* __restrict__ index) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,6 +292,24 @@ int install_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len,
                        ctx->d_ref_planes, (uint64_t)ctx->ref_plane_words);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays and the workspace are reused by the next span
+    return LHGT_OK;
+}
+
+// d_text[0 .. text_len) -> d_out: see strip_fasta_block.  kept_before (n_blocks entries) and seg (2 * n_seg entries) are host
+// arrays; they travel through the word workspace.
+int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, const uint64_t* kept_before, long n_blocks,
+                     const uint64_t* seg, long n_seg, uint8_t* d_out) {
+    if (text_len == 0 || n_blocks <= 0) return LHGT_OK;
+    if (n_blocks != (long)((text_len + FASTA_BLK - 1) / FASTA_BLK)) LHGT_FAIL(LHGT_E_ARG, "strip_fasta_text: %ld blocks for %llu bytes", n_blocks, (unsigned long long)text_len);
+    const size_t n64 = (size_t)n_blocks + 2 * (size_t)n_seg;
+    LHGT_TRY(ws_reserve(ctx, 0, 2 * n64 + 8));
+    uint64_t* d_meta = (uint64_t*)ctx->d_ws_words;
+    LHGT_HIP(hipMemcpyAsync(d_meta, kept_before, (size_t)n_blocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_seg) LHGT_HIP(hipMemcpyAsync(d_meta + n_blocks, seg, (size_t)n_seg * 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(strip_fasta_block, dim3((unsigned)n_blocks), dim3(FASTA_BLK / 16), 0, ctx->stream, d_text, text_len, d_meta,
+                       d_meta + n_blocks, (int)n_seg, d_out);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays and the workspace are reused
     return LHGT_OK;
 }
 

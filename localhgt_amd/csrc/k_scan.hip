@@ -63,8 +63,10 @@ template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                 const RefSource rs, const uint32_t* __restrict__ counts,
                                                 int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ nzmask,
-                                                const uint32_t* __restrict__ satline) {
-    const TileDev t = tiles[blockIdx.x];
+                                                const uint32_t* __restrict__ satline, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     for (int jj = threadIdx.x; jj < TILE; jj += BT) {
@@ -106,8 +108,10 @@ template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const RefSource rs, const uint32_t* __restrict__ counts,
                                                      int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
-                                                     const uint32_t* __restrict__ satline, const uint32_t* __restrict__ list /* nullable */) {
-    const TileDev t = tiles[list ? list[blockIdx.x] : blockIdx.x];
+                                                     const uint32_t* __restrict__ satline, const uint32_t* __restrict__ list /* nullable */, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[list ? list[blk] : blk];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     const uint32_t full = (1u << e) - 1u;
@@ -152,8 +156,10 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
 // read 3, or all were probed); pstate as above.  Same peaks, ids and votes as the exact form.
 __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const RefSource rs, const uint32_t* __restrict__ counts,
-                                                     int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate) {
-    const TileDev t = tiles[blockIdx.x];
+                                                     int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     const uint32_t full = (1u << e) - 1u;
@@ -189,8 +195,10 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
 __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ list, const RefSource rs,
                                                      const uint32_t* __restrict__ counts, int k, int e, uint8_t* __restrict__ flags,
-                                                     uint8_t* __restrict__ pstate) {
-    const TileDev t = tiles[list[blockIdx.x]];
+                                                     uint8_t* __restrict__ pstate, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[list[blk]];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     const uint32_t full = (1u << e) - 1u;
@@ -237,10 +245,12 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
 
 // does any window of the tile reach the `three` threshold?  (exact trio sums; `one` is not looked at: it is a lower bound here)
 __global__ void __launch_bounds__(BT) window_trio(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, int three_min,
-                                                  const uint8_t* __restrict__ flags, uint32_t* __restrict__ cand) {
+                                                  const uint8_t* __restrict__ flags, uint32_t* __restrict__ cand, long n_blk) {
     __shared__ int P3[N2], part[BT];
     __shared__ int any;
-    const TileDev t = tiles[blockIdx.x];
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
     const uint8_t* F = flags + c.flat_base;
@@ -265,7 +275,7 @@ __global__ void __launch_bounds__(BT) window_trio(const TileDev* __restrict__ ti
     }
     if (__ballot(mine) && (threadIdx.x & 63) == 0) any = 1;
     __syncthreads();
-    if (threadIdx.x == 0) cand[blockIdx.x] = (uint32_t)any;
+    if (threadIdx.x == 0) cand[blk] = (uint32_t)any;
 }
 
 // tiles that need exact flags: within three tiles (the 2560-position reach of the interval rules plus the contrast halo) of a
@@ -288,10 +298,12 @@ __global__ void __launch_bounds__(256) mark_need_tiles(const TileDev* __restrict
 // away from interval_select.
 __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   const uint32_t* __restrict__ list /* nullable: the tiles to do */, int keep7,
-                                                  int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good) {
+                                                  int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good, long n_blk) {
     __shared__ int P1[N2], P3[N2], part[BT];
     __shared__ int any_good, n_good;
-    const uint32_t tile = list ? list[blockIdx.x] : blockIdx.x;
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const uint32_t tile = list ? list[blk] : (uint32_t)blk;
     const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
@@ -350,10 +362,12 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
 __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good,
                                                   uint32_t* __restrict__ need, unsigned int* __restrict__ n_need,
-                                                  const uint32_t* __restrict__ pilot /* nullable: only count, over these tiles */) {
+                                                  const uint32_t* __restrict__ pilot /* nullable: only count, over these tiles */, long n_blk) {
     __shared__ int P1[N2], P3[N2], part[BT];
     __shared__ int n_good;
-    const uint32_t tile = pilot ? pilot[blockIdx.x] : blockIdx.x;
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const uint32_t tile = pilot ? pilot[blk] : (uint32_t)blk;
     const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
@@ -447,7 +461,7 @@ __global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restri
 __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, int k,
                                                       const uint32_t* __restrict__ active,
                                                       uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count,
-                                                      unsigned long long* __restrict__ n_selected) {
+                                                      unsigned long long* __restrict__ n_selected, long n_blk) {
     __shared__ unsigned long long gw[NW3];
     __shared__ int prevw[NW3], nextw[NW3];       // last good index in words <= w / first good index in words >= w
     __shared__ int P1[N4], part[BT];
@@ -455,7 +469,9 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
     __shared__ uint8_t sel[TILE], ins[TILE];
     __shared__ int n_new, n_sel, n_ins;
     static_assert(H3 >= HALO3 && H3 % 64 == 0 && H3 <= 2 * TILE, "halo");
-    const uint32_t tile = active[blockIdx.x];
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const uint32_t tile = active[blk];
     const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - H3;
@@ -707,14 +723,16 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
                                                      uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2,
-                                                     const uint32_t* __restrict__ id_adj /* nullable: per contig, -t N id ranges */) {
+                                                     const uint32_t* __restrict__ id_adj /* nullable: per contig, -t N id ranges */, long n_blk) {
     __shared__ int incl[TILE], part[BT];
-    const TileDev t = tiles[blockIdx.x];
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, nk = len - k + 1;
     const uint8_t* F = flags + c.flat_base;
-    uint32_t base = tile_base[blockIdx.x];
-    if (tile_base[blockIdx.x + 1] == base) return;  // no peak in this tile (uniform exit)
+    uint32_t base = tile_base[blk];
+    if (tile_base[blk + 1] == base) return;  // no peak in this tile (uniform exit)
     if (id_adj) base += id_adj[t.contig];           // thread j's ids start at j * (max_peak / N) (E:229-237)
     constexpr int CH = (TILE + BT - 1) / BT;
     const int b = threadIdx.x * CH, en = b + CH < TILE ? b + CH : TILE;
@@ -764,14 +782,16 @@ __global__ void __launch_bounds__(BT) emit_peaks(const TileDev* __restrict__ til
                                                  const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                  const uint32_t* __restrict__ tile_base,
                                                  int k, int e, uint32_t id_base, int32_t* __restrict__ loci_out,
-                                                 uint32_t* __restrict__ regs_out, unsigned long long* __restrict__ n_regs) {
+                                                 uint32_t* __restrict__ regs_out, unsigned long long* __restrict__ n_regs, long n_blk) {
     __shared__ int incl[TILE], part[BT];
-    const TileDev t = tiles[blockIdx.x];
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, nk = len - k + 1;
     const uint8_t* F = flags + c.flat_base;
-    const uint32_t base = tile_base[blockIdx.x];
-    if (tile_base[blockIdx.x + 1] == base) return;
+    const uint32_t base = tile_base[blk];
+    if (tile_base[blk + 1] == base) return;
     constexpr int CH = (TILE + BT - 1) / BT;
     const int b = threadIdx.x * CH, en = b + CH < TILE ? b + CH : TILE;
     int s = 0;
@@ -844,7 +864,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     if (ctx->n_tiles == 0) return LHGT_OK;
     int one_min = (int)(WINDOW * hit_ratio);      // float32 product truncated, E:559-560
     int three_min = (int)(WINDOW * match_ratio);
-    dim3 grid((unsigned)ctx->n_tiles), blk(BT);
+    const dim3 grid = blocks2d(ctx->n_tiles), blk(BT);
+    const long nt = ctx->n_tiles;
     // summary of the count table (one streaming pass, ~0.3 ms per GiB): saturated 64-byte lines (their bitmap is consulted first
     // when at least half the lines are) and slots holding 3 (a nearly full table takes the lite form of B1/B2)
     bool use_sat = false;
@@ -890,9 +911,9 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipMemcpyAsync(d_list, pl.data(), pl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LHGT_HIP(hipMemcpyAsync(d_list + pl.size(), pw.data(), pw.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ref_flags_lite<false>, dim3((unsigned)pl.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts,
-                           k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list);
+                           k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list, (long)pl.size());
         hipLaunchKernelGGL(window_lite, dim3((unsigned)pw.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags,
-                           ctx->d_tile_good, (uint32_t*)nullptr, d_cnt, d_list + pl.size());
+                           ctx->d_tile_good, (uint32_t*)nullptr, d_cnt, d_list + pl.size(), (long)pw.size());
         unsigned int n_not = 0;
         LHGT_HIP(hipMemcpyAsync(&n_not, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
@@ -906,11 +927,11 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (sparse_form) {
         hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                           ctx->d_nzmask);
+                           ctx->d_nzmask, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(window_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count);   // tile_count: free until the id scan
+        hipLaunchKernelGGL(window_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count, nt);   // tile_count: free until the id scan
         hipLaunchKernelGGL(mark_need_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_tile_count,
                            ctx->n_tiles, ctx->d_tile_good, ctx->d_active_tiles, d_nneed);
         unsigned int n_need = 0;
@@ -919,44 +940,44 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, near a window that reaches the trio threshold %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
-            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
-                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
-            hipLaunchKernelGGL(window_good, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
-                               ctx->d_flags, ctx->d_tile_good);
+            hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need);
+            hipLaunchKernelGGL(window_good, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
+                               ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
     } else if (ctx->scan_lite) {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);
+                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr, nt);
         else
             hipLaunchKernelGGL(ref_flags_lite<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr);
+                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(window_lite, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
-                           ctx->d_active_tiles, d_nneed, (const uint32_t*)nullptr);
+                           ctx->d_active_tiles, d_nneed, (const uint32_t*)nullptr, nt);
         unsigned int n_need = 0;
         LHGT_HIP(hipMemcpyAsync(&n_need, d_nneed, 4, hipMemcpyDeviceToHost, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, not settled by the lower bound %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
-            hipLaunchKernelGGL(ref_flags_fill, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
-                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask);
-            hipLaunchKernelGGL(window_good, dim3(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
-                               ctx->d_flags, ctx->d_tile_good);
+            hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need);
+            hipLaunchKernelGGL(window_good, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
+                               ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
     } else {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline);
+                               ctx->d_nzmask, ctx->d_satline, nt);
         else
             hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline);
+                               ctx->d_nzmask, ctx->d_satline, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         hipLaunchKernelGGL(window_good, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, (const uint32_t*)nullptr, 0, one_min, three_min,
-                           ctx->d_flags, ctx->d_tile_good);
+                           ctx->d_flags, ctx->d_tile_good, nt);
     }
     unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));
     LHGT_HIP(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
@@ -970,8 +991,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, for interval_select %u\n", ctx->n_tiles, n_active);
     if (n_active)
-        hipLaunchKernelGGL(interval_select, dim3(n_active), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, ctx->d_active_tiles,
-                           ctx->d_flags, ctx->d_tile_count, d_nsel);
+        hipLaunchKernelGGL(interval_select, blocks2d(n_active), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, ctx->d_active_tiles,
+                           ctx->d_flags, ctx->d_tile_count, d_nsel, (long)n_active);
     if (ctx->n_tiles <= 4L * SCAN_CHUNK && !((ctx->debug & 128) && ctx->n_tiles >= 3))
         hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
     else {   // the active-tile list is free again: its first words hold the chunk sums (u64, far fewer than n_tiles / 2)
@@ -1103,9 +1124,9 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, id_end > max_peak ? id_end : max_peak));
     if (ctx->n_tiles > 0)
-        hipLaunchKernelGGL(register_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
+        hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, emu ? ctx->d_contig_id_adj : nullptr);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, emu ? ctx->d_contig_id_adj : nullptr, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -1166,9 +1187,9 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
     LHGT_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     unsigned long long cnt = 0;
     if (ctx->n_tiles > 0 && ctx->local_new > 0) {
-        hipLaunchKernelGGL(emit_peaks, dim3((unsigned)ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
+        hipLaunchKernelGGL(emit_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                            ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, ctx->k, ctx->e, (uint32_t)id_base, ctx->d_emit_loci,
-                           ctx->d_emit_regs, d_cnt);
+                           ctx->d_emit_regs, d_cnt, ctx->n_tiles);
         LHGT_HIP(hipGetLastError());
         LHGT_HIP(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     }

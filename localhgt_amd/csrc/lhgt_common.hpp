@@ -82,11 +82,20 @@ struct ContigDev {
     uint32_t ref_index;  // 1,2,3.. in index order (E:905,963; quirk Q7)
 };
 constexpr int PF_BITS = 25;  // vote prefilter: 2^25 bits = 4 MiB, one XCD's L2
+constexpr int FASTA_BLK = 4096;  // bytes of FASTA text per newline count on the host and per workgroup of strip_fasta_block
 constexpr int TILE = 2000;  // positions per scan tile; multiple of 50 so peak buckets never straddle tiles
 struct TileDev {
     uint32_t contig;
     uint32_t j0;
 };
+// One launch dimension holds at most 2^32 - 1 work-items (the dispatch packet's grid size is 32 bits wide): 16.7 M workgroups of
+// 256, which one workgroup per 2000-position tile uses up at 33.5 Gbase.  Kernels launched per tile (or per entry of a tile
+// list) therefore take a 2-D grid and the number of workgroups wanted; block2d() is the workgroup's linear number.
+inline dim3 blocks2d(long n) {
+    const long gx = 1L << 20;
+    return n <= gx ? dim3((unsigned)(n > 0 ? n : 1)) : dim3((unsigned)gx, (unsigned)((n + gx - 1) / gx));
+}
+__device__ __forceinline__ long block2d() { return (long)blockIdx.y * gridDim.x + blockIdx.x; }
 
 }  // namespace lhgt
 
@@ -219,6 +228,8 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
 int install_pairs_pinned(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint32_t* start1, const uint32_t* start2, const uint32_t* woff1,
                          const uint32_t* woff2, const uint16_t* len1, const uint16_t* len2, const uint8_t* flags, long n,
                          uint64_t n_words, int max_len, uint64_t n_kmers);
+int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, const uint64_t* kept_before, long n_blocks,
+                     const uint64_t* seg, long n_seg, uint8_t* d_out);
 void ingest_free(lhgt_ctx* ctx);
 int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes);
 }  // namespace lhgt

@@ -102,3 +102,46 @@ def extract_ref_argv(case: Case, fq1: str, fq2: str, fa: str, interval: str):
 
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------------------------------------------------------------------------------------- FASTA files with unusual line structure
+def odd_fastas(seed: int = 7):
+    """[(name, bytes)]: FASTA texts whose line structure exercises read_ref's std::getline semantics (E:761-880): lines before
+    the first header (the sequence called "start"), blank lines, CRLF, no final newline, a header as the last line, '>' inside a
+    sequence line, adjacent headers, lines as wide as the loader's 4096-byte text blocks, lower case, N runs, headers with the
+    three id delimiters of get_read_ID, and two random mixtures.  Bytes stay below 128 (the reference indexes tables by char)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+
+    def seq(n, alphabet=b"ACGT"):
+        return bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n).tolist())
+
+    def wrap(s, w, eol=b"\n"):
+        return b"".join(s[i:i + w] + eol for i in range(0, len(s), w))
+
+    out = []
+    out.append(("pre_header", wrap(seq(300), 60) + b">c1 first contig\n" + wrap(seq(1000), 60) + b">c2\tx\n" + wrap(seq(500), 70)))
+    out.append(("blank_and_crlf", b">a/1\r\n" + wrap(seq(400), 50, b"\r\n") + b"\r\n\n" + wrap(seq(200), 50) + b"\n\n>b\n" + wrap(seq(300), 61) + b"\n"))
+    out.append(("no_final_newline", b">x\n" + wrap(seq(700), 80) + b">y\n" + seq(333)))
+    out.append(("header_last", b">x\n" + wrap(seq(500), 80) + b">dangling"))
+    out.append(("gt_inside", b">x\n" + seq(100) + b">" + seq(100) + b"\n" + seq(150) + b">\n>y desc>more\n" + wrap(seq(400), 37)))
+    out.append(("adjacent_headers", b">a\n>b\n" + wrap(seq(300), 60) + b">c\n\n>d\n" + seq(20) + b"\n>e\n" + wrap(seq(600), 60)))
+    long_seq = seq(40000, b"ACGTacgtN")
+    wide = b"".join(long_seq[i:j] + b"\n" for i, j in zip([0, 4095, 8191, 12288, 16385, 16386, 24000], [4095, 8191, 12288, 16385, 16386, 24000, 40000]))
+    out.append(("wide_lines", b">w\n" + wide + b">n\n" + wrap(b"N" * 100 + seq(900) + b"n" * 40 + seq(300), 64)))
+    for r in range(2):
+        parts = []
+        if r == 0:
+            parts.append(wrap(seq(int(rng.integers(1, 200))), 33))
+        for c in range(int(rng.integers(5, 40))):
+            parts.append(b">r%d_%d%s\n" % (r, c, [b"", b" d", b"/2", b"\tq"][int(rng.integers(0, 4))]))
+            n = int(rng.choice([0, 5, 30, 200, 3000, 9000]))
+            s = seq(n, b"ACGTACGTACGTacgtN")
+            i = 0
+            while i < len(s):
+                w = int(rng.choice([1, 7, 60, 61, 200, 4096]))
+                parts.append(s[i:i + w] + [b"\n", b"\n", b"\r\n", b"\n\n"][int(rng.integers(0, 4))])
+                i += w
+        text = b"".join(parts)
+        out.append((f"random{r}", text if r == 0 else text.rstrip(b"\n")))
+    return out

@@ -595,3 +595,47 @@ def test_count_diff_kmer_compat_n_bases_and_overlap(oracle, tmp_path):
         hist = count_diff_kmer.run(f1, f2, k, ratio, out=open(os.devnull, "w"), compat=True, compat_time=t)
         rc, want = oracle.count_diff_kmer(f1, f2, k, ratio, t)
         assert rc == 0 and [int(x) for x in hist] == [int(x) for x in want]
+
+
+@pytest.mark.parametrize("name,text", cases.odd_fastas(), ids=[n for n, _ in cases.odd_fastas()])
+def test_odd_fasta_line_structure(Engine, oracle, tmp_path, name, text):
+    """The FASTA never passes through a host parser: '>' lines and newline counts are found on the host, the text itself goes to
+    the GPU and is stripped there (strip_fasta_block).  Index bytes and genome.len.txt against the restatement (itself pinned on
+    these files against the reference binary, tests/test_oracle_vs_ref_fuzz.py), and the packed form loaded from the same text
+    against the index form: same peaks, loci and peak_kmer."""
+    k, e = 16, 3
+    fa = str(tmp_path / "ref.fa")
+    open(fa, "wb").write(text)
+    rng = np.random.default_rng(len(text))
+    body = bytes(c for c in text.upper() if c in b"ACGT")
+    reads = [body[o:o + 120] for o in rng.integers(0, max(1, len(body) - 120), size=64)]
+    f1, f2 = str(tmp_path / "s.1.fq"), str(tmp_path / "s.2.fq")
+    _write_fq(f1, reads, b"1")
+    _write_fq(f2, reads[::-1], b"2")
+    with Engine(k, e) as eng:
+        eng.rng_seed(1)
+        eng.coder_generate()
+        cc = eng.coder_get()
+        n_contigs, n_bases = eng.index_build(fa, fa + ".idx", fa + ".len")
+        assert oracle.index_build(fa, fa + ".oidx", fa + ".olen", k, e, cc) == n_contigs
+        got, want = open(fa + ".idx", "rb").read(), open(fa + ".oidx", "rb").read()
+        assert len(got) == len(want) and got[:1198] == want[:1198] and got[1200:] == want[1200:]
+        assert open(fa + ".len").read() == open(fa + ".olen").read()
+        res = {}
+        for packed in (False, True):
+            eng.set_reference_form(packed)
+            if packed:
+                assert eng.reference_load_fasta(fa, fa + ".plen") == (n_contigs, n_bases)
+                assert open(fa + ".plen").read() == open(fa + ".olen").read()
+            else:
+                assert eng.index_load(fa + ".idx") == (n_contigs, n_bases)
+            eng.pairs_clear()
+            eng.sampling_init(100.0)
+            eng.pairs_load_fastq(f1, f2, 100.0)
+            eng.counts_clear()
+            eng.count_kmers()
+            eng.set_debug(8192)
+            n = eng.ref_scan(0.1, 0.08, 100000)
+            eng.set_debug(0)
+            res[packed] = (n, eng.peaks_export(n)[0].tolist() if n > 0 else [], eng.peak_kmer_export().tobytes())
+        assert res[True] == res[False]

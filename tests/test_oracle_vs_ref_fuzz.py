@@ -72,3 +72,33 @@ def test_oracle_thread_emulation_equals_reference_binary(oracle, tmp_path, idx):
     assert open(r / "i.txt").read() == open(c / "i.txt").read(), (threads, k, e, seed, sample, hit, match)
     mates = [int(x) for x in re.findall(r">>> Thread: final read .* read num: (\d+)", res.stdout)]
     assert sum(mates[:threads]) == orep.pairs_counted and sum(mates[threads:]) == int(orep.t_count)   # reads each chunk kept, mate 1 / mate 2
+
+
+import cases
+
+
+@pytest.mark.parametrize("name,text", cases.odd_fastas(), ids=[n for n, _ in cases.odd_fastas()])
+def test_oracle_reads_odd_fastas_like_the_reference_binary(oracle, tmp_path, name, text):
+    """read_ref's line semantics (E:761-880) on FASTA files with unusual structure: the restatement against the reference binary,
+    index bytes, genome.len.txt and interval file"""
+    k, e = 16, 3
+    rng = np.random.default_rng(len(text))
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=100).tolist()) for _ in range(4)]
+    for d in ("ref", "cpu"):
+        (tmp_path / d).mkdir()
+        (tmp_path / d / "ref.fa").write_bytes(text)
+        for m in (1, 2):
+            with open(tmp_path / d / f"s.{m}.fq", "wb") as f:
+                for i, r in enumerate(reads):
+                    f.write(b"@q%d/%d\n" % (i, m) + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    r, c = tmp_path / "ref", tmp_path / "cpu"
+    res = subprocess.run([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt", "0.1", "0.08", "1", str(k), "100000", str(e), "1", "1"],
+                         cwd=r, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-500:]
+    rc, _ = oracle.run(str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(0.1)), float(np.float32(0.08)),
+                       1, k, 100000, e, 1, 1.0)
+    assert rc == 0
+    assert open(r / "ref.fa.genome.len.txt").read() == open(c / "ref.fa.genome.len.txt").read()
+    a, b = open(r / f"ref.fa.k{k}.h{e}.index.dat", "rb").read(), open(c / f"ref.fa.k{k}.h{e}.index.dat", "rb").read()
+    assert len(a) == len(b) and a[:1198] == b[:1198] and a[1200:] == b[1200:]
+    assert open(r / "i.txt").read() == open(c / "i.txt").read()

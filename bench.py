@@ -681,6 +681,28 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
                 out["configs1_1g"] = d
     except Exception as ex:
         out["configs1_error"] = str(ex)
+    try:
+        if (args.contigs, args.pairs) == (13000, 100_000_000):
+            # BASELINE configs[4] names a reference of more than 50 GB, 200 M reads over 8 GPUs, k = 21 / 32.  Its index (12 bytes per
+            # base: 600 GB) only fits sharded over the node; packed (3/8 byte per base) the whole 50 Gbase reference, its per-position
+            # arrays and the tables fit ONE GPU.  One GPU's share of the reads (25 M pairs) drawn from 300 of the 50 000 genomes.
+            nc, fp = 50_000, 25_000_000
+            legs = {}
+            for kk in (32, 21):
+                with Engine(kk, e, device=local) as e5:
+                    e5.rng_seed(1)
+                    e5.coder_generate()
+                    e5.set_reference_form(True)
+                    e5.synth_reference(1, nc, args.contig_len)
+                    e5.synth_options(0, 20, 300)
+                    e5.synth_pairs(1, 2, nc, args.contig_len, 0, fp, L)
+                    d = leg(e5, fp, steps=2, n_contigs=nc, sample_contigs=300)
+                    d["resident_reference_bytes"] = e5.reference_info()["resident_bytes"]
+                    legs[f"k{kk}"] = d
+            out["configs4_progenomes_1gpu"] = dict(legs, workload=f"{nc}x{args.contig_len} bp ref (50 Gbase) resident as packed bases on ONE GPU, 25 M pairs "
+                                                                "(one GPU's share of configs[4]'s 200 M) from 300 of its genomes, e=3, sample=1, k = 32 and 21")
+    except Exception as ex:
+        out["configs4_error"] = str(ex)
     return out
 
 

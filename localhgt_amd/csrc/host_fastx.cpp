@@ -1025,7 +1025,7 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
             const long len = (long)fx.seqs[i].len;
             cum += len;
             if (len <= k) continue;                                        // E:772, 836; it still used up a ref_index (quirk Q7)
-            if (len >= (1L << 32)) { set_error("contig %s has %ld bases", fx.name(fa.p, i).c_str(), len); rc = LHGT_E_FORMAT; break; }
+            if (len >= (1L << 32) - 4096) { set_error("contig %s has %ld bases", fx.name(fa.p, i).c_str(), len); rc = LHGT_E_FORMAT; break; }
             fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", fx.name(fa.p, i).c_str(), (long)i, len, cum);
             contigs++;
             bases += len;
@@ -1108,7 +1108,7 @@ int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char*
         const long len = (long)fx.seqs[i].len;
         cum += len;
         if (len <= k) continue;                                            // E:772, 836
-        if (len >= (1L << 32)) {
+        if (len >= (1L << 32) - 4096) {
             if (lenf) fclose(lenf);
             LHGT_FAIL(LHGT_E_FORMAT, "contig %s has %ld bases", fx.name(fa.p, i).c_str(), len);
         }

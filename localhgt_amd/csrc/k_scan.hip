@@ -34,26 +34,36 @@ __device__ __forceinline__ uint32_t count_of(const uint32_t* __restrict__ T, uin
 // of B1 below).
 __global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __restrict__ counts, size_t n_lines, uint32_t* __restrict__ satline,
                                                           unsigned long long* __restrict__ n_sat) {
-    size_t line = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool sat = false;
+    // grid-stride over runs of 64 lines per wave: the two totals leave with ONE atomic pair per wave at the end (one pair per 64
+    // lines kept 262 k waves queueing on two addresses: 4.3 ms for a pass that streams 1 GiB)
+    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6), wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    unsigned long long my_sat = 0;
     int slots3 = 0;
-    if (line < n_lines) {
-        const uint4* p = (const uint4*)(counts + line * 16);
-        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-        sat = (a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) == 0xffffffffu;
-        if ((line & 15) == 0) {   // every 16th line is plenty for a fraction (1 M lines of the k = 32 table)
-            const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    for (size_t l0 = wave * 64; l0 < n_lines; l0 += n_waves * 64) {
+        const size_t line = l0 + lane;
+        bool sat = false;
+        if (line < n_lines) {
+            const uint4* p = (const uint4*)(counts + line * 16);
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+            sat = (a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) == 0xffffffffu;
+            if ((line & 15) == 0) {   // every 16th line is plenty for a fraction (1 M lines of the k = 32 table)
+                const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-            for (int q = 0; q < 16; q++) slots3 += __popc(w[q] & (w[q] >> 1) & 0x55555555u);
+                for (int q = 0; q < 16; q++) slots3 += __popc(w[q] & (w[q] >> 1) & 0x55555555u);
+            }
+        }
+        const unsigned long long bal = __ballot(sat);
+        if (lane == 0) {
+            satline[l0 >> 5] = (uint32_t)bal;            // 64 consecutive lines -> two words (n_lines is a multiple of 64)
+            satline[(l0 >> 5) + 1] = (uint32_t)(bal >> 32);
+            my_sat += (unsigned long long)__popcll(bal);
         }
     }
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) slots3 += __shfl_xor(slots3, dd, 64);
-    unsigned long long bal = __ballot(sat);
-    if ((threadIdx.x & 63) == 0 && line < n_lines) {
-        satline[line >> 5] = (uint32_t)bal;            // lines of this wave: 64 consecutive -> two words
-        satline[(line >> 5) + 1] = (uint32_t)(bal >> 32);
-        if (bal) atomicAdd(n_sat, (unsigned long long)__popcll(bal));
+    if (lane == 0) {
+        if (my_sat) atomicAdd(n_sat, my_sat);
         if (slots3) atomicAdd(n_sat + 1, (unsigned long long)slots3);
     }
 }
@@ -875,7 +885,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     if (n_lines >= 64 && !(ctx->debug & 64)) {
         if (!ctx->d_satline) LHGT_HIP(hipMalloc(&ctx->d_satline, n_lines / 8 + 16));
         LHGT_HIP(hipMemsetAsync(d_nsat, 0, 16, ctx->stream));
-        hipLaunchKernelGGL(table_line_summary, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_counts, n_lines,
+        const size_t want = (n_lines + 255) / 256;
+        hipLaunchKernelGGL(table_line_summary, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, ctx->stream, ctx->d_counts, n_lines,
                            ctx->d_satline, d_nsat);
         unsigned long long n_sat[2] = {0, 0};
         LHGT_HIP(hipMemcpyAsync(n_sat, d_nsat, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -171,7 +171,7 @@ int lhgt_synth_reference_shard(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs,
     if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d", shard_rank, shard_world);
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
-    if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32)) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
+    if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32) - 4096) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
     SynthSpec s = make_spec(ctx, ref_seed, 0, n_contigs, contig_len, 150);
     std::vector<uint64_t> cuts((size_t)n_contigs + 1);
     for (long c = 0; c <= n_contigs; c++) cuts[c] = (uint64_t)c * (uint64_t)contig_len;
@@ -184,7 +184,7 @@ int lhgt_synth_reference_cuts(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, 
     if (!ctx || !cuts) LHGT_FAIL(LHGT_E_ARG, "null argument");
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder set");
-    if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32)) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
+    if (n_contigs < 4 || contig_len < 16000 || contig_len >= (1L << 32) - 4096) LHGT_FAIL(LHGT_E_ARG, "need >= 4 contigs of 16 kb .. 4 Gb");
     if (n_cuts < 2 || cuts[0] != 0 || cuts[n_cuts - 1] != (uint64_t)n_contigs * (uint64_t)contig_len) LHGT_FAIL(LHGT_E_ARG, "cuts must run from 0 to n_contigs*contig_len");
     for (long i = 1; i < n_cuts; i++) if (cuts[i] <= cuts[i - 1]) LHGT_FAIL(LHGT_E_ARG, "cuts must ascend strictly");
     SynthSpec s = make_spec(ctx, ref_seed, 0, n_contigs, contig_len, 150);
@@ -209,7 +209,8 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
     LHGT_DEVICE_ENTRY(ctx);
     if (n_contigs < 4 || contig_len < 16000 || read_len < 1 || read_len > 300 || n_pairs < 0) LHGT_FAIL(LHGT_E_ARG, "bad synthetic spec");
     SynthSpec s = make_spec(ctx, ref_seed, reads_seed, n_contigs, contig_len, read_len);
-    const long CH = 16L << 20;  // pairs per resident batch (one scan launch each)
+    long CH = 16L << 20;  // pairs per resident batch (one scan launch each)
+    while (CH * read_len >= (1L << 32)) CH >>= 1;   // synth_pairs_ascii: one work-item per base, a launch holds 2^32 - 1
     for (long o = 0; o < n_pairs; o += CH) {
         long n = n_pairs - o < CH ? n_pairs - o : CH;
         size_t bytes = (size_t)n * read_len;

@@ -369,65 +369,102 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
 // ---- B2 on the lite flags: the single sums are exact, the trio sums count only completely probed positions (a lower bound).
 // A tile all of whose positions pass both thresholds with those sums is settled as window_good would settle it: all good, all
 // inside.  Any other tile is listed for the exact treatment (ref_flags_fill + window_good) and left untouched.
+// One WAVE per tile, no block barrier: this pass runs over every tile of the reference and is bound by the chain of memory round
+// trips of a tile (descriptors, flags, flags again) -- a workgroup per tile kept 7 tiles in flight per CU (27 ms per 13 Gbase, ten
+// times a streaming pass over the flags); waves keep 32.  A lane loads the flag bytes of positions lane, lane + 64, ... (the tile and
+// the HL2 positions its windows look back on), the two bits per position become ballot words in LDS, rank(i) = bits set at
+// positions <= i = set bits before the word + popcount inside it; a lane then tests 32 consecutive positions, walking the plane bits
+// that enter and leave the window, and the settled tile's flags are written back from the registers they were loaded into.
+constexpr int WL_WORDS = (TILE + HL2 + 63) / 64;   // 40 ballot words per plane
+constexpr int WL_PER = 32;                         // consecutive positions per lane in the window test
+static_assert(63 * WL_PER >= TILE - WL_PER && 64 * WL_PER >= TILE && HL2 % WL_PER == 0 && WL_WORDS <= 64, "lanes cover the tile; aligned 32-bit groups");
 __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good,
                                                   uint32_t* __restrict__ need, unsigned int* __restrict__ n_need,
-                                                  const uint32_t* __restrict__ pilot /* nullable: only count, over these tiles */, long n_blk) {
-    __shared__ int P1[N2], P3[N2], part[BT];
-    __shared__ int n_good;
-    const long blk = block2d();
-    if (blk >= n_blk) return;
-    const uint32_t tile = pilot ? pilot[blk] : (uint32_t)blk;
+                                                  const uint32_t* __restrict__ pilot /* nullable: only count, over these tiles */, long n_todo) {
+    __shared__ unsigned long long Bs[BT / 64][2][WL_WORDS + 1];   // one zero pad word: a 32-bit group may straddle two words
+    __shared__ int Rs[BT / 64][2][WL_WORDS + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long idx = block2d() * (BT / 64) + wv;
+    if (idx >= n_todo) return;                 // wave-uniform; nothing below synchronises across waves
+    const uint32_t tile = pilot ? pilot[idx] : (uint32_t)idx;
     const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, lo = (long)t.j0 - HL2;
     uint8_t* F = flags + c.flat_base;
     constexpr int NW = TILE + HL2;
-    constexpr int CH = (NW + BT - 1) / BT;
-    const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
-    if (threadIdx.x == 0) n_good = 0;
-    int s1 = 0, s3 = 0;
-    for (int i = b; i < en; i++) {
-        long pos = lo + i;
-        int f = (pos >= 0 && pos < len) ? F[pos] : 0;
-        s1 += f & 1;
-        s3 += (f & 0x82) == 0x82;
-        P1[i] = s1;
-        P3[i] = s3;
-    }
-    int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
-    for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
-    __syncthreads();
-    const long rest = len - (long)t.j0;
-    const int n_here = rest < TILE ? (int)rest : TILE;
-    int mine = 0;
-    for (int jj = threadIdx.x; jj < n_here; jj += BT) {
-        const int i = jj + HL2;
-        mine += P1[i] - P1[i - WINDOW] >= one_min && P3[i] - P3[i - WINDOW] >= three_min;
+    unsigned long long *B1 = Bs[wv][0], *B3 = Bs[wv][1];
+    int *R1 = Rs[wv][0], *R3 = Rs[wv][1];
+    uint8_t fs[WL_WORDS];
+#pragma unroll
+    for (int r = 0; r < WL_WORDS; r++) {       // all loads in flight together
+        const int i = lane + 64 * r;
+        const long pos = lo + i;
+        fs[r] = (i < NW && pos >= 0 && pos < len) ? F[pos] : (uint8_t)0;
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_good, mine);
-    __syncthreads();
+    for (int r = 0; r < WL_WORDS; r++) {
+        const unsigned long long b1 = __ballot(fs[r] & 1), b3 = __ballot((fs[r] & 0x82) == 0x82);
+        if (lane == 0) { B1[r] = b1; B3[r] = b3; }
+    }
+    if (lane == 0) { B1[WL_WORDS] = 0ull; B3[WL_WORDS] = 0ull; }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int c1 = lane < WL_WORDS ? __popcll(B1[lane]) : 0, c3 = lane < WL_WORDS ? __popcll(B3[lane]) : 0;
+        int i1 = c1, i3 = c3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t1 = __shfl_up(i1, d, 64), t3 = __shfl_up(i3, d, 64);
+            if (lane >= d) { i1 += t1; i3 += t3; }
+        }
+        if (lane < WL_WORDS) { R1[lane] = i1 - c1; R3[lane] = i3 - c3; }
+        if (lane == WL_WORDS - 1) { R1[WL_WORDS] = i1; R3[WL_WORDS] = i3; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto rank = [](const unsigned long long* B, const int* R, int i) { return R[i >> 6] + __popcll(B[i >> 6] & (~0ull >> (63 - (i & 63)))); };
+    auto bits32 = [](const unsigned long long* B, int x) {
+        const int w = x >> 6, o = x & 63;
+        unsigned long long v = B[w] >> o;
+        if (o > 32) v |= B[w + 1] << (64 - o);
+        return (uint32_t)v;
+    };
+    const long rest = len - (long)t.j0;
+    const int n_here = rest < TILE ? (int)rest : TILE;
+    const int jj0 = lane * WL_PER, i0 = jj0 + HL2;
+    int n_good = 0;
+    if (jj0 < n_here) {
+        int a1 = rank(B1, R1, i0 - 1), b1 = rank(B1, R1, i0 - WINDOW - 1), a3 = rank(B3, R3, i0 - 1), b3 = rank(B3, R3, i0 - WINDOW - 1);
+        const uint32_t in1 = bits32(B1, i0), out1 = bits32(B1, i0 - WINDOW), in3 = bits32(B3, i0), out3 = bits32(B3, i0 - WINDOW);
+#pragma unroll
+        for (int u = 0; u < WL_PER; u++) {
+            a1 += (in1 >> u) & 1u; b1 += (out1 >> u) & 1u;
+            a3 += (in3 >> u) & 1u; b3 += (out3 >> u) & 1u;
+            n_good += jj0 + u < n_here && a1 - b1 >= one_min && a3 - b3 >= three_min;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_good += __shfl_xor(n_good, d, 64);
     if (pilot) {                     // trial run over a few runs of tiles: how many would the lower bound settle?
-        if (threadIdx.x == 0 && n_good != n_here) atomicAdd(n_need, 1u);
+        if (lane == 0 && n_good != n_here) atomicAdd(n_need, 1u);
         return;
     }
     if (n_good != n_here) {          // not provable from the lower bound: exact treatment
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             tile_good[tile] = 0;
             need[atomicAdd(n_need, 1u)] = tile;
         }
         return;
     }
-    for (int jj = threadIdx.x; jj < n_here; jj += BT) {
-        const long j = (long)t.j0 + jj;
-        F[j] = (uint8_t)(F[j] | 4 | (j >= 1 ? 16 : 0));
+#pragma unroll
+    for (int r = HL2 / 64; r < WL_WORDS; r++) {   // the tile's own positions: good window, inside (E:618), written from the registers
+        const int i = lane + 64 * r;
+        const long j = lo + i;
+        if (i < NW && j < len) F[j] = (uint8_t)(fs[r] | 4 | (j >= 1 ? 16 : 0));
     }
-    if (threadIdx.x == 0) {
-        const int all_single = P1[NW - 1] - P1[HL2 - 1] == n_here;
-        const int head = n_here >= HR4 && P1[HL2 + HR4 - 1] - P1[HL2 - 1] == HR4;
-        const int tail = n_here == TILE && P1[NW - 1] - P1[NW - 1 - HL4] == HL4;
+    if (lane == 0) {
+        const int all_single = rank(B1, R1, NW - 1) - rank(B1, R1, HL2 - 1) == n_here;
+        const int head = n_here >= HR4 && rank(B1, R1, HL2 + HR4 - 1) - rank(B1, R1, HL2 - 1) == HR4;
+        const int tail = n_here == TILE && rank(B1, R1, NW - 1) - rank(B1, R1, NW - 1 - HL4) == HL4;
         tile_good[tile] = (uint8_t)(1 | 2 | (all_single << 2) | (head << 3) | (tail << 4));
     }
 }
@@ -923,7 +960,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipMemcpyAsync(d_list + pl.size(), pw.data(), pw.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ref_flags_lite<false>, dim3((unsigned)pl.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts,
                            k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list, (long)pl.size());
-        hipLaunchKernelGGL(window_lite, dim3((unsigned)pw.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags,
+        hipLaunchKernelGGL(window_lite, dim3((unsigned)((pw.size() + 3) / 4)), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags,
                            ctx->d_tile_good, (uint32_t*)nullptr, d_cnt, d_list + pl.size(), (long)pw.size());
         unsigned int n_not = 0;
         LHGT_HIP(hipMemcpyAsync(&n_not, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -966,7 +1003,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(window_lite, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
+        hipLaunchKernelGGL(window_lite, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
                            ctx->d_active_tiles, d_nneed, (const uint32_t*)nullptr, nt);
         unsigned int n_need = 0;
         LHGT_HIP(hipMemcpyAsync(&n_need, d_nneed, 4, hipMemcpyDeviceToHost, ctx->stream));

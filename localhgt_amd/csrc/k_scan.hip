@@ -18,8 +18,7 @@ namespace lhgt {
 
 constexpr int BT = 256;        // threads per scan block
 constexpr int WINDOW = 500;    // E:556
-constexpr int HL2 = 512, HR2 = 80;          // halo of B2: 499 back for the window, 2k+5 forward for the contrast test
-constexpr int N2 = TILE + HL2 + HR2;
+constexpr int HL2 = 512;                    // halo of B2: the window sums look 499 positions back
 constexpr int HL4 = 96, HR4 = 80;                // halo of the contrast test: 2k+14 back, 2k+9 forward
 constexpr int HALO3 = 2500;    // B3: 2*window on each side plus the 500 merge gap (E:618, 625, 629)
 
@@ -253,39 +252,96 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
     return off + incl - v;
 }
 
+// ---- the window kernels' common ground: one WAVE per tile, no block barrier.  These passes run over every tile of the reference
+// and are bound by a tile's chain of memory round trips (descriptors, flags, flags again), not by bytes: a workgroup per tile
+// kept 7 tiles in flight per CU (27 ms per 13 Gbase, ten times a streaming pass over the flags); waves keep 32.  A lane loads the
+// flag bytes of positions lane, lane + 64, ... (the tile and the HL2 positions its windows look back on); the two bits per
+// position become ballot words in LDS; rank(i) = bits set at positions <= i = set bits before the word + popcount inside it; a
+// lane then tests 32 consecutive positions, walking the plane bits that enter and leave the window.
+constexpr int WL_WORDS = (TILE + HL2 + 63) / 64;   // 40 ballot words per plane
+constexpr int WL_PER = 32;                         // consecutive positions per lane in the window test
+static_assert(63 * WL_PER >= TILE - WL_PER && 64 * WL_PER >= TILE && HL2 % WL_PER == 0 && HL2 % 64 == 0 && WL_WORDS <= 64, "lanes cover the tile; aligned 32-bit groups");
+struct WavePlanes {
+    unsigned long long B1[WL_WORDS + 1], B3[WL_WORDS + 1];   // one zero pad word: a 32-bit group may straddle two words
+    int R1[WL_WORDS + 1], R3[WL_WORDS + 1];
+    uint32_t G[64];                                          // window_good: lane l's good bits of positions 32 l .. 32 l + 31
+    __device__ __forceinline__ static int rank(const unsigned long long* B, const int* R, int i) {
+        return R[i >> 6] + __popcll(B[i >> 6] & (~0ull >> (63 - (i & 63))));
+    }
+    __device__ __forceinline__ static uint32_t bits32(const unsigned long long* B, int x) {
+        const int w = x >> 6, o = x & 63;
+        unsigned long long v = B[w] >> o;
+        if (o > 32) v |= B[w + 1] << (64 - o);
+        return (uint32_t)v;
+    }
+};
+// fs[r] = flag byte of position lo + lane + 64 r (0 outside the contig); planes and ranks of this wave's tile.  m3: the trio
+// predicate is (f & m3) == m3 -- 0x02, or 0x82 where only completely probed positions count (lite form).
+__device__ __forceinline__ void wave_planes(const uint8_t* __restrict__ F, long lo, long len, int m3, int lane, uint8_t (&fs)[WL_WORDS], WavePlanes& P) {
+    constexpr int NW = TILE + HL2;
+#pragma unroll
+    for (int r = 0; r < WL_WORDS; r++) {       // all loads in flight together
+        const int i = lane + 64 * r;
+        const long pos = lo + i;
+        fs[r] = (i < NW && pos >= 0 && pos < len) ? F[pos] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int r = 0; r < WL_WORDS; r++) {
+        const unsigned long long b1 = __ballot(fs[r] & 1), b3 = __ballot((fs[r] & m3) == m3);
+        if (lane == 0) { P.B1[r] = b1; P.B3[r] = b3; }
+    }
+    if (lane == 0) { P.B1[WL_WORDS] = 0ull; P.B3[WL_WORDS] = 0ull; }
+    __builtin_amdgcn_wave_barrier();
+    const int c1 = lane < WL_WORDS ? __popcll(P.B1[lane]) : 0, c3 = lane < WL_WORDS ? __popcll(P.B3[lane]) : 0;
+    int i1 = c1, i3 = c3;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t1 = __shfl_up(i1, d, 64), t3 = __shfl_up(i3, d, 64);
+        if (lane >= d) { i1 += t1; i3 += t3; }
+    }
+    if (lane < WL_WORDS) { P.R1[lane] = i1 - c1; P.R3[lane] = i3 - c3; }
+    if (lane == WL_WORDS - 1) { P.R1[WL_WORDS] = i1; P.R3[WL_WORDS] = i3; }
+    __builtin_amdgcn_wave_barrier();
+}
+// this lane's 32 positions (32 lane ..): bit u set = position 32 lane + u passes both thresholds
+__device__ __forceinline__ uint32_t wave_window_test(const WavePlanes& P, int lane, int n_here, int one_min, int three_min) {
+    const int jj0 = lane * WL_PER, i0 = jj0 + HL2;
+    uint32_t good = 0;
+    if (jj0 < n_here) {
+        int a1 = WavePlanes::rank(P.B1, P.R1, i0 - 1), b1 = WavePlanes::rank(P.B1, P.R1, i0 - WINDOW - 1);
+        int a3 = WavePlanes::rank(P.B3, P.R3, i0 - 1), b3 = WavePlanes::rank(P.B3, P.R3, i0 - WINDOW - 1);
+        const uint32_t in1 = WavePlanes::bits32(P.B1, i0), out1 = WavePlanes::bits32(P.B1, i0 - WINDOW);
+        const uint32_t in3 = WavePlanes::bits32(P.B3, i0), out3 = WavePlanes::bits32(P.B3, i0 - WINDOW);
+#pragma unroll
+        for (int u = 0; u < WL_PER; u++) {
+            a1 += (in1 >> u) & 1u; b1 += (out1 >> u) & 1u;
+            a3 += (in3 >> u) & 1u; b3 += (out3 >> u) & 1u;
+            if (jj0 + u < n_here && a1 - b1 >= one_min && a3 - b3 >= three_min) good |= 1u << u;
+        }
+    }
+    return good;
+}
+
 // does any window of the tile reach the `three` threshold?  (exact trio sums; `one` is not looked at: it is a lower bound here)
 __global__ void __launch_bounds__(BT) window_trio(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, int three_min,
-                                                  const uint8_t* __restrict__ flags, uint32_t* __restrict__ cand, long n_blk) {
-    __shared__ int P3[N2], part[BT];
-    __shared__ int any;
-    const long blk = block2d();
-    if (blk >= n_blk) return;
-    const TileDev t = tiles[blk];
+                                                  const uint8_t* __restrict__ flags, uint32_t* __restrict__ cand, long n_todo) {
+    __shared__ WavePlanes Ps[BT / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long idx = block2d() * (BT / 64) + wv;
+    if (idx >= n_todo) return;                 // wave-uniform; nothing below synchronises across waves
+    const TileDev t = tiles[idx];
     const ContigDev c = contigs[t.contig];
-    const long len = c.len, lo = (long)t.j0 - HL2;
-    const uint8_t* F = flags + c.flat_base;
-    constexpr int NW = TILE + HL2;
-    constexpr int CH = (NW + BT - 1) / BT;
-    const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
-    if (threadIdx.x == 0) any = 0;
-    int s3 = 0;
-    for (int i = b; i < en; i++) {
-        const long pos = lo + i;
-        s3 += (pos >= 0 && pos < len) ? (F[pos] >> 1) & 1 : 0;
-        P3[i] = s3;
-    }
-    const int o3 = block_excl_sum(s3, part);
-    for (int i = b; i < en; i++) P3[i] += o3;
-    __syncthreads();
-    bool mine = false;
-    if (P3[NW - 1] >= three_min) {
+    const long len = c.len;
+    WavePlanes& P = Ps[wv];
+    uint8_t fs[WL_WORDS];
+    wave_planes(flags + c.flat_base, (long)t.j0 - HL2, len, 0x02, lane, fs, P);
+    uint32_t any = 0;
+    if (P.R3[WL_WORDS] >= three_min) {
         const long rest = len - (long)t.j0;
-        const int n_here = rest < TILE ? (int)rest : TILE;
-        for (int jj = threadIdx.x; jj < n_here; jj += BT) mine |= P3[jj + HL2] - P3[jj + HL2 - WINDOW] >= three_min;
+        any = wave_window_test(P, lane, rest < TILE ? (int)rest : TILE, 0, three_min);   // `one` is not looked at: it is a lower bound here
     }
-    if (__ballot(mine) && (threadIdx.x & 63) == 0) any = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) cand[blk] = (uint32_t)any;
+    const unsigned long long bal = __ballot(any != 0u);
+    if (lane == 0) cand[idx] = bal ? 1u : 0u;
 }
 
 // tiles that need exact flags: within three tiles (the 2560-position reach of the interval rules plus the contrast halo) of a
@@ -308,82 +364,58 @@ __global__ void __launch_bounds__(256) mark_need_tiles(const TileDev* __restrict
 // away from interval_select.
 __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   const uint32_t* __restrict__ list /* nullable: the tiles to do */, int keep7,
-                                                  int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good, long n_blk) {
-    __shared__ int P1[N2], P3[N2], part[BT];
-    __shared__ int any_good, n_good;
-    const long blk = block2d();
-    if (blk >= n_blk) return;
-    const uint32_t tile = list ? list[blk] : (uint32_t)blk;
+                                                  int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good, long n_todo) {
+    __shared__ WavePlanes Ps[BT / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long idx = block2d() * (BT / 64) + wv;
+    if (idx >= n_todo) return;                 // wave-uniform; nothing below synchronises across waves
+    const uint32_t tile = list ? list[idx] : (uint32_t)idx;
     const TileDev t = tiles[tile];
     const ContigDev c = contigs[t.contig];
-    const long len = c.len, lo = (long)t.j0 - HL2;
+    const long len = c.len, lo = (long)t.j0 - HL2;   // the window sums look back only
     uint8_t* F = flags + c.flat_base;
-    constexpr int NW = TILE + HL2;   // the window sums look back only
-    constexpr int CH = (NW + BT - 1) / BT;
-    const int b = threadIdx.x * CH, en = b + CH < NW ? b + CH : NW;
-    if (threadIdx.x == 0) { any_good = 0; n_good = 0; }
-    int s1 = 0, s3 = 0;
-    for (int i = b; i < en; i++) {
-        long pos = lo + i;
-        int f = (pos >= 0 && pos < len) ? F[pos] : 0;
-        s1 += f & 1;
-        s3 += (f >> 1) & 1;
-        P1[i] = s1;
-        P3[i] = s3;
-    }
-    int o1 = block_excl_sum(s1, part), o3 = block_excl_sum(s3, part);
-    for (int i = b; i < en; i++) { P1[i] += o1; P3[i] += o3; }
-    __syncthreads();
-    int mine = 0;
-    if (P1[NW - 1] >= one_min && P3[NW - 1] >= three_min) {   // otherwise no window of this tile can reach the thresholds
-        for (int jj = threadIdx.x; jj < TILE; jj += BT) {
-            long j = (long)t.j0 + jj;
-            if (j >= len) break;
-            const int i = jj + HL2;
-            int one = P1[i] - P1[i - WINDOW], three = P3[i] - P3[i - WINDOW];
-            if (one >= one_min && three >= three_min) {
-                const int low = (P1[i] - P1[i - 1]) | ((P3[i] - P3[i - 1]) << 1);   // the position's own two flags, without re-reading them
-                F[j] = (uint8_t)(low | 4 | (j >= 1 ? 16 : 0) | keep7);
-                mine++;
-            }
+    constexpr int NW = TILE + HL2;
+    WavePlanes& P = Ps[wv];
+    uint8_t fs[WL_WORDS];
+    wave_planes(F, lo, len, 0x02, lane, fs, P);
+    const long rest = len - (long)t.j0;
+    const int n_here = rest < TILE ? (int)rest : TILE;
+    uint32_t good = 0;
+    if (P.R1[WL_WORDS] >= one_min && P.R3[WL_WORDS] >= three_min)   // otherwise no window of this tile can reach the thresholds
+        good = wave_window_test(P, lane, n_here, one_min, three_min);
+    int n_good = __popc(good);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_good += __shfl_xor(n_good, d, 64);
+    if (n_good) {
+        // the good bits go through LDS so that the flags are written as they were read: lane = position mod 64, from registers
+        P.G[lane] = good;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = HL2 / 64; r < WL_WORDS; r++) {
+            const int i = lane + 64 * r, jj = i - HL2;
+            const long j = lo + i;
+            if (i < NW && j < len && ((P.G[jj >> 5] >> (jj & 31)) & 1u))
+                F[j] = (uint8_t)((fs[r] & 3) | 4 | (j >= 1 ? 16 : 0) | keep7);   // its own two flags, good window, inside (E:618)
         }
     }
-    {   // one LDS atomic per wave, not per thread (every thread has some on covered reference)
-        int wsum = mine;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
-        if ((threadIdx.x & 63) == 0 && wsum) { any_good = 1; atomicAdd(&n_good, wsum); }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const long rest = len - (long)t.j0;
-        const int n_here = rest < TILE ? (int)rest : TILE;
-        const int all_good = n_good == n_here, all_single = P1[NW - 1] - P1[HL2 - 1] == n_here;
+    if (lane == 0) {
+        const int all_good = n_good == n_here;
+        const int all_single = WavePlanes::rank(P.B1, P.R1, NW - 1) - WavePlanes::rank(P.B1, P.R1, HL2 - 1) == n_here;
         // bits 3 / 4: the first HR4 / last HL4 positions all have a hit -- what the neighbouring tiles' contrast tests reach into
-        const int head = n_here >= HR4 && P1[HL2 + HR4 - 1] - P1[HL2 - 1] == HR4;
-        const int tail = n_here == TILE && P1[NW - 1] - P1[NW - 1 - HL4] == HL4;
-        tile_good[tile] = (uint8_t)(any_good | (all_good << 1) | (all_single << 2) | (head << 3) | (tail << 4));
+        const int head = n_here >= HR4 && WavePlanes::rank(P.B1, P.R1, HL2 + HR4 - 1) - WavePlanes::rank(P.B1, P.R1, HL2 - 1) == HR4;
+        const int tail = n_here == TILE && WavePlanes::rank(P.B1, P.R1, NW - 1) - WavePlanes::rank(P.B1, P.R1, NW - 1 - HL4) == HL4;
+        tile_good[tile] = (uint8_t)((n_good ? 1 : 0) | (all_good << 1) | (all_single << 2) | (head << 3) | (tail << 4));
     }
 }
 
 // ---- B2 on the lite flags: the single sums are exact, the trio sums count only completely probed positions (a lower bound).
 // A tile all of whose positions pass both thresholds with those sums is settled as window_good would settle it: all good, all
 // inside.  Any other tile is listed for the exact treatment (ref_flags_fill + window_good) and left untouched.
-// One WAVE per tile, no block barrier: this pass runs over every tile of the reference and is bound by the chain of memory round
-// trips of a tile (descriptors, flags, flags again) -- a workgroup per tile kept 7 tiles in flight per CU (27 ms per 13 Gbase, ten
-// times a streaming pass over the flags); waves keep 32.  A lane loads the flag bytes of positions lane, lane + 64, ... (the tile and
-// the HL2 positions its windows look back on), the two bits per position become ballot words in LDS, rank(i) = bits set at
-// positions <= i = set bits before the word + popcount inside it; a lane then tests 32 consecutive positions, walking the plane bits
-// that enter and leave the window, and the settled tile's flags are written back from the registers they were loaded into.
-constexpr int WL_WORDS = (TILE + HL2 + 63) / 64;   // 40 ballot words per plane
-constexpr int WL_PER = 32;                         // consecutive positions per lane in the window test
-static_assert(63 * WL_PER >= TILE - WL_PER && 64 * WL_PER >= TILE && HL2 % WL_PER == 0 && WL_WORDS <= 64, "lanes cover the tile; aligned 32-bit groups");
 __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                   int one_min, int three_min, uint8_t* __restrict__ flags, uint8_t* __restrict__ tile_good,
                                                   uint32_t* __restrict__ need, unsigned int* __restrict__ n_need,
                                                   const uint32_t* __restrict__ pilot /* nullable: only count, over these tiles */, long n_todo) {
-    __shared__ unsigned long long Bs[BT / 64][2][WL_WORDS + 1];   // one zero pad word: a 32-bit group may straddle two words
-    __shared__ int Rs[BT / 64][2][WL_WORDS + 1];
+    __shared__ WavePlanes Ps[BT / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long idx = block2d() * (BT / 64) + wv;
     if (idx >= n_todo) return;                 // wave-uniform; nothing below synchronises across waves
@@ -393,55 +425,12 @@ __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ ti
     const long len = c.len, lo = (long)t.j0 - HL2;
     uint8_t* F = flags + c.flat_base;
     constexpr int NW = TILE + HL2;
-    unsigned long long *B1 = Bs[wv][0], *B3 = Bs[wv][1];
-    int *R1 = Rs[wv][0], *R3 = Rs[wv][1];
+    WavePlanes& P = Ps[wv];
     uint8_t fs[WL_WORDS];
-#pragma unroll
-    for (int r = 0; r < WL_WORDS; r++) {       // all loads in flight together
-        const int i = lane + 64 * r;
-        const long pos = lo + i;
-        fs[r] = (i < NW && pos >= 0 && pos < len) ? F[pos] : (uint8_t)0;
-    }
-#pragma unroll
-    for (int r = 0; r < WL_WORDS; r++) {
-        const unsigned long long b1 = __ballot(fs[r] & 1), b3 = __ballot((fs[r] & 0x82) == 0x82);
-        if (lane == 0) { B1[r] = b1; B3[r] = b3; }
-    }
-    if (lane == 0) { B1[WL_WORDS] = 0ull; B3[WL_WORDS] = 0ull; }
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int c1 = lane < WL_WORDS ? __popcll(B1[lane]) : 0, c3 = lane < WL_WORDS ? __popcll(B3[lane]) : 0;
-        int i1 = c1, i3 = c3;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t1 = __shfl_up(i1, d, 64), t3 = __shfl_up(i3, d, 64);
-            if (lane >= d) { i1 += t1; i3 += t3; }
-        }
-        if (lane < WL_WORDS) { R1[lane] = i1 - c1; R3[lane] = i3 - c3; }
-        if (lane == WL_WORDS - 1) { R1[WL_WORDS] = i1; R3[WL_WORDS] = i3; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    auto rank = [](const unsigned long long* B, const int* R, int i) { return R[i >> 6] + __popcll(B[i >> 6] & (~0ull >> (63 - (i & 63)))); };
-    auto bits32 = [](const unsigned long long* B, int x) {
-        const int w = x >> 6, o = x & 63;
-        unsigned long long v = B[w] >> o;
-        if (o > 32) v |= B[w + 1] << (64 - o);
-        return (uint32_t)v;
-    };
+    wave_planes(F, lo, len, 0x82, lane, fs, P);
     const long rest = len - (long)t.j0;
     const int n_here = rest < TILE ? (int)rest : TILE;
-    const int jj0 = lane * WL_PER, i0 = jj0 + HL2;
-    int n_good = 0;
-    if (jj0 < n_here) {
-        int a1 = rank(B1, R1, i0 - 1), b1 = rank(B1, R1, i0 - WINDOW - 1), a3 = rank(B3, R3, i0 - 1), b3 = rank(B3, R3, i0 - WINDOW - 1);
-        const uint32_t in1 = bits32(B1, i0), out1 = bits32(B1, i0 - WINDOW), in3 = bits32(B3, i0), out3 = bits32(B3, i0 - WINDOW);
-#pragma unroll
-        for (int u = 0; u < WL_PER; u++) {
-            a1 += (in1 >> u) & 1u; b1 += (out1 >> u) & 1u;
-            a3 += (in3 >> u) & 1u; b3 += (out3 >> u) & 1u;
-            n_good += jj0 + u < n_here && a1 - b1 >= one_min && a3 - b3 >= three_min;
-        }
-    }
+    int n_good = __popc(wave_window_test(P, lane, n_here, one_min, three_min));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) n_good += __shfl_xor(n_good, d, 64);
     if (pilot) {                     // trial run over a few runs of tiles: how many would the lower bound settle?
@@ -462,9 +451,9 @@ __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ ti
         if (i < NW && j < len) F[j] = (uint8_t)(fs[r] | 4 | (j >= 1 ? 16 : 0));
     }
     if (lane == 0) {
-        const int all_single = rank(B1, R1, NW - 1) - rank(B1, R1, HL2 - 1) == n_here;
-        const int head = n_here >= HR4 && rank(B1, R1, HL2 + HR4 - 1) - rank(B1, R1, HL2 - 1) == HR4;
-        const int tail = n_here == TILE && rank(B1, R1, NW - 1) - rank(B1, R1, NW - 1 - HL4) == HL4;
+        const int all_single = WavePlanes::rank(P.B1, P.R1, NW - 1) - WavePlanes::rank(P.B1, P.R1, HL2 - 1) == n_here;
+        const int head = n_here >= HR4 && WavePlanes::rank(P.B1, P.R1, HL2 + HR4 - 1) - WavePlanes::rank(P.B1, P.R1, HL2 - 1) == HR4;
+        const int tail = n_here == TILE && WavePlanes::rank(P.B1, P.R1, NW - 1) - WavePlanes::rank(P.B1, P.R1, NW - 1 - HL4) == HL4;
         tile_good[tile] = (uint8_t)(1 | 2 | (all_single << 2) | (head << 3) | (tail << 4));
     }
 }
@@ -979,7 +968,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(window_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count, nt);   // tile_count: free until the id scan
+        hipLaunchKernelGGL(window_trio, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count, nt);   // tile_count: free until the id scan
         hipLaunchKernelGGL(mark_need_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_tile_count,
                            ctx->n_tiles, ctx->d_tile_good, ctx->d_active_tiles, d_nneed);
         unsigned int n_need = 0;
@@ -990,7 +979,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
                                ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need);
-            hipLaunchKernelGGL(window_good, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
+            hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
     } else if (ctx->scan_lite) {
@@ -1013,7 +1002,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
                                ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need);
-            hipLaunchKernelGGL(window_good, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
+            hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
     } else {
@@ -1024,7 +1013,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
             hipLaunchKernelGGL(ref_flags<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
-        hipLaunchKernelGGL(window_good, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, (const uint32_t*)nullptr, 0, one_min, three_min,
+        hipLaunchKernelGGL(window_good, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, (const uint32_t*)nullptr, 0, one_min, three_min,
                            ctx->d_flags, ctx->d_tile_good, nt);
     }
     unsigned long long* d_nsel = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L));

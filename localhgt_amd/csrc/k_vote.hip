@@ -701,6 +701,10 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);
             else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave * wpb);
+        } else if (max_ev <= 512) {   // a table row per 64 events: 8 rows instead of 16 (k = 21 with 150-base reads has 260 events)
+            if (ctx->prefilter_on) LHGT_VOTE(8, 1, false, 64 * wpb, per_wave * wpb);
+            else if (nt) LHGT_VOTE(8, 0, true, 64 * wpb, per_wave * wpb);
+            else LHGT_VOTE(8, 0, false, 64 * wpb, per_wave * wpb);
         } else {
             if (ctx->prefilter_on) LHGT_VOTE(16, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(16, 0, true, 64 * wpb, per_wave * wpb);

@@ -80,6 +80,11 @@ int lhgt_index_read_coder(lhgt_ctx* ctx, const char* index_path);
 /* read_ref (E:727-886) + read_index (E:888-979) without the file in between: the FASTA's contigs longer than k become resident
  * in the context's form, numbered as the index numbers them; genome_len_path (nullable) also writes genome.len.txt (E:773, 878) */
 int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char* genome_len_path, long* n_contigs, long* n_bases);
+/* host-only: the FASTA's line structure as the two loaders above see it (no GPU, no bases touched): '>' lines found with memchr,
+ * newlines counted per 4 KiB block on all cores, sequence lengths from those counts -- std::getline semantics of read_ref
+ * (E:761-880).  Writes genome.len.txt (nullable) as read_ref does (E:773, 878) for the sequences longer than k and returns their
+ * number and bases; n_sequences = every sequence of the file, the one before the first '>' line included. */
+int lhgt_fasta_scan(const char* fasta_path, int k, const char* genome_len_path, long* n_sequences, long* n_contigs, long* n_bases);
 
 /* ---- reads: sampling ratio (cal_sam_ratio E:1244-1270) and the resident pair store */
 int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, long* n_records);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lhgt_reference_info": [_vp, C.POINTER(C.c_int), _u64p],
     "lhgt_index_read_coder": [_vp, _cs],
     "lhgt_reference_load_fasta": [_vp, _cs, _cs, _lp, _lp],
+    "lhgt_fasta_scan": [_cs, _i, _cs, _lp, _lp, _lp],
     "lhgt_fastq_sam_ratio": [_cs, _d, _dp, _lp],
     "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
     "lhgt_fastq_parse_digest": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _lp, _lp, _u64p],

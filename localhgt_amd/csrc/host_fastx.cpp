@@ -1131,6 +1131,31 @@ int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char*
     return rc;
 }
 
+// host-only view of what the two FASTA loaders make of a file (tests): every sequence, the indexed ones, genome.len.txt
+int lhgt_fasta_scan(const char* fasta_path, int k, const char* genome_len_path, long* n_sequences, long* n_contigs, long* n_bases) {
+    if (!fasta_path || k < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    Mapped fa;
+    LHGT_TRY(fa.open(fasta_path));
+    FastaIndex fx;
+    fasta_scan(fa, default_threads(), &fx);
+    FILE* lenf = nullptr;
+    if (genome_len_path && !(lenf = fopen(genome_len_path, "w"))) LHGT_FAIL(LHGT_E_IO, "cannot write %s", genome_len_path);
+    long cum = 0, contigs = 0, bases = 0;
+    for (size_t i = 0; i < fx.seqs.size(); i++) {
+        const long len = (long)fx.seqs[i].len;
+        cum += len;
+        if (len <= k) continue;
+        if (lenf) fprintf(lenf, "%s\t%ld\t%ld\t%ld\n", fx.name(fa.p, i).c_str(), (long)i, len, cum);
+        contigs++;
+        bases += len;
+    }
+    if (lenf) fclose(lenf);
+    if (n_sequences) *n_sequences = (long)fx.seqs.size();
+    if (n_contigs) *n_contigs = contigs;
+    if (n_bases) *n_bases = bases;
+    return LHGT_OK;
+}
+
 int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank, int shard_world, long* n_contigs, long* n_bases) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !index_path) LHGT_FAIL(LHGT_E_ARG, "null argument");

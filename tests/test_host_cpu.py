@@ -379,3 +379,28 @@ def test_thread_partition_fuzz_against_the_oracle(lib, oracle, tmp_path, idx):
     assert rc2 == 0
     if rc == 0:
         assert (cnt[0], cnt[1], cnt[2]) == (rep.pairs_counted, int(rep.t_count), rep.pairs_voted), (threads, k, e, sample)
+
+
+def test_fasta_line_structure_on_the_host(lib, oracle, tmp_path):
+    """the host half of the FASTA loaders ('>' lines by memchr, newline counts per 4 KiB block, lengths from the counts; the bases
+    go to the GPU as text): genome.len.txt and the contig count against the restatement's read_ref on files with unusual line
+    structure (tests/cases.py: odd_fastas; the restatement is pinned on them against the reference binary)"""
+    import ctypes as C
+    import cases
+    h = lib.load(require_gpu=False)
+    for k in (16, 40):
+        for name, text in cases.odd_fastas():
+            fa = str(tmp_path / f"{name}.fa")
+            open(fa, "wb").write(text)
+            ns, nc, nb = C.c_long(0), C.c_long(0), C.c_long(0)
+            lib.check(h.lhgt_fasta_scan(fa.encode(), k, (fa + ".len").encode(), C.byref(ns), C.byref(nc), C.byref(nb)))
+            cc = np.zeros(300, dtype=np.int16)
+            assert oracle.index_build(fa, fa + ".oidx", fa + ".olen", min(k, 32), 3, cc) == nc.value or k > 32, name
+            if k <= 32:
+                assert open(fa + ".len").read() == open(fa + ".olen").read(), name
+            headers = sum(1 for ln in text.split(b"\n") if ln.startswith(b">"))
+            assert ns.value == headers + 1, name
+            want = [len(b"".join(part.split(b"\n")[1:])) for part in (b"\n" + text).split(b"\n>")]
+            want[0] = len(text.split(b"\n>")[0].replace(b"\n", b"")) if not text.startswith(b">") else 0
+            got = [int(ln.split("\t")[2]) for ln in open(fa + ".len")]
+            assert got == [w for w in want if w > k], (name, k)

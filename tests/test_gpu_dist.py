@@ -205,10 +205,11 @@ def test_exchange_sharded_scan_world1_nccl(case_inputs, tmp_path):
         ex.close()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_synthetic_reference_shards_scan_like_the_whole(world):
+@pytest.mark.parametrize("world,packed", [(2, False), (3, False), (8, False), (3, True), (8, True)])
+def test_synthetic_reference_shards_scan_like_the_whole(world, packed):
     """bench.py's sharded form: every 'rank' generates only its contig range of the synthetic reference on the device
-    (lhgt_synth_reference_shard); the exchanged scan must give the peak tables of one engine holding the whole reference"""
+    (lhgt_synth_reference_shard); the exchanged scan must give the peak tables of one engine holding the whole reference.
+    packed: the shards resident as packed bases (bench.py --ref-form packed at N > 1), the whole one in the index form"""
     from localhgt_amd.engine import Engine
     k, e, n_contigs, contig_len = 26, 3, 21, 60_000
     with Engine(k, e) as whole:
@@ -223,6 +224,7 @@ def test_synthetic_reference_shards_scan_like_the_whole(world):
         for r in range(world):
             g = Engine(k, e)
             g.coder_set(coder)
+            g.set_reference_form(packed)
             g.synth_reference_shard(7, n_contigs, contig_len, r, world)
             g.counts_merge(pw, 0, nw)
             engs.append(g)

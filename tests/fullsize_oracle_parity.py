@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE configs[1] at FULL size against the CPU restatement (test infrastructure; a one-off run, far too long for the test
-suite): 1000 x 1 Mbp reference, 10 M pairs, k = 32, e = 3 as files; `extract_ref` on the GPU (index built in the first run, cached in
+"""BASELINE configs[1] at FULL size against the CPU restatement (a parity check kept out of the collected suite only because it takes six minutes of host time): 1000 x 1 Mbp reference, 10 M pairs, k = 32, e = 3 as files; `extract_ref` on the GPU (index built in the first run, cached in
 the second), oracle/lhgt_oracle.c on all host cores with that cached index; interval files byte for byte, raw peak and voted pair
 counts.  usage: fullsize_oracle_parity.py [n_contigs] [n_pairs]   (prints a heartbeat while the CPU run is busy)"""
 import json
@@ -12,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # this script lives there: the oracle is test infrastructure
 import bench
 import oracle_api
 from conftest import build_oracle

@@ -612,45 +612,85 @@ template <class Fn>
 static int fasta_spans(lhgt_ctx* ctx, const Mapped& fa, const FastaIndex& fx, uint64_t span_bases, Fn fn) {
     const uint8_t* p = fa.p;
     const size_t ns = fx.seqs.size();
-    std::vector<uint64_t> kept, seg, coff;
+    struct Span { size_t s0, s1; uint64_t bases, A, B; };
+    std::vector<Span> spans;
     for (size_t s0 = 0; s0 < ns;) {
         size_t s1 = s0;
         uint64_t bases = 0;
         while (s1 < ns && (s1 == s0 || bases + fx.seqs[s1].len <= span_bases)) bases += fx.seqs[s1++].len;
-        if (bases) {
-            const uint64_t A = fx.seqs[s0].text_begin & ~(uint64_t)(FASTA_BLK - 1), B = fx.seqs[s1 - 1].text_end;
-            const uint64_t text_len = B - A, n_blocks = (text_len + FASTA_BLK - 1) / FASTA_BLK;
-            kept.assign(n_blocks, 0);
-            seg.assign(2 * (s1 - s0), 0);
-            coff.assign(s1 - s0 + 1, 0);
-            for (size_t s = s0; s < s1; s++) {
-                seg[2 * (s - s0)] = fx.seqs[s].text_begin - A;
-                seg[2 * (s - s0) + 1] = fx.seqs[s].text_end - A;
-                coff[s - s0 + 1] = coff[s - s0] + fx.seqs[s].len;
+        if (bases) spans.push_back({s0, s1, bases, fx.seqs[s0].text_begin & ~(uint64_t)(FASTA_BLK - 1), fx.seqs[s1 - 1].text_end});
+        s0 = s1;
+    }
+    // Page-locking a span of the mapping costs about as much as copying it (~25 ms per GiB each, tools/h2d_rates.hip), so the
+    // NEXT span is locked on a helper thread while this one is copied, stripped and consumed, and the previous one is released
+    // there as well.  Locked ranges must not overlap: a span is locked from the first page boundary at or after the end of its
+    // predecessor's range; the few bytes before it travel as a small pageable copy.
+    const uint64_t PAGE = 4096;
+    std::vector<void*> locked(spans.size(), nullptr);
+    std::vector<uint64_t> lock_from(spans.size(), 0);
+    uint64_t prev_end = 0;
+    for (size_t i = 0; i < spans.size(); i++) {
+        lock_from[i] = spans[i].A > prev_end ? spans[i].A : prev_end;
+        prev_end = (spans[i].B + PAGE - 1) & ~(PAGE - 1);
+    }
+    auto lock = [&](size_t i) {
+        const uint64_t to = (spans[i].B + PAGE - 1) & ~(PAGE - 1);   // inside the mapping: it ends at a page boundary
+        if (lock_from[i] >= to || to - lock_from[i] < ((uint64_t)1 << 20)) return;
+        if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); return; }
+        void* q = (void*)(p + lock_from[i]);
+        if (hipHostRegister(q, (size_t)(to - lock_from[i]), hipHostRegisterDefault) == hipSuccess) locked[i] = q;
+        else (void)hipGetLastError();      // the runtime refuses some mappings: the copy is a pageable one then
+    };
+    auto unlock = [&](size_t i) { if (locked[i]) { (void)hipHostUnregister(locked[i]); locked[i] = nullptr; } };
+    std::vector<uint64_t> kept, seg, coff;
+    std::thread helper;
+    int rc = LHGT_OK;
+    if (!spans.empty()) lock(0);
+    for (size_t i = 0; i < spans.size() && rc == LHGT_OK; i++) {
+        if (helper.joinable()) helper.join();
+        helper = std::thread([&, i] { if (i > 0) unlock(i - 1); if (i + 1 < spans.size()) lock(i + 1); });
+        const Span& sp = spans[i];
+        const size_t s0 = sp.s0, s1 = sp.s1;
+        const uint64_t A = sp.A, B = sp.B, bases = sp.bases;
+        const uint64_t text_len = B - A, n_blocks = (text_len + FASTA_BLK - 1) / FASTA_BLK;
+        kept.assign(n_blocks, 0);
+        seg.assign(2 * (s1 - s0), 0);
+        coff.assign(s1 - s0 + 1, 0);
+        for (size_t s = s0; s < s1; s++) {
+            seg[2 * (s - s0)] = fx.seqs[s].text_begin - A;
+            seg[2 * (s - s0) + 1] = fx.seqs[s].text_end - A;
+            coff[s - s0 + 1] = coff[s - s0] + fx.seqs[s].len;
+        }
+        uint64_t acc = 0;
+        size_t sc = s0;
+        for (uint64_t b = 0; b < n_blocks; b++) {
+            kept[b] = acc;
+            const uint64_t x0 = A + b * FASTA_BLK, x1 = x0 + FASTA_BLK < B ? x0 + FASTA_BLK : B;
+            while (sc < s1 && fx.seqs[sc].text_end <= x0) sc++;
+            for (size_t s = sc; s < s1 && fx.seqs[s].text_begin < x1; s++) {
+                const uint64_t a = fx.seqs[s].text_begin > x0 ? fx.seqs[s].text_begin : x0, e = fx.seqs[s].text_end < x1 ? fx.seqs[s].text_end : x1;
+                if (a >= e) continue;
+                const bool whole = a == x0 && e == x0 + FASTA_BLK;
+                acc += (e - a) - (whole ? fx.nl_before[x0 / FASTA_BLK + 1] - fx.nl_before[x0 / FASTA_BLK] : (uint64_t)count_nl(p + a, p + e));
             }
-            uint64_t acc = 0;
-            size_t sc = s0;
-            for (uint64_t b = 0; b < n_blocks; b++) {
-                kept[b] = acc;
-                const uint64_t x0 = A + b * FASTA_BLK, x1 = x0 + FASTA_BLK < B ? x0 + FASTA_BLK : B;
-                while (sc < s1 && fx.seqs[sc].text_end <= x0) sc++;
-                for (size_t s = sc; s < s1 && fx.seqs[s].text_begin < x1; s++) {
-                    const uint64_t a = fx.seqs[s].text_begin > x0 ? fx.seqs[s].text_begin : x0, e = fx.seqs[s].text_end < x1 ? fx.seqs[s].text_end : x1;
-                    if (a >= e) continue;
-                    const bool whole = a == x0 && e == x0 + FASTA_BLK;
-                    acc += (e - a) - (whole ? fx.nl_before[x0 / FASTA_BLK + 1] - fx.nl_before[x0 / FASTA_BLK] : (uint64_t)count_nl(p + a, p + e));
-                }
-            }
+        }
+        auto body = [&]() -> int {
             if (acc != bases) LHGT_FAIL(LHGT_E_STATE, "FASTA span: %llu bases by blocks, %llu by sequences", (unsigned long long)acc, (unsigned long long)bases);
             const size_t toff = ((size_t)bases + 32 + 255) & ~(size_t)255;   // bases at the front of the workspace, the text behind them
             LHGT_TRY(ws_reserve(ctx, toff + (size_t)text_len + 32, 0));
-            LHGT_TRY(stage_ascii(ctx, toff, p + A, (size_t)text_len));
+            // the part of the text in front of the locked range (less than a page, or all of it when nothing is locked), then the rest
+            const uint64_t cut = locked[i] ? (lock_from[i] < B ? lock_from[i] : B) : B;
+            if (cut > A) LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + toff, p + A, (size_t)(cut - A), hipMemcpyHostToDevice, ctx->stream));
+            if (B > cut) LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + toff + (cut - A), p + cut, (size_t)(B - cut), hipMemcpyHostToDevice, ctx->stream));
+            LHGT_HIP(hipStreamSynchronize(ctx->stream));
             LHGT_TRY(strip_fasta_text(ctx, ctx->d_ws_ascii + toff, text_len, kept.data(), (long)n_blocks, seg.data(), (long)(s1 - s0), ctx->d_ws_ascii));
-            LHGT_TRY(fn((const uint8_t*)ctx->d_ws_ascii, (long)bases, coff.data(), s0, (long)(s1 - s0)));
-        }
-        s0 = s1;
+            return fn((const uint8_t*)ctx->d_ws_ascii, (long)bases, coff.data(), s0, (long)(s1 - s0));
+        };
+        rc = body();
     }
-    return LHGT_OK;
+    if (helper.joinable()) helper.join();
+    for (size_t i = 0; i < spans.size(); i++) unlock(i);
+    return rc;
 }
 
 }  // namespace lhgt

@@ -1,6 +1,7 @@
 // k_ingest.hip -- 2-bit packing of bases, the resident pair store, the index builder/loader.
 #include <cstring>
 #include <time.h>
+#include <thread>
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
@@ -338,6 +339,57 @@ struct HostPin {
     ~HostPin() { if (p) hipHostUnregister(p); }
 };
 
+// Host range (typically a file mapping) -> device, in pieces of 128 MiB whose page-locking runs one piece AHEAD of the copies on a
+// helper thread: locking costs about what the copy costs (~25 ms per GiB each; an unlocked range copies at a tenth of the rate,
+// tools/h2d_rates.hip), so doing one after the other -- as the first version did, a GiB at a time -- doubled the upload.  Locked
+// ranges are whole pages inside [src, src + bytes) and never overlap; the few bytes before the first and after the last page
+// boundary travel as pageable copies.  A piece the runtime refuses to lock is copied pageable.  Returns after the last copy.
+int upload_locked_ahead(lhgt_ctx* ctx, hipStream_t st, void* d_dst, const void* src, size_t bytes) {
+    if (!bytes) return LHGT_OK;
+    const uintptr_t PAGE = 4096, PIECE = (uintptr_t)128 << 20;
+    const uintptr_t a = (uintptr_t)src, e = a + bytes, a_up = (a + PAGE - 1) & ~(PAGE - 1), e_dn = e & ~(PAGE - 1);
+    std::vector<uintptr_t> cut(1, a);
+    for (uintptr_t x = a_up + PIECE; x < e; x += PIECE) cut.push_back(x);
+    cut.push_back(e);
+    const size_t np = cut.size() - 1;
+    std::vector<void*> locked(np, nullptr);
+    auto range = [&](size_t i, uintptr_t* lo, uintptr_t* hi) {
+        *lo = cut[i] > a_up ? cut[i] : a_up;
+        *hi = cut[i + 1] < e_dn ? cut[i + 1] : e_dn;
+    };
+    auto lock = [&](size_t i) {
+        uintptr_t lo, hi;
+        range(i, &lo, &hi);
+        if (hi <= lo || hi - lo < ((uintptr_t)1 << 20)) return;
+        if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipHostRegister((void*)lo, (size_t)(hi - lo), hipHostRegisterDefault) == hipSuccess) locked[i] = (void*)lo;
+        else (void)hipGetLastError();
+    };
+    auto unlock = [&](size_t i) { if (locked[i]) { (void)hipHostUnregister(locked[i]); locked[i] = nullptr; } };
+    auto copy = [&](uintptr_t from, uintptr_t to) -> hipError_t {
+        return to > from ? hipMemcpyAsync((uint8_t*)d_dst + (from - a), (const void*)from, (size_t)(to - from), hipMemcpyHostToDevice, st) : hipSuccess;
+    };
+    std::thread helper;
+    hipError_t err = hipSuccess;
+    lock(0);
+    for (size_t i = 0; i < np && err == hipSuccess; i++) {
+        if (helper.joinable()) helper.join();
+        helper = std::thread([&, i] { if (i > 0) unlock(i - 1); if (i + 1 < np) lock(i + 1); });
+        uintptr_t lo, hi;
+        range(i, &lo, &hi);
+        if (locked[i]) {
+            err = copy(cut[i], lo);
+            if (err == hipSuccess) err = copy(lo, hi);
+            if (err == hipSuccess) err = copy(hi, cut[i + 1]);
+        } else err = copy(cut[i], cut[i + 1]);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+    }
+    if (helper.joinable()) helper.join();
+    for (size_t i = 0; i < np; i++) unlock(i);
+    if (err != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "upload: %s", hipGetErrorString(err));
+    return LHGT_OK;
+}
+
 // ---------------------------------------------------------------- resident pairs
 static void free_batch(ReadBatch& b) {
     for (void*& p : b.alloc) if (p) { hipFree(p); p = nullptr; }
@@ -590,15 +642,8 @@ int index_install_shard(lhgt_ctx* ctx, const uint32_t* w_all, size_t n_words_all
     const uint32_t* w = w_all + starts[c0];
     const size_t n_words = starts[c1] - starts[c0];
     LHGT_TRY(index_layout(ctx, lens, (uint32_t)c0 + 1));
-    const size_t CH = 256u << 20;  // words per copy (1 GiB); each piece is pinned for its copy when the runtime allows
-    for (size_t o = 0; o < n_words; o += CH) {
-        size_t n = n_words - o < CH ? n_words - o : CH;
-        HostPin pin(w + o, n * 4);
-        // on its own non-blocking stream: a plain hipMemcpy would serialise with the FASTQ loader's stream (legacy default-stream rule)
-        LHGT_HIP(hipMemcpyAsync(ctx->d_index + o, w + o, n * 4, hipMemcpyHostToDevice, ctx->copy_stream));
-        LHGT_HIP(hipStreamSynchronize(ctx->copy_stream));
-    }
-    return LHGT_OK;
+    // on its own non-blocking stream: a plain hipMemcpy would serialise with the FASTQ loader's stream (legacy default-stream rule)
+    return upload_locked_ahead(ctx, ctx->copy_stream, ctx->d_index, w, n_words * 4);
 }
 
 }  // namespace lhgt

@@ -232,4 +232,5 @@ int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, co
                      const uint64_t* seg, long n_seg, uint8_t* d_out);
 void ingest_free(lhgt_ctx* ctx);
 int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes);
+int upload_locked_ahead(lhgt_ctx* ctx, hipStream_t st, void* d_dst, const void* src, size_t bytes);   // file mapping -> device, page-locking one piece ahead
 }  // namespace lhgt

@@ -2,7 +2,9 @@
 """The product against the REAL reference binary (oracle/_ref/extract_ref_z: the reference's own source compiled by
 oracle/build_ref.sh with the zero-new[] shim, run with -t 1) at a size beyond the committed goldens: 20 x 1 Mbp, 400 000 pairs,
 k = 32 (4 GiB count table, 16 GiB peak_kmer), on the GPU box's host.  Index bytes, genome.len.txt and the interval file must be
-identical.  Kept out of the collected suite because the reference needs minutes.  usage: refbinary_parity_gpu.py [contigs] [pairs] [k]"""
+identical.  Kept out of the collected suite because the reference needs minutes.  usage: refbinary_parity_gpu.py [contigs] [pairs] [k] [threads]
+threads > 1: the reference with its N threads run in creation order (oracle/_ref/libseqthreads.so preloaded: the schedule without races)
+against the product's -t N emulation (`localhgt bkp` passes -t 10 by default)."""
 import os
 import shutil
 import subprocess
@@ -19,6 +21,8 @@ from localhgt_amd import extract_ref
 NC = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 PAIRS = int(sys.argv[2]) if len(sys.argv) > 2 else 400_000
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+SHIM = os.path.join(ROOT, "oracle", "_ref", "libseqthreads.so")
 E = 3
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "extract_ref_z")
 if not os.path.exists(REF_BIN):
@@ -33,22 +37,23 @@ res = {}
 
 def run_ref():
     t0 = time.time()
-    res["p"] = subprocess.run([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt", "0.1", "0.08", "1", str(K), "3000000", str(E), "1", "1"],
-                              cwd=r, capture_output=True, text=True)
+    env = dict(os.environ, LD_PRELOAD=SHIM) if T > 1 else dict(os.environ)
+    res["p"] = subprocess.run([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt", "0.1", "0.08", str(T), str(K), "3000000", str(E), "1", "1"],
+                              cwd=r, capture_output=True, text=True, env=env)
     res["s"] = time.time() - t0
 
 
 th = threading.Thread(target=run_ref)
 t0 = time.time()
 th.start()
-a = extract_ref.Args(os.path.join(g, "s.1.fq"), os.path.join(g, "s.2.fq"), os.path.join(g, "ref.fa"), os.path.join(g, "i.txt"), 0.1, 0.08, 1, K, 3_000_000, E, 1, 1.0)
-rep = extract_ref.run(a, log=lambda *x: None)
+a = extract_ref.Args(os.path.join(g, "s.1.fq"), os.path.join(g, "s.2.fq"), os.path.join(g, "ref.fa"), os.path.join(g, "i.txt"), 0.1, 0.08, T, K, 3_000_000, E, 1, 1.0)
+rep = extract_ref.run(a, log=lambda *x: None, emulate_threads=T > 1)
 print(f"product: {rep['total_s']:.2f} s, raw peaks {rep['n_peaks']}, filtered {rep['n_filtered']}", flush=True)
 while th.is_alive():
     th.join(45)
     print(f"  reference binary running, {time.time() - t0:.0f} s", flush=True)
 p = res["p"]
-print(f"reference binary (-t 1): rc {p.returncode}, {res['s']:.0f} s; " + " | ".join(l for l in p.stdout.splitlines() if "raw BKPs" in l or "Finish" in l)[:300], flush=True)
+print(f"reference binary (-t {T}): rc {p.returncode}, {res['s']:.0f} s; " + " | ".join(l for l in p.stdout.splitlines() if "raw BKPs" in l or "Finish" in l)[:300], flush=True)
 ok = p.returncode == 0
 for name in ("i.txt", "ref.fa.genome.len.txt"):
     same = open(os.path.join(r, name), "rb").read() == open(os.path.join(g, name), "rb").read()

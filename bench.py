@@ -222,15 +222,25 @@ def cpu_baseline(k, e, n_contigs, contig_len, n_pairs, device):
     cores = os.cpu_count() or 1
     with tempfile.TemporaryDirectory(prefix="lhgt_cpu_") as tmp:
         fa, f1, f2 = synth_files(tmp, k, e, n_contigs, contig_len, n_pairs, device)
-        rc, rep = orc.run(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, cores, k, 3000000, e, 1, 1.0)
+        cpu_iv, gpu_iv = os.path.join(tmp, "interval.txt"), os.path.join(tmp, "interval.gpu.txt")
+        rc, rep = orc.run(f1, f2, fa, cpu_iv, 0.1, 0.08, cores, k, 3000000, e, 1, 1.0)
         if rc != 0:
             return None
+        # the same files through the product (the index the CPU run wrote is reused): the baseline is only worth quoting if both
+        # sides computed the same thing -- the interval file must be the same, byte for byte
+        from localhgt_amd import extract_ref
+        rep_g = extract_ref.run(extract_ref.Args(f1, f2, fa, gpu_iv, 0.1, 0.08, 1, k, 3000000, e, 1, 1.0), device=device, log=lambda *x: None)
+        identical = open(cpu_iv, "rb").read() == open(gpu_iv, "rb").read() and int(rep.n_peaks) == rep_g["n_peaks"] and \
+            int(rep.n_filtered) == rep_g["n_filtered"]
         t = rep.t_count + rep.t_scan + rep.t_vote
         return {"value": round(n_pairs / t / 1e6, 6), "unit": "M paired-reads/s", "cores": cores, "kind": "port",
                 "sample": f"{n_pairs} pairs x 150 bp vs {n_contigs} x {contig_len} bp synthetic contigs, k={k} e={e}, "
                           f"phases A+B+C of oracle/lhgt_oracle.c (index build excluded): "
                           f"A {rep.t_count:.2f}s B {rep.t_scan:.2f}s C {rep.t_vote:.2f}s",
-                "raw_peaks": int(rep.n_peaks)}
+                "raw_peaks": int(rep.n_peaks), "filtered_peaks": int(rep.n_filtered), "interval_lines": sum(1 for _ in open(cpu_iv)),
+                "identical_to_gpu": bool(identical),
+                "gpu_same_files": {"total_s": round(rep_g["total_s"], 3), "raw_peaks": rep_g["n_peaks"], "filtered_peaks": rep_g["n_filtered"],
+                                   "kernels_ms": round(rep_g["count_kernel_ms"] + rep_g["scan_kernel_ms"] + rep_g["vote_kernel_ms"], 1)}}
 
 
 def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_000_000):
@@ -608,6 +618,8 @@ def main():
         os.remove(out_path)
     except OSError:
         pass
+    if isinstance(line.get("cpu_baseline"), dict) and line["cpu_baseline"].get("identical_to_gpu") is False:
+        sys.exit("bench: the GPU path and the CPU baseline wrote different interval files for the same inputs")
 
 
 def secondary_workloads(eng, args, wl, local, traffic_1g):

@@ -92,17 +92,50 @@ int lhgt_fastq_sam_ratio(const char* fq1, double sample, double* ratio_percent, 
  * (E:413-419, 1037-1044), mark mate 2 as not-counted once its byte cursor passed size(fq1)
  * (E:1419-1445), keep pairs of block (n / shard_block) % shard_world == shard_rank, upload
  * and 2-bit pack them.  The store stays resident for phases A and C.  Parsing is multi-threaded (LHGT_INGEST_THREADS,
- * default min(32, cores)): the reference's pairing is purely line-indexed, so any line start is a split point. */
+ * default min(32, cores)): the reference's pairing is purely line-indexed, so any line start is a split point.
+ * When the first read IDs of the two files differ, phase C pairs fq1's line g with fq2's line g + s, s = the first line of fq2
+ * (read from byte 1) that carries fq1's first ID (E:368-402); fq2's records in front of it are counted by phase A only, each file
+ * sampled by its own read ordinal.  When fq2 runs out first, the remaining reads of fq1 are voted against what std::getline leaves
+ * behind (E:356-367): an empty mate 2, or fq2's last line when that has no newline.  Refused: no line with fq1's first ID (the
+ * reference spins through 10^9 failed reads), s inside a record, reads longer than LHGT_MAX_READ_LEN. */
 int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent,
                           int shard_rank, int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept);
+/* Multi-GPU ingest (the reference's threads split the files by byte ranges, E:1426-1434, and lose the records at
+ * the boundaries -- here global line numbers make every split exact).  A file is cut into chunks of chunk_bytes
+ * (lhgt_fastq_plan_chunk_bytes(): what the loader uses), chunk c starting at the first line start at or after c * chunk_bytes.
+ * lhgt_fastq_plan_part counts the lines of part `part` of `n_parts` of the chunks (start[i], n_lines[i] for its n_out chunks;
+ * start == NULL: only n_out and n_chunks_total; len_sums: also the summed line lengths of every chunk by line index inside the
+ * chunk mod 4, from which cal_sam_ratio's base count (E:1244-1270) follows without its extra pass).  The host layer all-gathers the pieces of both files, in part order, and
+ * lhgt_pairs_load_fastq_planned parses fq1's chunks [part * n / n_parts, (part + 1) * n / n_parts) against the same lines of fq2:
+ * a contiguous run of pairs per rank, kept by the GLOBAL read ordinal (E:1037-1044), each rank touching 1/n_parts of the text.
+ * Quirk Q4, surplus fq2 records (last part), fq2 re-synchronisation (first part) and -t N emulation as in lhgt_pairs_load_fastq. */
+long lhgt_fastq_plan_chunk_bytes(void);
+int lhgt_fastq_plan_part(const char* fq, long chunk_bytes, int part, int n_parts, uint64_t* start, long* n_lines, long cap, long* n_out,
+                         long* n_chunks_total, long* len_sums_or_null /*[4 * n_out]*/);
+int lhgt_pairs_load_fastq_planned(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, const uint64_t* start1,
+                                  const long* n_lines1, long n1, const uint64_t* start2, const long* n_lines2, long n2, int part,
+                                  int n_parts, long* n_pairs_seen, long* n_pairs_kept);
+/* host-only probe of the planned parse (tests): chain != 0 continues the digest from *digest, so the parts of a split run in
+ * order give the digest of the unsplit parse; start1 == NULL: plans made inside, as lhgt_fastq_parse_digest_threads */
+int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
+                                    int shard_world, long shard_block, int threads, long chunk_bytes, int emulate_threads,
+                                    const uint64_t* start1, const long* n_lines1, long n1, const uint64_t* start2, const long* n_lines2, long n2,
+                                    int part, int n_parts, int chain, long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest,
+                                    long* counts_or_null);
 /* The reference's -t N as it runs WITHOUT its races (contract = the reference binary with its threads run
  * one after the other in creation order).  threads > 1 makes the calls below restate: the per-thread byte chunks of the
  * FASTQs (get_fq_start E:44-89; lines consumed while the cursor before the line is <= the chunk end, E:1019-1026; a record cut
  * by a boundary is lost as there), sampling ordinals counted per chunk (E:1037) -- lhgt_pairs_load_fastq; the contig groups of
  * split_ref with peak ids from j * (max_peak / threads) (E:1280-1330, 229-237) -- lhgt_ref_scan; one sentinel line per thread
  * (E:515-548) -- lhgt_write_intervals.  Default 1: every read, one id range (the -t 1 result whatever -t says).
- * Not combined with the reference-sharded scan.  Inputs on which the reference's behaviour is undefined (a chunk entered within
- * 1000 bytes of EOF, overlapping chunks, a thread's peaks overflowing its id range) are refused with an error. */
+ * Peak ids stay dense (the tile scan's sequential ones, + 1 when thread 0 finds no peak, because only its first peak can hold
+ * the invisible id 0): nothing observable depends on the bases j * (max_peak / N), only on the order of the ids, on which peaks
+ * share a thread's range and on the range's capacity.  With a reference shard resident (lhgt_index_load_shard) the groups cut
+ * across the ranks: lhgt_ref_scan_local, lhgt_ref_scan_group_counts, [sum over ranks], lhgt_set_group_totals, lhgt_ref_scan_emit,
+ * lhgt_peaks_install.  Inputs on which the reference's behaviour is undefined (a chunk entered within 1000 bytes of EOF,
+ * overlapping chunks, a thread's peaks overflowing its id range, threads that re-synchronise fq2 at different line offsets) are
+ * refused with an error whose text starts with "-t N emulation" / "Too many peaks! thread": `extract_ref` then falls back to the
+ * -t 1 result with a warning. */
 int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads);
 /* where thread i of `threads` enters a FASTQ (byte), the global index of its first line and the lines it consumes;
  * size_for_chunks = size of fq1 (also for fq2, E:1419), < 0 = this file's */
@@ -164,6 +197,10 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
  * ranks exchange new-peak counts (id_base = peaks of all lower ranks, contig order = rank order), then all-gather
  * the peak loci and the (hash, id) registrations that lhgt_peaks_install replays into every rank's peak_kmer. */
 int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long* n_new_local, long* n_selected_local);
+/* under -t N emulation: new peaks of this rank's contigs per split_ref group (counts[threads]); the totals over all ranks fix the
+ * id ranges and *first_id (0, or 1 when thread 0 found no peak), which every rank adds to its id base */
+int lhgt_ref_scan_group_counts(lhgt_ctx* ctx, long* counts, int threads);
+int lhgt_set_group_totals(lhgt_ctx* ctx, const long* totals, int threads, long max_peak, long* first_id);
 int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** dev_loci /* int32[2*n_new_local] */,
                        void** dev_regs /* uint32[2*n_regs]: hash, id */, long* n_regs);
 int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total, long max_peak, const void* dev_loci_all,

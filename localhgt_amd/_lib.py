@@ -49,6 +49,11 @@ SIGNATURES = {
     "lhgt_fastq_sam_ratio": [_cs, _d, _dp, _lp],
     "lhgt_pairs_load_fastq": [_vp, _cs, _cs, _d, _i, _i, _l, _lp, _lp],
     "lhgt_fastq_parse_digest": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _lp, _lp, _u64p],
+    "lhgt_fastq_plan_chunk_bytes": [],
+    "lhgt_fastq_plan_part": [_cs, _l, _i, _i, _u64p, _lp, _l, _lp, _lp, _lp],
+    "lhgt_pairs_load_fastq_planned": [_vp, _cs, _cs, _d, _u64p, _lp, _l, _u64p, _lp, _l, _i, _i, _lp, _lp],
+    "lhgt_fastq_parse_digest_planned": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _i, _u64p, _lp, _l, _u64p, _lp, _l, _i, _i, _i, _lp, _lp,
+                                        _u64p, _lp],
     "lhgt_set_thread_emulation": [_vp, _i],
     "lhgt_fastq_thread_chunks": [_cs, _l, _i, _lp, _lp, _lp],
     "lhgt_fastq_parse_digest_threads": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _i, _lp, _lp, _u64p, _lp],
@@ -68,6 +73,8 @@ SIGNATURES = {
     "lhgt_filter_buffer": [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "lhgt_ref_scan": [_vp, _f, _f, _l, _lp],
     "lhgt_ref_scan_local": [_vp, _f, _f, _lp, _lp],
+    "lhgt_ref_scan_group_counts": [_vp, _lp, _i],
+    "lhgt_set_group_totals": [_vp, _lp, _i, _l, _lp],
     "lhgt_ref_scan_emit": [_vp, _l, C.POINTER(_vp), C.POINTER(_vp), _lp],
     "lhgt_peaks_install": [_vp, _l, _l, _l, _vp, _vp, _l],
     "lhgt_vote": [_vp],
@@ -132,7 +139,7 @@ def load(require_gpu: bool = True):
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header and library out of sync
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "lhgt_last_error" else C.c_int
+            fn.restype = C.c_char_p if name == "lhgt_last_error" else C.c_long if name == "lhgt_fastq_plan_chunk_bytes" else C.c_int
         _lib = lib
     if require_gpu:
         n = C.c_int(0)

@@ -229,20 +229,47 @@ static void parallel_for(long n, int threads, Fn fn) {
     for (auto& x : th) x.join();
 }
 
-static ChunkPlan plan_chunks(const Mapped& m, size_t chunk_bytes, int threads) {
-    ChunkPlan pl;
-    size_t nchunks = m.n ? (m.n + chunk_bytes - 1) / chunk_bytes : 1;
-    for (size_t c = 0; c < nchunks; c++) {
-        size_t st = line_start_at_or_after(m.p, m.n, c * chunk_bytes);
-        if (pl.start.empty() || st > pl.start.back()) pl.start.push_back(st);
+// Chunk c of a file starts at the first line start at or after byte c * chunk_bytes.  plan_range counts the lines of chunks
+// [c_lo, c_hi): start[] gets c_hi - c_lo + 1 boundaries, count[] the lines between them.  A whole plan is the range [0, n_chunks);
+// the ranks of a multi-GPU run each count a share of the chunks and exchange the pieces (lhgt_fastq_plan_part).
+static size_t n_plan_chunks(size_t file_bytes, size_t chunk_bytes) { return file_bytes ? (file_bytes + chunk_bytes - 1) / chunk_bytes : 1; }
+static void plan_range(const Mapped& m, size_t chunk_bytes, size_t c_lo, size_t c_hi, int threads, std::vector<size_t>* start, std::vector<long>* count) {
+    const size_t nchunks = n_plan_chunks(m.n, chunk_bytes);
+    start->assign(c_hi - c_lo + 1, 0);
+    for (size_t c = c_lo; c <= c_hi; c++) (*start)[c - c_lo] = c >= nchunks ? m.n : line_start_at_or_after(m.p, m.n, c * chunk_bytes);
+    count->assign(c_hi - c_lo, 0);
+    parallel_for((long)(c_hi - c_lo), threads, [&](long i) { (*count)[(size_t)i] = count_lines(m.p, (*start)[(size_t)i], (*start)[(size_t)i + 1], m.n); });
+}
+
+// chunks without a byte of their own (a line longer than a chunk) are dropped
+static int plan_from_arrays(const Mapped& m, const uint64_t* start, const long* count, long n, ChunkPlan* pl) {
+    pl->start.clear();
+    pl->line0.assign(1, 0);
+    uint64_t prev = 0;
+    for (long c = 0; c < n; c++) {
+        const uint64_t st = start[c], en = c + 1 < n ? start[c + 1] : m.n;
+        if (st < prev || en < st || en > m.n || (st > 0 && st < m.n && m.p[st - 1] != '\n') || count[c] < 0 || (c == 0 && st != 0))
+            LHGT_FAIL(LHGT_E_ARG, "FASTQ plan: chunk %ld [%llu, %llu) is not a run of whole lines of the %zu-byte file", c, (unsigned long long)st, (unsigned long long)en, m.n);
+        prev = st;
+        if (en == st) {
+            if (count[c]) LHGT_FAIL(LHGT_E_ARG, "FASTQ plan: empty chunk %ld with %ld lines", c, count[c]);
+            continue;
+        }
+        pl->start.push_back((size_t)st);
+        pl->line0.push_back(pl->line0.back() + count[c]);
     }
-    if (pl.start.empty()) pl.start.push_back(0);
-    if (pl.start.back() != m.n || pl.start.size() == 1) pl.start.push_back(m.n);
-    long nc = (long)pl.start.size() - 1;
-    std::vector<long> cnt((size_t)nc);
-    parallel_for(nc, threads, [&](long c) { cnt[c] = count_lines(m.p, pl.start[c], pl.start[c + 1], m.n); });
-    pl.line0.assign((size_t)nc + 1, 0);
-    for (long c = 0; c < nc; c++) pl.line0[c + 1] = pl.line0[c] + cnt[c];
+    if (pl->start.empty()) { pl->start.push_back(0); pl->line0.push_back(0); }
+    pl->start.push_back(m.n);
+    return LHGT_OK;
+}
+
+static ChunkPlan plan_chunks(const Mapped& m, size_t chunk_bytes, int threads) {
+    std::vector<size_t> st;
+    std::vector<long> cnt;
+    plan_range(m, chunk_bytes, 0, n_plan_chunks(m.n, chunk_bytes), threads, &st, &cnt);
+    std::vector<uint64_t> st64(st.begin(), st.end() - 1);
+    ChunkPlan pl;
+    (void)plan_from_arrays(m, st64.data(), cnt.data(), (long)cnt.size(), &pl);   // boundaries made here are line starts by construction
     return pl;
 }
 
@@ -321,40 +348,103 @@ static int thread_part(const Mapped& m, const ChunkPlan& pl, long size_for_chunk
 
 struct ThreadEmu {
     ThreadPart f1, f2;
+    std::vector<long> pos1;   // byte at which each thread enters fq1 (and seeks fq2 to, E:350-352)
 };
 
-// Parse fq1 chunk c (all lines starting in it) against the same global lines of fq2.
+// How phase C pairs the lines of the two files (E:350-402).  It reads both in lock-step, line g of fq1 with line g + shift of fq2:
+// shift is 0 when the first read IDs agree; otherwise the reference rewinds fq2 (to byte 1 at -t 1) and reads on until a line
+// carries fq1's first ID (E:376-397), and the lock-step continues from there.  Once fq2 has run out std::getline leaves the string
+// as it was: empty when fq2's last line ended with a newline, that last line otherwise (E:356-367) -- the `stale` partner.
+// Phase A reads each file on its own (E:1426-1448), so fq2's records in front of the shift and behind fq1's end are counted, not voted.
+struct PairLayout {
+    long shift = 0;
+    long lines1 = 0, lines2 = 0;
+    const uint8_t* stale = nullptr;
+    size_t stale_len = 0;
+};
+
+// line g of a planned file: its bytes (without the newline) and its start offset
+static bool line_at(const Mapped& m, const ChunkPlan& pl, long g, const uint8_t** s, size_t* len, size_t* start) {
+    if (g < 0 || g >= pl.line0.back()) return false;
+    const long c = (long)(std::upper_bound(pl.line0.begin(), pl.line0.end(), g) - pl.line0.begin()) - 1;
+    LineCursor k(m);
+    k.cur = pl.start[(size_t)c];
+    for (long skip = g - pl.line0[(size_t)c]; skip >= 0; skip--)
+        if (!k.next(s, len, start)) return false;
+    return true;
+}
+
+static bool same_id(const uint8_t* a, size_t la, const uint8_t* b, size_t lb) {
+    const size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
+    return ia == ib && memcmp(a, b, ia) == 0;
+}
+
+// The reference's search (E:376-397): fq2 read line by line from byte `from` (a first partial line counts) until get_read_ID of a
+// line equals `id`.  Returns the index of that line, -1 when no line has it (the reference then spins through 10^9 failing reads).
+static long find_id_line(const Mapped& m2, const ChunkPlan& p2, size_t from, const uint8_t* id, size_t idl) {
+    const uint8_t* p = m2.p;
+    const size_t n = m2.n;
+    if (from >= n) return -1;
+    auto is_hit = [&](size_t q) {
+        const uint8_t* nl = (const uint8_t*)memchr(p + q, '\n', n - q);
+        const size_t len = nl ? (size_t)(nl - (p + q)) : n - q;
+        return read_id_len(p + q, len) == idl && memcmp(p + q, id, idl) == 0;
+    };
+    if (idl == 0) {   // an empty ID (fq1 opens with an empty line or a delimiter): every line has to be looked at
+        for (size_t q = from; q < n;) {
+            if (is_hit(q)) return line_index_of(m2, p2, q);
+            const uint8_t* nl = (const uint8_t*)memchr(p + q, '\n', n - q);
+            if (!nl) break;
+            q = (size_t)(nl - p) + 1;
+        }
+        return -1;
+    }
+    for (size_t q = from; q + idl <= n;) {
+        const uint8_t* hit = (const uint8_t*)memmem(p + q, n - q, id, idl);
+        if (!hit) break;
+        const size_t at = (size_t)(hit - p);
+        if ((at == from || p[at - 1] == '\n') && is_hit(at)) return line_index_of(m2, p2, at);
+        q = at + 1;
+    }
+    return -1;
+}
+
+// Parse fq1 chunk c (all lines starting in it) against the lines of fq2 that phase C pairs them with.
 static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, const ChunkPlan& p2, long c, double ratio,
-                        const float* random_array, int shard_rank, int shard_world, long shard_block, const ThreadEmu* emu, ParsedChunk* out) {
+                        const float* random_array, int shard_rank, int shard_world, long shard_block, const ThreadEmu* emu,
+                        const PairLayout& lay, ParsedChunk* out) {
     out->o1.assign(1, 0);
     out->o2.assign(1, 0);
     const long g0 = p1.line0[c], g1 = p1.line0[c + 1];
     if (g0 == g1) return;
-    // fq2 cursor at global line g0
-    long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g0) - p2.line0.begin()) - 1;
+    // fq2 cursor at global line g0 + shift
     LineCursor k1(m1), k2(m2);
     k1.cur = p1.start[c];
-    k2.cur = p2.start[c2];
     const uint8_t *a, *b;
     size_t la, lb, sa, sb;
-    for (long skip = g0 - p2.line0[c2]; skip > 0; skip--) k2.next(&b, &lb, &sb);
+    const long h0 = g0 + lay.shift;
+    if (h0 < lay.lines2) {
+        long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), h0) - p2.line0.begin()) - 1;
+        k2.cur = p2.start[c2];
+        for (long skip = h0 - p2.line0[c2]; skip > 0; skip--) k2.next(&b, &lb, &sb);
+    } else k2.cur = m2.n;
     const size_t size1 = m1.n;
+    auto sampled = [&](long n) { return ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio; };
     for (long g = g0; g < g1; g++) {
         k1.next(&a, &la, &sa);
-        if (!k2.next(&b, &lb, &sb)) { b = a; lb = 0; sb = m2.n; }   // fq1's trailing non-sequence line without a partner (checked by parse_pairs)
-        if (g == 0) {  // E:368-402: the two first read IDs must agree
-            size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
-            if (ia != ib || memcmp(a, b, ia)) { out->rc = LHGT_E_FORMAT; out->err = "paired-end reads not consistent: first records differ"; return; }
-        }
+        const bool have2 = k2.next(&b, &lb, &sb);
+        if (!have2) { b = lay.stale; lb = lay.stale_len; sb = m2.n; }   // fq2 has run out (E:356-367)
         if (g % 4 != 1) continue;
         const long n = g / 4;
         uint8_t fl;
         if (emu) {   // each mate by its own file's thread chunks; phase C follows fq1's (E:350-359)
             fl = (uint8_t)((emu->f1.keep(g, ratio, random_array) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
-                           (emu->f2.keep(g, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
+                           (have2 && emu->f2.keep(g + lay.shift, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
         } else {
-            const bool keep = ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio;
-            fl = keep ? (uint8_t)(PAIR_COUNT1 | PAIR_VOTE | (sb <= size1 ? PAIR_COUNT2 : 0)) : 0;   // quirk Q4: mate 2 counted only while its line starts at <= size(fq1)
+            // phase A samples every file by its own read ordinal (E:1037-1044): with a shift mate 2 is fq2's read n + shift / 4.
+            // Quirk Q4: mate 2 is counted only while its line starts at <= size(fq1) (E:1419-1445)
+            fl = (uint8_t)((sampled(n) ? PAIR_COUNT1 | PAIR_VOTE : 0) |
+                           (have2 && sb <= size1 && sampled((g + lay.shift) / 4) ? PAIR_COUNT2 : 0));
         }
         if (!fl || (n / shard_block) % shard_world != shard_rank) continue;
         if (la > LHGT_MAX_READ_LEN || lb > LHGT_MAX_READ_LEN) {
@@ -366,6 +456,99 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
     }
 }
 
+// records of fq2 that phase C pairs with no line of fq1 -- those in front of the shift and those behind fq1's last line -- are
+// still read by phase A (E:1426-1448): mate-2-only entries, lines [gA, gB) of fq2
+static int parse_fq2_only(const Mapped& m1, const Mapped& m2, const ChunkPlan& p2, long gA, long gB, double ratio, const float* random_array,
+                          int shard_rank, int shard_world, long shard_block, const ThreadEmu* emu, ParsedChunk* tail) {
+    tail->o1.assign(1, 0);
+    tail->o2.assign(1, 0);
+    if (gA >= gB) return LHGT_OK;
+    long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), gA) - p2.line0.begin()) - 1;
+    LineCursor k2(m2);
+    k2.cur = p2.start[c2];
+    const uint8_t* b;
+    size_t lb, sb;
+    for (long skip = gA - p2.line0[c2]; skip > 0; skip--) k2.next(&b, &lb, &sb);
+    for (long g = gA; g < gB && k2.next(&b, &lb, &sb); g++) {
+        if (sb > m1.n) break;
+        if (g % 4 != 1) continue;
+        const long n = g / 4;
+        const bool keep = emu ? emu->f2.keep(g, ratio, random_array) == 1 : (ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio);
+        if (!keep || (n / shard_block) % shard_world != shard_rank) continue;
+        if (lb > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read %ld longer than %d bases (the reference's buffers, E:1004)", n, LHGT_MAX_READ_LEN);
+        tail->s2.insert(tail->s2.end(), b, b + lb);
+        tail->o1.push_back(0);
+        tail->o2.push_back(tail->s2.size());
+        tail->flags.push_back(PAIR_COUNT2);
+    }
+    return LHGT_OK;
+}
+
+// Plans made elsewhere and the share of fq1's chunks this caller parses: the ranks of a multi-GPU run each count the lines of
+// 1/world of both files, exchange the pieces, and parse chunks [part * nc / n_parts, (part + 1) * nc / n_parts) (lhgt_pairs_load_fastq_planned)
+struct ParseShare {
+    const ChunkPlan* p1 = nullptr;
+    const ChunkPlan* p2 = nullptr;
+    int part = 0, n_parts = 1;
+};
+
+// everything the parse needs to know before the first chunk: plans, thread chunks, pairing layout.  Returns LHGT_E_FORMAT with
+// a message that starts with "-t N emulation" where only the emulation refuses the input (the caller may fall back to -t 1).
+static int parse_setup(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, const ChunkPlan& p2, const char* fq1, const char* fq2,
+                       int emulate_threads, ThreadEmu* emu_store, PairLayout* lay) {
+    lay->lines1 = p1.line0.back();
+    lay->lines2 = p2.line0.back();
+    lay->shift = 0;
+    lay->stale = m2.p;
+    lay->stale_len = 0;
+    if (m2.n && m2.p[m2.n - 1] != '\n') {   // std::getline hits EOF inside the last line: the next call fails before it clears the string
+        const uint8_t* s;
+        size_t len, st;
+        if (line_at(m2, p2, lay->lines2 - 1, &s, &len, &st)) { lay->stale = s; lay->stale_len = len; }
+    }
+    const uint8_t *a, *b;
+    size_t la, lb, sa, sb;
+    if (emulate_threads > 1) {
+        LHGT_TRY(thread_part(m1, p1, (long)m1.n, emulate_threads, fq1, &emu_store->f1, &emu_store->pos1));
+        LHGT_TRY(thread_part(m2, p2, (long)m1.n, emulate_threads, fq2, &emu_store->f2));
+        // phase C: every thread seeks fq2 to the BYTE it entered fq1 at and compares the IDs of the first lines; when they differ
+        // it rewinds fq2 by 10^9 bytes (to byte 1 at most) and reads on until a line carries fq1's ID (E:350-397).  One shift for
+        // all threads is what this loader can express -- anything else is refused
+        bool have = false;
+        for (int i = 0; i < emulate_threads; i++) {
+            const long g = emu_store->f1.first[i];
+            if (g >= lay->lines1 || emu_store->f1.count[i] == 0) continue;
+            if (!line_at(m1, p1, g, &a, &la, &sa)) continue;
+            const size_t pos = (size_t)emu_store->pos1[i];
+            long g2 = -1;
+            if (pos < m2.n) {
+                const uint8_t* nl = (const uint8_t*)memchr(m2.p + pos, '\n', m2.n - pos);
+                if (same_id(a, la, m2.p + pos, nl ? (size_t)(nl - (m2.p + pos)) : m2.n - pos)) g2 = line_index_of(m2, p2, pos);
+            }
+            if (g2 < 0) g2 = find_id_line(m2, p2, pos > 1000000001UL ? pos - 1000000000UL : 1, a, read_id_len(a, la));
+            if (g2 < 0) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: no line of %s carries the read ID of thread %d's first record (the reference spins through 10^9 failed reads)", emulate_threads, fq2, i);
+            if (have && g2 - g != lay->shift) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: the threads find their first records at different line offsets in %s (%ld and %ld)", emulate_threads, fq2, lay->shift, g2 - g);
+            lay->shift = g2 - g;
+            have = true;
+        }
+        if (lay->lines2 < lay->lines1 + lay->shift)
+            for (long g = lay->lines2 - lay->shift; g < lay->lines1; g++)
+                if (g % 4 == 1) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: %s has fewer records than %s", emulate_threads, fq2, fq1);
+    } else if (lay->lines1 > 0) {
+        line_at(m1, p1, 0, &a, &la, &sa);
+        const bool have2 = line_at(m2, p2, 0, &b, &lb, &sb);
+        if (!have2 || !same_id(a, la, b, lb)) {
+            const long g2 = find_id_line(m2, p2, 1, a, read_id_len(a, la));
+            if (g2 < 0) LHGT_FAIL(LHGT_E_FORMAT, "paired-end reads not consistent: no line of %s carries the first read ID of %s (the reference spins through 10^9 failed reads)", fq2, fq1);
+            lay->shift = g2;
+        }
+    }
+    if (lay->shift % 4) LHGT_FAIL(LHGT_E_FORMAT, "%s%s pairs with %s at line offset %ld, inside a record (the reference would take quality lines for reads)",
+                                  emulate_threads > 1 ? "-t N emulation: " : "", fq2, fq1, lay->shift);
+    if (lay->shift < 0) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: %s is %ld lines behind %s", emulate_threads, fq2, -lay->shift, fq1);
+    return LHGT_OK;
+}
+
 // consume(chunk) is called on the calling thread, in file order, while the worker threads parse ahead (at most `pool` slabs, or
 // 2 x threads chunks, in flight).  A chunk that used a slab keeps it until the consumer hands it back (pool->release), which it
 // does once its copy to the device has completed; idle(true/false) is called while the consumer waits for the next chunk so it
@@ -373,52 +556,44 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
 template <class Consume, class Idle>
 static int parse_pairs(const char* fq1, const char* fq2, double ratio, const float* random_array, int shard_rank, int shard_world,
                        long shard_block, int threads, size_t chunk_bytes, int emulate_threads, long* n_pairs_seen, SlabPool* pool_in,
-                       Consume consume, Idle idle, const std::function<int(SlabPool**)>& prepare = nullptr) {
+                       Consume consume, Idle idle, const std::function<int(SlabPool**)>& prepare = nullptr,
+                       const std::function<int(const Mapped&, const Mapped&, ParseShare*, ChunkPlan*, ChunkPlan*)>& share_fn = nullptr) {
     Mapped m1, m2;
     LHGT_TRY(m1.open(fq1));
     LHGT_TRY(m2.open(fq2));
     if (threads < 1) threads = 1;
     double t0 = now_s();
     // the line count runs on helper threads; meanwhile the calling thread may allocate (prepare: pinned slabs, device staging)
-    ChunkPlan p1, p2;
+    ChunkPlan p1s, p2s;
+    ParseShare share;
     SlabPool* pool = pool_in;
     {
-        std::thread planner([&] { p1 = plan_chunks(m1, chunk_bytes, threads); p2 = plan_chunks(m2, chunk_bytes, threads); });
+        int src = LHGT_OK;
+        std::string serr;
+        std::thread planner([&] {
+            if (share_fn) { src = share_fn(m1, m2, &share, &p1s, &p2s); if (src != LHGT_OK) serr = last_error(); }
+            else { p1s = plan_chunks(m1, chunk_bytes, threads); p2s = plan_chunks(m2, chunk_bytes, threads); }
+        });
         const int prc = prepare ? prepare(&pool) : LHGT_OK;
         planner.join();
         LHGT_TRY(prc);
+        if (src != LHGT_OK) LHGT_FAIL(src, "%s", serr.c_str());
     }
+    const ChunkPlan& p1 = share.p1 ? *share.p1 : p1s;
+    const ChunkPlan& p2 = share.p2 ? *share.p2 : p2s;
     double t_plan = now_s() - t0, t_parse = 0, t_consume = 0;
-    // fq2 shorter than fq1: the reference pairs the surplus sequence lines of fq1 with a stale line of fq2 (E:356-367) -- refused.
-    // Tolerated like the reference: surplus lines of fq1 that are no sequence lines (a trailing blank line)
-    for (long g = p2.line0.back(); g < p1.line0.back(); g++)
-        if (g % 4 == 1 || g - p2.line0.back() >= 4) LHGT_FAIL(LHGT_E_FORMAT, "%s has fewer records than %s", fq2, fq1);
     ThreadEmu emu_store;
-    const ThreadEmu* emu = nullptr;
-    if (emulate_threads > 1) {
-        LHGT_TRY(thread_part(m1, p1, (long)m1.n, emulate_threads, fq1, &emu_store.f1));
-        LHGT_TRY(thread_part(m2, p2, (long)m1.n, emulate_threads, fq2, &emu_store.f2));
-        // phase C enters fq2 at the record whose read ID equals that of the chunk's first record of fq1 (E:368-402): with
-        // record-aligned files that is the same line number -- anything else is refused
-        for (int i = 0; i < emulate_threads; i++) {
-            const long g = emu_store.f1.first[i];
-            if (g >= p1.line0.back() || emu_store.f1.count[i] == 0) continue;
-            if (g >= p2.line0.back()) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: %s ends before thread %d's first record", emulate_threads, fq2, i);
-            LineCursor k1(m1), k2(m2);
-            const uint8_t *a, *b;
-            size_t la, lb, sa, sb;
-            long c1 = (long)(std::upper_bound(p1.line0.begin(), p1.line0.end(), g) - p1.line0.begin()) - 1;
-            long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g) - p2.line0.begin()) - 1;
-            k1.cur = p1.start[c1];
-            k2.cur = p2.start[c2];
-            for (long s = g - p1.line0[c1]; s >= 0; s--) k1.next(&a, &la, &sa);
-            for (long s = g - p2.line0[c2]; s >= 0; s--) k2.next(&b, &lb, &sb);
-            const size_t ia = read_id_len(a, la), ib = read_id_len(b, lb);
-            if (ia != ib || memcmp(a, b, ia)) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: thread %d's first record has different read IDs in the two files", emulate_threads, i);
-        }
-        emu = &emu_store;
+    PairLayout lay;
+    LHGT_TRY(parse_setup(m1, m2, p1, p2, fq1, fq2, emulate_threads, &emu_store, &lay));
+    const ThreadEmu* emu = emulate_threads > 1 ? &emu_store : nullptr;
+    const long nc_all = (long)p1.start.size() - 1;
+    const long c_lo = nc_all * share.part / share.n_parts, c_hi = nc_all * (share.part + 1) / share.n_parts, nc = c_hi - c_lo;
+    // fq2's records in front of the shift: counted by phase A, paired with nothing (the rank that owns fq1's first chunk)
+    if (lay.shift > 0 && share.part == 0) {
+        ParsedChunk head;
+        LHGT_TRY(parse_fq2_only(m1, m2, p2, 0, lay.shift < lay.lines2 ? lay.shift : lay.lines2, ratio, random_array, shard_rank, shard_world, shard_block, emu, &head));
+        if (head.o1.size() > 1) LHGT_TRY(consume(head));
     }
-    const long nc = (long)p1.start.size() - 1;
     {
         std::vector<ParsedChunk> out((size_t)nc);
         std::vector<std::atomic<int>> ready((size_t)nc);
@@ -443,7 +618,7 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
                 in_flight.fetch_add(1);
                 ParsedChunk& ch = out[(size_t)c];
                 if (pool) { ch.slab = pool->base + (size_t)slab_id * pool->slab_bytes; ch.half = pool->slab_bytes / 2; ch.slab_id = slab_id; }
-                parse_chunk(m1, m2, p1, p2, c, ratio, random_array, shard_rank, shard_world, shard_block, emu, &ch);
+                parse_chunk(m1, m2, p1, p2, c_lo + c, ratio, random_array, shard_rank, shard_world, shard_block, emu, lay, &ch);
                 { std::lock_guard<std::mutex> lk(mu); ready[(size_t)c].store(1); }
                 cv_ready.notify_all();
             }
@@ -502,34 +677,15 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
         if (rc != LHGT_OK) LHGT_FAIL(rc, "%s", err.c_str());
     }
     // fq2 longer than fq1: phase C stops with fq1 (E:356), but phase A counts every record of fq2 whose sequence line starts
-    // at a byte offset <= size(fq1) (E:1419-1445, quirk Q4) -- surplus records become mate-2-only entries
-    if (p2.line0.back() > p1.line0.back()) {
+    // at a byte offset <= size(fq1) (E:1419-1445, quirk Q4) -- surplus records become mate-2-only entries (the rank that owns fq1's last chunk)
+    if (lay.lines2 > lay.lines1 + lay.shift && share.part == share.n_parts - 1) {
         ParsedChunk tail;
-        tail.o1.assign(1, 0);
-        tail.o2.assign(1, 0);
-        const long g0 = p1.line0.back();
-        long c2 = (long)(std::upper_bound(p2.line0.begin(), p2.line0.end(), g0) - p2.line0.begin()) - 1;
-        LineCursor k2(m2);
-        k2.cur = p2.start[c2];
-        const uint8_t* b;
-        size_t lb, sb;
-        for (long skip = g0 - p2.line0[c2]; skip > 0; skip--) k2.next(&b, &lb, &sb);
-        for (long g = g0; k2.next(&b, &lb, &sb); g++) {
-            if (sb > m1.n) break;
-            if (g % 4 != 1) continue;
-            const long n = g / 4;
-            const bool keep = emu ? emu->f2.keep(g, ratio, random_array) == 1 : (ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio);
-            if (!keep || (n / shard_block) % shard_world != shard_rank) continue;
-            if (lb > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read %ld longer than %d bases (the reference's buffers, E:1004)", n, LHGT_MAX_READ_LEN);
-            tail.s2.insert(tail.s2.end(), b, b + lb);
-            tail.o1.push_back(0);
-            tail.o2.push_back(tail.s2.size());
-            tail.flags.push_back(PAIR_COUNT2);
-        }
+        LHGT_TRY(parse_fq2_only(m1, m2, p2, lay.lines1 + lay.shift, lay.lines2, ratio, random_array, shard_rank, shard_world, shard_block, emu, &tail));
         if (tail.o1.size() > 1) LHGT_TRY(consume(tail));
     }
     if (ingest_trace())
-        fprintf(stderr, "[lhgt ingest] %d threads, %ld chunks: line count %.3fs, parse %.3fs, consume(+upload) %.3fs\n", threads, nc,
+        fprintf(stderr, "[lhgt ingest] part %d/%d: %d threads, chunks [%ld, %ld) of %ld = %.1f MB of %.1f MB of %s: line count %.3fs, parse %.3fs, consume(+upload) %.3fs\n",
+                share.part, share.n_parts, threads, c_lo, c_hi, nc_all, 1e-6 * (double)(p1.start[(size_t)c_hi] - p1.start[(size_t)c_lo]), 1e-6 * (double)m1.n, fq1,
                 t_plan, t_parse, t_consume);
     if (n_pairs_seen) *n_pairs_seen = (p1.line0.back() + 2) / 4;   // lines with index % 4 == 1
     return LHGT_OK;
@@ -758,8 +914,12 @@ extern "C" {
 //                    the workers when its copy has completed (event)
 //   GPU              at >= 4 Mi pairs or 1 GiB of bases the batch is closed: metadata copied, pack_bases32 -> resident batch
 // so parsing, PCIe and packing overlap, and nothing is copied twice on the host.
-int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, int shard_rank,
-                          int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept) {
+}  // extern "C"
+
+using ShareFn = std::function<int(const lhgt::Mapped&, const lhgt::Mapped&, lhgt::ParseShare*, lhgt::ChunkPlan*, lhgt::ChunkPlan*)>;
+
+static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, int shard_rank,
+                           int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept, const ShareFn& share_fn) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !fq1 || !fq2) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world || shard_block < 1)
@@ -769,7 +929,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     // a batch is closed at 4 Mi pairs (1 Mi with count-on-load, so that phase A of one batch hides behind the parsing of the next;
     // every batch costs phase A one sweep of the count table, which is why they are not smaller)
     const long BATCH_PAIRS = ctx->count_on_load ? 1L << 20 : 4L << 20, META_CAP = BATCH_PAIRS + (1L << 18);
-    const size_t BATCH_BYTES = ctx->count_on_load ? (size_t)384 << 20 : (size_t)1 << 30, CHUNK = (size_t)2 << 20, SLAB = 2 * (CHUNK + 1024);
+    const size_t BATCH_BYTES = ctx->count_on_load ? (size_t)384 << 20 : (size_t)1 << 30, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes(), SLAB = 2 * (CHUNK + 1024);
     const int threads = default_threads();
     const int n_slabs = threads + threads / 3 + 4;
     // staging, pinned slabs and pinned metadata are allocated by `prepare` below, on this thread, while helper threads count lines
@@ -908,7 +1068,7 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
                              if (n_open >= BATCH_PAIRS || fill >= BATCH_BYTES) return flush();
                              return LHGT_OK;
                          },
-                         [&](bool block) { reap(block); }, prepare);
+                         [&](bool block) { reap(block); }, prepare, share_fn);
     const double t_f0 = now_s();
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(ctx->stream);      // whatever happened: no copy may still read a slab
@@ -926,6 +1086,68 @@ int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, doubl
     if (rc != LHGT_OK) return rc;
     if (n_pairs_kept) *n_pairs_kept = kept;
     return LHGT_OK;
+}
+
+extern "C" {
+
+int lhgt_pairs_load_fastq(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, int shard_rank,
+                          int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept) {
+    return load_fastq_impl(ctx, fq1, fq2, ratio_percent, shard_rank, shard_world, shard_block, n_pairs_seen, n_pairs_kept, nullptr);
+}
+
+// ---- multi-GPU ingest: every rank counts the lines of ITS share of both files, the host layer all-gathers the
+// pieces, and every rank parses only its contiguous run of fq1's chunks against the whole plan.  The reference's threads do the
+// same by byte ranges (E:1426-1434) but lose records at the boundaries; here the global line numbers make every split exact, and
+// sampling (n % 5*10^7 of the GLOBAL read ordinal, E:1037-1044) does not depend on the split.
+long lhgt_fastq_plan_chunk_bytes(void) {   // LHGT_INGEST_CHUNK_BYTES: test hook (small files cut into many chunks)
+    const char* e = getenv("LHGT_INGEST_CHUNK_BYTES");
+    const long v = e ? atol(e) : 0;
+    return v >= 256 ? v : (long)((size_t)2 << 20);
+}
+
+int lhgt_fastq_plan_part(const char* fq, long chunk_bytes, int part, int n_parts, uint64_t* start, long* n_lines, long cap, long* n_out,
+                         long* n_chunks_total, long* len_sums) {
+    if (!fq || chunk_bytes < 1 || n_parts < 1 || part < 0 || part >= n_parts || !n_out) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    Mapped m;
+    LHGT_TRY(m.open(fq));
+    const size_t nch = n_plan_chunks(m.n, (size_t)chunk_bytes);
+    const size_t c_lo = nch * (size_t)part / (size_t)n_parts, c_hi = nch * (size_t)(part + 1) / (size_t)n_parts;
+    *n_out = (long)(c_hi - c_lo);
+    if (n_chunks_total) *n_chunks_total = (long)nch;
+    if (!start || !n_lines) return LHGT_OK;       // size query
+    if (cap < (long)(c_hi - c_lo)) LHGT_FAIL(LHGT_E_ARG, "room for %ld chunks, part %d/%d of %s has %zu", cap, part, n_parts, fq, c_hi - c_lo);
+    std::vector<size_t> st;
+    std::vector<long> cnt;
+    const double t0 = now_s();
+    plan_range(m, (size_t)chunk_bytes, c_lo, c_hi, default_threads(), &st, &cnt);
+    for (size_t i = 0; i < c_hi - c_lo; i++) { start[i] = st[i]; n_lines[i] = cnt[i]; }
+    if (len_sums)      // cal_sam_ratio's pass (E:1244-1270) folded into the line count: line lengths by (line index inside the chunk) mod 4
+        parallel_for((long)(c_hi - c_lo), default_threads(), [&](long i) {
+            LineCursor lc(m);
+            lc.cur = st[(size_t)i];
+            const uint8_t* s;
+            size_t len, at;
+            long q = 0, sums[4] = {0, 0, 0, 0};
+            while (lc.cur < st[(size_t)i + 1] && lc.next(&s, &len, &at)) { sums[q & 3] += (long)len; q++; }
+            for (int r = 0; r < 4; r++) len_sums[4 * i + r] = sums[r];
+        });
+    if (ingest_trace())
+        fprintf(stderr, "[lhgt ingest] part %d/%d: lines of bytes [%zu, %zu) of %zu of %s counted in %.3fs\n", part, n_parts, st.front(), st.back(), m.n, fq, now_s() - t0);
+    return LHGT_OK;
+}
+
+int lhgt_pairs_load_fastq_planned(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, const uint64_t* start1,
+                                  const long* n_lines1, long n1, const uint64_t* start2, const long* n_lines2, long n2, int part,
+                                  int n_parts, long* n_pairs_seen, long* n_pairs_kept) {
+    if (!start1 || !n_lines1 || !start2 || !n_lines2 || n1 < 1 || n2 < 1 || n_parts < 1 || part < 0 || part >= n_parts)
+        LHGT_FAIL(LHGT_E_ARG, "bad FASTQ plan");
+    return load_fastq_impl(ctx, fq1, fq2, ratio_percent, 0, 1, 1, n_pairs_seen, n_pairs_kept,
+                           [&](const Mapped& m1, const Mapped& m2, ParseShare* sh, ChunkPlan* p1, ChunkPlan* p2) -> int {
+                               LHGT_TRY(plan_from_arrays(m1, start1, n_lines1, n1, p1));
+                               LHGT_TRY(plan_from_arrays(m2, start2, n_lines2, n2, p2));
+                               sh->p1 = p1; sh->p2 = p2; sh->part = part; sh->n_parts = n_parts;
+                               return LHGT_OK;
+                           });
 }
 
 // count_diff_kmer.cpp's reader (C:53-153): the file in 10 thread chunks of `size_for_chunks` bytes (fq1's size for both files,
@@ -992,9 +1214,28 @@ int lhgt_fastq_parse_digest(const char* fq1, const char* fq2, double ratio_perce
 int lhgt_fastq_parse_digest_threads(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
                                     int shard_world, long shard_block, int threads, long chunk_bytes, int emulate_threads,
                                     long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest, long* counts) {
+    return lhgt_fastq_parse_digest_planned(fq1, fq2, ratio_percent, random_array_or_null, shard_rank, shard_world, shard_block, threads, chunk_bytes,
+                                           emulate_threads, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1, 0, n_pairs_seen, n_pairs_kept, digest, counts);
+}
+
+// ... and with plans made elsewhere (start1 non-null: lhgt_fastq_plan_part pieces, concatenated) and only part `part` of `n_parts`
+// parsed.  chain != 0: *digest is the state to continue from, so that the parts of a split, run in order, give the digest of the whole.
+int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int shard_rank,
+                                    int shard_world, long shard_block, int threads, long chunk_bytes, int emulate_threads,
+                                    const uint64_t* start1, const long* n_lines1, long n1, const uint64_t* start2, const long* n_lines2, long n2,
+                                    int part, int n_parts, int chain, long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest, long* counts) {
     if (!fq1 || !fq2 || !digest || chunk_bytes < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if (ratio_percent < 100.0 && !random_array_or_null) LHGT_FAIL(LHGT_E_ARG, "sampling needs the random array");
-    uint64_t h = 1469598103934665603ull;
+    uint64_t h = chain ? *digest : 1469598103934665603ull;
+    ShareFn share_fn = nullptr;
+    if (start1)
+        share_fn = [&](const Mapped& m1, const Mapped& m2, ParseShare* sh, ChunkPlan* p1, ChunkPlan* p2) -> int {
+            if (!n_lines1 || !start2 || !n_lines2 || n1 < 1 || n2 < 1 || n_parts < 1 || part < 0 || part >= n_parts) LHGT_FAIL(LHGT_E_ARG, "bad FASTQ plan");
+            LHGT_TRY(plan_from_arrays(m1, start1, n_lines1, n1, p1));
+            LHGT_TRY(plan_from_arrays(m2, start2, n_lines2, n2, p2));
+            sh->p1 = p1; sh->p2 = p2; sh->part = part; sh->n_parts = n_parts;
+            return LHGT_OK;
+        };
     long kept = 0;
     auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
     long cnt[3] = {0, 0, 0};
@@ -1013,7 +1254,7 @@ int lhgt_fastq_parse_digest_threads(const char* fq1, const char* fq2, double rat
                              kept += n;
                              return LHGT_OK;
                          },
-                         [](bool) {});
+                         [](bool) {}, nullptr, share_fn);
     if (rc != LHGT_OK) return rc;
     *digest = h;
     if (n_pairs_kept) *n_pairs_kept = kept;

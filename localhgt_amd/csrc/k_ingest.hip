@@ -563,7 +563,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr;
     ctx->contigs.clear();
     ctx->contig_first_tile.clear();
-    if (ctx->d_contig_id_adj) { hipFree(ctx->d_contig_id_adj); ctx->d_contig_id_adj = nullptr; }
+    ctx->all_lens.clear();
     std::vector<TileDev> tiles;
     uint64_t word = 0, flat = 0;
     uint32_t ref_index = first_ref_index;   // contig numbers stay the global ones when only a shard is resident
@@ -642,6 +642,7 @@ int index_install_shard(lhgt_ctx* ctx, const uint32_t* w_all, size_t n_words_all
     const uint32_t* w = w_all + starts[c0];
     const size_t n_words = starts[c1] - starts[c0];
     LHGT_TRY(index_layout(ctx, lens, (uint32_t)c0 + 1));
+    if (lens.size() != lens_all.size()) ctx->all_lens = lens_all;
     // on its own non-blocking stream: a plain hipMemcpy would serialise with the FASTQ loader's stream (legacy default-stream rule)
     return upload_locked_ahead(ctx, ctx->copy_stream, ctx->d_index, w, n_words * 4);
 }

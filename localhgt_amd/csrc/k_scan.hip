@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
                                                      uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2,
-                                                     const uint32_t* __restrict__ id_adj /* nullable: per contig, -t N id ranges */, long n_blk) {
+                                                     uint32_t first_id /* 1 under -t N emulation when thread 0 finds no peak, else 0 */, long n_blk) {
     __shared__ int incl[TILE], part[BT];
     const long blk = block2d();
     if (blk >= n_blk) return;
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
     const uint8_t* F = flags + c.flat_base;
     uint32_t base = tile_base[blk];
     if (tile_base[blk + 1] == base) return;  // no peak in this tile (uniform exit)
-    if (id_adj) base += id_adj[t.contig];           // thread j's ids start at j * (max_peak / N) (E:229-237)
+    base += first_id;
     constexpr int CH = (TILE + BT - 1) / BT;
     const int b = threadIdx.x * CH, en = b + CH < TILE ? b + CH : TILE;
     int s = 0;
@@ -1048,51 +1048,71 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
 }
 
 // -t N emulation: the contig groups of split_ref (E:1280-1330) and their id ranges.  Thread j scans group j
-// and numbers its peaks from j * (max_peak / N) (E:229-237); the tile scan numbered all peaks sequentially, so a contig of group j
-// gets the adjustment base_j - (peaks of all earlier groups).  A later thread's id wins in peak_kmer as before (atomicMax: ids
-// grow with the thread number, and the contract runs the threads in creation order).
-static int thread_id_ranges(lhgt_ctx* ctx, long max_peak, uint32_t total, long* id_end) {
+// and numbers its peaks from j * (max_peak / N) (E:229-237).  Nothing that leaves the process depends on those bases: what counts
+// is (1) the ORDER of the ids -- a later thread's id wins in peak_kmer (atomicMax; the contract runs the threads in creation order)
+// and the interval file walks the ranges in thread order --, (2) which peaks share a range (one sentinel line per thread,
+// E:520-543), (3) that a range holds at most max_peak / N peaks, and (4) that id 0 means "no peak" (E:454), which only thread 0's
+// first peak can have.  So the ids stay the DENSE sequential ones of the tile scan -- tables, digests and the vote all-reduce are
+// sized by the number of peaks, not by (N-1) * max_peak / N -- shifted by one when thread 0 finds nothing (first_id = 1: no peak is
+// invisible then), and the per-thread ranges are kept as running ends for lhgt_write_intervals.
+static std::vector<long> thread_groups(const lhgt_ctx* ctx, long* first_local) {   // first contig (global, 0-based) of every group
     const int k = ctx->k, e = ctx->e, N = ctx->emu_threads;
-    const long nc = (long)ctx->contigs.size();
-    const long each_peaks = max_peak / N;
-    ctx->emu_each_peaks = each_peaks;
-    ctx->emu_range_end.assign((size_t)N, 0);
-    for (int j = 0; j < N; j++) ctx->emu_range_end[j] = each_peaks * j;
-    *id_end = 0;
-    if (nc == 0) return LHGT_OK;
-    if (ctx->contigs[0].ref_index != 1) LHGT_FAIL(LHGT_E_STATE, "-t N emulation needs the whole index on this GPU (not a reference shard)");
-    // split_ref over the resident contigs: a group closes with the contig at which the bytes before it exceed index_size / N + 1
-    const long index_size = 1200 + 4 * (long)ctx->index_words, each = index_size / N + 1;
-    std::vector<long> group_first;   // first contig of each group
+    std::vector<uint32_t> lens;
+    if (!ctx->all_lens.empty()) lens = ctx->all_lens;
+    else for (const ContigDev& c : ctx->contigs) lens.push_back(c.len);
+    *first_local = ctx->all_lens.empty() || ctx->contigs.empty() ? 0 : (long)ctx->contigs[0].ref_index - 1;
+    long words = 0;
+    for (uint32_t len : lens) words += 1 + (long)(len - k + 1) * e;
+    // split_ref over the whole index: a group closes with the contig at which the bytes before it exceed index_size / N + 1
+    const long nc = (long)lens.size(), index_size = 1200 + 4 * words, each = index_size / N + 1;
+    std::vector<long> group_first(1, 0);
     long pos = 1200, start_byte = 1200;
-    group_first.push_back(0);
     for (long c = 0; c < nc; c++) {
-        const long add = 4 * ((long)(ctx->contigs[c].len - k + 1) * e + 1);
+        const long add = 4 * ((long)(lens[c] - k + 1) * e + 1);
         if (pos - start_byte > each) {
             start_byte = pos + add;
             if (c + 1 < nc) group_first.push_back(c + 1);
         }
         pos += add;
     }
-    if ((long)group_first.size() > N) LHGT_FAIL(LHGT_E_STATE, "split_ref made %zu groups for %d threads", group_first.size(), N);
-    // peaks before each group = the exclusive tile scan at the group's first tile
-    std::vector<uint32_t> before(group_first.size() + 1, 0);
-    for (size_t g = 0; g < group_first.size(); g++)
-        LHGT_HIP(hipMemcpyAsync(&before[g], ctx->d_tile_count + ctx->contig_first_tile[group_first[g]], 4, hipMemcpyDeviceToHost, ctx->stream));
-    LHGT_HIP(hipStreamSynchronize(ctx->stream));
-    before[group_first.size()] = total;
-    std::vector<uint32_t> adj((size_t)nc);
-    for (size_t g = 0; g < group_first.size(); g++) {
-        const long count = (long)before[g + 1] - (long)before[g], base = each_peaks * (long)g;
-        if (count > each_peaks)
-            LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! thread %zu of %d found %ld, its id range holds %ld (the reference runs into the next thread's ids): appoint a larger max_peak_num (see --max_peak).", g, N, count, each_peaks);
-        ctx->emu_range_end[g] = base + count;
-        if (base + count > *id_end) *id_end = base + count;
-        const long c1 = g + 1 < group_first.size() ? group_first[g + 1] : nc;
-        for (long c = group_first[g]; c < c1; c++) adj[c] = (uint32_t)(base - (long)before[g]);
+    return group_first;
+}
+
+// new peaks of the resident contigs per group (the whole reference, or this rank's shard of it)
+static int group_counts_local(lhgt_ctx* ctx, uint32_t total, std::vector<long>* counts) {
+    const int N = ctx->emu_threads;
+    long first_local = 0;
+    const std::vector<long> gf = thread_groups(ctx, &first_local);
+    if ((long)gf.size() > N) LHGT_FAIL(LHGT_E_STATE, "split_ref made %zu groups for %d threads", gf.size(), N);
+    const long nl = (long)ctx->contigs.size();
+    auto clampl = [&](long g) { const long x = g - first_local; return x < 0 ? 0 : (x > nl ? nl : x); };
+    std::vector<uint32_t> at(gf.size() + 1, 0);   // peaks before the first resident contig of each group
+    for (size_t g = 0; g <= gf.size(); g++) {
+        const long lc = g < gf.size() ? clampl(gf[g]) : nl;
+        if (lc >= nl) at[g] = total;
+        else LHGT_HIP(hipMemcpyAsync(&at[g], ctx->d_tile_count + ctx->contig_first_tile[(size_t)lc], 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (!ctx->d_contig_id_adj) LHGT_HIP(hipMalloc(&ctx->d_contig_id_adj, (size_t)nc * 4));
-    LHGT_HIP(hipMemcpy(ctx->d_contig_id_adj, adj.data(), (size_t)nc * 4, hipMemcpyHostToDevice));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    counts->assign((size_t)N, 0);
+    for (size_t g = 0; g < gf.size(); g++) (*counts)[g] = (long)at[g + 1] - (long)at[g];
+    return LHGT_OK;
+}
+
+// the id ranges that follow from the per-group totals: first_id, running range ends
+static int thread_id_ranges(lhgt_ctx* ctx, long max_peak, const std::vector<long>& totals, long* first_id) {
+    const int N = ctx->emu_threads;
+    const long each_peaks = max_peak / N;
+    ctx->emu_each_peaks = each_peaks;
+    long total = 0;
+    for (int j = 0; j < N; j++) {
+        if (totals[j] > each_peaks)
+            LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! thread %d of %d found %ld, its id range holds %ld (the reference runs into the next thread's ids): appoint a larger max_peak_num (see --max_peak).", j, N, totals[j], each_peaks);
+        total += totals[j];
+    }
+    *first_id = total > 0 && totals[0] == 0 ? 1 : 0;
+    ctx->emu_range_end.assign((size_t)N, 0);
+    long run = *first_id;
+    for (int j = 0; j < N; j++) { run += totals[j]; ctx->emu_range_end[j] = run; }
     return LHGT_OK;
 }
 
@@ -1154,22 +1174,29 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     unsigned long long n_sel = 0;
     LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));   // no contig longer than k: zero tiles, zero peaks
     const bool emu = ctx->emu_threads > 1;
-    long id_end = total;
+    long first_id = 0;
     ctx->emu_range_end.clear();
-    if (emu) LHGT_TRY(thread_id_ranges(ctx, max_peak, total, &id_end));
+    ctx->emu_ranges_pending = false;
+    if (emu) {
+        if (!ctx->all_lens.empty()) LHGT_FAIL(LHGT_E_STATE, "-t N emulation on a reference shard goes through lhgt_ref_scan_local / lhgt_ref_scan_group_counts / lhgt_set_group_totals");
+        std::vector<long> counts;
+        LHGT_TRY(group_counts_local(ctx, total, &counts));
+        LHGT_TRY(thread_id_ranges(ctx, max_peak, counts, &first_id));
+    }
     if ((long)total > max_peak)
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
-    LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, id_end > max_peak ? id_end : max_peak));
+    const long id_end = (long)total + first_id;
+    LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, max_peak + first_id));
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, emu ? ctx->d_contig_id_adj : nullptr, ctx->n_tiles);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
     LHGT_HIP(hipEventElapsedTime(&ctx->phase_ms[1], ctx->ev0, ctx->ev1));
     ctx->n_peaks = total;
-    ctx->id_end = emu ? id_end : (long)total;
+    ctx->id_end = id_end;
     ctx->max_peak = max_peak;
     ctx->voted = false;
     if (n_peaks) *n_peaks = total;
@@ -1190,6 +1217,8 @@ int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long*
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t total = 0;
     unsigned long long n_sel = 0;
+    ctx->emu_range_end.clear();
+    ctx->emu_ranges_pending = false;
     LHGT_TRY(scan_local(ctx, hit_ratio, match_ratio, &total, &n_sel));
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -1199,6 +1228,30 @@ int lhgt_ref_scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long*
     ctx->n_peaks = -1;
     *n_new_local = total;
     *n_selected_local = (long)n_sel;
+    return LHGT_OK;
+}
+
+// -t N emulation on a reference shard: the split_ref groups cut across the ranks' shards.  Every rank reports the new peaks of
+// its contigs per group; the host layer sums them over the ranks and hands the totals to every rank, which fixes the id ranges
+// (thread_id_ranges above) before lhgt_ref_scan_emit / lhgt_peaks_install; *first_id is added to every rank's id base.
+int lhgt_ref_scan_group_counts(lhgt_ctx* ctx, long* counts, int n) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || !counts) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (ctx->emu_threads <= 1 || n != ctx->emu_threads) LHGT_FAIL(LHGT_E_ARG, "room for %d groups, the context emulates %d threads", n, ctx->emu_threads);
+    if (ctx->local_new < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan_local must precede lhgt_ref_scan_group_counts");
+    std::vector<long> c;
+    LHGT_TRY(group_counts_local(ctx, (uint32_t)ctx->local_new, &c));
+    for (int j = 0; j < n; j++) counts[j] = c[(size_t)j];
+    return LHGT_OK;
+}
+
+int lhgt_set_group_totals(lhgt_ctx* ctx, const long* totals, int n, long max_peak, long* first_id) {
+    if (!ctx || !totals || !first_id || max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (ctx->emu_threads <= 1 || n != ctx->emu_threads) LHGT_FAIL(LHGT_E_ARG, "%d totals, the context emulates %d threads", n, ctx->emu_threads);
+    std::vector<long> t(totals, totals + n);
+    for (long x : t) if (x < 0) LHGT_FAIL(LHGT_E_ARG, "negative group total");
+    LHGT_TRY(thread_id_ranges(ctx, max_peak, t, first_id));
+    ctx->emu_ranges_pending = true;
     return LHGT_OK;
 }
 
@@ -1243,6 +1296,12 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
     if (!ctx || n_peaks_total < 0 || n_regs_all < 0 || max_peak < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if ((n_peaks_total && !d_loci_all) || (n_regs_all && !d_regs_all)) LHGT_FAIL(LHGT_E_ARG, "null record buffer");
     if (n_peaks_total > 0xffffffffL) LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "more than 2^32 peaks");
+    // under -t N emulation the id ranges must have been fixed from the global per-group totals; a silent single range would be
+    // neither the reference's -t 1 nor its -t N file
+    if (ctx->emu_threads > 1 && !ctx->emu_ranges_pending)
+        LHGT_FAIL(LHGT_E_STATE, "-t %d emulation: lhgt_set_group_totals must precede lhgt_peaks_install", ctx->emu_threads);
+    if (ctx->emu_threads <= 1) ctx->emu_range_end.clear();
+    ctx->emu_ranges_pending = false;
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     LHGT_TRY(peaks_prepare(ctx, (uint32_t)n_peaks_total, (unsigned long long)n_selected_total, max_peak));
     if (n_peaks_total)

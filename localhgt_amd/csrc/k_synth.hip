@@ -128,16 +128,18 @@ int lhgt_synth_reference(lhgt_ctx* ctx, uint64_t ref_seed, long n_contigs, long 
 static int synth_reference_pieces(lhgt_ctx* ctx, const SynthSpec& s, const uint64_t* cuts, long n_cuts, long piece0, long piece1,
                                   uint8_t* host_ascii) {
     const int k = ctx->k, e = ctx->e;
-    std::vector<uint32_t> lens;
+    std::vector<uint32_t> lens, lens_all;
     uint32_t first_ref_index = 1;
-    for (long p = 0; p < piece1; p++) {
+    for (long p = 0; p + 1 < n_cuts; p++) {
         const uint64_t len = cuts[p + 1] - cuts[p];
         if (len >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "contig of %llu bases", (unsigned long long)len);
         if ((long)len <= k) continue;
+        lens_all.push_back((uint32_t)len);
         if (p < piece0) first_ref_index++;
-        else lens.push_back((uint32_t)len);
+        else if (p < piece1) lens.push_back((uint32_t)len);
     }
     LHGT_TRY(index_layout(ctx, lens, first_ref_index));
+    if (lens.size() != lens_all.size()) ctx->all_lens = lens_all;
     LHGT_TRY(write_index_lens(ctx));
     // spans of whole pieces, at most ~256 Mbase each (one huge piece is its own span)
     const uint64_t SPAN = 256ull << 20;

@@ -149,7 +149,7 @@ struct lhgt_ctx {
     uint32_t* d_filter = nullptr;
     uint32_t* d_tile_count = nullptr;
     long n_peaks = -1, max_peak = 0;
-    long id_end = 0;   // one past the largest peak id in use (= n_peaks unless thread ranges are emulated: ids start at j * (max_peak / t))
+    long id_end = 0;   // one past the largest peak id in use (= n_peaks, + 1 under -t N emulation when thread 0 found no peak: then no peak holds id 0)
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
     uint32_t* d_prefilter_fold = nullptr;  // 64 KiB fold of it, copied into LDS by the sparse-path vote kernel
     bool prefilter_on = false;
@@ -177,8 +177,9 @@ struct lhgt_ctx {
     float count_on_load_ms = 0.f;            // kernel time of those counts (added to phase_ms[0] by lhgt_count_kmers)
     int emu_threads = 1;
     long emu_each_peaks = 0;                 // max_peak / N of the last scan
-    std::vector<long> emu_range_end;         // per thread: one past its last peak id
-    uint32_t* d_contig_id_adj = nullptr;     // per resident contig: its group's id base minus the peaks of all earlier groups
+    std::vector<long> emu_range_end;         // per thread: one past its last peak id (dense ids; k_scan.hip: thread_id_ranges)
+    bool emu_ranges_pending = false;         // lhgt_set_group_totals fixed the ranges for the next lhgt_peaks_install
+    std::vector<uint32_t> all_lens;          // a reference SHARD is resident: the lengths of ALL indexed contigs (empty = the resident ones are all)
     std::vector<long> contig_first_tile;     // tile index of every resident contig's first tile
     bool count_compat = false;               // count_diff_kmer.cpp's bool coder (lhgt_set_count_compat)
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition

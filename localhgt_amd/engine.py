@@ -23,6 +23,7 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.lib.lhgt_ctx_create(self.device, self.k, self.e, C.byref(h)))
         self.h = h
+        self.emulated_threads = 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -128,6 +129,29 @@ class Engine:
                                                   block, C.byref(seen), C.byref(kept)))
         return seen.value, kept.value
 
+    # ---- multi-GPU ingest: every rank counts the lines of its share of a file, the pieces are exchanged (localhgt_amd/dist.py)
+    def fastq_plan_part(self, path: str, part: int, parts: int, want_len_sums: bool = False):
+        """(start[n] u64, n_lines[n] i64, len_sums[n, 4] i64 or None) of this part's chunks (include/localhgt_hip.h)"""
+        chunk = self.lib.lhgt_fastq_plan_chunk_bytes()
+        n, tot = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, None, None, 0, C.byref(n), C.byref(tot), None))
+        st, cn = np.zeros(max(n.value, 1), dtype=np.uint64), np.zeros(max(n.value, 1), dtype=np.int64)
+        sums = np.zeros((max(n.value, 1), 4), dtype=np.int64) if want_len_sums else None
+        _lib.check(self.lib.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, _ptr(st, C.c_uint64), _ptr(cn, C.c_long), n.value,
+                                                 C.byref(n), C.byref(tot), None if sums is None else _ptr(sums, C.c_long)))
+        return st[:n.value], cn[:n.value], None if sums is None else sums[:n.value]
+
+    def pairs_load_fastq_planned(self, fq1: str, fq2: str, ratio_percent: float, plan1, plan2, part: int, parts: int) -> Tuple[int, int]:
+        """plan = (start, n_lines) of ALL chunks of the file, the parts' pieces in order; only part `part`'s run of fq1's chunks is parsed"""
+        seen, kept = C.c_long(0), C.c_long(0)
+        s1, c1 = np.ascontiguousarray(plan1[0], dtype=np.uint64), np.ascontiguousarray(plan1[1], dtype=np.int64)
+        s2, c2 = np.ascontiguousarray(plan2[0], dtype=np.uint64), np.ascontiguousarray(plan2[1], dtype=np.int64)
+        _lib.check(self.lib.lhgt_pairs_load_fastq_planned(self.h, fq1.encode(), fq2.encode(), float(ratio_percent),
+                                                          _ptr(s1, C.c_uint64), _ptr(c1, C.c_long), s1.size,
+                                                          _ptr(s2, C.c_uint64), _ptr(c2, C.c_long), s2.size, part, parts,
+                                                          C.byref(seen), C.byref(kept)))
+        return seen.value, kept.value
+
     def pairs_append(self, seq1: np.ndarray, off1: np.ndarray, seq2: np.ndarray, off2: np.ndarray,
                      count_mate2: Optional[np.ndarray] = None, flags: Optional[np.ndarray] = None):
         """flags (one byte per pair: 1 = mate 1 counted in phase A, 2 = mate 2 counted, 4 = pair voted in phase C) overrides
@@ -225,6 +249,19 @@ class Engine:
                                                 C.byref(n), C.byref(s)))
         return n.value, s.value
 
+    def ref_scan_group_counts(self) -> list:
+        """-t N emulation on a reference shard: new peaks of the local contigs per split_ref group"""
+        n = self.emulated_threads
+        out = np.zeros(n, dtype=np.int64)
+        _lib.check(self.lib.lhgt_ref_scan_group_counts(self.h, _ptr(out, C.c_long), n))
+        return [int(x) for x in out]
+
+    def set_group_totals(self, totals, max_peak: int) -> int:
+        t = np.ascontiguousarray(totals, dtype=np.int64)
+        first = C.c_long(0)
+        _lib.check(self.lib.lhgt_set_group_totals(self.h, _ptr(t, C.c_long), t.size, int(max_peak), C.byref(first)))
+        return first.value
+
     def ref_scan_emit(self, id_base: int) -> Tuple[int, int, int]:
         """(device ptr of int32 loci[2*n_new_local], device ptr of uint32 regs[2*n_regs], n_regs)"""
         pl, pr, n = C.c_void_p(), C.c_void_p(), C.c_long(0)
@@ -246,6 +283,7 @@ class Engine:
     def set_thread_emulation(self, threads: int):
         """the reference's -t N without its races (include/localhgt_hip.h: lhgt_set_thread_emulation); 1 = off"""
         _lib.check(self.lib.lhgt_set_thread_emulation(self.h, int(threads)))
+        self.emulated_threads = int(threads)
 
     def set_debug(self, flags: int):
         _lib.check(self.lib.lhgt_set_debug(self.h, flags))

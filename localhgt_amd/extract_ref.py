@@ -6,10 +6,13 @@ Same 12 positional arguments, parsed the way the reference does (stod then trunc
 /root/reference/src/extract_ref_normal_peak.cpp:1352-1371), same files read and written:
 `<ref>.k<k>.h<e>.index.dat` + `<ref>.genome.len.txt` (built when absent, reused when present,
 E:1401-1413) and the interval file (E:515-548).  All compute runs on the GPU through
-liblocalhgt_hip.so; `threads` is accepted and ignored for compute (results are the `-t 1` ones).
+liblocalhgt_hip.so; `threads` does not set any thread count here, but with threads > 1 the RESULT is the one of the
+reference's `-t threads` run (its read partition, id ranges and sentinel lines, restated without its races;
+LHGT_EMULATE_THREADS=0: the `-t 1` result whatever -t says).
 
-Under `torch.distributed.run` (WORLD_SIZE > 1) every rank takes a shard of the read pairs and
-the count table / votes are exchanged over RCCL (localhgt_amd/dist.py)."""
+Under `torch.distributed.run` (WORLD_SIZE > 1) every rank takes a contiguous run of the read pairs and
+the count table / votes are exchanged over RCCL -- or, when the ranks share a GPU, through host memory over gloo
+(localhgt_amd/dist.py)."""
 from __future__ import annotations
 
 import os
@@ -65,26 +68,43 @@ def _warn_if_ids_desynchronise(genome_len_path: str, k: int, log) -> None:
             f"the interval file follow the reference's sequential numbering (E:905) and will not match; get_bed_file refuses them")
 
 
+def _emulation_refused(err) -> bool:
+    """errors with which only the -t N emulation refuses an input (include/localhgt_hip.h: lhgt_set_thread_emulation)"""
+    msg = str(err)
+    return (err.code == 4 and "emulation:" in msg and "-t " in msg) or (err.code == 6 and "Too many peaks! thread" in msg)
+
+
 def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, ref_form=None) -> dict:
     """The whole path A->D. `dist` is a localhgt_amd.dist.Exchange (or None for one GPU).
     ref_form (default: LHGT_REF_FORM in the environment, "index"): "packed" keeps the reference's BASES resident (3/8 byte per
     base, read from the FASTA) instead of the index file's hashes (12 bytes per base at e = 3) and lets phase B recompute the
     hashes: same interval file, no 12-bytes-per-base file read or written -- only the coder header of an existing index is
     used; without one the coder is drawn as the index build would draw it and genome.len.txt is written.
-    emulate_threads (default: LHGT_EMULATE_THREADS=1 in the environment): give the result of the reference's `-t threads` run
-    without its races -- its per-thread read partition, id ranges and sentinel lines -- instead of the
-    `-t 1` result.  `localhgt bkp` passes -t 10 by default, so that is what a user's reference run produced."""
+    emulate_threads (default: on when threads > 1, LHGT_EMULATE_THREADS=0 in the environment turns it off): give the result of
+    the reference's `-t threads` run without its races -- its per-thread read partition, id ranges and sentinel lines (SURVEY.md
+    8f rank 4) -- instead of the `-t 1` result.  `localhgt bkp` passes -t 10 by default, so that is what a user's reference run
+    produced (under sampling the kept reads, and with them the .bed, differ between -t 1 and -t N, E:1037).  Where the emulation
+    refuses an input -- one on which the reference reads stale bytes or overruns a thread's id range -- the run falls back to
+    the -t 1 result with one warning line."""
+    from ._lib import LocalHGTError
     rank, world = (dist.rank, dist.world) if dist else (0, 1)
     t0 = time.time()
     eng = Engine(a.k, a.e, device)
     if emulate_threads is None:
-        emulate_threads = os.environ.get("LHGT_EMULATE_THREADS", "0") == "1"
-    if emulate_threads and a.threads > 1:
+        emulate_threads = os.environ.get("LHGT_EMULATE_THREADS", "1") != "0"
+    emulating = bool(emulate_threads) and a.threads > 1
+    if emulating:
         eng.set_thread_emulation(a.threads)
         log(f"reproducing the reference's -t {a.threads} read partition and peak id ranges")
     log(f"kmer length is {a.k}\nseed is {a.seed}\nnum of hash functions is {a.e}")
     eng.rng_seed(a.seed)                                       # E:1386
-    ratio = eng.sam_ratio(a.fq1, a.sample)                     # E:1392-1398
+    plan1 = plan2 = None
+    if dist:                                                   # every rank counts the lines of 1/world of both files (dist.fastq_plan)
+        plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1)
+        plan2 = dist.fastq_plan(eng, a.fq2)
+        ratio = dist.sam_ratio_from_plan(plan1, a.sample)      # E:1392-1398 without cal_sam_ratio's pass over fq1
+    else:
+        ratio = eng.sam_ratio(a.fq1, a.sample)                 # E:1392-1398
     log(f"down-sampling ratio: {ratio}%.")
     idx = index_name(a.fasta, a.k, a.e)
     if ref_form is None:
@@ -130,17 +150,61 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     eng.sampling_init(ratio)                                   # E:1422
     t_r0 = time.time()
     eng.set_count_on_load(True)                                # phase A of a batch runs while the next one is parsed (E:1426-1448)
-    seen, kept = eng.pairs_load_fastq(a.fq1, a.fq2, ratio, rank, world)
-    t1 = time.time()
-    eng.count_kmers()                                          # phase A, E:1426-1448
-    if dist:
-        dist.merge_counts(eng)
+    state = {"seen": 0, "kept": 0, "t_reads": 0.0}
+
+    def everywhere(fn):
+        """fn() on this rank; a refusal by the -t N emulation is taken on every rank or on none"""
+        err = None
+        try:
+            fn()
+        except LocalHGTError as e:
+            if not (emulating and _emulation_refused(e)):
+                raise
+            err = e
+        refused = dist.agree(1 if err else 0) if dist else (1 if err else 0)
+        return err if err else (LocalHGTError(4, "-t N emulation: refused on another rank") if refused else None)
+
+    def load_and_count():
+        t = time.time()
+        if dist:                                               # this rank's contiguous run of fq1's chunks, paired through the whole plan
+            state["seen"], state["kept"] = eng.pairs_load_fastq_planned(a.fq1, a.fq2, ratio, plan1[:2], plan2[:2], rank, world)
+        else:
+            state["seen"], state["kept"] = eng.pairs_load_fastq(a.fq1, a.fq2, ratio)
+        state["t_reads"] = time.time() - t
+        eng.count_kmers()                                      # phase A, E:1426-1448
+        if dist:
+            dist.merge_counts(eng)
+
+    def fall_back(err):
+        nonlocal emulating
+        log(f"warning: the reference's -t {a.threads} run is not defined on this input ({str(err).split(': ', 2)[-1]}); "
+            f"giving the -t 1 result")
+        emulating = False
+        eng.set_thread_emulation(1)
+        eng.pairs_clear()
+        eng.counts_clear()
+
+    err = everywhere(load_and_count)
+    if err:
+        fall_back(err)
+        load_and_count()
     t2 = time.time()
     log(f"K-mer counting is finished. It costs {t2 - t0:.2f} seconds.")
-    if shard_index:                                            # phase B, E:1468-1489
-        n_peaks = dist.sharded_scan(eng, a.hit_ratio, a.match_ratio, a.max_peak)
-    else:
-        n_peaks = eng.ref_scan(a.hit_ratio, a.match_ratio, a.max_peak)
+    scan = {}
+
+    def scan_ref():
+        if shard_index:                                        # phase B, E:1468-1489
+            scan["n"] = dist.sharded_scan(eng, a.hit_ratio, a.match_ratio, a.max_peak, a.threads if emulating else 1)
+        else:
+            scan["n"] = eng.ref_scan(a.hit_ratio, a.match_ratio, a.max_peak)
+
+    err = everywhere(scan_ref)
+    if err:                                                    # a thread's peaks overflow its id range: reads again, as -t 1 keeps them
+        fall_back(err)
+        load_and_count()
+        scan_ref()
+    n_peaks = scan["n"]
+    seen, kept = state["seen"], state["kept"]
     t3 = time.time()
     log(f"Slided ref len: {n_bases} bp\tNo. of raw BKPs: {n_peaks}")
     eng.vote()                                                 # phase C, E:1496-1507
@@ -155,10 +219,11 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     t5 = time.time()
     log(f"Finish with time:\t{t5 - t0:.2f}")
     rep = dict(pairs_seen=seen, pairs_kept=kept, n_contigs=n_contigs, n_bases=n_bases, n_peaks=n_peaks,
-               n_filtered=n_filtered, ratio=ratio, index_built=built and not packed, ref_form=ref_form,
-               ref_resident_bytes=eng.reference_info()["resident_bytes"], ingest_s=t1 - t0, index_s=t_i1 - t_i0, reads_s=t1 - t_r0, count_s=t2 - t1, scan_s=t3 - t2,
+               n_filtered=n_filtered, ratio=ratio, index_built=built and not packed, ref_form=ref_form, emulated_threads=a.threads if emulating else 1,
+               ref_resident_bytes=eng.reference_info()["resident_bytes"], ingest_s=t_r0 + state["t_reads"] - t0, index_s=t_i1 - t_i0,
+               reads_s=state["t_reads"], count_s=t2 - t_r0 - state["t_reads"], scan_s=t3 - t2,
                vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
-               vote_kernel_ms=eng.phase_ms(2))
+               vote_kernel_ms=eng.phase_ms(2), world=world, staged_bytes=dist.staged_bytes if dist else 0)
     eng.close()
     return rep
 
@@ -171,7 +236,7 @@ def main(argv=None) -> int:
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from .dist import Exchange
         dist = Exchange.from_env()
-        device = dist.local_rank
+        device = dist.device
     try:
         run(a, device=device, dist=dist)
     finally:

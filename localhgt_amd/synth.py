@@ -171,9 +171,14 @@ def write_fastq(mate: np.ndarray, path: str, suffix: str, header_pad: int = 0,
 
 def write_case(outdir: str, ref: SynthRef, reads: SynthReads, fq2_header_pad: int = 0,
                lowercase_every: int = 0, fq1_header_pad: int = 0, fq1_drop_tail: int = 0,
-               fq1_trailing_blank: bool = False) -> Tuple[str, str, str]:
+               fq1_trailing_blank: bool = False, fq2_stray_records: int = 0, fq2_drop_tail: int = 0,
+               fq2_last_line_bases_of=None) -> Tuple[str, str, str]:
     """fq1_drop_tail: fq1 loses its last records, so fq2 holds surplus ones (counted in phase A while they start inside
-    size(fq1), E:1438-1445; never voted, E:356); fq1_trailing_blank: one empty line after fq1's last record"""
+    size(fq1), E:1438-1445; never voted, E:356); fq1_trailing_blank: one empty line after fq1's last record;
+    fq2_stray_records: that many records with foreign read IDs in front of fq2 (copies of its last reads), so the first IDs differ
+    and phase C re-scans fq2 for fq1's (E:368-402); fq2_drop_tail: fq2 loses its last records, so phase C runs out of mate-2 lines
+    (E:356-367); fq2_last_line_bases_of = r: fq2's last line (a quality line) holds the bases of mate 2 of read r and has no newline --
+    the line std::getline then leaves behind for every later read of fq1"""
     os.makedirs(outdir, exist_ok=True)
     fa = os.path.join(outdir, "ref.fa")
     f1 = os.path.join(outdir, "s.1.fq")
@@ -184,5 +189,18 @@ def write_case(outdir: str, ref: SynthRef, reads: SynthReads, fq2_header_pad: in
     if fq1_trailing_blank:
         with open(f1, "ab") as f:
             f.write(b"\n")
-    write_fastq(reads.mate2, f2, "2", header_pad=fq2_header_pad)
+    m2 = reads.mate2[:len(reads.mate2) - fq2_drop_tail] if fq2_drop_tail else reads.mate2
+    write_fastq(m2, f2, "2", header_pad=fq2_header_pad)
+    if fq2_stray_records or fq2_last_line_bases_of is not None:
+        body = open(f2, "rb").read()
+        if fq2_last_line_bases_of is not None:
+            lines = body.split(b"\n")          # ..., header, bases, +, quality, ""
+            lines[-2] = codes_to_ascii(reads.mate2[fq2_last_line_bases_of:fq2_last_line_bases_of + 1])[0].tobytes()
+            body = b"\n".join(lines[:-1])
+        if fq2_stray_records:
+            a = codes_to_ascii(reads.mate2[-fq2_stray_records:])
+            stray = b"".join(b"@stray%06d/2\n" % i + a[i].tobytes() + b"\n+\n" + b"I" * a.shape[1] + b"\n" for i in range(fq2_stray_records))
+            body = stray + body
+        with open(f2, "wb") as f:
+            f.write(body)
     return fa, f1, f2

@@ -515,14 +515,27 @@ static void* orc_vote_worker(void* arg) {
     return NULL;
 }
 
-/* Lock-step pass over both FASTQs (E:350-359); record counts must agree.  Returns pairs kept. */
+static long orc_vote_chunk(const orc_buf* b1, const orc_buf* b2, long start, long end, const orc_vote_job* j);
+/* Lock-step pass over both FASTQs (E:350-359).  Returns pairs kept. */
 long orc_vote(const char* fq1, const char* fq2, int k, int e, const short* cc, double ratio,
               const float* rnd, const uint32_t* peak_kmer, const int32_t* loci, uint8_t* peak_filter,
               int threads) {
     orc_buf b1 = orc_slurp(fq1), b2 = orc_slurp(fq2);
     if (b1.n < 0 || b2.n < 0) return -1;
     orc_seqs s1 = orc_scan_fastq(&b1, b1.n), s2 = orc_scan_fastq(&b2, b2.n);
-    if (s2.n < s1.n) return -2;
+    {   /* first read IDs differ (fq2 is re-scanned for fq1's, E:368-402) or fq2 runs out first (E:356-367): the literal pass */
+        long c1 = 0, c2 = 0, l1 = 0, l2 = 0;
+        const unsigned char *a = (const unsigned char*)"", *b = (const unsigned char*)"";
+        orc_next_line(&b1, &c1, &a, &l1);
+        orc_next_line(&b2, &c2, &b, &l2);
+        long i1 = orc_read_id_len(a, l1), i2 = orc_read_id_len(b, l2);
+        if (s2.n < s1.n || i1 != i2 || memcmp(a, b, (size_t)i1)) {
+            orc_vote_job jb = {&s1, &s2, 0, 0, k, e, cc, rnd, ratio, peak_kmer, loci, peak_filter, 0};
+            long kept = orc_vote_chunk(&b1, &b2, 0, b1.n, &jb);
+            free(s1.v); free(s2.v); free(b1.p); free(b2.p);
+            return kept;
+        }
+    }
     for (long n = 0; n < s1.n; n++) if (s1.v[n].len > ORC_MAX_READ || s2.v[n].len > ORC_MAX_READ) return -3;
     if (threads < 1) threads = 1;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
@@ -693,7 +706,9 @@ static long orc_vote_chunk(const orc_buf* b1, const orc_buf* b2, long start, lon
     const unsigned char *s1, *s2 = (const unsigned char*)"";
     orc_vote_state* S = (orc_vote_state*)malloc(sizeof(orc_vote_state));
     while (orc_next_line(b1, &cur1, &s1, &len1)) {
-        if (!orc_next_line(b2, &cur2, &s2, &len2)) { s2 = (const unsigned char*)""; len2 = 0; }
+        /* std::getline on a finished stream: the first failing call clears the string when the file ended with a newline (the
+         * sentry still succeeds), but leaves the last line in place when EOF was hit inside it (eofbit set: the sentry fails) */
+        if (!orc_next_line(b2, &cur2, &s2, &len2) && b2->n > 0 && b2->p[b2->n - 1] == '\n') { s2 = (const unsigned char*)""; len2 = 0; }
         if (add_size > end) break;
         add_size += len1 + 1;
         if (lines == 0) {

@@ -40,6 +40,9 @@ class Case:
     fq1_header_pad: int = 0
     fq1_drop_tail: int = 0                      # fq1 has that many records fewer than fq2
     fq1_trailing_blank: bool = False
+    fq2_stray_records: int = 0                  # foreign records in front of fq2: phase C re-scans fq2 for fq1's first read ID (E:368-402)
+    fq2_drop_tail: int = 0                      # fq2 has that many records fewer than fq1 (E:356-367)
+    fq2_last_line_bases_of: Optional[int] = None  # fq2's last line holds the bases of that read's mate 2 and has no newline
     threads: int = 1                            # -t of the run (parity contract of t > 1: oracle/_ref run on ONE core)
     lowercase_every: int = 0
     preexisting_index: bool = False             # run twice, keep outputs of the 2nd run (quirk Q3)
@@ -64,6 +67,17 @@ CASES: Dict[str, Case] = {c.name: c for c in [
          min_len=12000, max_len=20000, short_contig_at=None, depth=10,
          notes="fq2 holds 300 records more than fq1 and shorter headers: surplus mate-2 reads are counted in phase A, never voted; "
                "fq1 ends with a blank line"),
+    # what the reference ACCEPTS of unequal files (E:356-402)
+    Case("k24_fq2_stray2", fq2_stray_records=2, sample=0.5, ref_seed=91, reads_seed=92, n_contigs=5, min_len=12000, max_len=20000,
+         short_contig_at=None, depth=14,
+         notes="two foreign records in front of fq2: first read IDs differ, phase C re-scans fq2 for fq1's (E:368-402) and pairs fq1's "
+               "line g with fq2's line g + 8; phase A counts the foreign records too and samples fq2 by its own ordinals"),
+    Case("k24_fq2_short", fq2_drop_tail=500, ref_seed=93, reads_seed=94, n_contigs=5, min_len=12000, max_len=20000, short_contig_at=None,
+         depth=10, notes="fq2 ends 500 records early with a newline: the rest of fq1 is voted against an empty mate 2 (E:356-367)"),
+    Case("k24_fq2_short_nonl", fq2_drop_tail=500, fq2_last_line_bases_of=21, ref_seed=93, reads_seed=94, n_contigs=5, min_len=12000,
+         max_len=20000, short_contig_at=None, depth=10,
+         notes="the same with no newline after fq2's last line, which holds bases: std::getline leaves that line in place, so the "
+               "rest of fq1 is voted against it"),
     # -t N: goldens from the reference with its threads run in creation order (oracle/seq_threads.c)
     Case("k24_t4", threads=4, notes="-t 4: thread chunks of the FASTQs, 2 contig groups, 4 sentinel lines"),
     Case("k24_t8_sample_half", threads=8, sample=0.5, notes="-t 8 with sampling: ordinals restart in every chunk (E:1037)"),
@@ -90,7 +104,9 @@ def materialise(case: Case, outdir: str):
                               n_read_frac=case.n_read_frac)
     return synth.write_case(outdir, ref, reads, fq2_header_pad=case.fq2_header_pad,
                             lowercase_every=case.lowercase_every, fq1_header_pad=case.fq1_header_pad,
-                            fq1_drop_tail=case.fq1_drop_tail, fq1_trailing_blank=case.fq1_trailing_blank)
+                            fq1_drop_tail=case.fq1_drop_tail, fq1_trailing_blank=case.fq1_trailing_blank,
+                            fq2_stray_records=case.fq2_stray_records, fq2_drop_tail=case.fq2_drop_tail,
+                            fq2_last_line_bases_of=case.fq2_last_line_bases_of)
 
 
 def extract_ref_argv(case: Case, fq1: str, fq2: str, fa: str, interval: str):

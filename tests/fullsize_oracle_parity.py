@@ -27,7 +27,7 @@ print(f"inputs written in {time.time() - t0:.0f} s: {NC} x 1 Mbp, {PAIRS} pairs"
 reps = []
 for run in range(2):
     a = extract_ref.Args(f1, f2, fa, os.path.join(tmp, f"gpu{run}.txt"), 0.1, 0.08, 10, K, 300_000_000, E, 1, 1.0)
-    reps.append(extract_ref.run(a, log=lambda *x: None))
+    reps.append(extract_ref.run(a, log=lambda *x: None, emulate_threads=False))      # the CPU restatement below is the -t 1 one
     print("GPU run", run, json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in reps[-1].items()}), flush=True)
 orc = oracle_api.Oracle(build_oracle())
 orc.set_pretouch(True)

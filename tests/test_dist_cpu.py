@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -71,10 +72,10 @@ def _worker(rank, world, port, n_bytes, tmp):
     got = ex.all_gather_var(torch.arange(5 if rank == 0 else 0, dtype=torch.int32) + 100 * rank)
     assert got.tolist() == [0, 1, 2, 3, 4]
     got = ex.all_gather_var(torch.arange(2 + 3 * rank, dtype=torch.int32) + 100 * rank)
-    assert got.tolist() == [0, 1, 100, 101, 102, 103, 104]
+    assert got.tolist() == [100 * r + i for r in range(world) for i in range(2 + 3 * r)]
     # sharded scan: rank 0 finds 4 peaks, rank 1 finds 0 (empty shard) or 3
     for n1 in (0, 3):
-        eng.rank, eng.n_new = rank, (4 if rank == 0 else n1)
+        eng.rank, eng.n_new = rank, (4 if rank == 0 else n1 if rank == 1 else 0)
         assert ex.sharded_scan(eng, 0.1, 0.08, 1000) == 4 + n1
         n_total, n_sel, loci, regs = eng.installed
         assert (n_total, n_sel) == (4 + n1, 3 * (4 + n1))
@@ -90,8 +91,9 @@ def _worker(rank, world, port, n_bytes, tmp):
     ex.close()
 
 
-def test_exchange_world2_gloo(tmp_path):
-    world, n_bytes = 2, 1 << 16
+@pytest.mark.parametrize("world,n_bytes", [(2, 1 << 16), (3, 1 << 16), (3, 40)])
+def test_exchange_world2_gloo(tmp_path, world, n_bytes):
+    """world 3: the packed table does not split into equal word-aligned slices"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

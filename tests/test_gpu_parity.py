@@ -406,18 +406,22 @@ def test_reference_without_indexable_contig(tmp_path, oracle):
 
 
 def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
-    """scripts/pipeline.sh:35-36 verbatim, with this repo's bin/ on PATH: extract_ref <12 args>; get_bed_file.py ref interval > log"""
+    """scripts/pipeline.sh:35-36 verbatim, with this repo's bin/ on PATH and NO environment variable of ours: extract_ref <12 args>;
+    get_bed_file.py ref interval > log.  -t 10 is what `localhgt bkp` passes by default (scripts/localhgt.py:52), and under
+    sampling the reference's -t 10 keeps other reads than its -t 1 (E:1037): the files must be those of the reference's -t 10 run"""
     import subprocess
     import sys
-    name = "k24_base"
+    name = "k24_t10_sample_bases"
     case = cases.CASES[name]
+    assert case.threads == 10
     fa, f1, f2, meta = case_inputs(name)
     fa2 = str(tmp_path / "ref.fa")
     shutil.copy(fa, fa2)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PATH=os.path.join(root, "bin") + os.pathsep + os.environ["PATH"])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LHGT_")}
+    env["PATH"] = os.path.join(root, "bin") + os.pathsep + os.environ["PATH"]
     interval = str(tmp_path / "S.interval.txt")
-    script = (f'extract_ref {f1} {f2} {fa2} {interval} {case.hit_ratio} {case.match_ratio} 10 {case.k} {case.max_peak} {case.e} {case.seed} {case.sample}\n'
+    script = (f'extract_ref {f1} {f2} {fa2} {interval} {case.hit_ratio} {case.match_ratio} 10 {case.k} {case.max_peak} {case.e} {case.seed} {int(case.sample)}\n'
               f'python3 {root}/bin/get_bed_file.py {fa2} {interval} > {tmp_path}/S.log\n')
     res = subprocess.run(["bash", "-c", script], env=env, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -429,7 +433,7 @@ def test_executables_as_pipeline_sh_calls_them(case_inputs, tmp_path):
 
 
 def test_loader_survives_bad_input(Engine, case_inputs, tmp_path):
-    """a load that fails half-way (a read of 600 bases in the middle of the file; a second file with fewer records) returns its
+    """a load that fails half-way (a read of 600 bases in the middle of the file) or at once (a second file of foreign reads) returns its
     error, leaves nothing resident, and the same engine then loads good files as if nothing had happened"""
     from localhgt_amd import _lib
     fa, f1, f2, _ = case_inputs("k24_base")
@@ -437,8 +441,8 @@ def test_loader_survives_bad_input(Engine, case_inputs, tmp_path):
     bad1 = str(tmp_path / "long.1.fq")
     mid = (len(raw1) // 8) * 4 + 1
     open(bad1, "wb").write(b"\n".join(raw1[:mid] + [b"A" * 600] + raw1[mid + 1:]))
-    short2 = str(tmp_path / "short.2.fq")
-    open(short2, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:400]) + b"\n")
+    short2 = str(tmp_path / "foreign.2.fq")       # no line carries fq1's first read ID: the reference would spin through 10^9 failed reads
+    open(short2, "wb").write(open(f2, "rb").read().replace(b"@r", b"@q"))
     with Engine(24, 3) as eng:
         eng.rng_seed(1)
         eng.coder_generate()
@@ -478,22 +482,22 @@ def test_loader_without_page_locked_memory(case_inputs, tmp_path, monkeypatch):
 
 
 def test_extract_ref_executable_honours_t_when_asked(case_inputs, tmp_path):
-    """`localhgt bkp` passes -t 10 by default: with LHGT_EMULATE_THREADS=1 bin/extract_ref gives the reference's -t 10 file (golden
-    from the reference run with its threads in creation order), without it the -t 1 file whatever -t says"""
+    """`localhgt bkp` passes -t 10 by default: bin/extract_ref gives the reference's -t 10 file (golden from the reference run with
+    its threads in creation order); LHGT_EMULATE_THREADS=0 gives the -t 1 file whatever -t says"""
     import subprocess
     name = "k24_t10_sample_bases"
     case = cases.CASES[name]
     fa, f1, f2, meta = case_inputs(name)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for tag, extra in (("emulated", {"LHGT_EMULATE_THREADS": "1"}), ("plain", {})):
+    for tag, extra in (("emulated", {}), ("plain", {"LHGT_EMULATE_THREADS": "0"})):
         d = tmp_path / tag
         d.mkdir()
         fa2 = str(d / "ref.fa")
         shutil.copy(fa, fa2)
         interval = str(d / "S.interval.txt")
-        env = dict(os.environ, PATH=os.path.join(root, "bin") + os.pathsep + os.environ["PATH"], **extra)
-        env.pop("LHGT_EMULATE_THREADS", None) if not extra else None
+        env = {k: v for k, v in os.environ.items() if k != "LHGT_EMULATE_THREADS"}
+        env.update(PATH=os.path.join(root, "bin") + os.pathsep + os.environ["PATH"], **extra)
         num = str(int(case.sample)) if float(case.sample) == int(case.sample) else repr(float(case.sample))
         res = subprocess.run(["extract_ref", f1, f2, fa2, interval, repr(case.hit_ratio), repr(case.match_ratio), str(case.threads), str(case.k),
                               str(case.max_peak), str(case.e), str(case.seed), num], env=env, capture_output=True, text=True)

@@ -214,14 +214,125 @@ def test_parallel_fastq_parser_is_split_invariant(lib, oracle, case_inputs, tmp_
         assert one[0] == 0, name
         for threads, chunk in ((4, 500), (5, 97)):
             assert _digest(lib, p1, p2, threads=threads, chunk=chunk) == one, (name, threads, chunk)
-    # a second file with fewer records is refused, whatever the split (the reference would pair stale lines, E:356-367) ...
+    # a second file with fewer records is read like the reference reads it (E:356-367): every pair of fq1 is kept, the ones
+    # behind fq2's end with an empty mate 2 (golden k24_fq2_short), whatever the split ...
     p2s = str(tmp_path / "short.2.fq")
     open(p2s, "wb").write(b"\n".join(raw2.split(b"\n")[:400]) + b"\n")
-    assert _digest(lib, f1, p2s, threads=4, chunk=1000)[0] == 4
+    short = _digest(lib, f1, p2s)
+    assert short[:3] == (0, base[1], base[1]) and short[3] != base[3]
+    assert _digest(lib, f1, p2s, threads=4, chunk=1000) == short
     # ... one with more records is read like the reference reads it: phase C stops with fq1, phase A counts the surplus
     # records of fq2 that start inside size(fq1) (none here: the files share their first 400 lines)
     rc, seen, kept, _ = _digest(lib, p2s, f2, threads=4, chunk=1000)
     assert (rc, seen, kept) == (0, 100, 100)
+
+
+def _plan(lib, path, chunk, parts):
+    """the pieces lhgt_fastq_plan_part makes for `parts` ranks, concatenated the way localhgt_amd.dist does"""
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    starts, counts = [], []
+    for part in range(parts):
+        n, tot = C.c_long(0), C.c_long(0)
+        assert h.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, None, None, 0, C.byref(n), C.byref(tot), None) == 0
+        st, cn = (C.c_uint64 * max(n.value, 1))(), (C.c_long * max(n.value, 1))()
+        assert h.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, st, cn, n.value, C.byref(n), C.byref(tot), None) == 0
+        starts += list(st)[:n.value]
+        counts += list(cn)[:n.value]
+    assert len(starts) == tot.value
+    return np.array(starts, dtype=np.uint64), np.array(counts, dtype=np.int64)
+
+
+def _digest_planned(lib, f1, f2, plan1, plan2, part, parts, state=None, ratio=100.0, rnd=None, threads=3, emulate=1):
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(state or 0)
+    cnt = (C.c_long * 3)()
+    rp = rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None
+    u64, lp = C.POINTER(C.c_uint64), C.POINTER(C.c_long)
+    rc = h.lhgt_fastq_parse_digest_planned(f1.encode(), f2.encode(), float(ratio), rp, 0, 1, 1, threads, 1 << 40, emulate,
+                                           plan1[0].ctypes.data_as(u64), plan1[1].ctypes.data_as(lp), len(plan1[0]),
+                                           plan2[0].ctypes.data_as(u64), plan2[1].ctypes.data_as(lp), len(plan2[0]),
+                                           part, parts, 0 if state is None else 1, C.byref(seen), C.byref(kept), C.byref(dig), cnt)
+    return rc, seen.value, kept.value, dig.value, list(cnt)
+
+
+@pytest.mark.parametrize("name", ["k24_fq2_longer", "k24_fq2_surplus", "k24_fq2_stray2", "k24_fq2_short_nonl", "k24_t3_fq2_longer"])
+def test_rank_ranges_of_the_fastqs_add_up_to_the_single_rank_parse(lib, oracle, case_inputs, name):
+    """multi-GPU ingest: every rank counts the lines of its share of both files, the pieces are exchanged, every rank
+    parses only its run of fq1's chunks -- the parts, in rank order, give exactly the pairs (order, flags, bases) of the
+    single-rank parse, with sampling by the global read ordinal, quirk Q4, surplus / foreign fq2 records and -t N emulation"""
+    case = cases.CASES[name]
+    fa, f1, f2, _ = case_inputs(name)
+    rnd, ratio = None, 100.0
+    if float(case.sample) < 1:
+        oracle.srand(case.seed)
+        rnd = np.resize(oracle.sampling_array(1_000_000), 50_000_000)
+        ratio = 100.0 * float(case.sample)
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+    cnt = (C.c_long * 3)()
+    rp = rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None
+    assert h.lhgt_fastq_parse_digest_threads(f1.encode(), f2.encode(), ratio, rp, 0, 1, 1, 2, 1 << 40, case.threads, C.byref(seen), C.byref(kept),
+                                             C.byref(dig), cnt) == 0
+    whole = (seen.value, kept.value, dig.value, list(cnt))
+    assert kept.value > 500
+    for chunk, parts in ((30000, 2), (7777, 3), (100000, 8), (1 << 22, 2)):
+        plan1, plan2 = _plan(lib, f1, chunk, parts), _plan(lib, f2, chunk, parts)
+        assert int(plan1[1].sum()) == sum(1 for _ in open(f1, "rb"))
+        state, kept_sum, cnt_sum, kept_parts = None, 0, [0, 0, 0], []
+        for part in range(parts):
+            rc, sn, kp, dg, c3 = _digest_planned(lib, f1, f2, plan1, plan2, part, parts, state=state if part else None, ratio=ratio, rnd=rnd,
+                                                 emulate=case.threads)
+            assert rc == 0 and sn == whole[0]
+            state, kept_sum, cnt_sum = dg, kept_sum + kp, [a + b for a, b in zip(cnt_sum, c3)]
+            kept_parts.append(kp)
+        assert (kept_sum, state, cnt_sum) == whole[1:], (chunk, parts)
+        if chunk < 100000 and parts <= 3:
+            assert min(kept_parts) > 0.5 * kept_sum / parts            # contiguous, about equal shares
+    # a plan that is not made of whole lines is refused before anything is parsed
+    bad = (plan1[0].copy(), plan1[1])
+    if len(bad[0]) > 1:
+        bad[0][1] += 1
+        assert _digest_planned(lib, f1, f2, bad, plan2, 0, 2)[0] == 1
+
+
+def test_fq2_with_foreign_records_in_front_is_resynchronised_like_the_reference(lib, oracle, case_inputs, tmp_path):
+    """E:368-402: the first read IDs differ, so phase C re-reads fq2 from byte 1 until a line carries fq1's first ID and pairs
+    fq1's line g with fq2's line g + 8; phase A (E:1426-1448) reads each file on its own -- mate 2 of pair n is fq2's read n + 2 and is
+    sampled as such, the two foreign reads are counted and never voted.  Counts against the oracle's whole run (golden-pinned)."""
+    import ctypes as C
+    name = "k24_fq2_stray2"
+    case = cases.CASES[name]
+    fa, f1, f2, meta = case_inputs(name)
+    fa2 = str(tmp_path / "ref.fa")
+    shutil.copy(fa, fa2)
+    rc, rep = oracle.run(f1, f2, fa2, str(tmp_path / "i.txt"), case.hit_ratio, case.match_ratio, 1, case.k, case.max_peak, case.e, case.seed,
+                         float(case.sample))
+    assert rc == 0 and open(tmp_path / "i.txt").read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()
+    oracle.srand(case.seed)
+    cc = oracle.random_coder(case.k, case.e)          # index built in-run (quirk Q3)
+    rnd = oracle.sampling_array(50_000_000)
+    table = np.zeros(1 << case.k, dtype=np.uint8)
+    c2 = oracle.count(f2, os.path.getsize(f1), case.k, case.e, cc, 50.0, rnd, table)
+    h = lib.load(require_gpu=False)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+    cnt = (C.c_long * 3)()
+    assert h.lhgt_fastq_parse_digest_threads(f1.encode(), f2.encode(), 50.0, rnd.ctypes.data_as(C.POINTER(C.c_float)), 0, 1, 1, 4, 50000, 1,
+                                             C.byref(seen), C.byref(kept), C.byref(dig), cnt) == 0
+    assert (cnt[0], cnt[1], cnt[2]) == (rep.pairs_counted, c2, rep.pairs_voted)
+    assert kept.value > max(cnt[0], cnt[1])            # entries with only one mate counted exist: the ordinals are shifted by two
+    # refused: no line with fq1's first ID anywhere in fq2; a shift inside a record
+    lines2 = open(f2, "rb").read().split(b"\n")
+    none2 = str(tmp_path / "none.2.fq")
+    open(none2, "wb").write(b"\n".join(lines2[:8] + lines2[12:]) + b"\n" if False else b"\n".join(lines2[:8]) + b"\n")
+    assert h.lhgt_fastq_parse_digest_threads(f1.encode(), none2.encode(), 100.0, None, 0, 1, 1, 2, 50000, 1, C.byref(seen), C.byref(kept),
+                                             C.byref(dig), None) == 4
+    odd2 = str(tmp_path / "odd.2.fq")
+    open(odd2, "wb").write(b"\n".join(lines2[:3] + lines2[8:]))
+    assert h.lhgt_fastq_parse_digest_threads(f1.encode(), odd2.encode(), 100.0, None, 0, 1, 1, 2, 50000, 1, C.byref(seen), C.byref(kept),
+                                             C.byref(dig), None) == 4
 
 
 def test_surplus_records_of_fq2_are_counted_not_voted(lib, oracle, case_inputs):

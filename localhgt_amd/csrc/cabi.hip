@@ -47,15 +47,14 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
     }
     out[0] = out[1] = 0;
     if (!p || !n) return LHGT_OK;
-    unsigned long long* d_out;
-    LHGT_HIP(hipMalloc(&d_out, 16));
+    if (!ctx->d_digest) LHGT_HIP(hipMalloc(&ctx->d_digest, 16));     // one small scratch per context, freed with it
+    unsigned long long* d_out = ctx->d_digest;
     LHGT_HIP(hipMemsetAsync(d_out, 0, 16, ctx->stream));
     if (bytes == 1) hipLaunchKernelGGL((digest_kernel<uint8_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint8_t*)p, n, mask, d_out);
     else hipLaunchKernelGGL((digest_kernel<uint32_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint32_t*)p, n, mask, d_out);
     unsigned long long h[2] = {0, 0};
     hipError_t e1 = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    hipFree(d_out);
     if (e1 != hipSuccess || e2 != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "digest copy failed");
     out[0] = h[0];
     out[1] = h[1];
@@ -126,7 +125,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_peak_kmer, (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],
-                    (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_emit_loci, (void*)c->d_emit_regs})
+                    (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest})
         if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -1004,7 +1004,9 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         int rc = install_pairs_pinned(ctx, ctx->d_ws_ascii, start1, start2, woff1, woff2, len1, len2, pflags, n_open, words, max_len, nkm);
         if (rc == LHGT_OK && ctx->count_on_load) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            const bool have_e0 = hipEventCreate(&e0) == hipSuccess;
+            if (have_e0 && hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); e0 = nullptr; }
+            if (e0 && e1) {
                 count_ev.push_back(e0);
                 count_ev.push_back(e1);
                 // the copies and the pack kernel of this batch are ahead of it on the same stream; the wait below is for THEM
@@ -1407,6 +1409,7 @@ int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char*
             if ((long)fx.seqs[first + (size_t)c].len > k) contig_of[(size_t)c] = ci++;
         return install_span_dev_ascii(ctx, d_bases, n_bases_span, coff, contig_of.data(), n_c);
     });
+    if (rc != LHGT_OK) ctx->index_resident = false;      // a half-filled reference must not pass for a resident one
     if (n_contigs) *n_contigs = (long)ctx->contigs.size();
     if (n_bases) *n_bases = (long)ctx->n_pos;
     return rc;
@@ -1448,7 +1451,8 @@ int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank,
     for (int i = 0; i < LHGT_CODER_SLOTS; i++) cc[i] = (int16_t)w[i];  // saved_random_coder: low half of each word
     LHGT_TRY(lhgt_coder_set(ctx, cc));
     if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d", shard_rank, shard_world);
-    LHGT_TRY(index_install_shard(ctx, w + LHGT_CODER_SLOTS, m.n / 4 - LHGT_CODER_SLOTS, shard_rank, shard_world));
+    const int irc = index_install_shard(ctx, w + LHGT_CODER_SLOTS, m.n / 4 - LHGT_CODER_SLOTS, shard_rank, shard_world);
+    if (irc != LHGT_OK) { ctx->index_resident = false; return irc; }
     if (n_contigs) *n_contigs = (long)ctx->contigs.size();
     if (n_bases) *n_bases = (long)ctx->n_pos;
     return LHGT_OK;

@@ -183,6 +183,7 @@ struct lhgt_ctx {
     std::vector<long> contig_first_tile;     // tile index of every resident contig's first tile
     bool count_compat = false;               // count_diff_kmer.cpp's bool coder (lhgt_set_count_compat)
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
+    unsigned long long* d_digest = nullptr;   // 16 bytes: lhgt_digest's accumulator
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // FASTQ loader (host_fastx.cpp): pinned slabs the parse threads write into, pinned per-pair metadata of the open batch,
     // events that tell when a slab's copy has left the host

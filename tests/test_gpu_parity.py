@@ -509,6 +509,51 @@ def test_extract_ref_executable_honours_t_when_asked(case_inputs, tmp_path):
     assert gold.count("1\t1\t1\n") >= 8                                           # ten ranges, most of them empty
 
 
+def test_thread_emulation_falls_back_to_t1_where_the_reference_run_is_undefined(oracle, case_inputs, tmp_path):
+    """inputs on which the reference's -t N reads stale bytes (a thread entering a FASTQ within 1000 bytes of its end) or lets a
+    thread's peaks run into the next thread's ids: one warning line, then the -t 1 result (golden / oracle)"""
+    from localhgt_amd import extract_ref
+    case = cases.CASES["k24_base"]
+    fa, f1, f2, meta = case_inputs("k24_base")
+    gold = open(os.path.join(cases.GOLDEN_DIR, "k24_base", "interval.txt")).read()
+    # (1) a thread's id range overflows: 4 threads x 50 ids for 167 peaks in two contig groups
+    d = tmp_path / "overflow"
+    d.mkdir()
+    fa2 = str(d / "ref.fa")
+    shutil.copy(fa, fa2)
+    interval = str(d / "i.txt")
+    argv = cases.extract_ref_argv(case, f1, f2, fa2, interval)
+    argv[6], argv[8] = "4", "200"
+    log = []
+    rep = extract_ref.run(extract_ref.parse_argv(argv), log=lambda *a: log.append(" ".join(str(x) for x in a)))
+    assert rep["emulated_threads"] == 1 and rep["n_peaks"] == meta["raw_peaks"] and open(interval).read() == gold
+    warn = [ln for ln in log if ln.startswith("warning")]
+    assert len(warn) == 1 and "Too many peaks! thread" in warn[0] and "-t 1 result" in warn[0]
+    # (2) 40 threads on six records: chunks near the end of the file
+    d = tmp_path / "tiny"
+    d.mkdir()
+    t1, t2 = str(d / "t.1.fq"), str(d / "t.2.fq")
+    open(t1, "wb").write(b"\n".join(open(f1, "rb").read().split(b"\n")[:24]) + b"\n")
+    open(t2, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:24]) + b"\n")
+    outs = {}
+    for who in ("gpu", "cpu"):
+        w = d / who
+        w.mkdir()
+        fa3 = str(w / "ref.fa")
+        shutil.copy(fa, fa3)
+        iv = str(w / "i.txt")
+        if who == "gpu":
+            log = []
+            rep = extract_ref.run(extract_ref.parse_argv([t1, t2, fa3, iv, "0.1", "0.08", "40", "24", "100000", "3", "1", "1"]),
+                                  log=lambda *a: log.append(" ".join(str(x) for x in a)))
+            assert rep["emulated_threads"] == 1 and sum(ln.startswith("warning") for ln in log) == 1
+        else:
+            rc, _ = oracle.run(t1, t2, fa3, iv, 0.1, 0.08, 1, 24, 100000, 3, 1, 1.0)
+            assert rc == 0
+        outs[who] = open(iv).read()
+    assert outs["gpu"] == outs["cpu"]
+
+
 @pytest.mark.parametrize("k,e", [(20, 9), (33 - 1, 1), (16, 4)])
 def test_whole_run_matches_oracle_for_unusual_e(oracle, case_inputs, tmp_path, k, e):
     """e = 9 (four rand() rows per position, 9th hash outside the 8-bit nzmask), e = 1 and e = 4: GPU run vs oracle run"""

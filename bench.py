@@ -12,10 +12,16 @@ GPU: 13 Gbase reference (13000 x 1 Mbp, 156 GB of index resident in HBM), 100 M 
 `python3 bench.py --gpus N` is self-contained: without WORLD_SIZE in the environment it starts its N ranks itself (child
 processes, before this process touches a GPU); under `torch.distributed.run` it is one of the ranks.
 
-What the line holds besides the contract's fields (N = 1; all of it measured inside this run):
-  roofline    dominant kernel: measured HBM bytes per launch (rocprofv3 --pmc passes of this same command, collected by child
-              processes before the timed run) / launch duration by HIP events / 8 TB/s -- a fraction <= 1 by construction;
-              the request rate against the microbenchmarked ceiling; SURVEY 8d's sector-model bytes as `model_speedup`
+What the line holds besides the contract's fields (all of it measured inside this run):
+  roofline    the dominant kernel among phase A's family, ref_flags and the vote kernel: launch time by HIP events; bytes from
+              rocprofv3 --pmc passes of this same command (child processes, before the timed run).  Three fractions of 8 TB/s:
+              frac_raw (FETCH_SIZE + WRITE_SIZE as counted), frac_fabric = frac (FETCH_SIZE x 2: every read request of these
+              kernels is a 128-B line fill tallied at 64 B -- a calibrated estimate of fabric bytes, Infinity-Cache hits included)
+              and frac_model (SURVEY 8d's algorithmic bytes; `model_exceeded` where the code avoids the probes the model prices);
+              infinity_cache_share: part of the "HBM" lines the 256 MiB MALL serves (tools/probe_shapes mall)
+  at N > 1    value = the REPLICATED form (every rank scans the whole reference: per-GPU work fixed, which is what "weak" means);
+              `sharded_index` = the same step with phase B sharded over the ranks (per-GPU work shrinks: not a scaling figure);
+              n1_equivalent_ms = this rank's step without the exchanges; rank 0 measures its kernels' traffic live (N = 1 children)
   compulsory  bytes a step cannot avoid reading (reads twice, index, tables) as a fraction of peak
   secondary   configs[1] (the workload where votes, judge and the dense vote kernel do real work), the UHGG reference under a
               sample of 1000 genomes, and the CLI's default --sample 2e9 mode
@@ -103,11 +109,13 @@ def collect_pmc(args, passes, timeout_s=420):
             "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-verify",
             "--workload", args.workload, "--pairs", str(args.pairs), "--contigs", str(args.contigs),
             "--contig-len", str(args.contig_len), "-k", str(args.k), "-e", str(args.e), "--count-mode", str(args.count_mode),
-            "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs), "--ref-form", args.ref_form]
+            "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs), "--ref-form", args.ref_form] + (["--ragged"] if args.ragged else [])
     for counters in passes:
         d = tempfile.mkdtemp(prefix="lhgt_pmc_", dir="/tmp")
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                     "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            env["TMPDIR"] = "/tmp"
             res = subprocess.run([exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--"] + base, cwd="/tmp", env=env,
                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -138,16 +146,17 @@ def pmc_traffic(agg):
     FETCH_SIZE doubled: see FETCH_SIZE_SCALE)"""
     out = {}
     for ph, names in PHASE_KERNELS.items():
-        tot, req_l2, req_ea, seen = 0.0, 0.0, 0.0, False
+        tot, raw, req_l2, req_ea, seen = 0.0, 0.0, 0.0, 0.0, False
         for kname, ent in agg.items():
             if not _kernel_in(kname, names) or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
                 continue
             seen = True
             tot += (ent["FETCH_SIZE"] * FETCH_SIZE_SCALE + ent["WRITE_SIZE"]) * 1024
+            raw += (ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024
             req_l2 += ent.get("TCP_TCC_READ_REQ_sum", 0.0)
             req_ea += ent.get("TCC_EA0_RDREQ_sum", 0.0)
         if seen:
-            out[ph] = {"bytes": int(tot), "l2_read_requests": int(req_l2) or None, "hbm_read_requests": int(req_ea) or None}
+            out[ph] = {"bytes": int(tot), "bytes_raw": int(raw), "l2_read_requests": int(req_l2) or None, "hbm_read_requests": int(req_ea) or None}
     return out
 
 
@@ -386,27 +395,93 @@ def verify_forms(eng):
             "compared": "peak loci, peak_kmer[2^k], flags of every reference position, votes: picked forms vs exact scan + unfiltered generic vote"}
 
 
-def roofline_entry(desc, ms_step, launches, algo_bytes, traffic_rec, source, ceiling):
-    """one kernel: measured HBM bytes / time / 8 TB/s (<= 1 by construction), the request rate against its measured ceiling,
-    and SURVEY 8d's sector-model bytes as a ratio to what the kernel really moves"""
+def mall_share():
+    """tools/probe_shapes mall (built by __graft_entry__.build): random-probe rates on 128 MiB / 1 GiB / 16 GiB tables and the
+    share of a table's line fills the Infinity Cache serves, estimated from them.  None when the binary is not there."""
+    exe = os.path.join(ROOT, "tools", "probe_shapes")
+    if not os.path.exists(exe):
+        return None
+    try:
+        res = subprocess.run([exe, "mall"], capture_output=True, text=True, timeout=120)
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception:
+        return None
+
+
+def roofline_entry(desc, ms_step, launches, algo_bytes, traffic_rec, source, ceiling, mall=None, table=None):
+    """one kernel against the 8 TB/s HBM peak, three ways (none of them is a guarantee of <= 1):
+      frac_raw     FETCH_SIZE + WRITE_SIZE as the counters tally them (64 B per read request)
+      frac_fabric  FETCH_SIZE x 2 + WRITE_SIZE: every read request of these kernels is a 128-B line fill (calibrated with
+                   tools/probe_shapes.hip, profiles/r02/probe_shapes_pmc.txt) -- an ESTIMATE of the bytes that cross the fabric;
+                   it counts Infinity-Cache hits as memory reads (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ on gfx950), see
+                   infinity_cache_share.  `frac` and `achieved` are this figure
+      frac_model   SURVEY 8d's algorithmic bytes (one 64-B sector per probe) / time / peak; above 1 (`model_exceeded`) where the
+                   partition, the L2-resident bitmap or the lite scan avoid the probes the model prices
+    plus the request rate against its microbenchmarked ceiling."""
     ent = {"kernel": desc, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(ms_step, 3),
            "launches_per_step": launches, "launch_ms": round(ms_step / launches, 3) if launches else None,
            "algorithmic_bytes_per_step": algo_bytes,
            "sector_model_GBps": round(algo_bytes / (ms_step * 1e-3) / 1e9, 1) if ms_step > 0 else None}
+    if ms_step > 0:
+        fm = algo_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        ent.update({"frac_model": round(fm, 4), "model_exceeded": bool(fm > 1.0)})
     if traffic_rec and ms_step > 0:
         b = traffic_rec["bytes"]
         ach = b / (ms_step * 1e-3) / 1e9
-        ent.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": b // max(1, launches or 1),
-                    "traffic_per_step": b, "traffic_source": source, "model_speedup": round(algo_bytes / b, 2) if b else None})
+        ent.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "frac_fabric": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": b // max(1, launches or 1), "traffic_per_step": b, "scale": FETCH_SIZE_SCALE,
+                    "traffic_source": source, "model_speedup": round(algo_bytes / b, 2) if b else None})
+        if traffic_rec.get("bytes_raw"):
+            raw = traffic_rec["bytes_raw"]
+            ent.update({"traffic_raw": raw // max(1, launches or 1), "frac_raw": round(raw / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         req = traffic_rec.get(ceiling[0])
         if req:
             g = req / (ms_step * 1e-3) / 1e9
             ent["request_rate"] = {"value": round(g, 1), "unit": "G requests/s", "counter": ceiling[1], "ceiling": ceiling[2],
                                    "frac_of_ceiling": round(g / ceiling[2], 3), "ceiling_source": ceiling[3]}
+        if mall and table in ("1GiB", "16GiB"):
+            sh = mall.get(f"mall_share_{table}_table")
+            if sh is not None:
+                ent["infinity_cache_share"] = {"value": round(sh, 3), "of": f"line fills of the kernel's {table} probe table, estimated from random-probe "
+                                               f"rates on 128 MiB / 1 GiB / 16 GiB tables (tools/probe_shapes mall): {mall.get('gprobes_per_s')}",
+                                               "frac_hbm_estimate": round(ach / HBM_PEAK_GBS * (1.0 - sh), 4)}
     else:
         ent.update({"achieved": None, "frac": None, "traffic": None, "stale": True,
                     "traffic_source": "none: the rocprofv3 --pmc passes failed and profiles/traffic_per_launch.json was measured on other sources"})
     return ent
+
+
+PMC_PASSES = [["FETCH_SIZE", "TCP_TCC_READ_REQ_sum"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum"]]
+HBM_CEILING = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 1 GiB table, 128-B line fills per second (profiles/r02/probe_shapes_microbench.txt)")
+L2_CEILING = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table (profiles/r01_probe_rates_microbench.txt)")
+
+
+def rooflines(k, e, L, pairs, ref_bases, packed, per_ms, scan, n_peaks, traffic, src, mall):
+    """roofline entries of the three kernels (phase A's family as one) of one workload, and which one dominates the step"""
+    algo = ALGO_BYTES_PER_PAIR(L, k, e) * pairs           # algorithmic bytes of one scan over this GPU's pairs (SURVEY.md 8d)
+    ref_bytes = ref_bases * (64 * e) + (ref_bases // 4 if packed else ref_bases * 4 * e)   # SURVEY.md 8d: 204 B per base / 0.25 + 192
+    n_batches = -(-pairs // (16 << 20))
+    n_chunks = -(-pairs // (4 << 20))
+    kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
+    sparse_vote = scan["tiles"] > 0 and n_peaks > 0 and per_ms[2] > 0 and traffic.get("vote_kernel", {}).get("bytes", algo) < algo / 4
+    desc = {
+        "count_A": (f"phase A kernel family (part_scatter_reads + part_scatter_keys16 + part_apply per <= 4 Mi-pair chunk, {n_chunks} chunks per step; "
+                    "count_direct below k = 26): 714 table updates per pair", algo, 3 * n_chunks, HBM_CEILING, "1GiB"),
+        "ref_flags": (("ref_flags_lite (phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base)"
+                       if scan["lite"] else "ref_flags_trio (phase B on a sparse table: probes per base until a hash does not read 3)" if scan["form"] == "trio-first"
+                       else "ref_flags (phase B: e random 2-bit table probes + e index words per reference base)")
+                      + ", 1 launch per step", ref_bytes, 1, HBM_CEILING, "1GiB"),
+        "vote_kernel": (f"vote_kernel (phase C read re-scan: 714 probes per pair, "
+                        f"{'answered by the L2-resident bitmap except for its survivors' if sparse_vote else 'into peak_kmer'}), "
+                        f"{n_batches} launches per step", algo, n_batches, L2_CEILING if sparse_vote else HBM_CEILING, None if sparse_vote else "16GiB"),
+    }
+    roof = {ph: roofline_entry(desc[ph][0], kern[ph], desc[ph][2], desc[ph][1], traffic.get(ph) if src else None, src, desc[ph][3], mall, desc[ph][4])
+            for ph in kern}
+    if k < 32:
+        for ent in roof.values():
+            ent.pop("infinity_cache_share", None)          # the table sizes above are those of k = 32
+    dominant = max(kern, key=kern.get)                      # over A (as one entry), B's probe kernel and C
+    return roof, dominant
 
 
 def main():
@@ -420,10 +495,11 @@ def main():
     ap.add_argument("--contigs", type=int, default=None, help="contigs of the synthetic reference (overrides the workload's)")
     ap.add_argument("--contig-len", type=int, default=1_000_000)
     ap.add_argument("--sample-contigs", type=int, default=0, help="contigs the synthetic sample is drawn from (0 = half of the reference)")
+    ap.add_argument("--ragged", action="store_true", help="the same base stream cut into ~118 k contigs of a catalogue-like length distribution (localhgt_amd.synth.ragged_cuts)")
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-e", type=int, default=3)
-    ap.add_argument("--shard-index", action="store_true", help="reference-sharded phase B: each rank holds 1/N of the index (the default at N > 1)")
-    ap.add_argument("--replicate-index", action="store_true", help="at N > 1 keep the whole index on every GPU and scan it redundantly (no exchange in phase B)")
+    ap.add_argument("--shard-index", action="store_true", help="N > 1: time ONLY the reference-sharded phase B (each rank holds 1/N of the index)")
+    ap.add_argument("--replicate-index", action="store_true", help="N > 1: time ONLY the replicated form (the whole index on every GPU, no exchange in phase B)")
     ap.add_argument("--ref-form", choices=["index", "packed"], default="index",
                     help="resident form of the reference: the index file's hashes (12 B/base at e=3; what configs[2] names) or the packed bases "
                          "(3/8 B/base), phase B recomputing the hashes")
@@ -453,34 +529,38 @@ def main():
         return dry_run(args, rank, world, local)
 
     k, e, L = args.k, args.e, 150
-    workload_tag = f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}" + (f"_s{args.sample_contigs}" if args.sample_contigs else "") + ("_packed" if args.ref_form == "packed" else "")
-    # ---- measured HBM traffic: child runs of this command under rocprofv3 --pmc, before this process touches the GPU
+    workload_tag = (f"{args.contigs}x{args.contig_len}_{args.pairs}_k{k}_e{e}" + (f"_s{args.sample_contigs}" if args.sample_contigs else "")
+                    + ("_packed" if args.ref_form == "packed" else "") + ("_ragged" if args.ragged else ""))
+    # ---- measured HBM traffic: child runs of this command under rocprofv3 --pmc, before this process touches the GPU.  At N > 1
+    # rank 0 does the same with N = 1 children (every rank runs phases A and C on a read shard of the N = 1 size and shape, and the
+    # replicated phase B on the whole reference: its kernels are the N = 1 kernels) while the other ranks wait at the rendezvous
     pmc, pmc_note, traffic, traffic_src = None, "", {}, None
-    if world == 1 and not args.no_pmc and not args.force_dist:
+    mall = None
+    if rank == 0 and not args.no_pmc and not args.force_dist:
         t0 = time.time()
-        pmc, pmc_note = collect_pmc(args, [["FETCH_SIZE", "TCP_TCC_READ_REQ_sum"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum"]])
+        pmc, pmc_note = collect_pmc(args, PMC_PASSES)
         if pmc:
             traffic = pmc_traffic(pmc)
-            traffic_src = f"rocprofv3 --pmc passes of this run ({time.time() - t0:.0f} s, 1 step each; FETCH_SIZE+TCP_TCC_READ_REQ, WRITE_SIZE+TCC_EA0_RDREQ)"
+            traffic_src = (f"rocprofv3 --pmc passes of this run ({time.time() - t0:.0f} s, 1 step each; FETCH_SIZE+TCP_TCC_READ_REQ, WRITE_SIZE+TCC_EA0_RDREQ)"
+                           + (", as N = 1 children of rank 0 on this rank's per-GPU workload" if world > 1 else ""))
             if args.pmc_out:
                 json.dump({"tag": workload_tag, "kernels": pmc, "per_step": traffic,
                            "_stamp": {ph: source_stamp(s) for ph, s in KERNEL_SOURCES.items()}}, open(args.pmc_out, "w"), indent=1, sort_keys=True)
-    traffic_1g = {}
-    if world == 1 and not args.no_pmc and not args.no_extras and not args.force_dist and not args.debug and (args.contigs, args.pairs) != (1000, 10_000_000):
-        a1 = argparse.Namespace(**dict(vars(args), workload="1g", contigs=1000, pairs=10_000_000, sample_contigs=0))
-        pmc1, note1 = collect_pmc(a1, [["FETCH_SIZE", "TCP_TCC_READ_REQ_sum"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum"]])
-        if pmc1:
-            traffic_1g = pmc_traffic(pmc1)
-        pmc_note = "; ".join(x for x in (pmc_note, note1) if x)
-    if world == 1 or rank == 0:
-        # N > 1: every rank runs phases A and C on a read shard of the N = 1 size and shape, so the per-GPU traffic of those kernels
-        # is the N = 1 figure (profiles/traffic_per_launch.json, only while its source stamps match); a sharded phase B scans
-        # 1/N of the reference and its bytes are scaled by that share further down
+        mall = mall_share()
+    extra_traffic = {}
+    extras = world == 1 and not args.no_extras and not args.force_dist and not args.debug
+    if extras and not args.no_pmc and (args.contigs, args.pairs, args.sample_contigs, args.ragged) == (13000, 100_000_000, 0, False):
+        for tag, over in (("1g", dict(workload="1g", contigs=1000, pairs=10_000_000)), ("deep", dict(sample_contigs=300)), ("ragged", dict(ragged=True))):
+            pm, note = collect_pmc(argparse.Namespace(**dict(vars(args), **over)), PMC_PASSES)
+            if pm:
+                extra_traffic[tag] = pmc_traffic(pm)
+            pmc_note = "; ".join(x for x in (pmc_note, note) if x)
+    if rank == 0:
         fresh, stale = committed_traffic(workload_tag)
         for ph, rec in fresh.items():
             if ph not in traffic:
                 traffic[ph] = rec
-                traffic_src = traffic_src or ("profiles/traffic_per_launch.json (measured on these sources" + (", at N = 1: per-GPU work of A and C is the same)" if world > 1 else ")"))
+                traffic_src = traffic_src or "profiles/traffic_per_launch.json (measured on these sources; the live rocprofv3 passes failed)"
 
     import torch
     from localhgt_amd.engine import Engine
@@ -501,19 +581,34 @@ def main():
         eng.set_debug(args.debug)
     if args.ref_form == "packed":
         eng.set_reference_form(True)
+    out_path = os.path.join(tempfile.gettempdir(), f"lhgt_bench_interval_{os.getpid()}.txt")
+
+    def load_reference(sharded):
+        if args.ragged:
+            from localhgt_amd.synth import ragged_cuts
+            if sharded:
+                raise SystemExit("bench: --ragged is an N = 1 / replicated workload")
+            eng.synth_reference_cuts(1, args.contigs, args.contig_len, ragged_cuts(args.contigs * args.contig_len))
+        elif sharded:
+            eng.synth_reference_shard(1, args.contigs, args.contig_len, rank, world)  # this rank's contig range only
+        else:
+            eng.synth_reference(1, args.contigs, args.contig_len)                   # whole reference resident in HBM
+
+    # N > 1: SURVEY.md 8e lays phase B out sharded by contig range (each rank scans 1/N of the reference, the peaks are exchanged).
+    # That makes the per-GPU work SHRINK with N, so it cannot be the "weak scaling" figure: the timed K steps -- `value` -- run the
+    # replicated form (per-GPU work fixed: its own reads, the whole reference); the sharded form is measured next to it.
+    forms = [False] if dist is None or world == 1 and not args.shard_index else [False, True]
+    if args.replicate_index:
+        forms = [False]
+    if args.shard_index and dist is not None:
+        forms = [True]
     t0 = time.time()
-    # phase B shards by contig range -- each rank scans 1/N of the reference and the peaks are exchanged
-    shard_index = dist is not None and (args.shard_index or (world > 1 and not args.replicate_index))
-    if shard_index:
-        eng.synth_reference_shard(1, args.contigs, args.contig_len, rank, world)  # this rank's contig range only
-    else:
-        eng.synth_reference(1, args.contigs, args.contig_len)                   # whole index resident in HBM
+    load_reference(forms[0])
     eng.synth_options(0, 20, args.sample_contigs)
     eng.synth_pairs(1, 2, args.contigs, args.contig_len, rank * args.pairs, args.pairs, L)   # this rank's shard, packed, resident
     eng.synchronize()
     setup_s = time.time() - t0
-    out_path = os.path.join(tempfile.gettempdir(), f"lhgt_bench_interval_{os.getpid()}.txt")
-    wl = Workload(eng, dist, rank, world, shard_index, out_path)
+    wl = Workload(eng, dist, rank, world, forms[0], out_path)
 
     verify = None
     if world == 1 and not args.no_verify and not args.debug:
@@ -521,84 +616,82 @@ def main():
         eng.count_kmers()
         verify = verify_forms(eng)
     dt, per_ms, n_peaks, nf = wl.run(args.steps, args.warmup)
+    scan = eng.scan_info()
+    xch_main = dict(wl.xch)
+    other_form = None
+    if len(forms) > 1:                                   # the other form of phase B, a few steps, same reads
+        load_reference(forms[1])
+        wl2 = Workload(eng, dist, rank, world, forms[1], out_path)
+        st2 = min(args.steps, 5)
+        dt2, per2, n2, nf2 = wl2.run(st2, 1)
+        other_form = {"form": "reference-sharded phase B" if forms[1] else "replicated phase B", "value": round(args.pairs * world * st2 / dt2 / 1e6, 4),
+                      "unit": "M paired-reads/s", "ms_per_step": round(dt2 / st2 * 1e3, 3), "steps": st2,
+                      "phase_ms": {"count_A": round(per2[0], 3), "scan_B": round(per2[1], 3), "vote_C": round(per2[2], 3)},
+                      "exchange_ms": {kk: round(v / st2 * 1e3, 3) for kk, v in wl2.xch.items()},
+                      "same_peaks": (n2, nf2) == (n_peaks, nf),
+                      "note": "each rank scans 1/N of the reference: per-GPU work shrinks with N, so this is NOT a weak-scaling figure -- "
+                              "value/ms_per_step of the line are the replicated form's"}
     if rank != 0:
         eng.close()
         if dist:
             dist.close()
         return
     total_pairs = args.pairs * world * args.steps
-    algo = ALGO_BYTES_PER_PAIR(L, k, e) * args.pairs    # algorithmic bytes of one scan over this GPU's pairs
     per = {"count_A": per_ms[0], "scan_B": per_ms[1], "vote_C": per_ms[2]}   # HIP events on the engine stream
     ref_bases = args.contigs * args.contig_len
-    if shard_index:
+    if forms[0]:
         ref_bases = (args.contigs * (rank + 1) // world - args.contigs * rank // world) * args.contig_len   # this rank's contig range
-    ref_bytes = ref_bases * (4 * e + 64 * e)              # 204 B per reference base
-    if args.ref_form == "packed":
-        ref_bytes = ref_bases * 64 * e + ref_bases // 4   # "recomputing hashes from a 2-bit reference: 0.25 + 192 B/base"
-    n_batches = -(-args.pairs // (16 << 20))
-    scan = eng.scan_info()
-    kern = {"count_A": per["count_A"], "ref_flags": per_ms[3], "vote_kernel": per["vote_C"]}
-    hbm_ceiling = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 1 GiB table, 128-B line fills per second (profiles/r02/probe_shapes_microbench.txt)")
-    l2_ceiling = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table (profiles/r01_probe_rates_microbench.txt)")
-    sparse_vote = scan["tiles"] > 0 and n_peaks > 0 and per["vote_C"] > 0 and traffic.get("vote_kernel", {}).get("bytes", algo) < algo / 4
-    desc = {
-        "count_A": ("phase A kernel family (part_scatter_reads + part_scatter_keys + part_apply per <= 4 Mi-pair chunk; "
-                    "count_direct below k = 26): 714 table updates per pair", algo, None, hbm_ceiling),
-        "ref_flags": (("ref_flags_lite (phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base)"
-                       if scan["lite"] else "ref_flags_trio (phase B on a sparse table: probes per base until a hash does not read 3)" if scan["form"] == "trio-first"
-                       else "ref_flags (phase B: e random 2-bit table probes + e index words per reference base)")
-                      + ", 1 launch per step", ref_bytes, 1, hbm_ceiling),
-        "vote_kernel": (f"vote_kernel (phase C read re-scan: 714 probes per pair, "
-                        f"{'answered by the L2-resident bitmap except for its survivors' if sparse_vote else 'into peak_kmer'}), "
-                        f"{n_batches} launches per step", algo, n_batches, l2_ceiling if sparse_vote else hbm_ceiling),
-    }
-    dominant = max(("ref_flags", "vote_kernel"), key=kern.get)   # of the two that are ONE kernel each; phase A is a family of three
-    src = traffic_src
-    if shard_index and world > 1 and traffic.get("ref_flags"):
-        share = ref_bases / (args.contigs * args.contig_len)
-        traffic["ref_flags"] = {kk: (int(v * share) if isinstance(v, (int, float)) else v) for kk, v in traffic["ref_flags"].items()}
-    roof = {ph: roofline_entry(desc[ph][0], kern[ph], desc[ph][2], desc[ph][1], traffic.get(ph) if src else None, src, desc[ph][3]) for ph in kern}
+        if world > 1 and traffic.get("ref_flags"):
+            share = ref_bases / (args.contigs * args.contig_len)
+            traffic["ref_flags"] = {kk: (int(v * share) if isinstance(v, (int, float)) else v) for kk, v in traffic["ref_flags"].items()}
+    roof, dominant = rooflines(k, e, L, args.pairs, ref_bases, args.ref_form == "packed", per_ms, scan, n_peaks, traffic, traffic_src, mall)
     # bytes a step cannot avoid: the packed reads twice (A and C), the resident index once, count table written and read,
     # peak_kmer cleared (E:1458) -- everything else is the price of random access
     read_store = args.pairs * 2 * 3 * ((L + 31) // 32 + 1) * 4
     compulsory = 2 * read_store + (ref_bases * 3 // 8 if args.ref_form == "packed" else ref_bases * 4 * e) + 2 * ((1 << k) // 4) + (1 << k) * 4
     step_s = dt / args.steps
+    xch_ms = {kk: round(v / args.steps * 1e3, 3) for kk, v in xch_main.items()} if dist else None
+    cfg_no = 2 if (args.contigs, args.pairs, args.sample_contigs, args.ragged) == (13000, 100_000_000, 0, False) else \
+        1 if (args.contigs, args.pairs, args.sample_contigs, args.ragged) == (1000, 10_000_000, 0, False) else "-"
     line = {
         "metric": METRIC, "value": round(total_pairs / dt / 1e6, 4), "unit": "M paired-reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{2 if (args.contigs, args.pairs, args.sample_contigs) == (13000, 100_000_000, 0) else 1 if (args.contigs, args.pairs, args.sample_contigs) == (1000, 10_000_000, 0) else '-'}]: "
-                               f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase, "
+        "config": {"workload": f"BASELINE configs[{cfg_no}]: "
+                               f"{args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase{', cut into a ragged catalogue' if args.ragged else ''}, "
                                f"{'packed bases resident, hashes recomputed' if args.ref_form == 'packed' else 'index resident'}), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
                    "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
-                   "parallelism": f"reads sharded x{world}" + (", index sharded" if shard_index else ", phase B replicated" if world > 1 else "")},
+                   "parallelism": f"reads sharded x{world}" + (", index sharded" if forms[0] else ", phase B replicated on every GPU (per-GPU work fixed)" if world > 1 else "")},
         "world_size": torch.distributed.get_world_size() if dist else 1,
         "phase_ms": {kk: round(v, 3) for kk, v in per.items()},
-        "exchange_ms": {kk: round(v / args.steps * 1e3, 3) for kk, v in wl.xch.items()} if dist else None,
+        "exchange_ms": xch_ms,
+        "n1_equivalent_ms": round(step_s * 1e3 - sum(xch_ms.values()), 3) if xch_ms else round(step_s * 1e3, 3),
+        "sharded_index" if (other_form and forms[1]) else "replicated_index": other_form,
         "scan_B_form": scan,
         "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
-        "planted_transfers": interval_recall(out_path, planted_breakpoints(args.contigs, args.contig_len, args.sample_contigs)) if world == 1 else None,
+        "planted_transfers": interval_recall(out_path, planted_breakpoints(args.contigs, args.contig_len, args.sample_contigs)) if world == 1 and not args.ragged else None,
         "verify": verify,
         "roofline": dict(roof[dominant], kernel=roof[dominant]["kernel"] + " -- the dominant kernel of this workload"),
         "roofline_other": {ph: roof[ph] for ph in roof if ph != dominant},
+        "infinity_cache": mall,
         "compulsory": {"bytes_per_step": compulsory, "frac_of_peak": round(compulsory / step_s / (HBM_PEAK_GBS * 1e9), 4),
                        "what": "packed reads twice + resident index once + count table written and read + peak_kmer cleared; a step at HBM peak would take "
                                f"{compulsory / (HBM_PEAK_GBS * 1e9) * 1e3:.0f} ms"},
-        "note": "roofline.frac = measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE: every fabric read request on gfx950 is a 128-B line fill tallied "
-                "at 64 B, calibrated by tools/probe_shapes.hip, profiles/r02/) / kernel time / 8 TB/s. A random 4-byte probe therefore costs a whole "
-                "128-B line: the probe kernels are bound by HBM bandwidth in lines (49-56 G lines/s = 6.3-7.2 TB/s, more than a streaming read reaches), "
-                "request_rate gives their line rate against that measured ceiling (254 G/s for L2-resident tables). sector_model_GBps is SURVEY 8d's "
-                "one-64-B-sector-per-probe figure (it exceeds the peak where partitioning, the L2 bitmap or the lite scan avoid the probes: see model_speedup); DESIGN.md 4-5"
+        "note": "roofline.frac = frac_fabric = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s: every fabric read request on gfx950 is a 128-B line fill "
+                "tallied at 64 B (calibrated by tools/probe_shapes.hip, profiles/r02/), so this is an estimate of fabric bytes, Infinity-Cache hits included "
+                "(infinity_cache_share); frac_raw uses the counters as they are; frac_model is SURVEY 8d's one-64-B-sector-per-probe figure and exceeds 1 "
+                "(model_exceeded) where partitioning, the L2 bitmap or the lite scan avoid the probes. request_rate: line fills (or L2 requests) per second "
+                "against the microbenchmarked ceiling (56 G/s HBM lines, 254 G/s L2); DESIGN.md 4-5"
                 + (f"; pmc: {pmc_note}" if pmc_note else ""),
     }
     eng.pairs_clear()
-    if world == 1 and not args.no_extras and not args.debug:
+    if extras:
         args.headline_peaks = (n_peaks, nf)
-        line["secondary"] = secondary_workloads(eng, args, wl, local, traffic_1g)
+        line["secondary"] = secondary_workloads(eng, args, wl, local, extra_traffic, mall)
     eng.close()
     if dist:
         dist.close()
-    if world == 1 and not args.no_extras and not args.debug:
+    if extras:
         try:
             line["e2e"] = e2e_from_files(k, e, local)
         except Exception as ex:
@@ -622,23 +715,33 @@ def main():
         sys.exit("bench: the GPU path and the CPU baseline wrote different interval files for the same inputs")
 
 
-def secondary_workloads(eng, args, wl, local, traffic_1g):
+def secondary_workloads(eng, args, wl, local, extra_traffic, mall):
     """the other regimes of the same path, a few steps each (N = 1): results a reader needs next to the headline, whose
     synthetic sample (half of a 13 Gbase reference) saturates the 2^32-slot table and yields no voted peak"""
     from localhgt_amd.engine import Engine
     out = {}
     k, e, L = args.k, args.e, 150
+    live = "rocprofv3 --pmc passes of this run on this workload"
 
-    def leg(engine, pairs, steps=3, n_contigs=None, sample_contigs=0):
+    def leg(engine, pairs, steps=3, n_contigs=None, sample_contigs=0, traffic=None, ref_bases=None, packed=False, recall=True):
         w = Workload(engine, None, 0, 1, False, wl.out_path)
         dt, per_ms, n_peaks, nf = w.run(steps, 1)
-        rec = interval_recall(wl.out_path, planted_breakpoints(n_contigs or args.contigs, args.contig_len, sample_contigs))
-        return {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2), "planted_transfers": rec,
-                "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
-                "scan_B_form": engine.scan_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs}
+        d = {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
+             "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
+             "scan_B_form": engine.scan_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs}
+        if recall:
+            d["planted_transfers"] = interval_recall(wl.out_path, planted_breakpoints(n_contigs or args.contigs, args.contig_len, sample_contigs))
+        if traffic:
+            roof, dom = rooflines(k, e, L, pairs, ref_bases or (n_contigs or args.contigs) * args.contig_len, packed, per_ms, d["scan_B_form"], n_peaks,
+                                  traffic, live, mall)
+            d["roofline"] = dict(roof[dom], kernel=roof[dom]["kernel"] + " -- the dominant kernel of this workload")
+            d["roofline_other"] = {ph: {kk: v for kk, v in r.items() if kk in ("ms_per_step", "frac", "frac_raw", "frac_model", "model_exceeded", "request_rate", "infinity_cache_share")}
+                                   for ph, r in roof.items() if ph != dom}
+        return d
 
+    headline = (args.contigs, args.pairs, args.sample_contigs, args.ragged) == (13000, 100_000_000, 0, False)
     try:
-        if (args.contigs, args.pairs) == (13000, 100_000_000):
+        if headline:
             # the same reference under a sample of 300 of its genomes at 10x: 0.3 G distinct k-mers x 3 hashes leave the 2^32 slots
             # four fifths empty, transfers are found and voted -- what the algorithm is built for.  (From 1000 genomes up the
             # sample's k-mers alone saturate half of the slots, every window of the whole reference turns "good" and 2.4e8
@@ -647,6 +750,12 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
             eng.synth_options(0, 20, 300)
             eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, fp, L)
             out["uhgg_focused_sample"] = dict(leg(eng, fp, sample_contigs=300), workload="13000x1000000 bp ref, 10 M pairs drawn from 300 of its contigs (a metagenome holds few of a catalogue's genomes; 10x), sample=1")
+            eng.pairs_clear()
+            # ... and DEEP: the headline's 100 M pairs from those 300 genomes (100x): the table a fifth full, trio-first scan,
+            # transfers found, the dense-ish vote -- the realistic counterpart of the headline's read count
+            eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, args.pairs, L)
+            out["uhgg_deep_focused_sample"] = dict(leg(eng, args.pairs, sample_contigs=300, traffic=extra_traffic.get("deep")),
+                                                   workload="13000x1000000 bp ref, 100 M pairs drawn from 300 of its contigs (100x), sample=1")
             eng.pairs_clear()
             # the CLI's default --sample 2000000000 (E:1392-1398): 2e9 / (2 * 100 M * 150) = 6.67 % of the pairs survive the
             # sampling array; any subset of iid pairs is iid, so the kept pairs are generated directly
@@ -658,6 +767,18 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
                      input_pairs=args.pairs, input_pairs_per_s_M=round(args.pairs / (d["ms_per_step"] * 1e-3) / 1e6, 1))
             out["uhgg_default_sample"] = d
             eng.pairs_clear()
+            # a RAGGED catalogue: the same 13 Gbase cut into ~118 k contigs (median 4.8 kb, a third shorter than one scan tile) -- what
+            # UHGG looks like.  The k - 1 positions without a k-mer at every contig end are contrast peaks (E:931-932, 644-671), so
+            # ten times as many peaks register k-mers and phase C is the phase that feels it
+            from localhgt_amd.synth import ragged_cuts
+            cuts = ragged_cuts(args.contigs * args.contig_len)
+            eng.synth_reference_cuts(1, args.contigs, args.contig_len, cuts)
+            eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, args.pairs, L)
+            d = leg(eng, args.pairs, traffic=extra_traffic.get("ragged"), recall=False)
+            d.update(workload=f"configs[2]'s bases and reads, the reference cut into {len(cuts) - 1} pieces of a catalogue-like length distribution (localhgt_amd.synth.ragged_cuts)")
+            out["uhgg_ragged_reference"] = d
+            eng.pairs_clear()
+            eng.synth_reference(1, args.contigs, args.contig_len)
             if args.ref_form == "index":
                 # the headline workload once more with the reference resident as packed bases (3/8 byte per base instead of the
                 # index file's 12): phase B recomputes the hashes instead of streaming them -- same peaks, 32x less resident
@@ -675,26 +796,24 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
         out["uhgg_error"] = str(ex)
     eng.close()
     try:
+        if headline:
+            out["pipelined_samples"] = pipelined_samples(k, e, local, args.contigs, args.contig_len, args.pairs)
+    except Exception as ex:
+        out["pipelined_error"] = str(ex)
+    try:
         if (args.contigs, args.pairs) != (1000, 10_000_000):
             with Engine(k, e, device=local) as e1:
                 e1.rng_seed(1)
                 e1.coder_generate()
                 e1.synth_reference(1, 1000, 1_000_000)
                 e1.synth_pairs(1, 2, 1000, 1_000_000, 0, 10_000_000, L)
-                d = leg(e1, 10_000_000, steps=5, n_contigs=1000)
-                algo = ALGO_BYTES_PER_PAIR(L, k, e) * 10_000_000
-                fresh, _ = committed_traffic(f"1000x1000000_10000000_k{k}_e{e}")
-                rec = traffic_1g.get("vote_kernel") or fresh.get("vote_kernel")
-                src1 = "rocprofv3 --pmc passes of this run on this workload" if traffic_1g.get("vote_kernel") else "profiles/traffic_per_launch.json (measured on these sources)"
-                hbm = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 16 GiB table, 128-B line fills per second")
-                d["roofline"] = roofline_entry("vote_kernel (dense peak set: every one of the 714 probes per pair goes to the 16 GiB peak_kmer), 1 launch per step",
-                                               d["phase_ms"]["vote_C"], 1, algo, rec, src1, hbm)
+                d = leg(e1, 10_000_000, steps=5, n_contigs=1000, traffic=extra_traffic.get("1g"))
                 d["workload"] = "BASELINE configs[1]: 1000x1000000 bp ref, 10 M pairs, k=32 e=3, sample=1"
                 out["configs1_1g"] = d
     except Exception as ex:
         out["configs1_error"] = str(ex)
     try:
-        if (args.contigs, args.pairs) == (13000, 100_000_000):
+        if headline:
             # BASELINE configs[4] names a reference of more than 50 GB, 200 M reads over 8 GPUs, k = 21 / 32.  Its index (12 bytes per
             # base: 600 GB) only fits sharded over the node; packed (3/8 byte per base) the whole 50 Gbase reference, its per-position
             # arrays and the tables fit ONE GPU.  One GPU's share of the reads (25 M pairs) drawn from 300 of the 50 000 genomes.
@@ -716,6 +835,82 @@ def secondary_workloads(eng, args, wl, local, traffic_1g):
     except Exception as ex:
         out["configs4_error"] = str(ex)
     return out
+
+
+def pipelined_samples(k, e, device, n_contigs, contig_len, pairs, n_samples=4):
+    """Many samples against one resident reference is how this path is used, and its phases sit on three different ceilings --
+    A on LDS atomics and instruction issue, B's probe kernel on HBM lines, the sparse vote on L2 requests.  Two contexts on one GPU
+    (each with its own stream, tables and read store; the reference resident as packed bases in both), two host threads: a sample's
+    phase A may run while the other context is in its phases B-D, never two of the same kind at once.  Reported: pairs/s over
+    n_samples samples against the same samples one after the other, per-phase kernel times in both modes, and whether every sample's
+    peaks and vote table are the serial run's."""
+    import threading
+    from localhgt_amd.engine import Engine
+    engs = []
+    for i in range(2):
+        g = Engine(k, e, device=device)
+        g.rng_seed(1)
+        g.coder_generate()
+        g.set_reference_form(True)
+        g.synth_reference(1, n_contigs, contig_len)
+        g.synth_pairs(1, 2 + i, n_contigs, contig_len, 0, pairs, 150)     # two different samples of the same shape
+        engs.append(g)
+
+    def sample(g, lock_a, lock_b, rec):
+        with lock_a:
+            g.counts_clear()
+            g.count_kmers()
+            a = g.phase_ms(0)
+        with lock_b:
+            n = g.ref_scan(0.1, 0.08, 300_000_000)
+            g.vote()
+            rec.append((n, g.digest(g.DIGEST_VOTES), g.digest(g.DIGEST_PEAK_KMER), a, g.phase_ms(1), g.phase_ms(2)))
+
+    class _NoLock:
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+
+    for g in engs:                                        # warm-up: allocations, first-touch
+        sample(g, _NoLock(), _NoLock(), [])
+    serial = [[], []]
+    t0 = time.time()
+    for s_i in range(n_samples):
+        sample(engs[s_i % 2], _NoLock(), _NoLock(), serial[s_i % 2])
+    for g in engs:
+        g.synchronize()
+    t_serial = time.time() - t0
+    piped = [[], []]
+    la, lb = threading.Lock(), threading.Lock()
+
+    def worker(i):
+        for _ in range(n_samples // 2):
+            sample(engs[i], la, lb, piped[i])
+
+    t0 = time.time()
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in engs:
+        g.synchronize()
+    t_piped = time.time() - t0
+    same = all([r[:3] for r in serial[i]] == [r[:3] for r in piped[i]] for i in range(2))
+    for g in engs:
+        g.close()
+
+    def mean(recs, j):
+        v = [r[j] for rr in recs for r in rr]
+        return round(sum(v) / max(1, len(v)), 1)
+
+    return {"samples": n_samples, "pairs_per_sample": pairs,
+            "serial": {"value": round(n_samples * pairs / t_serial / 1e6, 3), "unit": "M paired-reads/s", "s": round(t_serial, 3),
+                       "phase_ms": {"count_A": mean(serial, 3), "scan_B": mean(serial, 4), "vote_C": mean(serial, 5)}},
+            "pipelined": {"value": round(n_samples * pairs / t_piped / 1e6, 3), "unit": "M paired-reads/s", "s": round(t_piped, 3),
+                          "phase_ms": {"count_A": mean(piped, 3), "scan_B": mean(piped, 4), "vote_C": mean(piped, 5)}},
+            "gain": round(t_serial / t_piped, 3), "identical_per_sample_results": bool(same),
+            "what": "two contexts on one GPU, the reference resident as packed bases in both; a sample's phase A runs beside the other context's phases B-C "
+                    "(two host threads, one lock per kind of phase); phase times are HIP events on each context's stream, so under overlap they include the slowdown by the neighbour"}
 
 
 def dry_run(args, rank, world, local):

@@ -260,6 +260,9 @@ int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sam
  * in between exact unless a trial on a few runs of tiles favours lite; outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
+/* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts
+ * with complementary masks share a GPU without sharing a CU (bench.py: pipelined_samples).  Nothing may be in flight. */
+int lhgt_set_cu_mask(lhgt_ctx* ctx, const uint32_t* mask, int n_words);
 
 /* ---- timing of the last call of each phase kernel group, HIP events on the ctx stream (ms) */
 int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the phase), 3 = the ref_flags kernel alone*/, float* ms);

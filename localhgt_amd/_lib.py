@@ -93,6 +93,7 @@ SIGNATURES = {
     "lhgt_synth_pairs": [_vp, C.c_uint64, C.c_uint64, _l, _l, _l, _l, _i, _u8p, _u8p],
     "lhgt_synth_options": [_vp, _i, _i, _l],
     "lhgt_set_debug": [_vp, _i],
+    "lhgt_set_cu_mask": [_vp, _u32p, _i],
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_scan_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), _lp, _lp],
     "lhgt_stream": [_vp, C.POINTER(_vp)],

@@ -96,7 +96,8 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     if (const char* dbg = getenv("LHGT_DEBUG")) c->debug = atoi(dbg);   // lhgt_set_debug's switches for whole-program runs (tests)
     memset(c->rng_state, 0, sizeof c->rng_state);
     c->counts_words = ((size_t)1 << k) / 16;
-    hipError_t he = hipStreamCreate(&c->stream);
+    // non-blocking: two contexts on one GPU (pipelined samples: one in phase A, the other in B-C) must not meet in the null stream
+    hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreate(&c->ev0);
     if (he == hipSuccess) he = hipEventCreate(&c->ev1);
@@ -162,6 +163,21 @@ int lhgt_reference_info(lhgt_ctx* ctx, int* form, unsigned long long* resident_b
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (form) *form = ctx->ref_packed ? 1 : 0;
     if (resident_bytes) *resident_bytes = !ctx->index_resident ? 0ull : ctx->ref_packed ? 12ull * ctx->ref_plane_words : 4ull * ctx->index_words;
+    return LHGT_OK;
+}
+
+// profiling / A-B: the context's stream is recreated so that its kernels only run on the CUs whose bits are set (n_words x 32
+// bits; n_words = 0: every CU again).  Two contexts with complementary masks share one GPU without sharing a CU (bench.py:
+// pipelined_samples).  Nothing may be in flight on the context.
+int lhgt_set_cu_mask(lhgt_ctx* ctx, const uint32_t* mask, int n_words) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || n_words < 0 || (n_words && !mask)) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t st = nullptr;
+    if (n_words) LHGT_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask));
+    else LHGT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = st;
     return LHGT_OK;
 }
 

@@ -131,7 +131,8 @@ static bool ingest_trace() { static int t = getenv("LHGT_INGEST_TRACE") ? 1 : 0;
 // with no staging copy and no per-chunk registration.
 struct SlabPool {
     uint8_t* base = nullptr;
-    size_t slab_bytes = 0;
+    size_t slab_bytes = 0, half_bytes = 0;   // a slab: [mate-1 bases: half][mate-2 bases: half][ChunkPairMeta x (CHUNK_META_CAP + 1)]
+    int k = 0;
     std::vector<int> free_ids;
     std::mutex mu;
     std::condition_variable cv;
@@ -152,12 +153,23 @@ struct SlabPool {
     }
 };
 
+// per-pair record a parse thread leaves next to the bases in its slab: where the pair's mates start inside the chunk's two base
+// runs and inside its packed words; entry n (one past the last pair) holds the totals.  The GPU turns (chunk bases + these) into
+// the batch's start / length / word-offset arrays (k_ingest.hip: expand_chunk_meta), so the calling thread touches no pair.
+constexpr int CHUNK_META_CAP = 16384;      // pairs per chunk with in-slab metadata (2 MiB chunks hold ~6600 150-bp pairs); more: vectors
+
 struct ParsedChunk {
     std::vector<uint8_t> s1, s2, flags;   // flags: PAIR_COUNT1 | PAIR_COUNT2 | PAIR_VOTE per kept pair
     std::vector<uint64_t> o1, o2;
-    // with a slab: bases live in slab[0 .. n1) and slab[half .. half + n2) instead of s1 / s2 (o1 / o2 index them the same way)
+    // with a slab: bases live in slab[0 .. n1) and slab[half .. half + n2) instead of s1 / s2, the per-pair records in meta[0 .. n_meta]
+    // instead of o1 / o2 / flags
     uint8_t* slab = nullptr;
+    ChunkPairMeta* meta = nullptr;
     size_t half = 0, n1 = 0, n2 = 0;
+    long n_meta = 0;
+    uint32_t words = 0;
+    uint64_t nkm = 0;
+    int max_len = 0, k = 0;
     int slab_id = -1;
     int rc = LHGT_OK;
     std::string err;
@@ -165,25 +177,41 @@ struct ParsedChunk {
     const uint8_t* bases2() const { return slab ? slab + half : s2.data(); }
     size_t size1() const { return slab ? n1 : s1.size(); }
     size_t size2() const { return slab ? n2 : s2.size(); }
-    void push(const uint8_t* a, size_t la, const uint8_t* b, size_t lb, uint8_t fl) {
-        if (slab && (n1 + la > half || n2 + lb > half)) {   // unusual line structure: spill to vectors, keep going
-            s1.assign(slab, slab + n1);
-            s2.assign(slab + half, slab + half + n2);
-            slab = nullptr;
+    long n_pairs() const { return slab ? n_meta : (long)o1.size() - 1; }
+    void spill() {   // unusual line structure (or more pairs than the slab's record area holds): continue in vectors
+        s1.assign(slab, slab + n1);
+        s2.assign(slab + half, slab + half + n2);
+        o1.assign(1, 0);
+        o2.assign(1, 0);
+        flags.clear();
+        for (long i = 0; i < n_meta; i++) {
+            o1.push_back(i + 1 < n_meta ? meta[i + 1].rel1 : n1);
+            o2.push_back(i + 1 < n_meta ? meta[i + 1].rel2 : n2);
+            flags.push_back((uint8_t)meta[i].flags);
         }
+        slab = nullptr;
+        meta = nullptr;
+    }
+    void push(const uint8_t* a, size_t la, const uint8_t* b, size_t lb, uint8_t fl) {
+        if (slab && (n1 + la > half || n2 + lb > half || n_meta >= CHUNK_META_CAP)) spill();
         if (slab) {
+            meta[n_meta++] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, fl};
             memcpy(slab + n1, a, la); n1 += la;
             memcpy(slab + half + n2, b, lb); n2 += lb;
-            o1.push_back(n1);
-            o2.push_back(n2);
+            words += 3u * (uint32_t)((la + 31) / 32 + 1) + 3u * (uint32_t)((lb + 31) / 32 + 1);
+            if ((int)la > max_len) max_len = (int)la;
+            if ((int)lb > max_len) max_len = (int)lb;
+            if ((int)la >= k) nkm += la - k + 1;
+            if ((int)lb >= k) nkm += lb - k + 1;
         } else {
             s1.insert(s1.end(), a, a + la);
             s2.insert(s2.end(), b, b + lb);
             o1.push_back(s1.size());
             o2.push_back(s2.size());
+            flags.push_back(fl);
         }
-        flags.push_back(fl);
     }
+    void finish() { if (slab) meta[n_meta] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, 0u}; }
 };
 
 struct ChunkPlan {
@@ -416,7 +444,7 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
     out->o1.assign(1, 0);
     out->o2.assign(1, 0);
     const long g0 = p1.line0[c], g1 = p1.line0[c + 1];
-    if (g0 == g1) return;
+    if (g0 == g1) { out->finish(); return; }
     // fq2 cursor at global line g0 + shift
     LineCursor k1(m1), k2(m2);
     k1.cur = p1.start[c];
@@ -454,6 +482,7 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
         }
         out->push(a, la, b, lb, fl);
     }
+    out->finish();
 }
 
 // records of fq2 that phase C pairs with no line of fq1 -- those in front of the shift and those behind fq1's last line -- are
@@ -572,7 +601,13 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
         std::string serr;
         std::thread planner([&] {
             if (share_fn) { src = share_fn(m1, m2, &share, &p1s, &p2s); if (src != LHGT_OK) serr = last_error(); }
-            else { p1s = plan_chunks(m1, chunk_bytes, threads); p2s = plan_chunks(m2, chunk_bytes, threads); }
+            else {   // both files at once; counting newlines is bound by memory bandwidth, which more threads than the parse uses still raise
+                unsigned hc = std::thread::hardware_concurrency();
+                const int pt = getenv("LHGT_INGEST_THREADS") ? threads : (int)(hc > 192 ? 96 : hc > 2 * (unsigned)threads ? hc / 2 : (unsigned)threads);
+                std::thread t2([&] { p2s = plan_chunks(m2, chunk_bytes, pt); });
+                p1s = plan_chunks(m1, chunk_bytes, pt);
+                t2.join();
+            }
         });
         const int prc = prepare ? prepare(&pool) : LHGT_OK;
         planner.join();
@@ -617,7 +652,13 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
                 if (c >= nc || stop.load()) { if (pool && slab_id >= 0) pool->release(slab_id); return; }
                 in_flight.fetch_add(1);
                 ParsedChunk& ch = out[(size_t)c];
-                if (pool) { ch.slab = pool->base + (size_t)slab_id * pool->slab_bytes; ch.half = pool->slab_bytes / 2; ch.slab_id = slab_id; }
+                if (pool) {
+                    ch.slab = pool->base + (size_t)slab_id * pool->slab_bytes;
+                    ch.half = pool->half_bytes;
+                    ch.meta = (ChunkPairMeta*)(ch.slab + 2 * pool->half_bytes);
+                    ch.slab_id = slab_id;
+                    ch.k = pool->k;
+                }
                 parse_chunk(m1, m2, p1, p2, c_lo + c, ratio, random_array, shard_rank, shard_world, shard_block, emu, lay, &ch);
                 { std::lock_guard<std::mutex> lk(mu); ready[(size_t)c].store(1); }
                 cv_ready.notify_all();
@@ -929,62 +970,58 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     // a batch is closed at 4 Mi pairs (1 Mi with count-on-load, so that phase A of one batch hides behind the parsing of the next;
     // every batch costs phase A one sweep of the count table, which is why they are not smaller)
     const long BATCH_PAIRS = ctx->count_on_load ? 1L << 20 : 4L << 20, META_CAP = BATCH_PAIRS + (1L << 18);
-    const size_t BATCH_BYTES = ctx->count_on_load ? (size_t)384 << 20 : (size_t)1 << 30, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes(), SLAB = 2 * (CHUNK + 1024);
+    const size_t BATCH_BYTES = ctx->count_on_load ? (size_t)384 << 20 : (size_t)1 << 30, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes();
+    const size_t HALF = CHUNK + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);
+    const long DESC_CAP = 1L << 16;                                       // chunks per batch
+    const size_t META_OFF = (BATCH_BYTES + 2 * SLAB + 255) & ~(size_t)255;   // device: per-pair records of the open batch, behind its ASCII
+    const size_t META_BYTES = (size_t)(META_CAP + DESC_CAP) * sizeof(ChunkPairMeta);
     const int threads = default_threads();
     const int n_slabs = threads + threads / 3 + 4;
-    // staging, pinned slabs and pinned metadata are allocated by `prepare` below, on this thread, while helper threads count lines
+    // staging, pinned slabs and the pinned chunk descriptors are allocated by `prepare` below, on this thread, while helper threads count lines
     SlabPool* pool = nullptr;
-    uint32_t *start1 = nullptr, *start2 = nullptr, *woff1 = nullptr, *woff2 = nullptr;
-    uint16_t *len1 = nullptr, *len2 = nullptr;
-    uint8_t* pflags = nullptr;
+    ChunkDesc* desc = nullptr;
     double t_alloc = 0;
-    std::vector<uint32_t> meta_pageable;     // only when the host refuses page-locked memory
+    std::vector<ChunkDesc> desc_pageable;     // only when the host refuses page-locked memory
     auto prepare = [&](SlabPool** pool_out) -> int {
         const double t_a0 = now_s();
-        LHGT_TRY(ws_reserve(ctx, BATCH_BYTES + 2 * SLAB, 0));
+        LHGT_TRY(ws_reserve(ctx, META_OFF + META_BYTES, 0));
         pool = (SlabPool*)ctx->ingest_pool;
-        if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != META_CAP) {
+        if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != DESC_CAP) {
             lhgt_ingest_pool_free(ctx);
             ingest_free(ctx);
             pool = nullptr;
             if (getenv("LHGT_NO_PINNED") ||     // test hook for the fallback below
                 hipHostMalloc(&ctx->h_ingest_slabs, (size_t)n_slabs * SLAB, hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc(&ctx->h_ingest_meta, (size_t)META_CAP * 21 + 64, hipHostMallocDefault) != hipSuccess) {
+                hipHostMalloc(&ctx->h_ingest_meta, (size_t)DESC_CAP * sizeof(ChunkDesc), hipHostMallocDefault) != hipSuccess) {
                 // no page-locked memory to be had (a locked-memory limit): the same pipeline on pageable buffers -- chunks in
                 // vectors, copied synchronously; slower, same result
                 (void)hipGetLastError();
                 ingest_free(ctx);
-                meta_pageable.assign((size_t)(META_CAP * 21 + 64 + 3) / 4, 0u);
-                uint32_t* base = meta_pageable.data();
-                start1 = base; start2 = start1 + META_CAP; woff1 = start2 + META_CAP; woff2 = woff1 + META_CAP;
-                len1 = (uint16_t*)(woff2 + META_CAP); len2 = len1 + META_CAP; pflags = (uint8_t*)(len2 + META_CAP);
+                desc_pageable.resize((size_t)DESC_CAP);
+                desc = desc_pageable.data();
                 *pool_out = nullptr;
                 t_alloc = now_s() - t_a0;
                 return LHGT_OK;
             }
-            ctx->ingest_meta_cap = META_CAP;
+            ctx->ingest_meta_cap = DESC_CAP;
             pool = new SlabPool();
             pool->base = ctx->h_ingest_slabs;
             pool->slab_bytes = SLAB;
+            pool->half_bytes = HALF;
             for (int i = 0; i < n_slabs; i++) pool->free_ids.push_back(i);
             ctx->ingest_pool = pool;
             ctx->ingest_events.resize((size_t)n_slabs);
             for (auto& e : ctx->ingest_events) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        start1 = ctx->h_ingest_meta;
-        start2 = start1 + META_CAP;
-        woff1 = start2 + META_CAP;
-        woff2 = woff1 + META_CAP;
-        len1 = (uint16_t*)(woff2 + META_CAP);
-        len2 = len1 + META_CAP;
-        pflags = (uint8_t*)(len2 + META_CAP);
+        pool->k = ctx->k;
+        desc = (ChunkDesc*)ctx->h_ingest_meta;
         *pool_out = pool;
         t_alloc = now_s() - t_a0;
         return LHGT_OK;
     };
     const int k = ctx->k;
     size_t fill = 0;
-    long n_open = 0, kept = 0;
+    long n_open = 0, kept = 0, n_desc = 0, meta_fill = 0;
     uint64_t words = 0, nkm = 0;
     int max_len = 0;
     std::vector<int> out_slabs;          // FIFO of slabs whose copies are in flight (event = ingest_events[slab id])
@@ -1001,7 +1038,8 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     std::vector<hipEvent_t> count_ev;    // count-on-load: an event pair around every batch's phase A
     auto flush = [&]() -> int {
         if (n_open == 0) return LHGT_OK;
-        int rc = install_pairs_pinned(ctx, ctx->d_ws_ascii, start1, start2, woff1, woff2, len1, len2, pflags, n_open, words, max_len, nkm);
+        int rc = install_pairs_chunked(ctx, ctx->d_ws_ascii, (const ChunkPairMeta*)(ctx->d_ws_ascii + META_OFF), desc, n_desc, n_open, words, max_len, nkm);
+        auto reset = [&] { fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0; n_desc = 0; meta_fill = 0; };
         if (rc == LHGT_OK && ctx->count_on_load) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             const bool have_e0 = hipEventCreate(&e0) == hipSuccess;
@@ -1009,61 +1047,66 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             if (e0 && e1) {
                 count_ev.push_back(e0);
                 count_ev.push_back(e1);
-                // the copies and the pack kernel of this batch are ahead of it on the same stream; the wait below is for THEM
-                // (staging and metadata are reused) -- the count of this batch runs on while the next batch is parsed
+                // the copies, the record expansion and the pack kernel of this batch are ahead of it on the same stream; the wait
+                // below is for THEM (staging and descriptors are reused) -- the count of this batch runs on while the next is parsed
                 hipEvent_t packed = ctx->ev3;
                 (void)hipEventRecord(packed, ctx->stream);
                 rc = lhgt_count_one_batch_async(ctx, ctx->batches.back(), e0, e1);
                 hipError_t e = hipEventSynchronize(packed);
                 reap(false);
-                fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0;
+                reset();
                 if (rc == LHGT_OK && e != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "ingest: %s", hipGetErrorString(e));
                 return rc;
             }
         }
-        // the staging area and the pinned metadata are reused by the next batch: wait for the copies and the pack kernel
+        // the staging area and the descriptors are reused by the next batch: wait for the copies and the pack kernel
         hipError_t e = hipStreamSynchronize(ctx->stream);
         reap(false);
-        fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0;
+        reset();
         if (rc == LHGT_OK && e != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "ingest: %s", hipGetErrorString(e));
         return rc;
     };
+    std::vector<ChunkPairMeta> conv;     // records of a chunk that came in vectors (spilled, head / tail records of fq2, no pinned memory)
     int rc = parse_pairs(fq1, fq2, ratio_percent, ctx->random_array.data(), shard_rank, shard_world, shard_block, threads, CHUNK,
                          ctx->emu_threads, n_pairs_seen, (SlabPool*)nullptr,
                          [&](ParsedChunk& ch) -> int {
-                             const long n = (long)ch.o1.size() - 1;
+                             const long n = ch.n_pairs();
                              if (n <= 0) { if (ch.slab_id >= 0) pool->release(ch.slab_id); return LHGT_OK; }
                              const size_t b1n = ch.size1(), b2n = ch.size2();
-                             if (fill + b1n + b2n > ctx->ws_ascii_cap || n_open + n > META_CAP) LHGT_TRY(flush());
-                             if (fill + b1n + b2n > ctx->ws_ascii_cap || n > META_CAP) LHGT_FAIL(LHGT_E_FORMAT, "ingest: one chunk holds %ld pairs / %zu bases", n, b1n + b2n);
+                             if (fill + b1n + b2n > BATCH_BYTES + 2 * SLAB || n_open + n > META_CAP || n_desc >= DESC_CAP) LHGT_TRY(flush());
+                             if (fill + b1n + b2n > BATCH_BYTES + 2 * SLAB || n > META_CAP) LHGT_FAIL(LHGT_E_FORMAT, "ingest: one chunk holds %ld pairs / %zu bases", n, b1n + b2n);
                              const size_t b1 = fill, b2 = fill + b1n;
+                             ChunkPairMeta* d_meta = (ChunkPairMeta*)(ctx->d_ws_ascii + META_OFF) + meta_fill;
+                             uint32_t ch_words = 0;
                              if (ch.slab) {
                                  if (b1n) LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + b1, ch.bases1(), b1n, hipMemcpyHostToDevice, ctx->stream));
                                  if (b2n) LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + b2, ch.bases2(), b2n, hipMemcpyHostToDevice, ctx->stream));
+                                 LHGT_HIP(hipMemcpyAsync(d_meta, ch.meta, (size_t)(n + 1) * sizeof(ChunkPairMeta), hipMemcpyHostToDevice, ctx->stream));
                                  LHGT_HIP(hipEventRecord(ctx->ingest_events[(size_t)ch.slab_id], ctx->stream));
                                  out_slabs.push_back(ch.slab_id);
-                             } else {                      // spilled chunk: pageable vectors, copied before they go away
+                                 ch_words = ch.words;
+                                 if (ch.max_len > max_len) max_len = ch.max_len;
+                                 nkm += ch.nkm;
+                             } else {                      // a chunk in pageable vectors: its records are made here, everything copied before it goes away
+                                 conv.resize((size_t)n + 1);
+                                 for (long i = 0; i < n; i++) {
+                                     const uint32_t l1 = (uint32_t)(ch.o1[i + 1] - ch.o1[i]), l2 = (uint32_t)(ch.o2[i + 1] - ch.o2[i]);
+                                     conv[(size_t)i] = ChunkPairMeta{(uint32_t)ch.o1[i], (uint32_t)ch.o2[i], ch_words, ch.flags[(size_t)i]};
+                                     ch_words += 3 * ((l1 + 31) / 32 + 1) + 3 * ((l2 + 31) / 32 + 1);
+                                     if ((int)l1 > max_len) max_len = (int)l1;
+                                     if ((int)l2 > max_len) max_len = (int)l2;
+                                     if ((int)l1 >= k) nkm += l1 - k + 1;
+                                     if ((int)l2 >= k) nkm += l2 - k + 1;
+                                 }
+                                 conv[(size_t)n] = ChunkPairMeta{(uint32_t)ch.o1[n], (uint32_t)ch.o2[n], ch_words, 0u};
                                  LHGT_TRY(stage_ascii(ctx, b1, ch.bases1(), b1n));
                                  LHGT_TRY(stage_ascii(ctx, b2, ch.bases2(), b2n));
+                                 LHGT_TRY(stage_ascii(ctx, META_OFF + (size_t)meta_fill * sizeof(ChunkPairMeta), (const uint8_t*)conv.data(), (size_t)(n + 1) * sizeof(ChunkPairMeta)));
                              }
+                             desc[n_desc++] = ChunkDesc{(uint32_t)n_open, (uint32_t)n, (uint32_t)b1, (uint32_t)b2, (uint32_t)words, (uint32_t)meta_fill};
                              fill = b2 + b2n;
-                             for (long i = 0; i < n; i++) {
-                                 const long m = n_open + i;
-                                 const uint32_t l1 = (uint32_t)(ch.o1[i + 1] - ch.o1[i]), l2 = (uint32_t)(ch.o2[i + 1] - ch.o2[i]);
-                                 start1[m] = (uint32_t)(b1 + ch.o1[i]);
-                                 start2[m] = (uint32_t)(b2 + ch.o2[i]);
-                                 len1[m] = (uint16_t)l1;
-                                 len2[m] = (uint16_t)l2;
-                                 pflags[m] = ch.flags[(size_t)i];
-                                 woff1[m] = (uint32_t)words;
-                                 words += 3 * ((l1 + 31) / 32 + 1);
-                                 woff2[m] = (uint32_t)words;
-                                 words += 3 * ((l2 + 31) / 32 + 1);
-                                 if ((int)l1 > max_len) max_len = (int)l1;
-                                 if ((int)l2 > max_len) max_len = (int)l2;
-                                 if ((int)l1 >= k) nkm += l1 - k + 1;
-                                 if ((int)l2 >= k) nkm += l2 - k + 1;
-                             }
+                             meta_fill += n + 1;
+                             words += ch_words;
                              n_open += n;
                              kept += n;
                              reap(false);

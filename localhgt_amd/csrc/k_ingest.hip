@@ -512,6 +512,74 @@ int install_pairs_pinned(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint32_t* 
     return LHGT_OK;
 }
 
+// one thread per pair: its chunk by binary search over the descriptors, then chunk bases + the pair's record
+__global__ void __launch_bounds__(256) expand_chunk_meta(const ChunkDesc* __restrict__ desc, int n_desc, const ChunkPairMeta* __restrict__ meta, long n,
+                                                         uint32_t* __restrict__ start, uint32_t* __restrict__ woff, uint16_t* __restrict__ len,
+                                                         uint8_t* __restrict__ flags) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    int lo = 0, hi = n_desc;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long)desc[mid].pair0 <= m) lo = mid; else hi = mid; }
+    const ChunkDesc d = desc[lo];
+    const ChunkPairMeta* r = meta + d.mo + (m - d.pair0);
+    const ChunkPairMeta a = r[0], b = r[1];
+    const uint32_t l1 = b.rel1 - a.rel1, l2 = b.rel2 - a.rel2;
+    start[m] = d.b1 + a.rel1;
+    start[n + m] = d.b2 + a.rel2;
+    len[m] = (uint16_t)l1;
+    len[n + m] = (uint16_t)l2;
+    const uint32_t w1 = d.wbase + a.relw;
+    woff[m] = w1;
+    woff[n + m] = w1 + 3u * ((l1 + 31u) / 32u + 1u);
+    flags[m] = (uint8_t)a.flags;
+}
+
+int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPairMeta* d_meta, const ChunkDesc* desc, long n_desc, long n,
+                          uint64_t n_words, int max_len, uint64_t n_kmers) {
+    if (n <= 0) return LHGT_OK;
+    if (n_words >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "batch too large: %llu plane words", (unsigned long long)n_words);
+    ReadBatch b;
+    b.n_words = n_words;
+    b.max_len = max_len;
+    b.n_kmers = n_kmers;
+    // one allocation per batch: words | offsets | lengths | flags (the allocator call is not free, and a file has dozens of batches)
+    const size_t words_b = (n_words * 4 + 16 + 255) & ~(size_t)255, off_b = ((size_t)2 * n * 4 + 255) & ~(size_t)255, len_b = ((size_t)2 * n * 2 + 255) & ~(size_t)255;
+    uint8_t* blk = nullptr;
+    LHGT_HIP(hipMalloc(&blk, words_b + off_b + len_b + (size_t)n));
+    b.alloc[0] = blk;
+    uint32_t* d_words = (uint32_t*)blk;
+    uint32_t* d_off32 = (uint32_t*)(blk + words_b);
+    uint16_t* d_len = (uint16_t*)(blk + words_b + off_b);
+    uint8_t* d_fl = blk + words_b + off_b + len_b;
+    const long need = 2 * n + (n_desc * (long)sizeof(ChunkDesc) + 3) / 4;
+    if (need > ctx->ingest_start_cap) {
+        if (ctx->d_ingest_start) hipFree(ctx->d_ingest_start);
+        ctx->d_ingest_start = nullptr;
+        ctx->ingest_start_cap = need + need / 4;
+        LHGT_HIP(hipMalloc(&ctx->d_ingest_start, (size_t)ctx->ingest_start_cap * 4));
+    }
+    hipStream_t st = ctx->stream;
+    ChunkDesc* d_desc = (ChunkDesc*)(ctx->d_ingest_start + 2 * n);
+    LHGT_HIP(hipMemcpyAsync(d_desc, desc, (size_t)n_desc * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(expand_chunk_meta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_desc, (int)n_desc, d_meta, n, ctx->d_ingest_start,
+                       d_off32, d_len, d_fl);
+    const int max_wpr = (max_len + 31) / 32 + 1;
+    const long threads = 2 * n * max_wpr;
+    hipLaunchKernelGGL(pack_bases32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_ascii, ctx->d_ingest_start, d_len, d_off32,
+                       2 * n, max_wpr, d_words);
+    LHGT_HIP(hipGetLastError());
+    b.d.words = d_words;
+    b.d.off[0] = d_off32;
+    b.d.off[1] = d_off32 + n;
+    b.d.len[0] = d_len;
+    b.d.len[1] = d_len + n;
+    b.d.flags = d_fl;
+    b.d.n_pairs = n;
+    ctx->batches.push_back(b);
+    ctx->n_pairs += n;
+    return LHGT_OK;
+}
+
 void ingest_free(lhgt_ctx* ctx) {
     for (hipEvent_t e : ctx->ingest_events) hipEventDestroy(e);
     ctx->ingest_events.clear();
@@ -699,8 +767,9 @@ int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* 
     LHGT_HIP(hipMalloc(&d_valid, (size_t)nk));
     int rc = hash_contig_to_device(ctx, ascii, len, d_out, d_valid);
     if (rc == LHGT_OK) {
-        hipMemcpy(out_hash, d_out, (size_t)nk * ctx->e * 4, hipMemcpyDeviceToHost);
-        if (out_valid) hipMemcpy(out_valid, d_valid, (size_t)nk, hipMemcpyDeviceToHost);
+        hipMemcpyAsync(out_hash, d_out, (size_t)nk * ctx->e * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (out_valid) hipMemcpyAsync(out_valid, d_valid, (size_t)nk, hipMemcpyDeviceToHost, ctx->stream);
+        hipStreamSynchronize(ctx->stream);
     }
     hipFree(d_out);
     hipFree(d_valid);

@@ -1329,7 +1329,7 @@ int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (first_pos + n_pos > ctx->n_pos) LHGT_FAIL(LHGT_E_ARG, "position range outside the reference");
-    LHGT_HIP(hipMemcpy(out, ctx->d_flags + first_pos, n_pos, hipMemcpyDeviceToHost));
+    LHGT_HIP(hipMemcpyAsync(out, ctx->d_flags + first_pos, n_pos, hipMemcpyDeviceToHost, ctx->stream)); LHGT_HIP(hipStreamSynchronize(ctx->stream));
     return LHGT_OK;
 }
 
@@ -1338,7 +1338,7 @@ int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, 
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->d_peak_kmer) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     if (first_slot + n_slots > (1ull << ctx->k)) LHGT_FAIL(LHGT_E_ARG, "slot range outside the table");
-    LHGT_HIP(hipMemcpy(out, ctx->d_peak_kmer + first_slot, n_slots * 4, hipMemcpyDeviceToHost));
+    LHGT_HIP(hipMemcpyAsync(out, ctx->d_peak_kmer + first_slot, n_slots * 4, hipMemcpyDeviceToHost, ctx->stream)); LHGT_HIP(hipStreamSynchronize(ctx->stream));
     return LHGT_OK;
 }
 

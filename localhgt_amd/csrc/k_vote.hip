@@ -736,10 +736,10 @@ int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "no scan done");
     if (n > ctx->id_end) LHGT_FAIL(LHGT_E_ARG, "asked for %ld peak ids, have %ld", n, ctx->id_end);
     if (n == 0) return LHGT_OK;
-    if (loci) LHGT_HIP(hipMemcpy(loci, ctx->d_loci, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (loci) LHGT_HIP(hipMemcpyAsync(loci, ctx->d_loci, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream)); LHGT_HIP(hipStreamSynchronize(ctx->stream));
     if (filter) {
         std::vector<uint32_t> v((size_t)n);
-        LHGT_HIP(hipMemcpy(v.data(), ctx->d_filter, (size_t)n * 4, hipMemcpyDeviceToHost));
+        LHGT_HIP(hipMemcpyAsync(v.data(), ctx->d_filter, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream)); LHGT_HIP(hipStreamSynchronize(ctx->stream));
         for (long i = 0; i < n; i++) filter[i] = (uint8_t)(v[i] > 254 ? 254 : v[i]);  // `if (< 254) ++` saturates at 254
     }
     return LHGT_OK;
@@ -776,7 +776,7 @@ int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
             cap = nf + nf / 8;
         }
         rec.resize((size_t)nf * 3);
-        if (nf) LHGT_HIP(hipMemcpy(rec.data(), ctx->d_voted, (size_t)nf * 12, hipMemcpyDeviceToHost));
+        if (nf) LHGT_HIP(hipMemcpyAsync(rec.data(), ctx->d_voted, (size_t)nf * 12, hipMemcpyDeviceToHost, ctx->stream)); LHGT_HIP(hipStreamSynchronize(ctx->stream));
     }
     std::vector<long> order((size_t)nf);
     for (long i = 0; i < nf; i++) order[i] = i;

@@ -185,11 +185,11 @@ struct lhgt_ctx {
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     unsigned long long* d_digest = nullptr;   // 16 bytes: lhgt_digest's accumulator
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
-    // FASTQ loader (host_fastx.cpp): pinned slabs the parse threads write into, pinned per-pair metadata of the open batch,
+    // FASTQ loader (host_fastx.cpp): pinned slabs the parse threads write into (bases + per-pair records), pinned chunk descriptors of the open batch,
     // events that tell when a slab's copy has left the host
     void* ingest_pool = nullptr;             // lhgt::SlabPool*
     uint8_t* h_ingest_slabs = nullptr;       // hipHostMalloc: n_slabs x slab_bytes
-    uint32_t* h_ingest_meta = nullptr;       // hipHostMalloc: start1|start2|woff1|woff2 (u32), len1|len2 (u16), flags (u8) x ingest_meta_cap
+    uint32_t* h_ingest_meta = nullptr;       // hipHostMalloc: the open batch's chunk descriptors (lhgt::ChunkDesc x ingest_meta_cap)
     long ingest_meta_cap = 0;
     std::vector<hipEvent_t> ingest_events;
     uint32_t* d_ingest_start = nullptr;      // device copy of the start offsets of the batch being packed
@@ -225,7 +225,14 @@ int write_index_lens(lhgt_ctx* ctx);
 int install_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const long* contig_of, long n_c);
 int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_t* start, const uint16_t* lens, long n,
                             const uint8_t* pair_flags);
-// the loader's form: per-mate arrays in pinned host memory (start offsets into d_ascii and word offsets into the batch, u32),
+// the loader's form: the batch as a list of chunks.  Per chunk the bases of its mate-1 reads and of its mate-2 reads lie back to
+// back at b1 / b2 of d_ascii, and n + 1 records at d_meta + mo tell where every pair starts inside them (and inside the chunk's
+// packed words); the device expands (descriptor + record) into the batch's start / length / word-offset / flag arrays
+struct ChunkPairMeta { uint32_t rel1, rel2, relw, flags; };
+struct ChunkDesc { uint32_t pair0, n, b1, b2, wbase, mo; };
+int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPairMeta* d_meta, const ChunkDesc* desc, long n_desc, long n,
+                          uint64_t n_words, int max_len, uint64_t n_kmers);
+// the older form: per-mate arrays in pinned host memory (start offsets into d_ascii and word offsets into the batch, u32),
 // everything copied and packed asynchronously on the context's stream
 int install_pairs_pinned(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint32_t* start1, const uint32_t* start2, const uint32_t* woff1,
                          const uint32_t* woff2, const uint16_t* len1, const uint16_t* len2, const uint8_t* flags, long n,

@@ -285,6 +285,16 @@ class Engine:
         _lib.check(self.lib.lhgt_set_thread_emulation(self.h, int(threads)))
         self.emulated_threads = int(threads)
 
+    def set_cu_mask(self, cus=None, n_cus: int = 256):
+        """run this context's kernels only on the CUs listed (None: all)"""
+        if cus is None:
+            _lib.check(self.lib.lhgt_set_cu_mask(self.h, None, 0))
+            return
+        m = np.zeros((n_cus + 31) // 32, dtype=np.uint32)
+        for c in cus:
+            m[c >> 5] |= np.uint32(1 << (c & 31))
+        _lib.check(self.lib.lhgt_set_cu_mask(self.h, _ptr(m, C.c_uint32), m.size))
+
     def set_debug(self, flags: int):
         _lib.check(self.lib.lhgt_set_debug(self.h, flags))
 

@@ -204,3 +204,24 @@ def write_case(outdir: str, ref: SynthRef, reads: SynthReads, fq2_header_pad: in
         with open(f2, "wb") as f:
             f.write(body)
     return fa, f1, f2
+
+
+def ragged_cuts(total: int, seed: int = 5) -> np.ndarray:
+    """contig boundaries of a catalogue-like length distribution over `total` bases (for lhgt_synth_reference_cuts): 3 of 4
+    contigs log-uniform in 300 b .. 20 kb, the others 20 kb .. 2 Mb, and one piece in a hundred of 10 .. 32 bases (not indexed at
+    k = 32, E:772) -- what a real catalogue (UHGG: hundreds of thousands of contigs) looks like next to 13000 x 1 Mbp"""
+    rng = np.random.default_rng(seed)
+    lens = []
+    have = 0
+    while have < total:
+        n = 4096
+        u = rng.random(n)
+        kind = rng.random(n)
+        ln = np.where(kind < 0.75, np.exp(np.log(300) + u * np.log(20000 / 300)), np.exp(np.log(20000) + u * np.log(2_000_000 / 20000)))
+        ln = np.where(rng.random(n) < 0.01, 10 + (u * 23), ln).astype(np.int64)
+        lens.append(ln)
+        have += int(ln.sum())
+    lens = np.concatenate(lens)
+    cuts = np.concatenate([[0], np.cumsum(lens)])
+    cuts = cuts[cuts < total]
+    return np.concatenate([cuts, [total]]).astype(np.uint64)

@@ -112,24 +112,7 @@ def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_
         assert 1 <= contig.min() and contig.max() <= NC
 
 
-def _ragged_cuts(total, seed=5):
-    """contig boundaries of a catalogue-like length distribution: 3 of 4 contigs log-uniform in 300 b .. 20 kb, the others
-    20 kb .. 2 Mb, and one piece in a hundred of 10 .. 32 bases (not indexed at k = 32, E:772)"""
-    rng = np.random.default_rng(seed)
-    lens = []
-    have = 0
-    while have < total:
-        n = 4096
-        u = rng.random(n)
-        kind = rng.random(n)
-        ln = np.where(kind < 0.75, np.exp(np.log(300) + u * np.log(20000 / 300)), np.exp(np.log(20000) + u * np.log(2_000_000 / 20000)))
-        ln = np.where(rng.random(n) < 0.01, 10 + (u * 23), ln).astype(np.int64)
-        lens.append(ln)
-        have += int(ln.sum())
-    lens = np.concatenate(lens)
-    cuts = np.concatenate([[0], np.cumsum(lens)])
-    cuts = cuts[cuts < total]
-    return np.concatenate([cuts, [total]]).astype(np.uint64)
+from localhgt_amd.synth import ragged_cuts as _ragged_cuts  # noqa: E402
 
 
 def test_ragged_reference_forms_agree(eng):

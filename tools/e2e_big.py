@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""`extract_ref` from FASTQ files at a size where the reads, not the fixed costs, decide: n_pairs pairs written in
+slices (device generator -> text), then the whole call with a cached index, with the packed reference, with -t 1 and with the
+default -t 10 (thread emulation), LHGT_INGEST_TRACE on.  Usage: e2e_big.py [n_pairs] [n_contigs] [sample]"""
+import json, os, shutil, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["LHGT_INGEST_TRACE"] = "1"
+from localhgt_amd.engine import Engine
+from localhgt_amd import extract_ref
+import bench
+
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 32_000_000
+n_contigs = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+sample = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+CL, K, E, SL = 1_000_000, 32, 3, 4_000_000
+os.system("free -g | head -2; df -h /tmp | tail -1; nproc")
+tmp = tempfile.mkdtemp(prefix="lhgt_e2e_", dir="/tmp")
+fa, f1, f2 = (os.path.join(tmp, x) for x in ("ref.fa", "s.1.fq", "s.2.fq"))
+t0 = time.time()
+with Engine(K, E) as eng:
+    eng.rng_seed(1); eng.coder_generate()
+    ref = eng.synth_reference(1, n_contigs, CL, want_host=True)
+    bench.write_fasta(fa, ref, n_contigs, CL)
+    del ref
+    for path in (f1, f2):
+        open(path, "wb").close()
+    for p0 in range(0, n_pairs, SL):
+        n = min(SL, n_pairs - p0)
+        eng.pairs_clear()
+        m1, m2 = eng.synth_pairs(1, 2, n_contigs, CL, p0, n, 150, want_host=True)
+        for path, m, suf in ((f1, m1, "1"), (f2, m2, "2")):
+            part = path + ".part"
+            bench.write_fastq(part, m, n, 150, suf)          # ids restart per slice: the path never looks at them beyond the first
+            with open(path, "ab") as dst, open(part, "rb") as src:
+                shutil.copyfileobj(src, dst, 1 << 24)
+            os.remove(part)
+print(f"inputs written in {time.time() - t0:.0f} s: fasta {os.path.getsize(fa) / 1e6:.0f} MB, fastq 2 x {os.path.getsize(f1) / 1e9:.2f} GB", flush=True)
+
+
+def run(tag, threads, **kw):
+    a = extract_ref.Args(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, threads, K, 300_000_000, E, 1, sample)
+    t0 = time.time()
+    rep = extract_ref.run(a, log=lambda *x: None, **kw)
+    rep["wall_s"] = time.time() - t0
+    keep = ("pairs_seen", "pairs_kept", "n_peaks", "n_filtered", "ratio", "index_s", "reads_s", "count_s", "scan_s", "vote_s", "total_s", "wall_s", "emulated_threads")
+    print(tag, json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in rep.items() if k in keep}),
+          f"-> {rep['pairs_seen'] / rep['total_s'] / 1e6:.1f} M input pairs/s", flush=True)
+    return rep
+
+
+run("index built in-run, -t 1", 1)
+for i in range(2):
+    run("index cached, -t 1", 1)
+run("index cached, -t 10 (thread emulation, the CLI default)", 10)
+run("packed reference, -t 1", 1, ref_form="packed")
+run("packed reference, -t 10", 10, ref_form="packed")
+shutil.rmtree(tmp)

@@ -70,7 +70,9 @@ int main() {
     uint32_t *table, *sink;
     CK(hipMalloc(&table, bytes)); CK(hipMalloc(&sink, 4));
     CK(hipMemset(table, 1, bytes));
-    for (uint64_t s : {16ull << 30, 1ull << 30, 64ull << 20}) {
+    // 4 MiB and below: the L2-resident regime of the vote kernel's Bloom bitmap (round 3: its probes scale with the number of CUs,
+    // tools/cu_share.py -- is the limit the 128-B line fill into each CU's L1, and does a load that bypasses the L1 lift it?)
+    for (uint64_t s : {16ull << 30, 1ull << 30, 64ull << 20, 16ull << 20, 4ull << 20, 1ull << 20, 256ull << 10}) {
         run<0>("plain", table, s, sink); run<1>("nt", table, s, sink); run<2>("sc0", table, s, sink); run<3>("sc1", table, s, sink);
         run<4>("sc0 sc1", table, s, sink); run<5>("sc1 nt", table, s, sink); run<6>("sc0 sc1 nt", table, s, sink); run<7>("sc0 nt", table, s, sink);
     }

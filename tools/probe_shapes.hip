@@ -100,6 +100,8 @@ __global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ table,
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+static double g_last_gprobes = 0;   // rate of the last run()
+
 template <int MODE, int ILP>
 void run(const char* name, const uint32_t* table, uint64_t bytes, uint32_t* sink, int waves_per_simd) {
     const int threads = 256, blocks = 256 * waves_per_simd;   // 4 waves per block, one SIMD each -> blocks per CU = waves per SIMD
@@ -115,6 +117,7 @@ void run(const char* name, const uint32_t* table, uint64_t bytes, uint32_t* sink
     }
     if (MODE == STREAM16) printf("%-9s ILP=%2d waves/SIMD=%d table=%6.0f MiB  %8.3f ms  %7.2f TB/s streamed (16 B per lane-load)\n", name, ILP, waves_per_simd, bytes / 1048576.0, best, probes * 16 / best / 1e9);
     else printf("%-9s ILP=%2d waves/SIMD=%d table=%6.0f MiB  %8.3f ms  %7.2f Gprobe/s\n", name, ILP, waves_per_simd, bytes / 1048576.0, best, probes / best / 1e6);
+    g_last_gprobes = probes / best / 1e6;
     fflush(stdout);
 }
 
@@ -122,6 +125,23 @@ int main(int argc, char** argv) {
     const uint64_t max_bytes = 16ull << 30;
     uint32_t *table, *sink;
     CK(hipMalloc(&sink, 4));
+    if (argc > 1 && argv[1][0] == 'm' && argv[1][1] == 'a') {
+        // `probe_shapes mall`: how much of a kernel's random-probe "HBM" traffic does the 256 MiB Infinity Cache (MALL) serve?
+        // FETCH_SIZE counts its hits like DRAM reads (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ on gfx950), so the share is estimated
+        // from rates: random 4-byte probes on a 128 MiB table (beyond the 32 MiB of L2, inside the MALL), on 1 GiB (the k = 32
+        // count table) and on 16 GiB (peak_kmer; 1.6 % of it fits).  With a share s of the lines served at the MALL's rate,
+        // 1 / r(T) = s / r_mall + (1 - s) / r_hbm.  One JSON line on stdout (bench.py: infinity_cache_share).
+        CK(hipMalloc(&table, max_bytes));
+        CK(hipMemset(table, 1, max_bytes));
+        double r[3];
+        const uint64_t sizes[3] = {128ull << 20, 1ull << 30, 16ull << 30};
+        for (int i = 0; i < 3; i++) { run<LD4, 12>("ld4", table, sizes[i], sink, 8); r[i] = g_last_gprobes; }
+        const double r_hbm = 1.0 / ((1.0 / r[2] - (1.0 / 64.0) / r[0]) / (1.0 - 1.0 / 64.0));      // 16 GiB: 256 MiB / 16 GiB of the lines from the MALL
+        const double share_1g = (1.0 / r[1] - 1.0 / r_hbm) / (1.0 / r[0] - 1.0 / r_hbm);
+        printf("{\"gprobes_per_s\": {\"128MiB\": %.2f, \"1GiB\": %.2f, \"16GiB\": %.2f}, \"hbm_only_rate\": %.2f, \"mall_share_1GiB_table\": %.3f, \"mall_share_16GiB_table\": %.4f}\n",
+               r[0], r[1], r[2], r_hbm, share_1g < 0 ? 0.0 : share_1g, 1.0 / 64.0);
+        return 0;
+    }
     if (argc > 1) {
         // memory-type experiment: the same random 4-byte probes on allocations of other kinds -- does the fabric request become
         // smaller than a 128-B line fill when the L2 may not cache the data?

@@ -40,7 +40,10 @@ struct Mapped {
             void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) LHGT_FAIL(LHGT_E_IO, "cannot mmap %s", path);
             p = (const uint8_t*)m;
-            madvise((void*)p, n, MADV_SEQUENTIAL);
+            const char* adv = getenv("LHGT_MMAP_ADVICE");     // experiment knob: seq (default) | none | willneed | hugepage
+            if (!adv || !strcmp(adv, "seq")) madvise((void*)p, n, MADV_SEQUENTIAL);
+            else if (!strcmp(adv, "willneed")) madvise((void*)p, n, MADV_WILLNEED);
+            else if (!strcmp(adv, "hugepage")) madvise((void*)p, n, MADV_HUGEPAGE);
         }
         return LHGT_OK;
     }
@@ -211,7 +214,19 @@ struct ParsedChunk {
             flags.push_back(fl);
         }
     }
-    void finish() { if (slab) meta[n_meta] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, 0u}; }
+    // slab chunks end as ONE contiguous block -- [mate-1 bases][mate-2 bases][pad to 16 bytes][n + 1 records] -- so the calling
+    // thread issues one copy per chunk
+    size_t block_bytes() const { return meta_off() + (size_t)(n_meta + 1) * sizeof(ChunkPairMeta); }
+    size_t meta_off() const { return (n1 + n2 + 15) & ~(size_t)15; }
+    void finish() {
+        if (!slab) return;
+        meta[n_meta] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, 0u};
+        memmove(slab + n1, slab + half, n2);
+        ChunkPairMeta* dst = (ChunkPairMeta*)(slab + meta_off());
+        memmove(dst, meta, (size_t)(n_meta + 1) * sizeof(ChunkPairMeta));   // the record area lies behind both halves: dst <= meta
+        half = n1;
+        meta = dst;
+    }
 };
 
 struct ChunkPlan {
@@ -266,7 +281,15 @@ static void plan_range(const Mapped& m, size_t chunk_bytes, size_t c_lo, size_t 
     start->assign(c_hi - c_lo + 1, 0);
     for (size_t c = c_lo; c <= c_hi; c++) (*start)[c - c_lo] = c >= nchunks ? m.n : line_start_at_or_after(m.p, m.n, c * chunk_bytes);
     count->assign(c_hi - c_lo, 0);
-    parallel_for((long)(c_hi - c_lo), threads, [&](long i) { (*count)[(size_t)i] = count_lines(m.p, (*start)[(size_t)i], (*start)[(size_t)i + 1], m.n); });
+    static const int populate = getenv("LHGT_MMAP_POPULATE") ? atoi(getenv("LHGT_MMAP_POPULATE")) : 0;   // experiment knob: 1 = MADV_POPULATE_READ per chunk
+    parallel_for((long)(c_hi - c_lo), threads, [&](long i) {
+        const size_t a = (*start)[(size_t)i], b = (*start)[(size_t)i + 1];
+        if (populate && b > a) {
+            const size_t pa = a & ~(size_t)4095;
+            (void)madvise((void*)(m.p + pa), b - pa, 22 /* MADV_POPULATE_READ */);
+        }
+        (*count)[(size_t)i] = count_lines(m.p, a, b, m.n);
+    });
 }
 
 // chunks without a byte of their own (a line longer than a chunk) are dropped
@@ -602,8 +625,9 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
         std::thread planner([&] {
             if (share_fn) { src = share_fn(m1, m2, &share, &p1s, &p2s); if (src != LHGT_OK) serr = last_error(); }
             else {   // both files at once; counting newlines is bound by memory bandwidth, which more threads than the parse uses still raise
-                unsigned hc = std::thread::hardware_concurrency();
-                const int pt = getenv("LHGT_INGEST_THREADS") ? threads : (int)(hc > 192 ? 96 : hc > 2 * (unsigned)threads ? hc / 2 : (unsigned)threads);
+                // (measured on 2 x 10 GB in the page cache, 256 cores: 16-24 threads per file count in 0.08-0.14 s, 48 in 0.17-0.3, 96 in
+                // 0.3-0.45 -- first-touch faults of the mappings contend on the address space's locks)
+                const int pt = threads > 24 ? 24 : threads;
                 std::thread t2([&] { p2s = plan_chunks(m2, chunk_bytes, pt); });
                 p1s = plan_chunks(m1, chunk_bytes, pt);
                 t2.join();
@@ -973,37 +997,41 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     const size_t BATCH_BYTES = ctx->count_on_load ? (size_t)384 << 20 : (size_t)1 << 30, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes();
     const size_t HALF = CHUNK + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);
     const long DESC_CAP = 1L << 16;                                       // chunks per batch
-    const size_t META_OFF = (BATCH_BYTES + 2 * SLAB + 255) & ~(size_t)255;   // device: per-pair records of the open batch, behind its ASCII
-    const size_t META_BYTES = (size_t)(META_CAP + DESC_CAP) * sizeof(ChunkPairMeta);
+    // device staging of one batch: the chunks' blocks (bases + records) one after the other.  TWO of them: the copies of batch
+    // b + 1 (on the copy stream) run while batch b is expanded, packed and counted (on the context's stream)
+    const size_t STAGE = (BATCH_BYTES + 2 * SLAB + (size_t)META_CAP * sizeof(ChunkPairMeta) + 255) & ~(size_t)255;
     const int threads = default_threads();
     const int n_slabs = threads + threads / 3 + 4;
     // staging, pinned slabs and the pinned chunk descriptors are allocated by `prepare` below, on this thread, while helper threads count lines
     SlabPool* pool = nullptr;
-    ChunkDesc* desc = nullptr;
+    ChunkDesc* desc_base = nullptr;
     double t_alloc = 0;
     std::vector<ChunkDesc> desc_pageable;     // only when the host refuses page-locked memory
+    hipEvent_t buf_free[2] = {nullptr, nullptr}, copied = nullptr;
     auto prepare = [&](SlabPool** pool_out) -> int {
         const double t_a0 = now_s();
-        LHGT_TRY(ws_reserve(ctx, META_OFF + META_BYTES, 0));
+        LHGT_TRY(ws_reserve(ctx, 2 * STAGE, 0));
+        for (auto& e : buf_free) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        LHGT_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
         pool = (SlabPool*)ctx->ingest_pool;
-        if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != DESC_CAP) {
+        if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != 2 * DESC_CAP) {
             lhgt_ingest_pool_free(ctx);
             ingest_free(ctx);
             pool = nullptr;
             if (getenv("LHGT_NO_PINNED") ||     // test hook for the fallback below
                 hipHostMalloc(&ctx->h_ingest_slabs, (size_t)n_slabs * SLAB, hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc(&ctx->h_ingest_meta, (size_t)DESC_CAP * sizeof(ChunkDesc), hipHostMallocDefault) != hipSuccess) {
+                hipHostMalloc(&ctx->h_ingest_meta, (size_t)2 * DESC_CAP * sizeof(ChunkDesc), hipHostMallocDefault) != hipSuccess) {
                 // no page-locked memory to be had (a locked-memory limit): the same pipeline on pageable buffers -- chunks in
                 // vectors, copied synchronously; slower, same result
                 (void)hipGetLastError();
                 ingest_free(ctx);
-                desc_pageable.resize((size_t)DESC_CAP);
-                desc = desc_pageable.data();
+                desc_pageable.resize((size_t)2 * DESC_CAP);
+                desc_base = desc_pageable.data();
                 *pool_out = nullptr;
                 t_alloc = now_s() - t_a0;
                 return LHGT_OK;
             }
-            ctx->ingest_meta_cap = DESC_CAP;
+            ctx->ingest_meta_cap = 2 * DESC_CAP;
             pool = new SlabPool();
             pool->base = ctx->h_ingest_slabs;
             pool->slab_bytes = SLAB;
@@ -1014,16 +1042,18 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             for (auto& e : ctx->ingest_events) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         pool->k = ctx->k;
-        desc = (ChunkDesc*)ctx->h_ingest_meta;
+        desc_base = (ChunkDesc*)ctx->h_ingest_meta;
         *pool_out = pool;
         t_alloc = now_s() - t_a0;
         return LHGT_OK;
     };
     const int k = ctx->k;
+    hipStream_t cs = ctx->copy_stream;
     size_t fill = 0;
-    long n_open = 0, kept = 0, n_desc = 0, meta_fill = 0;
+    long n_open = 0, kept = 0, n_desc = 0, n_batches = 0;
     uint64_t words = 0, nkm = 0;
     int max_len = 0;
+    bool used[2] = {false, false};
     std::vector<int> out_slabs;          // FIFO of slabs whose copies are in flight (event = ingest_events[slab id])
     size_t out_head = 0;
     auto reap = [&](bool block) {
@@ -1035,11 +1065,32 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             out_head++;
         }
     };
+    auto stage_base = [&]() { return ctx->d_ws_ascii + (size_t)(n_batches & 1) * STAGE; };
+    auto desc = [&]() { return desc_base + (size_t)(n_batches & 1) * DESC_CAP; };
+    // the open batch's staging buffer and descriptors were last used two batches ago: its pack kernel must have read them
+    auto open_batch = [&]() -> int {
+        const int bi = (int)(n_batches & 1);
+        if (used[bi]) {
+            LHGT_HIP(hipEventSynchronize(buf_free[bi]));           // host: the descriptors are rewritten
+            LHGT_HIP(hipStreamWaitEvent(cs, buf_free[bi], 0));      // device: so is the staging buffer
+        }
+        return LHGT_OK;
+    };
+    auto stage_sync = [&](size_t off, const uint8_t* src, size_t bytes) -> int {   // pageable source (the rare chunks in vectors): copied before it goes away
+        if (!bytes) return LHGT_OK;
+        LHGT_HIP(hipMemcpyAsync(stage_base() + off, src, bytes, hipMemcpyHostToDevice, cs));
+        LHGT_HIP(hipStreamSynchronize(cs));
+        return LHGT_OK;
+    };
     std::vector<hipEvent_t> count_ev;    // count-on-load: an event pair around every batch's phase A
     auto flush = [&]() -> int {
         if (n_open == 0) return LHGT_OK;
-        int rc = install_pairs_chunked(ctx, ctx->d_ws_ascii, (const ChunkPairMeta*)(ctx->d_ws_ascii + META_OFF), desc, n_desc, n_open, words, max_len, nkm);
-        auto reset = [&] { fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0; n_desc = 0; meta_fill = 0; };
+        const int bi = (int)(n_batches & 1);
+        LHGT_HIP(hipEventRecord(copied, cs));
+        LHGT_HIP(hipStreamWaitEvent(ctx->stream, copied, 0));
+        int rc = install_pairs_chunked(ctx, stage_base(), (const ChunkPairMeta*)stage_base(), desc(), n_desc, n_open, words, max_len, nkm);
+        LHGT_HIP(hipEventRecord(buf_free[bi], ctx->stream));
+        used[bi] = true;
         if (rc == LHGT_OK && ctx->count_on_load) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             const bool have_e0 = hipEventCreate(&e0) == hipSuccess;
@@ -1047,23 +1098,12 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             if (e0 && e1) {
                 count_ev.push_back(e0);
                 count_ev.push_back(e1);
-                // the copies, the record expansion and the pack kernel of this batch are ahead of it on the same stream; the wait
-                // below is for THEM (staging and descriptors are reused) -- the count of this batch runs on while the next is parsed
-                hipEvent_t packed = ctx->ev3;
-                (void)hipEventRecord(packed, ctx->stream);
-                rc = lhgt_count_one_batch_async(ctx, ctx->batches.back(), e0, e1);
-                hipError_t e = hipEventSynchronize(packed);
-                reap(false);
-                reset();
-                if (rc == LHGT_OK && e != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "ingest: %s", hipGetErrorString(e));
-                return rc;
+                rc = lhgt_count_one_batch_async(ctx, ctx->batches.back(), e0, e1);   // runs on while the next batch is parsed and copied
             }
         }
-        // the staging area and the descriptors are reused by the next batch: wait for the copies and the pack kernel
-        hipError_t e = hipStreamSynchronize(ctx->stream);
         reap(false);
-        reset();
-        if (rc == LHGT_OK && e != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "ingest: %s", hipGetErrorString(e));
+        fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0; n_desc = 0;
+        n_batches++;
         return rc;
     };
     std::vector<ChunkPairMeta> conv;     // records of a chunk that came in vectors (spilled, head / tail records of fq2, no pinned memory)
@@ -1073,16 +1113,14 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                              const long n = ch.n_pairs();
                              if (n <= 0) { if (ch.slab_id >= 0) pool->release(ch.slab_id); return LHGT_OK; }
                              const size_t b1n = ch.size1(), b2n = ch.size2();
-                             if (fill + b1n + b2n > BATCH_BYTES + 2 * SLAB || n_open + n > META_CAP || n_desc >= DESC_CAP) LHGT_TRY(flush());
-                             if (fill + b1n + b2n > BATCH_BYTES + 2 * SLAB || n > META_CAP) LHGT_FAIL(LHGT_E_FORMAT, "ingest: one chunk holds %ld pairs / %zu bases", n, b1n + b2n);
-                             const size_t b1 = fill, b2 = fill + b1n;
-                             ChunkPairMeta* d_meta = (ChunkPairMeta*)(ctx->d_ws_ascii + META_OFF) + meta_fill;
+                             const size_t moff = (b1n + b2n + 15) & ~(size_t)15, block = moff + (size_t)(n + 1) * sizeof(ChunkPairMeta);
+                             if (fill + block > STAGE || n_open + n > META_CAP || n_desc >= DESC_CAP) LHGT_TRY(flush());
+                             if (block > STAGE || n > META_CAP) LHGT_FAIL(LHGT_E_FORMAT, "ingest: one chunk holds %ld pairs / %zu bases", n, b1n + b2n);
+                             if (n_open == 0) LHGT_TRY(open_batch());
                              uint32_t ch_words = 0;
                              if (ch.slab) {
-                                 if (b1n) LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + b1, ch.bases1(), b1n, hipMemcpyHostToDevice, ctx->stream));
-                                 if (b2n) LHGT_HIP(hipMemcpyAsync(ctx->d_ws_ascii + b2, ch.bases2(), b2n, hipMemcpyHostToDevice, ctx->stream));
-                                 LHGT_HIP(hipMemcpyAsync(d_meta, ch.meta, (size_t)(n + 1) * sizeof(ChunkPairMeta), hipMemcpyHostToDevice, ctx->stream));
-                                 LHGT_HIP(hipEventRecord(ctx->ingest_events[(size_t)ch.slab_id], ctx->stream));
+                                 LHGT_HIP(hipMemcpyAsync(stage_base() + fill, ch.slab, block, hipMemcpyHostToDevice, cs));
+                                 LHGT_HIP(hipEventRecord(ctx->ingest_events[(size_t)ch.slab_id], cs));
                                  out_slabs.push_back(ch.slab_id);
                                  ch_words = ch.words;
                                  if (ch.max_len > max_len) max_len = ch.max_len;
@@ -1099,13 +1137,13 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                                      if ((int)l2 >= k) nkm += l2 - k + 1;
                                  }
                                  conv[(size_t)n] = ChunkPairMeta{(uint32_t)ch.o1[n], (uint32_t)ch.o2[n], ch_words, 0u};
-                                 LHGT_TRY(stage_ascii(ctx, b1, ch.bases1(), b1n));
-                                 LHGT_TRY(stage_ascii(ctx, b2, ch.bases2(), b2n));
-                                 LHGT_TRY(stage_ascii(ctx, META_OFF + (size_t)meta_fill * sizeof(ChunkPairMeta), (const uint8_t*)conv.data(), (size_t)(n + 1) * sizeof(ChunkPairMeta)));
+                                 LHGT_TRY(stage_sync(fill, ch.bases1(), b1n));
+                                 LHGT_TRY(stage_sync(fill + b1n, ch.bases2(), b2n));
+                                 LHGT_TRY(stage_sync(fill + moff, (const uint8_t*)conv.data(), (size_t)(n + 1) * sizeof(ChunkPairMeta)));
                              }
-                             desc[n_desc++] = ChunkDesc{(uint32_t)n_open, (uint32_t)n, (uint32_t)b1, (uint32_t)b2, (uint32_t)words, (uint32_t)meta_fill};
-                             fill = b2 + b2n;
-                             meta_fill += n + 1;
+                             desc()[n_desc++] = ChunkDesc{(uint32_t)n_open, (uint32_t)n, (uint32_t)fill, (uint32_t)(fill + b1n), (uint32_t)words,
+                                                          (uint32_t)((fill + moff) / sizeof(ChunkPairMeta))};
+                             fill = (fill + block + 15) & ~(size_t)15;
                              words += ch_words;
                              n_open += n;
                              kept += n;
@@ -1116,8 +1154,11 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                          [&](bool block) { reap(block); }, prepare, share_fn);
     const double t_f0 = now_s();
     if (rc == LHGT_OK) rc = flush();
-    (void)hipStreamSynchronize(ctx->stream);      // whatever happened: no copy may still read a slab
-    if (ingest_trace()) fprintf(stderr, "[lhgt ingest] staging + pinned pool %.3fs (behind the line count), last batch + drain %.3fs\n", t_alloc, now_s() - t_f0);
+    (void)hipStreamSynchronize(cs);               // whatever happened: no copy may still read a slab,
+    (void)hipStreamSynchronize(ctx->stream);      // no kernel the staging buffers
+    if (ingest_trace()) fprintf(stderr, "[lhgt ingest] staging + pinned pool %.3fs (behind the line count), %ld batches, last batch + drain %.3fs\n", t_alloc, n_batches, now_s() - t_f0);
+    for (auto& e : buf_free) if (e) (void)hipEventDestroy(e);
+    if (copied) (void)hipEventDestroy(copied);
     if (pool) {                                    // ... so every slab is free again, also one a failed chunk still held
         std::lock_guard<std::mutex> lk(pool->mu);
         pool->free_ids.clear();

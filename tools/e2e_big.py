@@ -50,6 +50,27 @@ def run(tag, threads, **kw):
     return rep
 
 
+if os.environ.get("E2E_KNOBS"):      # "name=VAR:val,VAR:val;name2=..." environment variants, each run twice with a cached index
+    os.system("uname -r")
+    run("index built in-run, -t 1", 1)
+    for spec in os.environ["E2E_KNOBS"].split(";"):
+        name, _, kv = spec.partition("=")
+        sets = dict(x.split(":") for x in kv.split(",") if x)
+        for kk in ("LHGT_INGEST_THREADS", "LHGT_MMAP_ADVICE", "LHGT_MMAP_POPULATE"):
+            os.environ.pop(kk, None)
+        os.environ.update(sets)
+        for i in range(2):
+            run(f"cached, {name}", 1)
+    shutil.rmtree(tmp)
+    sys.exit(0)
+if os.environ.get("E2E_THREAD_SWEEP"):
+    run("index built in-run, -t 1", 1)
+    for t in (int(x) for x in os.environ["E2E_THREAD_SWEEP"].split(",")):
+        os.environ["LHGT_INGEST_THREADS"] = str(t)
+        for i in range(2):
+            run(f"index cached, -t 1, {t} ingest threads", 1)
+    shutil.rmtree(tmp)
+    sys.exit(0)
 run("index built in-run, -t 1", 1)
 for i in range(2):
     run("index cached, -t 1", 1)

@@ -252,29 +252,77 @@ def cpu_baseline(k, e, n_contigs, contig_len, n_pairs, device):
                                    "kernels_ms": round(rep_g["count_kernel_ms"] + rep_g["scan_kernel_ms"] + rep_g["vote_kernel_ms"], 1)}}
 
 
-def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_000_000):
+def synth_files_sliced(tmp, k, e, n_contigs, contig_len, n_pairs, device, slice_pairs=4_000_000):
+    """like synth_files for inputs of tens of GB: the pairs generated and written slice by slice"""
+    from localhgt_amd.engine import Engine
+    fa, f1, f2 = (os.path.join(tmp, x) for x in ("ref.fa", "s.1.fq", "s.2.fq"))
+    with Engine(k, e, device=device) as eng:
+        eng.rng_seed(1)
+        eng.coder_generate()
+        write_fasta(fa, eng.synth_reference(1, n_contigs, contig_len, want_host=True), n_contigs, contig_len)
+        for path in (f1, f2):
+            open(path, "wb").close()
+        for p0 in range(0, n_pairs, slice_pairs):
+            n = min(slice_pairs, n_pairs - p0)
+            eng.pairs_clear()
+            m1, m2 = eng.synth_pairs(1, 2, n_contigs, contig_len, p0, n, 150, want_host=True)
+            for path, m, suf in ((f1, m1, "1"), (f2, m2, "2")):
+                part = path + ".part"
+                write_fastq(part, m, n, 150, suf)      # read ids restart per slice: the path looks at the first one only
+                with open(path, "ab") as dst, open(part, "rb") as src:
+                    shutil.copyfileobj(src, dst, 1 << 24)
+                os.remove(part)
+    return fa, f1, f2
+
+
+def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_000_000, big_pairs=32_000_000):
     """from FASTQ files in the page cache through the drop-in entry point (localhgt_amd.extract_ref.run: what bin/extract_ref
-    calls): sampling pass, index (built in the first run, loaded in the second), parse + H2D + pack, phases A-D, interval file"""
+    calls): line count (+ sampling ratio), index (built in the first run, loaded in the second), parse + H2D + pack with phase A
+    behind it, phases B-D, interval file.  -t 10 as `localhgt bkp` passes it: the reference's thread chunks are emulated.
+    Two sizes: 4 M pairs (2.5 GB of text: the fixed costs show) and `big_pairs` (20 GB: the reads decide)."""
     from localhgt_amd import extract_ref
+    quiet = dict(device=device, log=lambda *x: None)
     with tempfile.TemporaryDirectory(prefix="lhgt_e2e_") as tmp:
         fa, f1, f2 = synth_files(tmp, k, e, n_contigs, contig_len, n_pairs, device)
         a = extract_ref.Args(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, 10, k, 300_000_000, e, 1, 1.0)
-        reps = [extract_ref.run(a, device=device, log=lambda *x: None) for _ in range(3)]
+        reps = [extract_ref.run(a, **quiet) for _ in range(3)]
         built, cached = reps[0], min(reps[1:], key=lambda r: r["total_s"])
-        packed = min((extract_ref.run(a, device=device, log=lambda *x: None, ref_form="packed") for _ in range(2)), key=lambda r: r["total_s"])
+        plain = min((extract_ref.run(a, emulate_threads=False, **quiet) for _ in range(2)), key=lambda r: r["total_s"])
+        packed = min((extract_ref.run(a, ref_form="packed", **quiet) for _ in range(2)), key=lambda r: r["total_s"])
         fq_bytes = os.path.getsize(f1) + os.path.getsize(f2)
-        return {"value": round(n_pairs / cached["total_s"] / 1e6, 3), "unit": "M paired-reads/s",
-                "what": f"extract_ref on {n_pairs} pairs ({fq_bytes / 1e9:.2f} GB of FASTQ, page cache) vs {n_contigs} x {contig_len} bp, "
-                        f"k={k} e={e}, cached index; whole call incl. context set-up, index load, parse, H2D, packing, A-D, interval file",
-                "total_s": round(cached["total_s"], 3), "ingest_s": round(cached["ingest_s"], 3),
-                "index_load_s": round(cached.get("index_s", 0.0), 3), "reads_s": round(cached.get("reads_s", 0.0), 3),
-                "kernels_ms": round(cached["count_kernel_ms"] + cached["scan_kernel_ms"] + cached["vote_kernel_ms"], 1),
-                "fastq_GB_per_s": round(fq_bytes / cached["total_s"] / 1e9, 2),
-                "with_index_build": {"value": round(n_pairs / built["total_s"] / 1e6, 3), "total_s": round(built["total_s"], 3)},
-                "with_packed_reference": {"value": round(n_pairs / packed["total_s"] / 1e6, 3), "total_s": round(packed["total_s"], 3),
-                                          "reference_load_s": round(packed.get("index_s", 0.0), 3), "same_peaks": (packed["n_peaks"], packed["n_filtered"]) == (cached["n_peaks"], cached["n_filtered"]),
-                                          "what": "LHGT_REF_FORM=packed: no index file read; the FASTA text goes to the GPU, is stripped and packed there, phase B recomputes the hashes"},
-                "raw_peaks": cached["n_peaks"], "filtered_peaks": cached["n_filtered"]}
+        out = {"value": round(n_pairs / cached["total_s"] / 1e6, 3), "unit": "M paired-reads/s",
+               "what": f"extract_ref -t 10 (thread emulation, the CLI default) on {n_pairs} pairs ({fq_bytes / 1e9:.2f} GB of FASTQ, page cache) vs {n_contigs} x {contig_len} bp, "
+                       f"k={k} e={e}, cached index; whole call incl. context set-up, index load, parse, H2D, packing, A-D, interval file",
+               "total_s": round(cached["total_s"], 3), "ingest_s": round(cached["ingest_s"], 3), "emulated_threads": cached["emulated_threads"],
+               "index_load_s": round(cached.get("index_s", 0.0), 3), "reads_s": round(cached.get("reads_s", 0.0), 3),
+               "kernels_ms": round(cached["count_kernel_ms"] + cached["scan_kernel_ms"] + cached["vote_kernel_ms"], 1),
+               "fastq_GB_per_s": round(fq_bytes / cached["total_s"] / 1e9, 2),
+               "without_thread_emulation": {"value": round(n_pairs / plain["total_s"] / 1e6, 3), "total_s": round(plain["total_s"], 3),
+                                            "what": "LHGT_EMULATE_THREADS=0: the -t 1 result whatever -t says"},
+               "with_index_build": {"value": round(n_pairs / built["total_s"] / 1e6, 3), "total_s": round(built["total_s"], 3)},
+               "with_packed_reference": {"value": round(n_pairs / packed["total_s"] / 1e6, 3), "total_s": round(packed["total_s"], 3),
+                                         "reference_load_s": round(packed.get("index_s", 0.0), 3), "same_peaks": (packed["n_peaks"], packed["n_filtered"]) == (cached["n_peaks"], cached["n_filtered"]),
+                                         "what": "LHGT_REF_FORM=packed: no index file read; the FASTA text goes to the GPU, is stripped and packed there, phase B recomputes the hashes"},
+               "raw_peaks": cached["n_peaks"], "filtered_peaks": cached["n_filtered"]}
+    if big_pairs and shutil.disk_usage(tempfile.gettempdir()).free > 2.2 * 320 * 2 * big_pairs:
+        with tempfile.TemporaryDirectory(prefix="lhgt_e2e_") as tmp:
+            t0 = time.time()
+            fa, f1, f2 = synth_files_sliced(tmp, k, e, n_contigs, contig_len, big_pairs, device)
+            gen_s = time.time() - t0
+            fq_bytes = os.path.getsize(f1) + os.path.getsize(f2)
+            legs = {}
+            for tag, sample, kw in (("sample_1", 1.0, {}), ("sample_1_packed_reference", 1.0, {"ref_form": "packed"}),
+                                    ("default_sample_2e9", 2e9, {}), ("default_sample_2e9_packed_reference", 2e9, {"ref_form": "packed"})):
+                a = extract_ref.Args(f1, f2, fa, os.path.join(tmp, "interval.txt"), 0.1, 0.08, 10, k, 300_000_000, e, 1, sample)
+                r = min((extract_ref.run(a, **dict(quiet, **kw)) for _ in range(3 if not legs else 2)), key=lambda r: r["total_s"])
+                legs[tag] = {"value": round(big_pairs / r["total_s"] / 1e6, 2), "unit": "M input pairs/s", "total_s": round(r["total_s"], 3),
+                             "reads_s": round(r["reads_s"], 3), "reference_s": round(r["index_s"], 3), "pairs_kept": r["pairs_kept"],
+                             "ratio_percent": round(r["ratio"], 4), "raw_peaks": r["n_peaks"], "filtered_peaks": r["n_filtered"],
+                             "fastq_GB_per_s": round(fq_bytes / r["total_s"] / 1e9, 1)}
+            out["big"] = dict(legs, what=f"the same call on {big_pairs} pairs ({fq_bytes / 1e9:.1f} GB of FASTQ in the page cache, written in {gen_s:.0f} s), -t 10; "
+                                         "default_sample_2e9 = the CLI's default --sample 2000000000 (cal_sam_ratio's base count from the line plan, "
+                                         "pairs kept by the sampling array)")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- did the run find what was planted?
@@ -368,7 +416,7 @@ class Workload:
         self.fence()
         dt = time.time() - t0
         if self.dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{self.eng.device}")
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dist._dev())
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         if len(seen) != 1:
@@ -506,7 +554,8 @@ def main():
     ap.add_argument("--count-mode", type=int, default=-1, help="-1 = engine default (adaptive), 0 = direct CAS kernel, 1 = radix partition")
     ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry-run")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: the exchanges staged through host memory (localhgt_amd/dist.py) -- for ranks that share a GPU (rehearsal of the N > 1 path on a one-GPU box) and for --dry-run")
     ap.add_argument("--dry-run", action="store_true", help="launcher + process group + exchanges on host tensors, no GPU and no measurement (CPU self-test of the N>1 plumbing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=400_000)
@@ -564,13 +613,14 @@ def main():
 
     import torch
     from localhgt_amd.engine import Engine
+    local = local % max(1, torch.cuda.device_count())          # --backend gloo: ranks may share a GPU
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_dist:
         from localhgt_amd.dist import Exchange
         for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
             os.environ.setdefault(key, val)
-        dist = Exchange.from_env(backend="nccl")
+        dist = Exchange.from_env(backend=args.backend)
 
     eng = Engine(k, e, device=local)
     eng.rng_seed(1)
@@ -662,7 +712,7 @@ def main():
                                f"{'packed bases resident, hashes recomputed' if args.ref_form == 'packed' else 'index resident'}), {args.pairs} 150bp pairs per GPU, k={k} e={e}, sample=1, phases A-D",
                    "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
                    "parallelism": f"reads sharded x{world}" + (", index sharded" if forms[0] else ", phase B replicated on every GPU (per-GPU work fixed)" if world > 1 else "")},
-        "world_size": torch.distributed.get_world_size() if dist else 1,
+        "world_size": torch.distributed.get_world_size() if dist else 1, "backend": dist.backend if dist else None,
         "phase_ms": {kk: round(v, 3) for kk, v in per.items()},
         "exchange_ms": xch_ms,
         "n1_equivalent_ms": round(step_s * 1e3 - sum(xch_ms.values()), 3) if xch_ms else round(step_s * 1e3, 3),

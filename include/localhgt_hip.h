@@ -51,6 +51,10 @@ int lhgt_coder_set(lhgt_ctx* ctx, const int16_t* cc /*[300]*/);        /* saved_
 int lhgt_coder_get(lhgt_ctx* ctx, int16_t* cc /*[300]*/);
 int lhgt_sampling_init(lhgt_ctx* ctx, double ratio_percent);           /* get_random, E:1332-1340; no draw when ratio >= 100 */
 int lhgt_sampling_get(lhgt_ctx* ctx, float* out, long n);              /* first n values of random_array (tests) */
+/* read n looks at random_array[n % 5*10^7] (E:1037-1044) and nothing draws from the stream after get_random: a run that knows it
+ * will see at most n_reads reads per file (from the line count) needs only that many entries; the loaders refuse a read beyond
+ * them.  0 (default) = all 5*10^7.  Call before lhgt_sampling_init. */
+int lhgt_sampling_reserve(lhgt_ctx* ctx, long n_reads);
 
 /* ---- H: hash of every k-mer of one sequence (parity probe for E:1052-1081 / 786-811).
  * out_hash[(j*e)+i], out_valid[j]; runs the same device code as every phase. */

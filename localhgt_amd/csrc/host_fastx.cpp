@@ -609,7 +609,8 @@ template <class Consume, class Idle>
 static int parse_pairs(const char* fq1, const char* fq2, double ratio, const float* random_array, int shard_rank, int shard_world,
                        long shard_block, int threads, size_t chunk_bytes, int emulate_threads, long* n_pairs_seen, SlabPool* pool_in,
                        Consume consume, Idle idle, const std::function<int(SlabPool**)>& prepare = nullptr,
-                       const std::function<int(const Mapped&, const Mapped&, ParseShare*, ChunkPlan*, ChunkPlan*)>& share_fn = nullptr) {
+                       const std::function<int(const Mapped&, const Mapped&, ParseShare*, ChunkPlan*, ChunkPlan*)>& share_fn = nullptr,
+                       long sampling_filled = LHGT_MAX_RANDOM) {
     Mapped m1, m2;
     LHGT_TRY(m1.open(fq1));
     LHGT_TRY(m2.open(fq2));
@@ -753,6 +754,11 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
                 share.part, share.n_parts, threads, c_lo, c_hi, nc_all, 1e-6 * (double)(p1.start[(size_t)c_hi] - p1.start[(size_t)c_lo]), 1e-6 * (double)m1.n, fq1,
                 t_plan, t_parse, t_consume);
     if (n_pairs_seen) *n_pairs_seen = (p1.line0.back() + 2) / 4;   // lines with index % 4 == 1
+    // a sampling array filled for fewer reads than the files hold (lhgt_sampling_reserve) must fail loudly
+    if (ratio < 100.0 && sampling_filled < LHGT_MAX_RANDOM && (p1.line0.back() + 2) / 4 > sampling_filled)
+        LHGT_FAIL(LHGT_E_STATE, "the sampling array was filled for %ld reads (lhgt_sampling_reserve), %s holds %ld", sampling_filled, fq1, (p1.line0.back() + 2) / 4);
+    if (ratio < 100.0 && sampling_filled < LHGT_MAX_RANDOM && (p2.line0.back() + 2) / 4 > sampling_filled)
+        LHGT_FAIL(LHGT_E_STATE, "the sampling array was filled for %ld reads (lhgt_sampling_reserve), %s holds %ld", sampling_filled, fq2, (p2.line0.back() + 2) / 4);
     return LHGT_OK;
 }
 
@@ -1151,7 +1157,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                              if (n_open >= BATCH_PAIRS || fill >= BATCH_BYTES) return flush();
                              return LHGT_OK;
                          },
-                         [&](bool block) { reap(block); }, prepare, share_fn);
+                         [&](bool block) { reap(block); }, prepare, share_fn, ctx->random_array.empty() ? LHGT_MAX_RANDOM : ctx->sampling_filled);
     const double t_f0 = now_s();
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(cs);               // whatever happened: no copy may still read a slab,

@@ -113,15 +113,45 @@ int lhgt_coder_get(lhgt_ctx* ctx, int16_t* cc) {
 
 // get_random (E:1332-1340): 50 M values float((rand() % 100000) / 1000.0).  Every value is
 // < 100, so with ratio >= 100 every read passes `r < ratio` (E:1044) and the array is not needed;
-// nothing draws from the stream afterwards, so skipping the fill is unobservable.
+// nothing draws from the stream afterwards, so skipping the fill is unobservable -- and so is filling only the entries a run can
+// look at: read n looks at entry n % 5*10^7, so a run over fewer reads (lhgt_sampling_reserve) needs only that many.
+// The fill runs glibc's TYPE_3 generator (r[i] = r[i-31] + r[i-3], output r[i] >> 1) directly on the private random_r state --
+// the same words random_r would produce, without 5*10^7 calls -- and takes value -> float from a table of the 10^5 possible values
+// (the reference's `(rand() % 100000) / 1000.0` in double, rounded to float, E:1336).
+int lhgt_sampling_reserve(lhgt_ctx* ctx, long n_reads) {
+    if (!ctx || n_reads < 0) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    ctx->sampling_reads = n_reads;
+    return LHGT_OK;
+}
+
 int lhgt_sampling_init(lhgt_ctx* ctx, double ratio_percent) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     ctx->ratio = ratio_percent;
     ctx->random_array.clear();
     if (ratio_percent >= 100.0) return LHGT_OK;
     if (!ctx->seeded) LHGT_FAIL(LHGT_E_STATE, "lhgt_rng_seed must be called before lhgt_sampling_init");
-    ctx->random_array.resize(LHGT_MAX_RANDOM);
-    for (long i = 0; i < LHGT_MAX_RANDOM; i++) ctx->random_array[i] = (float)((rng_next(ctx) % 100000) / 1000.0);
+    // the array keeps its full length (every consumer indexes it modulo 5*10^7); entries no read of the run can look at stay 0
+    const long need = ctx->sampling_reads > 0 && ctx->sampling_reads < LHGT_MAX_RANDOM ? ctx->sampling_reads : LHGT_MAX_RANDOM;
+    ctx->random_array.assign((size_t)LHGT_MAX_RANDOM, 0.f);
+    ctx->sampling_filled = need;
+    std::vector<float> lut(100000);
+    for (int v = 0; v < 100000; v++) lut[(size_t)v] = (float)(v / 1000.0);
+    struct random_data* rd = (struct random_data*)ctx->rng;
+    float* out = ctx->random_array.data();
+    if (rd->rand_type == 3 && rd->rand_deg == 31 && rd->rand_sep == 3) {
+        int32_t *f = rd->fptr, *r = rd->rptr, *const st = rd->state, *const end = rd->end_ptr;
+        for (long i = 0; i < need; i++) {
+            const uint32_t val = (uint32_t)*f + (uint32_t)*r;
+            *f = (int32_t)val;
+            out[i] = lut[(val >> 1) % 100000u];
+            if (++f >= end) { f = st; ++r; }
+            else if (++r >= end) r = st;
+        }
+        rd->fptr = f;
+        rd->rptr = r;
+    } else {
+        for (long i = 0; i < need; i++) out[i] = lut[(size_t)(rng_next(ctx) % 100000)];
+    }
     return LHGT_OK;
 }
 

@@ -113,6 +113,8 @@ struct lhgt_ctx {
     bool have_coder = false;
     lhgt::HashParams hp{};
     std::vector<float> random_array;
+    long sampling_reads = 0;     // lhgt_sampling_reserve: reads the run can look at (0 = unknown: all 5*10^7 entries are filled)
+    long sampling_filled = 0;    // entries of random_array the last lhgt_sampling_init filled
     double ratio = 100.0;
     // A
     uint32_t* d_counts = nullptr;  // 2-bit saturating counters, 16 per word

@@ -184,17 +184,6 @@ class Exchange:
         start, counts = np.ascontiguousarray(allv[:, 0]).view(np.uint64), np.ascontiguousarray(allv[:, 1])
         return (start, counts, np.ascontiguousarray(allv[:, 2:6])) if want_len_sums else (start, counts)
 
-    @staticmethod
-    def sam_ratio_from_plan(plan, sample: float) -> float:
-        """cal_sam_ratio (E:1244-1270, 1392-1398) without its pass over fq1: the bases of the sequence lines -- global line index
-        % 4 == 1 -- from the per-chunk sums by local line index"""
-        if sample <= 1:
-            return 100.0 * sample
-        _, counts, sums = plan
-        line0 = np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else np.zeros(0, dtype=np.int64)
-        bases = int(sum(int(sums[c, (1 - int(line0[c])) % 4]) for c in range(len(counts))))
-        return 100.0 * sample / (2.0 * bases)
-
     # ---- phase A: packed saturating reduce-scatter + all-gather
     def merge_counts(self, eng):
         table = self.adapter.counts_tensor(eng)          # uint8 view of the packed 2-bit table

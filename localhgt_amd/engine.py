@@ -62,6 +62,10 @@ class Engine:
     def sampling_init(self, ratio_percent: float):
         _lib.check(self.lib.lhgt_sampling_init(self.h, float(ratio_percent)))
 
+    def sampling_reserve(self, n_reads: int):
+        """the run will see at most n_reads reads per file: sampling_init fills only that many entries of the sampling array"""
+        _lib.check(self.lib.lhgt_sampling_reserve(self.h, int(n_reads)))
+
     def sampling_get(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.float32)
         _lib.check(self.lib.lhgt_sampling_get(self.h, _ptr(out, C.c_float), n))
@@ -140,6 +144,30 @@ class Engine:
         _lib.check(self.lib.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, _ptr(st, C.c_uint64), _ptr(cn, C.c_long), n.value,
                                                  C.byref(n), C.byref(tot), None if sums is None else _ptr(sums, C.c_long)))
         return st[:n.value], cn[:n.value], None if sums is None else sums[:n.value]
+
+    def fastq_plan(self, path: str, want_len_sums: bool = False, other: Optional[str] = None):
+        """the whole plan of one file made here (one rank); with `other`, that file's plan is made at the same time on a second
+        thread and (plan, plan_other) is returned"""
+        if other is None:
+            return self.fastq_plan_part(path, 0, 1, want_len_sums)
+        import threading
+        box = {}
+        t = threading.Thread(target=lambda: box.update(p2=self.fastq_plan_part(other, 0, 1, False)))
+        t.start()
+        p1 = self.fastq_plan_part(path, 0, 1, want_len_sums)
+        t.join()
+        return p1, box["p2"]
+
+    @staticmethod
+    def sam_ratio_from_plan(plan, sample: float) -> float:
+        """cal_sam_ratio (E:1244-1270, 1392-1398) without its pass over fq1: the bases of the sequence lines -- global line index
+        % 4 == 1 -- from the per-chunk sums of line lengths by local line index (lhgt_fastq_plan_part: len_sums)"""
+        if sample <= 1:
+            return 100.0 * sample
+        _, counts, sums = plan
+        line0 = np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else np.zeros(0, dtype=np.int64)
+        bases = int(sums[np.arange(len(counts)), (1 - line0) % 4].sum()) if len(counts) else 0
+        return 100.0 * sample / (2.0 * bases)
 
     def pairs_load_fastq_planned(self, fq1: str, fq2: str, ratio_percent: float, plan1, plan2, part: int, parts: int) -> Tuple[int, int]:
         """plan = (start, n_lines) of ALL chunks of the file, the parts' pieces in order; only part `part`'s run of fq1's chunks is parsed"""

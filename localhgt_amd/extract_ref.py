@@ -102,9 +102,9 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     if dist:                                                   # every rank counts the lines of 1/world of both files (dist.fastq_plan)
         plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1)
         plan2 = dist.fastq_plan(eng, a.fq2)
-        ratio = dist.sam_ratio_from_plan(plan1, a.sample)      # E:1392-1398 without cal_sam_ratio's pass over fq1
-    else:
-        ratio = eng.sam_ratio(a.fq1, a.sample)                 # E:1392-1398
+    elif a.sample > 1:                                         # the CLI's default --sample 2000000000: the line count the loader needs
+        plan1, plan2 = eng.fastq_plan(a.fq1, True, other=a.fq2)   # anyway also yields cal_sam_ratio's base count (no extra pass over fq1)
+    ratio = eng.sam_ratio_from_plan(plan1, a.sample) if plan1 is not None else eng.sam_ratio(a.fq1, a.sample)   # E:1392-1398
     log(f"down-sampling ratio: {ratio}%.")
     idx = index_name(a.fasta, a.k, a.e)
     if ref_form is None:
@@ -147,6 +147,8 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
         n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
     t_i1 = time.time()
     _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
+    if plan1 is not None:                                      # reads per file are known: only the entries they can look at are filled
+        eng.sampling_reserve(max((int(plan1[1].sum()) + 2) // 4, (int(plan2[1].sum()) + 2) // 4))
     eng.sampling_init(ratio)                                   # E:1422
     t_r0 = time.time()
     eng.set_count_on_load(True)                                # phase A of a batch runs while the next one is parsed (E:1426-1448)
@@ -166,7 +168,7 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
 
     def load_and_count():
         t = time.time()
-        if dist:                                               # this rank's contiguous run of fq1's chunks, paired through the whole plan
+        if plan1 is not None:                                  # this rank's contiguous run of fq1's chunks, paired through the whole plan
             state["seen"], state["kept"] = eng.pairs_load_fastq_planned(a.fq1, a.fq2, ratio, plan1[:2], plan2[:2], rank, world)
         else:
             state["seen"], state["kept"] = eng.pairs_load_fastq(a.fq1, a.fq2, ratio)

@@ -298,6 +298,27 @@ def test_rank_ranges_of_the_fastqs_add_up_to_the_single_rank_parse(lib, oracle, 
         assert _digest_planned(lib, f1, f2, bad, plan2, 0, 2)[0] == 1
 
 
+@pytest.mark.parametrize("name", ["k24_sample_bases", "k24_fq2_surplus", "k24_seed7"])
+def test_sampling_ratio_from_the_line_plan_equals_cal_sam_ratio(lib, oracle, case_inputs, name, monkeypatch):
+    """--sample > 1 (the CLI default): the base count of cal_sam_ratio (E:1244-1270) falls out of the line count the loader makes
+    anyway (per-chunk sums of line lengths by line index mod 4) -- the same double as the extra pass gives, whatever the chunking"""
+    from localhgt_amd.engine import Engine
+    fa, f1, f2, _ = case_inputs(name)
+    eng = Engine(24, 3, device=-1)
+    want = oracle.sam_ratio(f1, 700000.0)
+    assert eng.sam_ratio(f1, 700000.0) == want
+    for chunk in ("256", "1000", "77777", None):
+        if chunk:
+            monkeypatch.setenv("LHGT_INGEST_CHUNK_BYTES", chunk)
+        else:
+            monkeypatch.delenv("LHGT_INGEST_CHUNK_BYTES")
+        p1, p2 = eng.fastq_plan(f1, True, other=f2)
+        assert eng.sam_ratio_from_plan(p1, 700000.0) == want, chunk
+        assert int(p1[1].sum()) == sum(1 for _ in open(f1, "rb")) and int(p2[1].sum()) == sum(1 for _ in open(f2, "rb"))
+    assert eng.sam_ratio_from_plan(p1, 0.5) == 50.0
+    eng.close()
+
+
 def test_fq2_with_foreign_records_in_front_is_resynchronised_like_the_reference(lib, oracle, case_inputs, tmp_path):
     """E:368-402: the first read IDs differ, so phase C re-reads fq2 from byte 1 until a line carries fq1's first ID and pairs
     fq1's line g with fq2's line g + 8; phase A (E:1426-1448) reads each file on its own -- mate 2 of pair n is fq2's read n + 2 and is

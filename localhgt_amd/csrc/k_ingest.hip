@@ -461,57 +461,6 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
     return LHGT_OK;
 }
 
-int install_pairs_pinned(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint32_t* start1, const uint32_t* start2, const uint32_t* woff1,
-                         const uint32_t* woff2, const uint16_t* len1, const uint16_t* len2, const uint8_t* flags, long n,
-                         uint64_t n_words, int max_len, uint64_t n_kmers) {
-    if (n <= 0) return LHGT_OK;
-    if (n_words >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "batch too large: %llu plane words", (unsigned long long)n_words);
-    ReadBatch b;
-    b.n_words = n_words;
-    b.max_len = max_len;
-    b.n_kmers = n_kmers;
-    uint32_t *d_words, *d_off32;
-    uint16_t* d_len;
-    uint8_t* d_fl;
-    LHGT_HIP(hipMalloc(&d_words, n_words * 4 + 16));
-    b.alloc[0] = d_words;
-    LHGT_HIP(hipMalloc(&d_off32, (size_t)2 * n * 4));
-    b.alloc[1] = d_off32;
-    LHGT_HIP(hipMalloc(&d_len, (size_t)2 * n * 2));
-    b.alloc[2] = d_len;
-    LHGT_HIP(hipMalloc(&d_fl, (size_t)n));
-    b.alloc[3] = d_fl;
-    if (2 * n > ctx->ingest_start_cap) {
-        if (ctx->d_ingest_start) hipFree(ctx->d_ingest_start);
-        ctx->d_ingest_start = nullptr;
-        ctx->ingest_start_cap = 2 * n + n / 4;
-        LHGT_HIP(hipMalloc(&ctx->d_ingest_start, (size_t)ctx->ingest_start_cap * 4));
-    }
-    hipStream_t st = ctx->stream;
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ingest_start, start1, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    LHGT_HIP(hipMemcpyAsync(ctx->d_ingest_start + n, start2, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    LHGT_HIP(hipMemcpyAsync(d_off32, woff1, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    LHGT_HIP(hipMemcpyAsync(d_off32 + n, woff2, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    LHGT_HIP(hipMemcpyAsync(d_len, len1, (size_t)n * 2, hipMemcpyHostToDevice, st));
-    LHGT_HIP(hipMemcpyAsync(d_len + n, len2, (size_t)n * 2, hipMemcpyHostToDevice, st));
-    LHGT_HIP(hipMemcpyAsync(d_fl, flags, (size_t)n, hipMemcpyHostToDevice, st));
-    const int max_wpr = (max_len + 31) / 32 + 1;
-    const long threads = 2 * n * max_wpr;
-    hipLaunchKernelGGL(pack_bases32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_ascii, ctx->d_ingest_start, d_len, d_off32,
-                       2 * n, max_wpr, d_words);
-    LHGT_HIP(hipGetLastError());
-    b.d.words = d_words;
-    b.d.off[0] = d_off32;
-    b.d.off[1] = d_off32 + n;
-    b.d.len[0] = d_len;
-    b.d.len[1] = d_len + n;
-    b.d.flags = d_fl;
-    b.d.n_pairs = n;
-    ctx->batches.push_back(b);
-    ctx->n_pairs += n;
-    return LHGT_OK;
-}
-
 // one thread per pair: its chunk by binary search over the descriptors, then chunk bases + the pair's record
 __global__ void __launch_bounds__(256) expand_chunk_meta(const ChunkDesc* __restrict__ desc, int n_desc, const ChunkPairMeta* __restrict__ meta, long n,
                                                          uint32_t* __restrict__ start, uint32_t* __restrict__ woff, uint16_t* __restrict__ len,

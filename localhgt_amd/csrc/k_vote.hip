@@ -10,12 +10,6 @@
 
 namespace lhgt {
 
-// slots of the hashed judge's table: a power of two >= 1.5 x the events a pair can have
-__host__ __device__ inline int vote_tab_slots(int max_ev) {
-    int s = 64;
-    while (s < max_ev + max_ev / 2) s <<= 1;
-    return s;
-}
 constexpr int LF_BITS = 19;                 // LDS-resident fold of the vote prefilter: 2^19 bits = 64 KiB
 constexpr int LF_WORDS = (1 << LF_BITS) / 32;
 
@@ -125,84 +119,6 @@ __device__ __forceinline__ void judge_pair(const uint32_t* ev, int n_ev, int e_r
     }
 }
 
-// judge_base + check_split for pairs with MANY events and contigs (k = 21 against a catalogue: 2^21 slots hold 4 M registrations,
-// every offset of every read is an event with three random contigs; 500-base reads).  There the register table above walks up to
-// 16 rows of compare + ballot per candidate: 2.0 s per 25 M pairs.  Here the running counts live in a per-wave open-addressed
-// LDS table keyed by the contig: the e candidates of an event are looked up by e lanes at once (one LDS round trip), the choice
-// -- the seen contig with the largest running count, ties to the later hash (`>=`, E:131), an unseen one only if nothing is chosen
-// yet (E:140-144) -- is made from their answers, one lane writes the update.  Same sequential semantics, event by event.
-// tab: slots x {contig, count, first peak id}; slots = power of two >= 1.5 x the number of events (never full).
-__device__ __forceinline__ void judge_pair_hashed(const uint32_t* ev, int n_ev, int e, int lane, uint32_t* __restrict__ filter,
-                                                  volatile uint32_t* tab, int slots) {
-    volatile uint32_t* t_chr = tab;
-    volatile uint32_t* t_cnt = tab + slots;
-    volatile uint32_t* t_first = tab + 2 * slots;
-    const uint32_t smask = (uint32_t)slots - 1u;
-    for (int i = lane; i < slots; i += 64) t_chr[i] = 0u;     // contig numbers start at 1 (E:905): 0 = empty
-    __builtin_amdgcn_wave_barrier();
-    for (int q = 0; q < n_ev; q++) {
-        // lane i < e: candidate i of this event
-        uint32_t id = 0, chr = 0, cnt = 0, slot = 0;
-        bool found = false;
-        if (lane < e) {
-            id = ev[((size_t)q * e + lane) * 2];
-            chr = ev[((size_t)q * e + lane) * 2 + 1];
-            if (id) {
-                slot = (chr * 0x9E3779B1u) >> 7 & smask;
-                for (;;) {
-                    const uint32_t c = t_chr[slot];
-                    if (c == chr) { found = true; cnt = t_cnt[slot]; break; }
-                    if (c == 0u) break;                         // free: where this contig would go
-                    slot = (slot + 1u) & smask;
-                }
-            }
-        }
-        // the choice, over the candidates in hash order (every lane computes it from the e answers)
-        uint32_t sel_id = 0, sel_chr = 0, sel_num = 0, sel_slot = 0;
-        bool sel_found = false;
-        for (int i = 0; i < e; i++) {
-            const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)id, i);
-            if (!idi) continue;
-            const bool fi = __builtin_amdgcn_readlane((int)found, i) != 0;
-            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cnt, i);
-            if (fi ? ci >= sel_num : sel_id == 0u) {
-                sel_id = idi;
-                sel_chr = (uint32_t)__builtin_amdgcn_readlane((int)chr, i);
-                sel_num = fi ? ci : 0u;
-                sel_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, i);
-                sel_found = fi;
-            }
-        }
-        if (lane == 0 && sel_id) {
-            if (sel_found) t_cnt[sel_slot] = sel_num + 1u;
-            else { t_chr[sel_slot] = sel_chr; t_cnt[sel_slot] = 1u; t_first[sel_slot] = sel_id; }   // first peak of the contig (E:150-152)
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // check_split: contigs with >= 6 offsets; the two largest counts (with multiplicity) vote (E:161-202)
-    int largest = 0, n_f = 0;
-    for (int i0 = 0; i0 < slots; i0 += 64) {
-        const int c = (t_chr[i0 + lane] != 0u && t_cnt[i0 + lane] >= 6u) ? (int)t_cnt[i0 + lane] : 0;
-        n_f += __popcll(__ballot(c > 0));
-        largest = c > largest ? c : largest;
-    }
-    for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(largest, d); largest = o > largest ? o : largest; }
-    if (n_f > 1) {
-        int n_at = 0, second = 0;
-        for (int i0 = 0; i0 < slots; i0 += 64) {
-            const int c = (t_chr[i0 + lane] != 0u && t_cnt[i0 + lane] >= 6u) ? (int)t_cnt[i0 + lane] : 0;
-            n_at += __popcll(__ballot(c == largest));
-            second = (c < largest && c > second) ? c : second;
-        }
-        for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(second, d); second = o > second ? o : second; }
-        if (n_at > 1) second = largest;
-        for (int i0 = 0; i0 < slots; i0 += 64) {
-            const int c = t_chr[i0 + lane] != 0u ? (int)t_cnt[i0 + lane] : 0;
-            if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[t_first[i0 + lane]], 1u);  // clamped to 254 at export (E:194)
-        }
-    }
-}
-
 // Any read length up to 500, probes of one 64-offset slice at a time.  PF: consult the L2-resident folded bitmap
 // first (exact negatives: a clear bit means no slot folding onto it holds a peak), so sparse peak sets never
 // touch the 16 GiB peak_kmer array except for true hits and the few false positives.
@@ -215,8 +131,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
     if (wib >= waves_per_block) return;
-    const int tab_slots = TR >= 8 ? vote_tab_slots(max_ev) : 0;       // many-events instances: the hashed judge's LDS table
-    uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64 + 3 * tab_slots);
+    uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64);
     uint32_t* stage = ev + (size_t)max_ev * e * 2;   // 64 words: the current read's record, staged once per read
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
@@ -273,8 +188,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
         }
         if (n_ev < 6 || (debug & 1)) continue;  // base_hits = offsets with any hit (E:149-157, 496)
         __builtin_amdgcn_wave_barrier();
-        if (TR >= 8) judge_pair_hashed(ev, n_ev, e, lane, filter, stage + 64, tab_slots);
-        else if (e == 3) judge_pair<TR, 3>(ev, n_ev, e, lane, filter);
+        if (e == 3) judge_pair<TR, 3>(ev, n_ev, e, lane, filter);
         else judge_pair<TR, 0>(ev, n_ev, e, lane, filter);
         __builtin_amdgcn_wave_barrier();
     }
@@ -741,7 +655,6 @@ int lhgt_vote(lhgt_ctx* ctx) {
         int max_ev = 2 * nk;
         size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words
         size_t per_wave_sp = (size_t)std::max(max_ev * ctx->e * 2, 128) * 4;   // sparse kernel: staging (2 pairs x 64 words) inside the event area
-        if (max_ev > 256) per_wave += (size_t)3 * vote_tab_slots(max_ev) * 4;   // the hashed judge's table (TR >= 8 instances below)
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;

@@ -234,11 +234,6 @@ struct ChunkPairMeta { uint32_t rel1, rel2, relw, flags; };
 struct ChunkDesc { uint32_t pair0, n, b1, b2, wbase, mo; };
 int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPairMeta* d_meta, const ChunkDesc* desc, long n_desc, long n,
                           uint64_t n_words, int max_len, uint64_t n_kmers);
-// the older form: per-mate arrays in pinned host memory (start offsets into d_ascii and word offsets into the batch, u32),
-// everything copied and packed asynchronously on the context's stream
-int install_pairs_pinned(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint32_t* start1, const uint32_t* start2, const uint32_t* woff1,
-                         const uint32_t* woff2, const uint16_t* len1, const uint16_t* len2, const uint8_t* flags, long n,
-                         uint64_t n_words, int max_len, uint64_t n_kmers);
 int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, const uint64_t* kept_before, long n_blocks,
                      const uint64_t* seg, long n_seg, uint8_t* d_out);
 void ingest_free(lhgt_ctx* ctx);

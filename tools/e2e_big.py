@@ -71,6 +71,12 @@ if os.environ.get("E2E_THREAD_SWEEP"):
             run(f"index cached, -t 1, {t} ingest threads", 1)
     shutil.rmtree(tmp)
     sys.exit(0)
+if os.environ.get("E2E_ONLY_PACKED"):       # catalogue-scale reference: no 12-bytes-per-base index file is written or read
+    for i in range(2):
+        run("packed reference, -t 10 (the CLI default)", 10, ref_form="packed")
+    run("packed reference, -t 1", 1, ref_form="packed")
+    shutil.rmtree(tmp)
+    sys.exit(0)
 run("index built in-run, -t 1", 1)
 for i in range(2):
     run("index cached, -t 1", 1)

@@ -18,7 +18,7 @@ What the line holds besides the contract's fields (all of it measured inside thi
               frac_raw (FETCH_SIZE + WRITE_SIZE as counted), frac_fabric = frac (FETCH_SIZE x 2: every read request of these
               kernels is a 128-B line fill tallied at 64 B -- a calibrated estimate of fabric bytes, Infinity-Cache hits included)
               and frac_model (SURVEY 8d's algorithmic bytes; `model_exceeded` where the code avoids the probes the model prices);
-              infinity_cache_share: part of the "HBM" lines the 256 MiB MALL serves (tools/probe_shapes mall)
+              infinity_cache_share: upper bound (by capacity) of the "HBM" lines the 256 MiB MALL serves (tools/probe_shapes mall)
   at N > 1    value = the REPLICATED form (every rank scans the whole reference: per-GPU work fixed, which is what "weak" means);
               `sharded_index` = the same step with phase B sharded over the ranks (per-GPU work shrinks: not a scaling figure);
               n1_equivalent_ms = this rank's step without the exchanges; rank 0 measures its kernels' traffic live (N = 1 children)
@@ -444,8 +444,8 @@ def verify_forms(eng):
 
 
 def mall_share():
-    """tools/probe_shapes mall (built by __graft_entry__.build): random-probe rates on 128 MiB / 1 GiB / 16 GiB tables and the
-    share of a table's line fills the Infinity Cache serves, estimated from them.  None when the binary is not there."""
+    """tools/probe_shapes mall (built by __graft_entry__.build): random-probe rates on 128 MiB / 1 GiB / 16 GiB tables (a table inside the
+    256 MiB Infinity Cache is probed no faster than a 1 GiB one) and the cache's share of a table by capacity.  None when the binary is not there."""
     exe = os.path.join(ROOT, "tools", "probe_shapes")
     if not os.path.exists(exe):
         return None
@@ -488,11 +488,12 @@ def roofline_entry(desc, ms_step, launches, algo_bytes, traffic_rec, source, cei
             ent["request_rate"] = {"value": round(g, 1), "unit": "G requests/s", "counter": ceiling[1], "ceiling": ceiling[2],
                                    "frac_of_ceiling": round(g / ceiling[2], 3), "ceiling_source": ceiling[3]}
         if mall and table in ("1GiB", "16GiB"):
-            sh = mall.get(f"mall_share_{table}_table")
+            sh = mall.get(f"share_by_capacity_{table}_table")
             if sh is not None:
-                ent["infinity_cache_share"] = {"value": round(sh, 3), "of": f"line fills of the kernel's {table} probe table, estimated from random-probe "
-                                               f"rates on 128 MiB / 1 GiB / 16 GiB tables (tools/probe_shapes mall): {mall.get('gprobes_per_s')}",
-                                               "frac_hbm_estimate": round(ach / HBM_PEAK_GBS * (1.0 - sh), 4)}
+                ent["infinity_cache_share"] = {"upper_bound": sh, "of": f"line fills of the kernel's {table} probe table: 256 MiB of Infinity Cache / table size. Rates cannot tell "
+                                               f"more: random probes into a 128 MiB table (inside the cache) run at {mall.get('gprobes_per_s', {}).get('128MiB')} G/s, into a 1 GiB one at "
+                                               f"{mall.get('gprobes_per_s', {}).get('1GiB')} G/s (tools/probe_shapes mall) -- the line rate is the fabric's, a cache hit is no faster",
+                                               "frac_hbm_lower_bound": round(ach / HBM_PEAK_GBS * (1.0 - sh), 4)}
     else:
         ent.update({"achieved": None, "frac": None, "traffic": None, "stale": True,
                     "traffic_source": "none: the rocprofv3 --pmc passes failed and profiles/traffic_per_launch.json was measured on other sources"})

@@ -51,8 +51,8 @@ int main() {
     clear(); for (int i = 0; i < 256; i++) m[i >> 5] |= 1u << (i & 31); run("all 256", m);
     clear(); for (int i = 0; i < 32; i++) m[i >> 5] |= 1u << (i & 31); run("bits 0..31", m);
     clear(); for (int i = 0; i < 128; i++) m[i >> 5] |= 1u << (i & 31); run("bits 0..127", m);
-    clear(); for (int i = 0; i < 256; i += 8) m[i >> 5] |= 1u << (i & 31); run("bits i % 8 == 0", m);
-    clear(); for (int i = 0; i < 256; i += 2) m[i >> 5] |= 1u << (i & 31); run("even bits", m);
+    // (masks that leave an XCD without a CU -- bits with i % 8 == 0 only, the even bits -- were tried once: the runtime ignores them
+    //  and runs on all 256 CUs; a later process on the same box then died with a GPU hang, so they are not tried again)
     clear(); for (int i = 0; i < 256; i++) if ((i / 8) % 2 == 0) m[i >> 5] |= 1u << (i & 31); run("(i / 8) even", m);
     clear(); for (int i = 0; i < 256; i++) if ((i / 8) < 16) m[i >> 5] |= 1u << (i & 31); run("(i / 8) < 16  (= 0..127)", m);
     clear(); for (int i = 0; i < 256; i++) if ((i % 32) < 16) m[i >> 5] |= 1u << (i & 31); run("(i % 32) < 16", m);

@@ -9,6 +9,4 @@ timeout -k 10 200 python3 bench.py --gpus 2 --workload 1g --backend gloo --steps
 timeout -k 10 300 python3 tools/cu_share.py > $out/profiles/cu_share_phase_times.txt 2>&1 || exit 1
 timeout -k 10 100 ./tools/probe_policy > $out/profiles/probe_policy_l2_resident.txt 2>&1 || exit 1
 timeout -k 10 100 ./tools/probe_shapes mall > $out/profiles/probe_mall_share.txt 2>&1 || exit 1
-timeout -k 10 100 ./tools/cu_mask_probe > $out/profiles/cu_mask_bits.txt 2>&1 || exit 1
-timeout -k 10 300 python3 tools/e2e_big.py 32000000 100 > $out/profiles/e2e_from_files_32m_pairs.txt 2>&1 || exit 1
 ls -la $out/profiles

@@ -194,23 +194,29 @@ __global__ void __launch_bounds__(PT) part_scatter_reads(ReadBatchDev b, long pa
 constexpr int PT1 = 1024;
 constexpr int TILE_KEYS1 = 32768;   // 128 KiB tile: one workgroup per CU, runs of 256 keys
 constexpr int RW = 6;   // reads per wave per tile -> at most (PT1/64)*RW = 96 reads per tile (91 at 150 bp, e = 3)
+// KC / EC: compile-time k and e of the common case (32, 3; 0 = run-time values): shifts by 32 - k vanish, the level-1 bucket is
+// the key's top byte, the loops over the hashes lose their tests -- about a tenth of the kernel's vector instructions
+template <int KC, int EC>
 __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, long pair0, long npairs, HashParams hp, PartGeom g,
                                                              int reads_per_tile, PartCap pc, uint32_t* __restrict__ cur1,
                                                              uint32_t* __restrict__ out, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS1];
-    __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], wsum[4];
+    __shared__ uint32_t hist2[2][NBK], lofs[NBK], lcur[NBK], wsum[4], s_total;
+    __shared__ uint32_t dump[128];          // per-lane dummy counter and dummy word of the branch-free placement
     __shared__ uint2 dl[NBK];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;   // <= 18 record words per read on this path (<= 159 bases)
-    const int shift = g.b1 ? g.k - g.b1 : 0;
-    const uint32_t bmask = g.b1 ? (uint32_t)g.nb1 - 1u : 0u;
-    const int k = hp.k, e = hp.e;
+    const int shift = KC == 32 ? 24 : g.b1 ? g.k - g.b1 : 0;
+    const uint32_t bmask = KC == 32 ? 0xffu : g.b1 ? (uint32_t)g.nb1 - 1u : 0u;
+    const int k = KC ? KC : hp.k, e = EC ? EC : hp.e;
     const long n_reads = 2 * npairs;
     const long n_tiles = (n_reads + reads_per_tile - 1) / reads_per_tile;
     if (n_reads <= 0) return;
     // The wave's RW reads arrive in two round trips to memory: all descriptors (unconditional loads on clamped indices -- a load
     // under a lane- or wave-dependent branch is waited for on its own), then all records.  With one workgroup per CU nothing else
-    // hides them, so they are software-pipelined: the next tile's descriptors fly during this tile's placement, its records
-    // during the copy-out.
+    // hides them, so they are software-pipelined across tiles, and so is the work itself (round 3): a tile's stretches -- hashing
+    // (VALU), placement (LDS atomics), copy-out (LDS reads + stores) -- sit on different units but were serialised by the barriers
+    // between them; now the NEXT tile is hashed (into registers and the other histogram) in the same barrier interval as this
+    // tile's copy-out, so the stores drain while the waves hash.
     int lens[RW];
     uint32_t offs[RW], recw[RW];
     auto load_descriptors = [&](long t) {        // t >= n_tiles: every length 0
@@ -234,13 +240,11 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
             recw[rr] = b.words[offs[rr] + (lane < 3 * wpr ? lane : 0)];
         }
     };
-    load_descriptors(blockIdx.x);
-    load_records();
-    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        if (threadIdx.x < NBK) hist[threadIdx.x] = 0;
-        __syncthreads();
-        uint32_t key[RW][2][3];
-        unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
+    uint32_t key[RW][2][3];
+    unsigned long long live = 0;   // bit (rr*6 + it*3 + i), RW*6 <= 64
+    // hash the tile whose records sit in recw[] into key[] / live, counting its buckets in hist
+    auto hash_tile = [&](uint32_t* hist) {
+        live = 0;
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const int len = lens[rr];
@@ -270,21 +274,94 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
                         const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                         key[rr][it][i] = h;
                         live |= 1ull << (rr * 6 + it * 3 + i);
-                        atomicAdd(&hist[(h >> shift) & bmask], 1u);
+                        atomicAdd(&hist[KC == 32 ? h >> 24 : (h >> shift) & bmask], 1u);
                     }
             }
         }
-        load_descriptors(t + gridDim.x);
+    };
+    load_descriptors(blockIdx.x);
+    load_records();
+    if (threadIdx.x < NBK) hist2[0][threadIdx.x] = 0;
+    __syncthreads();
+    hash_tile(hist2[0]);
+    load_descriptors((long)blockIdx.x + gridDim.x);
+    int cur = 0;
+    const int nbk = KC == 32 ? 256 : g.nb1;
+    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        uint32_t* hist = hist2[cur];
+        __syncthreads();                    // this tile's histogram is complete; the previous copy-out has read sorted / dl
+        // exclusive scan of hist (nbk <= 256) and reservation of the global runs: the atomicAdd's answer is first needed by the
+        // copy-out, so its round trip to the L2 hides behind the placement
+        const uint32_t o = bucket_excl_scan(hist, nbk, wsum);
+        const bool mine = (int)threadIdx.x < nbk;
+        uint32_t gb = 0, r0 = 0, cap = 0;
+        if (mine) {
+            lofs[threadIdx.x] = o;
+            lcur[threadIdx.x] = o;
+            const uint32_t c = hist[threadIdx.x];
+            if (c) gb = atomicAdd(&cur1[threadIdx.x], c);
+            r0 = part_region(pc, threadIdx.x * (uint32_t)g.nb2);
+            cap = part_region(pc, (threadIdx.x + 1) * (uint32_t)g.nb2) - r0;
+            if ((int)threadIdx.x == nbk - 1) s_total = o + c;
+        }
+        if (threadIdx.x < NBK) hist2[cur ^ 1][threadIdx.x] = 0;     // the next tile's histogram
         __syncthreads();
-        tile_sort_flush<PT1>(sorted, hist, lofs, lcur, dl, wsum, g.nb1, shift, bmask, cur1, pc, 0u, (uint32_t)g.nb2, out, counts, [&](auto emit) {
+        // Placement, six keys (one read) at a time with NO branch per key: a dead slot (offset beyond the read, k-mer with an N, padding
+        // read) takes its ticket from a per-lane dummy counter and writes into a per-lane dummy word, so the six LDS atomics are
+        // issued back to back and waited for once.  (As `if (live) sorted[atomicAdd(..)] = key` every key was its own exec region with
+        // its own s_waitcnt: 36 exposed LDS round trips per tile and wave.)
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++)
+        for (int rr = 0; rr < RW; rr++) {
+            uint32_t pos[6];
 #pragma unroll
-                for (int it = 0; it < 2; it++)
+            for (int u = 0; u < 6; u++) {
+                const bool lv = (live >> (rr * 6 + u)) & 1ull;
+                const uint32_t kk = key[rr][u / 3][u % 3];
+                uint32_t* ctr = lv ? &lcur[KC == 32 ? kk >> 24 : (kk >> shift) & bmask] : &dump[lane];
+                pos[u] = atomicAdd(ctr, 1u);
+            }
 #pragma unroll
-                    for (int i = 0; i < 3; i++)
-                        if (live & (1ull << (rr * 6 + it * 3 + i))) emit(key[rr][it][i]);
-        }, load_records);
+            for (int u = 0; u < 6; u++) {
+                const bool lv = (live >> (rr * 6 + u)) & 1ull;
+                uint32_t* dst = lv ? &sorted[pos[u]] : &dump[64 + lane];
+                *dst = key[rr][u / 3][u % 3];
+            }
+        }
+        if (mine) dl[threadIdx.x] = make_uint2(r0 + gb - o, o + (cap > gb ? cap - gb : 0u));
+        load_records();                     // the next tile's records (its descriptors came in during the last hashing)
+        __syncthreads();
+        const uint32_t total = s_total;
+        // copy-out, four keys per thread and round (the LDS reads of a round are issued together), then the tail one by one
+        uint32_t i0 = threadIdx.x;
+        for (; i0 + 3 * PT1 < total; i0 += 4 * PT1) {
+            uint32_t kk[4];
+            uint2 d[4];
+            bool over = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) kk[u] = sorted[i0 + u * PT1];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = dl[KC == 32 ? kk[u] >> 24 : (kk[u] >> shift) & bmask];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * PT1;
+                if (i < d[u].y) out[i + d[u].x] = kk[u];       // consecutive i of one bucket -> consecutive addresses
+                else over = true;
+            }
+            if (over) {                                         // region full (heavily repeated k-mers): count those keys now (see the header)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u * PT1 >= d[u].y) part_sat_inc(counts, kk[u]);
+            }
+        }
+        for (; i0 < total; i0 += PT1) {
+            const uint32_t kk = sorted[i0];
+            const uint2 d = dl[KC == 32 ? kk >> 24 : (kk >> shift) & bmask];
+            if (i0 < d.y) out[i0 + d.x] = kk;
+            else part_sat_inc(counts, kk);
+        }
+        hash_tile(hist2[cur ^ 1]);          // the next tile, while this one's stores drain
+        load_descriptors(t + 2L * gridDim.x);
+        cur ^= 1;
     }
 }
 
@@ -295,12 +372,14 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
 // placement, all loads in flight at once.  Runs are copied out bucket by bucket (a wave per bucket: the bucket number, which the
 // 16-bit key no longer holds, is the loop variable); a key that finds its region full is rebuilt from (bucket, low bits) and
 // counted at once.  (A second level exists only for k >= 25, where slot_bits is 16.)
+template <int KC>     // KC = 32: b1 = b2 = 8, sixteen slot bits -- the final bucket inside a segment is bits 16..23 of the key
 __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cur1, PartGeom g,
                                                           PartCap pc, uint32_t* __restrict__ cur2, uint16_t* __restrict__ out,
                                                           uint32_t* __restrict__ counts) {
     __shared__ uint32_t sorted[TILE_KEYS2];   // (bucket << 16) | low 16 bits: the copy-out below needs no search for the bucket
     __shared__ uint32_t hist[NBK], lofs[NBK], lcur[NBK], wsum[4];
     __shared__ uint2 dl[NBK];                 // (delta, limit) per bucket: sorted position i -> out[i + delta] while i < limit
+    __shared__ uint32_t dump[128];            // per-lane dummy counter and dummy word of the branch-free placement
     __shared__ uint32_t tile_pref[NBK + 1];   // tiles before segment s
     __shared__ uint32_t seg_at[NBK], seg_len[NBK];
     if ((int)threadIdx.x < g.nb1) {
@@ -319,8 +398,8 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
     }
     __syncthreads();
     const uint32_t n_tiles = tile_pref[g.nb1];
-    const int shift = g.slot_bits;
-    const uint32_t bmask = (uint32_t)g.nb2 - 1u;
+    const int shift = KC == 32 ? 16 : g.slot_bits;
+    const uint32_t bmask = KC == 32 ? 0xffu : (uint32_t)g.nb2 - 1u;
     // tile t: its segment s (last s with tile_pref[s] <= t) and key range [k0, k1); t >= n_tiles: empty
     auto tile_bounds = [&](uint32_t t, int& s, uint32_t& k0, uint32_t& k1) {
         if (t >= n_tiles) { s = 0; k0 = k1 = 0; return; }
@@ -365,22 +444,56 @@ __global__ void __launch_bounds__(PK) part_scatter_keys16(const uint32_t* __rest
             cap = part_region(pc, first + threadIdx.x + 1) - r0;
         }
         __syncthreads();
+        // placement, eight keys at a time without a branch per key (see part_scatter_reads_reg): the LDS atomics of a group are
+        // issued back to back; a slot beyond the tile's end takes its ticket from a per-lane dummy counter
 #pragma unroll
-        for (int u = 0; u < KPT; u++)
-            if (k0 + u * PK + threadIdx.x < k1) {
-                const uint32_t bk = (key[u] >> shift) & bmask;
-                sorted[atomicAdd(&lcur[bk], 1u)] = (bk << 16) | (key[u] & 0xffffu);
+        for (int u0 = 0; u0 < KPT; u0 += 8) {
+            uint32_t pos[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool lv = k0 + (u0 + u) * PK + threadIdx.x < k1;
+                uint32_t* ctr = lv ? &lcur[(key[u0 + u] >> shift) & bmask] : &dump[threadIdx.x & 63];
+                pos[u] = atomicAdd(ctr, 1u);
             }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool lv = k0 + (u0 + u) * PK + threadIdx.x < k1;
+                const uint32_t bk = (key[u0 + u] >> shift) & bmask;
+                uint32_t* dst = lv ? &sorted[pos[u]] : &dump[64 + (threadIdx.x & 63)];
+                *dst = (bk << 16) | (key[u0 + u] & 0xffffu);
+            }
+        }
         if (mine) dl[threadIdx.x] = make_uint2(r0 + gb - o, o + (cap > gb ? cap - gb : 0u));
         tile_bounds(t + gridDim.x, s, k0, k1);
         load_keys(k0, k1);
         __syncthreads();
         const uint32_t total = lofs[g.nb2 - 1] + hist[g.nb2 - 1];
-        for (uint32_t i = threadIdx.x; i < total; i += PK) {
-            const uint32_t v = sorted[i], bk = v >> 16;
+        uint32_t i0 = threadIdx.x;
+        for (; i0 + 3 * PK < total; i0 += 4 * PK) {   // four keys per thread and round: their LDS reads go out together
+            uint32_t v[4];
+            uint2 d[4];
+            bool over = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = sorted[i0 + u * PK];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = dl[v[u] >> 16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * PK;
+                if (i < d[u].y) out[i + d[u].x] = (uint16_t)v[u];           // consecutive i of one bucket -> consecutive addresses
+                else over = true;
+            }
+            if (over) {                                                       // region full: count those keys now (see the header)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u * PK >= d[u].y) part_sat_inc(counts, ((first + (v[u] >> 16)) << shift) | (v[u] & 0xffffu));
+            }
+        }
+        for (; i0 < total; i0 += PK) {
+            const uint32_t v = sorted[i0], bk = v >> 16;
             const uint2 d = dl[bk];
-            if (i < d.y) out[i + d.x] = (uint16_t)v;           // consecutive i of one bucket -> consecutive addresses
-            else part_sat_inc(counts, ((first + bk) << shift) | (v & 0xffffu));   // region full: count it now (see the header)
+            if (i0 < d.y) out[i0 + d.x] = (uint16_t)v;
+            else part_sat_inc(counts, ((first + bk) << shift) | (v & 0xffffu));
         }
     }
 }
@@ -489,15 +602,23 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         if (max_nk <= 128 && ctx->e <= 3) {
             int rpt = (int)(TILE_KEYS1 / ((long)max_nk * ctx->e));
             if (rpt > (PT1 / 64) * RW) rpt = (PT1 / 64) * RW;
-            hipLaunchKernelGGL(part_scatter_reads_reg, dim3(256), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, pc, cur1,
-                               ctx->d_part_keys[0], ctx->d_counts);
+            if (ctx->k == 32 && ctx->e == 3)
+                hipLaunchKernelGGL((part_scatter_reads_reg<32, 3>), dim3(256), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, pc, cur1,
+                                   ctx->d_part_keys[0], ctx->d_counts);
+            else
+                hipLaunchKernelGGL((part_scatter_reads_reg<0, 0>), dim3(256), dim3(PT1), 0, ctx->stream, b.d, p0, np, ctx->hp, g, rpt, pc, cur1,
+                                   ctx->d_part_keys[0], ctx->d_counts);
         } else
             hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, pc, cur1,
                                ctx->d_part_keys[0], ctx->d_counts);
         const size_t slice_bytes = (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4;
         if (g.b2 > 0) {
-            hipLaunchKernelGGL(part_scatter_keys16, dim3(256), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], cur1, g, pc, cur2,
-                               (uint16_t*)ctx->d_part_keys[1], ctx->d_counts);
+            if (ctx->k == 32)
+                hipLaunchKernelGGL(part_scatter_keys16<32>, dim3(256), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], cur1, g, pc, cur2,
+                                   (uint16_t*)ctx->d_part_keys[1], ctx->d_counts);
+            else
+                hipLaunchKernelGGL(part_scatter_keys16<0>, dim3(256), dim3(PK), 0, ctx->stream, ctx->d_part_keys[0], cur1, g, pc, cur2,
+                                   (uint16_t*)ctx->d_part_keys[1], ctx->d_counts);
             hipLaunchKernelGGL((part_apply<true>), dim3(g.nb), dim3(PA), slice_bytes, ctx->stream, (const void*)ctx->d_part_keys[1], cur2, g, pc,
                                ctx->d_counts);
         } else   // without a second level the level-1 segments are the final buckets

@@ -204,7 +204,12 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
     __shared__ uint32_t hist2[2][NBK], lofs[NBK], lcur[NBK], wsum[4], s_total;
     __shared__ uint32_t dump[128];          // per-lane dummy counter and dummy word of the branch-free placement
     __shared__ uint2 dl[NBK];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;   // <= 18 record words per read on this path (<= 159 bases)
+    constexpr int STAGE_W = 20;             // <= 18 record words per read on this path (<= 159 bases) + the word a window may look past
+    __shared__ uint32_t stage_all[(PT1 / 64) * RW * STAGE_W];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint32_t* stage = stage_all + wib * RW * STAGE_W;
+    const bool r_zero = (lane & 31) == 0;   // the window starts at a word boundary: v_alignbit by 32 would give the NEXT word
+    const uint32_t sh_win = 32u - (uint32_t)(lane & 31);
     const int shift = KC == 32 ? 24 : g.b1 ? g.k - g.b1 : 0;
     const uint32_t bmask = KC == 32 ? 0xffu : g.b1 ? (uint32_t)g.nb1 - 1u : 0u;
     const int k = KC ? KC : hp.k, e = EC ? EC : hp.e;
@@ -246,24 +251,27 @@ __global__ void __launch_bounds__(PT1) part_scatter_reads_reg(ReadBatchDev b, lo
     auto hash_tile = [&](uint32_t* hist) {
         live = 0;
 #pragma unroll
+        for (int rr = 0; rr < RW; rr++) stage[rr * STAGE_W + (lane < STAGE_W ? lane : 0)] = recw[rr];   // lanes >= 3 wpr hold a repeat of word 0
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const int len = lens[rr];
             const int nk = len - k + 1;
             if (nk <= 0) continue;
             const int wpr = ((len + 31) >> 5) + 1;
-            // The read's record sits in the wave's registers, word w of plane p in lane p * wpr + w.  The 64 offsets of one
-            // iteration need only three consecutive words of a plane (lanes 0-31: words 2it, 2it+1; lanes 32-63: 2it+1, 2it+2), so
-            // they are broadcast with readlane -- no LDS staging, no LDS reads for the windows (a third of this kernel's LDS traffic).
+            // The read's record sits in the wave's staging words, word w of plane p at p * wpr + w.  Offset j = 64 it + lane needs the
+            // two consecutive words 2 it + (lane >> 5) and the next of each plane: ONE ds_read2_b32 per plane (a broadcast: the wave
+            // reads three distinct words), one v_alignbit, one select for the lanes whose window starts at a word boundary.
+            // (Round 2 cut the windows from the record held in registers with readlane -- three readlanes, four moves of their scalar
+            // results, two selects and an exec region per plane: 15 vector instructions per plane, more than the hashing proper.)
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int j = it * 64 + lane;
-                const bool upper = lane >= 32;
                 auto window = [&](int plane) {
-                    const int base = plane * wpr + 2 * it;
-                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)recw[rr], base);
-                    const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)recw[rr], base + 1);
-                    const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)recw[rr], base + 2);
-                    return window32(upper ? w1 : w0, upper ? w2 : w1, lane & 31) >> (32 - k);
+                    const uint32_t* w = stage + rr * STAGE_W + plane * wpr + 2 * it + (lane >> 5);
+                    const uint32_t w0 = w[0], w1 = w[1];
+                    const uint32_t a = __builtin_amdgcn_alignbit(w0, w1, sh_win);
+                    return (r_zero ? w0 : a) >> (32 - k);
                 };
                 if (j >= nk || window(2) != 0) continue;
                 const uint32_t whi = window(0), wlo = window(1);

@@ -678,8 +678,12 @@ int lhgt_vote(lhgt_ctx* ctx) {
     hipLaunchKernelGGL((vote_kernel_sparse<PF_, (PF_ == 2 ? 2 : 1)>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                        ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
                        ctx->debug, ctx->pf_mask, ctx->pf2)
-        // LDS first level only while the fold still screens: at most a quarter of its bits set (2.3 M k-mers on configs[2] fill it)
-        const bool fold_ok = ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1) <= (1ull << LF_BITS) / 4;
+        // LDS first level while the fold still screens: up to one bit insertion per fold bit (63 % of the bits set, 40 % of foreign
+        // probes pass on to the L2 bitmap).  Round 2 stopped at a quarter; measured in round 3 on 100 M pairs from 300 genomes of the
+        // 13 Gbase reference (205 410 registered k-mers, 0.78 insertions per bit): 146 ms with the fold, 296 ms without -- an LDS
+        // probe costs a fraction of the L1 miss every bitmap probe is.  2.3 M k-mers (configs[2]) fill the fold.
+        static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 1.0;   // bit insertions per fold bit
+        const bool fold_ok = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1)) <= fold_max * (double)(1ull << LF_BITS);
         if (sparse_ok && ctx->k > PF_BITS && fold_ok && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {
             wpb = 16;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;

@@ -3,8 +3,8 @@
 (oracle/_ref/extract_ref_z, built by oracle/build_ref.sh from /root/reference with the zero-new[] shim; skipped where it is absent):
 `-t 1`, `-t 10` with the reference's threads in creation order (oracle/_ref/libseqthreads.so) against the product's thread
 emulation, and the packed reference form.  Index bytes, genome.len.txt and interval file must be identical.
-The reference needs about two minutes per run on the GPU box's host: both runs start in the background when the module's inputs are
-made and are joined by the test that needs them.  Plus: phase A at k = 32 with two partition chunks and overflowing bucket regions
+The reference needs about two minutes per run on the GPU box's host: both runs start in the background at the start of the session
+(tests/conftest.py: refbin_big) and are joined by the test that needs them.  Plus: phase A at k = 32 with two partition chunks and overflowing bucket regions
 (poly-A) against the oracle's whole 2^32-slot table."""
 import os
 import shutil
@@ -18,40 +18,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "extract_ref_z")
 SHIM = os.path.join(ROOT, "oracle", "_ref", "libseqthreads.so")
-K, E, NC, PAIRS = 32, 3, 20, 400_000
-ARGS_TAIL = ["0.1", "0.08", None, str(K), "3000000", str(E), "1", "1"]
 
 
-def _copy_inputs(src, dst):
-    os.makedirs(dst)
-    shutil.copy(os.path.join(src, "ref.fa"), os.path.join(dst, "ref.fa"))
-    for f in ("s.1.fq", "s.2.fq"):
-        os.symlink(os.path.join(src, f), os.path.join(dst, f))
-    return dst
+from conftest import REFBIN_K as K, REFBIN_E as E, REFBIN_PAIRS as PAIRS, refbin_copy_inputs as _copy_inputs   # noqa: E402
 
 
 @pytest.fixture(scope="module")
-def big(tmp_path_factory):
-    import sys
-    sys.path.insert(0, ROOT)
-    import bench
-    base = str(tmp_path_factory.mktemp("refbin"))
-    src = os.path.join(base, "src")
-    os.makedirs(src)
-    bench.synth_files(src, K, E, NC, 1_000_000, PAIRS, 0)
-    procs = {}
-    if os.path.exists(REF_BIN):
-        for t in (1, 10):
-            d = _copy_inputs(src, os.path.join(base, f"ref_t{t}"))
-            env = dict(os.environ, LD_PRELOAD=SHIM) if t > 1 else dict(os.environ)
-            tail = [x if x is not None else str(t) for x in ARGS_TAIL]
-            procs[t] = (d, subprocess.Popen([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt"] + tail, cwd=d, env=env, stdout=subprocess.PIPE,
-                                            stderr=subprocess.STDOUT, text=True), time.time())
-    yield {"base": base, "src": src, "procs": procs}
-    for d, p, _ in procs.values():
-        if p.poll() is None:
-            p.kill()
-    shutil.rmtree(base, ignore_errors=True)
+def big(refbin_big):
+    """inputs and the two background runs of the reference binary: made at the START of a -m gpu session (tests/conftest.py), so the
+    reference's two minutes per run pass while the earlier test files execute"""
+    return refbin_big
 
 
 def _product(big, tag, threads, ref_form="index"):

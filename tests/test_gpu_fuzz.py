@@ -90,6 +90,16 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     g, c = tmp_path / "gpu", tmp_path / "cpu"
     g.mkdir()
     k, e, seed, sample, hit, match, max_peak = _make_case(idx, str(g))
+    # every seventh case with "\r\n" line ends in all three files (std::getline keeps the '\r': one more non-base character per
+    # line, E:761-880 and E:1014), every eleventh with empty lines between the contigs of the FASTA -- checked on the CPU against
+    # the reference binary itself for the restatement (same files for -t 1 and -t 3) before they went in here
+    for f in ("ref.fa", "s.1.fq", "s.2.fq"):
+        body = open(g / f, "rb").read()
+        if idx % 7 == 6:
+            body = body.replace(b"\n", b"\r\n")
+        elif idx % 11 == 10 and f == "ref.fa":
+            body = body.replace(b"\n>", b"\n\n>")
+        open(g / f, "wb").write(body)
     shutil.copytree(g, c, dirs_exist_ok=True)
     # every fifth case as `-t N` (N = 2 .. 10): the product emulates the reference's thread chunks by default and is compared with
     # the oracle's -t N restatement -- or, where the emulation refuses the input and falls back, with its -t 1 run
@@ -117,6 +127,9 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
             rc, orep = oracle.run(*o, 1, k, max_peak, e, seed, sample)
         if rc == -5:                          # oracle: too many peaks
             assert gpu_rc == 6
+            return
+        if rc in (-4, -6) and idx % 7 == 6:   # a 500-character line plus its '\r' overruns the reference's buffers (E:1004): both refuse
+            assert gpu_rc != 0
             return
         assert rc == 0 and gpu_rc == 0, (rc, gpu_rc, k, e, sample)
     for name in ("i.txt", "ref.fa.genome.len.txt") + (() if packed else (f"ref.fa.k{k}.h{e}.index.dat",)):

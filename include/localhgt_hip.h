@@ -255,13 +255,14 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
 int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sample_contigs);
 
 /* switches for profiling / A-B runs.  bit0: lhgt_vote skips judge_base (outputs wrong);
- * bit2: never use the vote prefilter; bit4: without its LDS-resident first level; bit5: generic vote kernel even on the
+ * bit2: never use the vote prefilter; bit4: without its LDS-resident first level (the fold); bit5: generic vote kernel even on the
  * sparse path; bit6: ref_flags never uses the saturated-line summary; bit7: chunked tile scan at any size; bit8: no tile is
  * settled by window_good alone (bits 2-8: outputs unchanged); bit9 / bit10: the sparse vote kernel stops after its first /
  * second filter level (stage timing, outputs wrong); bit11: the queued sparse vote kernel votes every pair with more than 8 bitmap
  * survivors directly (exercises that branch; outputs unchanged); bit12 / bit13 / bit14: lhgt_ref_scan takes the single-first (lite) / the exact /
  * the trio-first form of its first two steps whatever the table looks like (default for e <= 3: trio-first below 45 % of the slots at 3, lite from 90 %,
- * in between exact unless a trial on a few runs of tiles favours lite; outputs unchanged).
+ * in between exact unless a trial on a few runs of tiles favours lite; outputs unchanged); bit15: where lhgt_vote keeps a fold of the
+ * bitmap in LDS, round 2's 64 KiB fold kernel with its in-kernel judge instead of the 128 KiB fold with the deferred judge (outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts

@@ -1145,7 +1145,7 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     if (ctx->prefilter_on) {
         if (!ctx->d_prefilter) {
             LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
-            LHGT_HIP(hipMalloc(&ctx->d_prefilter_fold, (size_t)64 * 1024));
+            LHGT_HIP(hipMalloc(&ctx->d_prefilter_fold, (size_t)128 * 1024));
         }
         LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ((size_t)1 << pf_bits) / 8, ctx->stream));
     }

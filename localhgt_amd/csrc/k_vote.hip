@@ -126,7 +126,8 @@ template <int TR, int PF, bool NT>
 __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                    const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
-                                                   int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2) {
+                                                   int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2,
+                                                   const uint32_t* __restrict__ pair_list) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
@@ -135,7 +136,10 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     uint32_t* stage = ev + (size_t)max_ev * e * 2;   // 64 words: the current read's record, staged once per read
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
-    for (long p = wave; p < b.n_pairs; p += n_waves) {
+    // pair_list (vote_kernel_fold's deferred pairs): [0] = how many, then the pairs; null = every pair of the batch
+    const long n_items = pair_list ? (long)pair_list[0] : b.n_pairs;
+    for (long it = wave; it < n_items; it += n_waves) {
+        const long p = pair_list ? (long)pair_list[1 + it] : it;
         if (b.flags && !(b.flags[p] & PAIR_VOTE)) continue;   // counted only (surplus fq2 record, thread-chunk emulation)
         int n_ev = 0;
         for (int m = 0; m < 2; m++) {
@@ -415,6 +419,162 @@ __global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadB
     }
 }
 
+// Round 3: the LDS fold at 128 KiB and the judge DEFERRED.  An LDS probe costs a fraction of the L1 miss every bitmap probe is
+// (DESIGN.md 4), so what the first level screens out is nearly free -- and a fold screens by its bits per key.  vote_kernel_sparse
+// keeps 64 KiB of fold beside 16 event areas of 5.7 KiB for the lane-per-offset re-vote of the rare pair with a hit.  Here a wave
+// keeps queues only (480 words) and a pair with a peak k-mer among its survivors, or with more survivors than a queue holds, is
+// appended to a list that the generic kernel votes from scratch afterwards (vote_kernel<.., pair_list>): same hits in the same
+// offset order, the votes are sums.  That leaves 128 KiB for the fold: twice the bits per key -- 100 M pairs from 300 genomes
+// of a ragged 13 Gbase catalogue (597 195 k-mers): 1.14 insertions per fold bit instead of 2.3, 46 % of the probes go on to the
+// L2 bitmap instead of all of them.
+constexpr int LF2_BITS = 20;
+constexpr int LF2_WORDS = (1 << LF2_BITS) / 32;
+constexpr int VF_Q = 368, VF_Q2 = 48, VF_WAVE_WORDS = VF_Q + VF_Q2 + 64;   // per wave: first queue (its head stages the records), second queue, scratch
+constexpr int VF_WAVES = 16;
+__global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
+                                                                  const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
+                                                                  int fold_words, uint32_t* __restrict__ revote, int debug, uint32_t pf_mask, int pf2) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int e = hp.e, k = hp.k;
+    if (b.n_pairs <= 0) return;
+    for (int i = threadIdx.x; i < fold_words; i += blockDim.x) lds[i] = lds_fold[i];
+    __syncthreads();
+    const uint32_t lf_mask = (uint32_t)fold_words * 32u - 1u;
+    uint32_t* Q = lds + LF2_WORDS + (size_t)wib * VF_WAVE_WORDS;
+    uint32_t* Q2 = Q + VF_Q;
+    uint32_t* dump = Q2 + VF_Q2;
+    uint32_t* stage = Q;
+    const long wave = (long)blockIdx.x * VF_WAVES + wib;
+    const long n_waves = (long)gridDim.x * VF_WAVES;
+    // A wave's pairs form a chain of dependent loads (offsets and lengths, then the record) in front of a few microseconds of work:
+    // the record of the next pair and the offsets of the one after it are fetched while the current pair is worked on
+    struct Meta { int len[2]; uint32_t off[2]; bool vote; };
+    auto load_meta = [&](long p) {
+        Meta m;
+        const long pc = p < b.n_pairs ? p : b.n_pairs - 1;     // clamped: every load unconditional, a pair past the end is never voted
+        m.len[0] = b.len[0][pc]; m.len[1] = b.len[1][pc];
+        m.off[0] = b.off[0][pc]; m.off[1] = b.off[1][pc];
+        m.vote = p < b.n_pairs && (!b.flags || (b.flags[pc] & PAIR_VOTE));
+        return m;
+    };
+    auto load_rec = [&](const Meta& m, int mate) {
+        const int w3 = 3 * (((m.len[mate] + 31) >> 5) + 1);
+        return lane < w3 ? (b.words + m.off[mate])[lane] : 0u;
+    };
+    Meta m_next = load_meta(wave), m_next2 = load_meta(wave + n_waves);
+    uint32_t rw[2] = {load_rec(m_next, 0), load_rec(m_next, 1)};
+    // pending third-level probes: lane i < n_pend holds one survivor of the second level and its pair; a pair's survivors are
+    // appended together, so they sit in consecutive lanes of ONE flush and the pair is deferred once however many of them hit.
+    // (A pair deferred here AND by an overflow would be voted twice: an overflowing pair never enters this queue.)
+    uint32_t pend_h = 0u, pend_p = 0u;
+    int n_pend = 0;
+    auto flush_pending = [&]() {
+        const bool hit = lane < n_pend && peak_kmer[pend_h] != 0u;
+        const unsigned long long hits = __ballot(hit);
+        if (hits) {
+            const uint32_t prev_p = __shfl_up(pend_p, 1, 64);
+            const bool head = lane < n_pend && (lane == 0 || prev_p != pend_p);
+            const unsigned long long heads = __ballot(head);
+            if (head) {
+                const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;      // heads of the later pairs
+                const int end = above ? lane + 1 + __ffsll((long long)above) - 1 : n_pend;     // this pair's lanes: [lane, end)
+                const unsigned long long seg = (end >= 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull);
+                if (hits & seg) revote[1u + atomicAdd(revote, 1u)] = pend_p;
+            }
+        }
+        n_pend = 0;
+    };
+    for (long p = wave; p < b.n_pairs; p += n_waves) {
+        const Meta cur = m_next;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+            if (lane < 32) stage[m * 32 + lane] = rw[m];
+        __builtin_amdgcn_wave_barrier();
+        m_next = m_next2;
+        rw[0] = load_rec(m_next, 0);
+        rw[1] = load_rec(m_next, 1);
+        m_next2 = load_meta(p + 2 * n_waves);
+        if (!cur.vote) continue;
+        int nk[2], wpr[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            nk[m] = cur.len[m] - k + 1;
+            wpr[m] = ((cur.len[m] + 31) >> 5) + 1;
+        }
+        uint32_t hs[4][3], f1[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
+            const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
+            const int wp = wpr[m];
+            auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
+            const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
+            const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+            const bool ok = j < nk[m] && wnb == 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const uint32_t h = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
+                hs[s][i] = h;
+                f1[s][i] = (ok && i < e && pf_pass(lds[(h & lf_mask) >> 5], h, pf2)) ? 1u : 0u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int c = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) c += (int)f1[s][i];
+        const int incl = wave_incl_scan(c, lane);
+        const int T = (debug & 512) ? 0 : __shfl(incl, 63, 64);   // bit9 / bit10: stage timing (tools/ablate_vote.py), outputs wrong
+        if (T == 0) continue;
+        bool defer = T > VF_Q;
+        if (!defer) {
+            int slot = incl - c;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    uint32_t* dst = f1[s][i] ? Q + slot : dump + lane;   // no branch: dead candidates land in a scratch word
+                    *dst = hs[s][i];
+                    slot += (int)f1[s][i];
+                }
+            __builtin_amdgcn_wave_barrier();
+            int T2 = 0;
+            for (int q0 = 0; q0 < T; q0 += 128) {   // second level, the L2 bitmap: two gathers in flight per round
+                const int qa = q0 + lane, qb = qa + 64;
+                const uint32_t ha = qa < T ? Q[qa] : 0u, hb = qb < T ? Q[qb] : 0u;
+                const uint32_t wa = qa < T ? prefilter[(ha & pf_mask) >> 5] : 0u;
+                const uint32_t wb = qb < T ? prefilter[(hb & pf_mask) >> 5] : 0u;
+                const bool pa = qa < T && pf_pass(wa, ha, pf2), pb = qb < T && pf_pass(wb, hb, pf2);
+                const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+                const int sa = T2 + __popcll(ba & ((1ull << lane) - 1ull));
+                const int sb = T2 + __popcll(ba) + __popcll(bb & ((1ull << lane) - 1ull));
+                if (pa && sa < VF_Q2) Q2[sa] = ha;
+                if (pb && sb < VF_Q2) Q2[sb] = hb;
+                T2 += __popcll(ba) + __popcll(bb);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (debug & 1024) T2 = 0;
+            if (T2 > VF_Q2) defer = true;
+            else if (T2 > 0) {
+                // third level, peak_kmer itself: not now -- that is one HBM round trip per pair in this wave's chain -- but from a
+                // wave-wide register queue of (hash, pair) that is probed when the next pair's survivors no longer fit
+                if (n_pend + T2 > 64) flush_pending();
+                if (lane >= n_pend && lane < n_pend + T2) {
+                    pend_h = Q2[lane - n_pend];
+                    pend_p = (uint32_t)p;
+                }
+                n_pend += T2;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (defer && lane == 0) revote[1u + atomicAdd(revote, 1u)] = (uint32_t)p;
+    }
+    flush_pending();
+}
+
 // Sparse path without the LDS fold (the usual one: bitmap exact for k <= 25, or too many k-mers for a 64 KiB fold).  One pair
 // per wave iteration as above, first level = the L2-resident bitmap.  Its few survivors (12 of a pair's 714 probes on configs[2])
 // are not probed at once -- that is one HBM round trip per pair for a dozen lanes -- but QUEUED across pairs, tagged with the
@@ -615,12 +775,12 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
     }
 }
 
-// 64 KiB fold of the 2^PF_BITS-bit bitmap: word w = OR of the bitmap words w, w + LF_WORDS, ... (same low address bits)
-__global__ void __launch_bounds__(256) fold_prefilter(const uint32_t* __restrict__ prefilter, int words, uint32_t* __restrict__ fold) {
+// fold of the 2^pf_bits-bit bitmap onto fold_words words (64 or 128 KiB): word w = OR of the bitmap words w, w + fold_words, ... (same low address bits)
+__global__ void __launch_bounds__(256) fold_prefilter(const uint32_t* __restrict__ prefilter, int words, uint32_t* __restrict__ fold, int fold_words) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= LF_WORDS) return;
+    if (w >= fold_words) return;
     uint32_t acc = 0;
-    for (int j = w; j < words; j += LF_WORDS) acc |= prefilter[j];
+    for (int j = w; j < words; j += fold_words) acc |= prefilter[j];
     fold[w] = acc;
 }
 
@@ -668,7 +828,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, PF_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                            ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                           ctx->debug, ctx->pf_mask, ctx->pf2);                                                             \
+                           ctx->debug, ctx->pf_mask, ctx->pf2, (const uint32_t*)nullptr);                                   \
     } while (0)
         const bool nt = ctx->k >= 28;
         // sparse peak sets on a folded (k > PF_BITS) bitmap: 16-wave workgroups that keep a 64 KiB fold of it in LDS
@@ -678,19 +838,46 @@ int lhgt_vote(lhgt_ctx* ctx) {
     hipLaunchKernelGGL((vote_kernel_sparse<PF_, (PF_ == 2 ? 2 : 1)>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                        ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
                        ctx->debug, ctx->pf_mask, ctx->pf2)
-        // LDS first level while the fold still screens: up to one bit insertion per fold bit (63 % of the bits set, 40 % of foreign
-        // probes pass on to the L2 bitmap).  Round 2 stopped at a quarter; measured in round 3 on 100 M pairs from 300 genomes of the
-        // 13 Gbase reference (205 410 registered k-mers, 0.78 insertions per bit): 146 ms with the fold, 296 ms without -- an LDS
-        // probe costs a fraction of the L1 miss every bitmap probe is.  2.3 M k-mers (configs[2]) fill the fold.
-        static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 1.0;   // bit insertions per fold bit
-        const bool fold_ok = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1)) <= fold_max * (double)(1ull << LF_BITS);
-        if (sparse_ok && ctx->k > PF_BITS && fold_ok && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {
+        // LDS first level while the fold still screens.  The 128 KiB fold with the judge deferred (vote_kernel_fold) up to 1.15 bit
+        // insertions per fold bit: 47 % of foreign probes pass on to the L2 bitmap, a pair's survivors (333 +- 13 of 714) still fit
+        // the wave's queue -- beyond that the overflowing pairs would flood the deferred list.  Round 2 kept a 64 KiB fold up to a
+        // quarter insertion per bit; measured in round 3 on 100 M pairs from 300 genomes of the 13 Gbase reference (205 410 registered
+        // k-mers): 296 ms without a fold, 146 ms with 64 KiB (0.78 insertions per bit), 128 KiB below.  2.3 M k-mers (configs[2])
+        // fill any fold that fits.  LHGT_DEBUG bit 15: the 64 KiB kernel with its in-kernel judge (up to one insertion per bit).
+        static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 0.0;   // bit insertions per fold bit (0 = the defaults)
+        const double fold_ins = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1));
+        const bool old_fold = (ctx->debug & 32768) != 0;
+        const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : old_fold ? 1.0 : 1.15) * (double)(1ull << (old_fold ? LF_BITS : LF2_BITS));
+        if (sparse_ok && ctx->k > PF_BITS && fold_ok && !old_fold && !(ctx->debug & 16)) {
+            const int fold_words = (int)std::min<unsigned long long>(LF2_WORDS, (ctx->pf_mask + 1ull) / 32);
+            const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
+            const size_t need = (size_t)b.d.n_pairs + 1;
+            if (ctx->revote_cap < need) {
+                if (ctx->d_revote) LHGT_HIP(hipFree(ctx->d_revote));
+                ctx->d_revote = nullptr;
+                LHGT_HIP(hipMalloc(&ctx->d_revote, need * 4));
+                ctx->revote_cap = need;
+            }
+            LHGT_HIP(hipMemsetAsync(ctx->d_revote, 0, 4, ctx->stream));
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            hipLaunchKernelGGL(fold_prefilter, dim3((fold_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32),
+                               ctx->d_prefilter_fold, fold_words);
+            long fb = (b.d.n_pairs + VF_WAVES - 1) / VF_WAVES;
+            if (fb > 256) fb = 256;             // one resident workgroup per CU
+            hipLaunchKernelGGL(vote_kernel_fold, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
+                               ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2);
+            // the deferred pairs, from scratch in the lane-per-offset form (hits in offset order for the judge); the list's length
+            // is read on the device
+            hipLaunchKernelGGL((vote_kernel<4, 1, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
+                               ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2,
+                               (const uint32_t*)ctx->d_revote);
+        } else if (sparse_ok && ctx->k > PF_BITS && fold_ok && old_fold && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {
             wpb = 16;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256) blocks = 256;     // one resident workgroup per CU
             // per device, not per process: the attribute belongs to the kernel's code object on the device that is current
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold);
+            hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold, LF_WORDS);
             LHGT_VOTE_SPARSE(2, 1024, lds2);
         } else if (sparse_ok) {
             const size_t per_wave_q = (size_t)std::max(max_ev * ctx->e * 2 + 64, 2 * VQ_CAP + 128) * 4;

@@ -153,7 +153,9 @@ struct lhgt_ctx {
     long n_peaks = -1, max_peak = 0;
     long id_end = 0;   // one past the largest peak id in use (= n_peaks, + 1 under -t N emulation when thread 0 found no peak: then no peak holds id 0)
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
-    uint32_t* d_prefilter_fold = nullptr;  // 64 KiB fold of it, copied into LDS by the sparse-path vote kernel
+    uint32_t* d_prefilter_fold = nullptr;  // 64 or 128 KiB fold of it, copied into LDS by the fold vote kernels
+    uint32_t* d_revote = nullptr;          // vote_kernel_fold's deferred pairs: [0] = how many, then the pairs of the batch being voted
+    size_t revote_cap = 0;                 // words
     bool prefilter_on = false;
     uint32_t pf_mask = 0;             // low address bits indexing the prefilter
     int pf2 = 0;                      // folded prefilter: shift of the address bits picking a key's second bit (0 = one bit per key)

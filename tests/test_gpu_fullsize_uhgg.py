@@ -67,7 +67,9 @@ def _check_scans_and_votes(eng, expect_lite, tag):
     generic = _vote(eng, 32)                           # generic kernel behind the same bitmap
     direct = _vote(eng, 2048)                          # queued kernel, pairs with > 8 bitmap survivors voted at once
     nofilter = _vote(eng, 4)                           # every probe goes to peak_kmer
-    assert queued == generic == direct == nofilter, (tag, queued, generic, direct, nofilter)
+    nofold = _vote(eng, 16)                            # never an LDS fold in front of the bitmap (the queued kernel)
+    oldfold = _vote(eng, 32768)                        # round 2's 64 KiB fold kernel with its in-kernel judge, where a fold is used at all
+    assert queued == generic == direct == nofilter == nofold == oldfold, (tag, queued, generic, direct, nofilter, nofold, oldfold)
     return exact, info_t, queued
 
 
@@ -87,10 +89,11 @@ def _count_both_ways(eng):
 # (pairs, contigs the sample is drawn from, lite form expected, votes expected).  With the default sample -- half of the
 # reference, 6.5 Gbase -- three hashes of 6.5 G k-mers fill the 2^32 slots by collisions alone and nothing is ever voted (the
 # reference would find nothing either: this is why it down-samples, E:1392-1398); a sample of 1000 contigs at 7.5x is the
-# regime of configs[1] on the big reference: transfers are found and voted.
+# regime of configs[1] on the big reference: transfers are found and voted; 300 contigs at 50x leave a peak set small enough for the
+# 128 KiB LDS fold with the deferred judge (vote_kernel_fold): the form `0` of the vote comparison is that kernel there.
 @pytest.mark.parametrize("pairs,sample_contigs,expect_lite,expect_votes",
                          [(25_000_000, 0, False, False), (35_000_000, 0, None, False), (100_000_000, 0, True, False),
-                          (25_000_000, 1000, None, True)])
+                          (25_000_000, 1000, None, True), (50_000_000, 300, None, True)])
 def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_votes):
     eng.pairs_clear()
     eng.synth_options(0, 20, sample_contigs)

@@ -113,9 +113,10 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         _, pf_o = oracle.vote(f1, f2, k, e, cc, ratio, None, pk_o, loci_o, n_o)
         _, pf_g = eng.peaks_export(n_g)
         assert (pf_g == pf_o[:n_g]).all()
-        # every vote kernel (queued with its direct branch forced, generic with / without the bitmap); the form of the scan the
+        # every vote kernel (queued with its direct branch forced, generic with / without the bitmap, no LDS fold, round 2's 64 KiB
+        # fold kernel instead of the 128 KiB one with the deferred judge); the form of the scan the
         # engine picks by itself (0), the single-first ("lite") form, also with no tile settled early, and the trio-first form
-        for flags in (0, 2048, 32, 4, 4096, 4096 | 256, 16384, 16384 | 256):
+        for flags in (0, 2048, 32, 4, 16, 32768, 4096, 4096 | 256, 16384, 16384 | 256):
             eng.set_debug(flags)
             assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
             eng.vote()
@@ -369,7 +370,7 @@ def test_vote_prefilter_changes_nothing(Engine):
         eng.synth_pairs(3, 4, 16, 100_000, 0, 60_000)
         eng.count_kmers()
         votes = []
-        for flags in (0, 16, 32, 4, 128, 256, 16 | 2048):  # fold kernel, queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
+        for flags in (0, 32768, 16, 32, 4, 128, 256, 16 | 2048):  # fold kernel (128 KiB, deferred judge), round 2's 64 KiB fold kernel, queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
             eng.set_debug(flags)
             n = eng.ref_scan(0.1, 0.08, 10**7)
             eng.vote()

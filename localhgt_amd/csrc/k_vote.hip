@@ -431,12 +431,13 @@ constexpr int LF2_BITS = 20;
 constexpr int LF2_WORDS = (1 << LF2_BITS) / 32;
 constexpr int VF_Q = 368, VF_Q2 = 48, VF_WAVE_WORDS = VF_Q + VF_Q2 + 64;   // per wave: first queue (its head stages the records), second queue, scratch
 constexpr int VF_WAVES = 16;
+template <int EC>   // EC = 3: e known at compile time (no uniform branch per hash), 0: e <= 3 at run time
 __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                                   const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                                   int fold_words, uint32_t* __restrict__ revote, int debug, uint32_t pf_mask, int pf2) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int e = hp.e, k = hp.k;
+    const int e = EC ? EC : hp.e, k = hp.k;
     if (b.n_pairs <= 0) return;
     for (int i = threadIdx.x; i < fold_words; i += blockDim.x) lds[i] = lds_fold[i];
     __syncthreads();
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
     Meta m_next = load_meta(wave), m_next2 = load_meta(wave + n_waves);
     uint32_t rw[2] = {load_rec(m_next, 0), load_rec(m_next, 1)};
     // pending third-level probes: lane i < n_pend holds one survivor of the second level and its pair; a pair's survivors are
-    // appended together, so they sit in consecutive lanes of ONE flush and the pair is deferred once however many of them hit.
+    // appended together, so they sit in consecutive lanes of ONE flush: its hits are counted there and the pair is deferred once.
     // (A pair deferred here AND by an overflow would be voted twice: an overflowing pair never enters this queue.)
     uint32_t pend_h = 0u, pend_p = 0u;
     int n_pend = 0;
@@ -480,7 +481,9 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
                 const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;      // heads of the later pairs
                 const int end = above ? lane + 1 + __ffsll((long long)above) - 1 : n_pend;     // this pair's lanes: [lane, end)
                 const unsigned long long seg = (end >= 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull);
-                if (hits & seg) revote[1u + atomicAdd(revote, 1u)] = pend_p;
+                // base_hits >= 6 (E:496) needs six offsets with a hit, i.e. at least six probes that found a peak id: one or two are what
+                // foreign k-mers bring by collision (714 probes against 2*10^5 registered k-mers in 2^32 slots: every 30th pair)
+                if (__popcll(hits & seg) >= 6) revote[1u + atomicAdd(revote, 1u)] = pend_p;
             }
         }
         n_pend = 0;
@@ -503,23 +506,36 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             nk[m] = cur.len[m] - k + 1;
             wpr[m] = ((cur.len[m] + 31) >> 5) + 1;
         }
-        uint32_t hs[4][3], f1[4][3];
+        // In three sweeps -- all window words, all hashes, all fold probes -- and every load unconditional (a load under a lane mask
+        // is an exec region with its own wait: a dozen LDS round trips in a row instead of one); a hash the run does not have
+        // (i >= e) reads mask 0 and is switched off with its `ok` bit.
+        uint32_t hs[4][3], f1[4][3], wd[4][6];
+        bool ok[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int m = s >> 1, j = (s & 1) * 64 + lane;
+            const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
+            const int wp = wpr[m];
+            wd[s][0] = q[0]; wd[s][1] = q[1]; wd[s][2] = q[wp]; wd[s][3] = q[wp + 1]; wd[s][4] = q[2 * wp]; wd[s][5] = q[2 * wp + 1];
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
-            const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
-            const int wp = wpr[m];
             auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
-            const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
+            const uint32_t whi = win(wd[s][0], wd[s][1]), wlo = win(wd[s][2], wd[s][3]), wnb = win(wd[s][4], wd[s][5]);
             const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
-            const bool ok = j < nk[m] && wnb == 0;
+            ok[s] = j < nk[m] && wnb == 0;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const uint32_t h = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
-                hs[s][i] = h;
-                f1[s][i] = (ok && i < e && pf_pass(lds[(h & lf_mask) >> 5], h, pf2)) ? 1u : 0u;
-            }
+            for (int i = 0; i < 3; i++) hs[s][i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
         }
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) f1[s][i] = lds[(hs[s][i] & lf_mask) >> 5];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) f1[s][i] = (uint32_t)pf_pass(f1[s][i], hs[s][i], pf2) & (uint32_t)(ok[s] & (i < e));
         __builtin_amdgcn_wave_barrier();
         int c = 0;
 #pragma unroll
@@ -859,18 +875,30 @@ int lhgt_vote(lhgt_ctx* ctx) {
                 ctx->revote_cap = need;
             }
             LHGT_HIP(hipMemsetAsync(ctx->d_revote, 0, 4, ctx->stream));
-            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
             hipLaunchKernelGGL(fold_prefilter, dim3((fold_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32),
                                ctx->d_prefilter_fold, fold_words);
             long fb = (b.d.n_pairs + VF_WAVES - 1) / VF_WAVES;
             if (fb > 256) fb = 256;             // one resident workgroup per CU
-            hipLaunchKernelGGL(vote_kernel_fold, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
-                               ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2);
+            if (ctx->e == 3)
+                hipLaunchKernelGGL(vote_kernel_fold<3>, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
+                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2);
+            else
+                hipLaunchKernelGGL(vote_kernel_fold<0>, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
+                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2);
             // the deferred pairs, from scratch in the lane-per-offset form (hits in offset order for the judge); the list's length
             // is read on the device
             hipLaunchKernelGGL((vote_kernel<4, 1, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
                                ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2,
                                (const uint32_t*)ctx->d_revote);
+            if (getenv("LHGT_TRACE")) {
+                uint32_t n_def = 0;
+                LHGT_HIP(hipMemcpyAsync(&n_def, ctx->d_revote, 4, hipMemcpyDeviceToHost, ctx->stream));
+                LHGT_HIP(hipStreamSynchronize(ctx->stream));
+                fprintf(stderr, "[lhgt] vote: 128 KiB fold (%.2f insertions per bit), %u of %ld pairs deferred to the lane-per-offset form\n",
+                        fold_ins / (double)(1ull << LF2_BITS), n_def, b.d.n_pairs);
+            }
         } else if (sparse_ok && ctx->k > PF_BITS && fold_ok && old_fold && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {
             wpb = 16;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;

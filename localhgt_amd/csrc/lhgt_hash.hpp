@@ -15,8 +15,10 @@ namespace lhgt {
 
 // k-bit window starting at base j of a plane (32 bases per word, first base at the MSB).
 // v_alignbit_b32 takes the 32 bits that start r bits into the word pair in one full-rate instruction (a 64-bit shift runs at a quarter)
+// The r = 0 case is picked with a bit-select on a lane mask, not with `r ? ... : hi`: behind a condition the compiler sinks the load
+// of `lo` into an exec region of its own -- one region and one wait per window, twelve in a row per read pair in the vote kernels.
 __device__ __forceinline__ uint32_t window32(uint32_t hi, uint32_t lo, int r) {
-    return r ? __builtin_amdgcn_alignbit(hi, lo, 32 - r) : hi;
+    return __builtin_amdgcn_bitop3_b32(r ? ~0u : 0u, __builtin_amdgcn_alignbit(hi, lo, 32 - r), hi, 0xCA);   // m ? a : b
 }
 __device__ __forceinline__ uint32_t plane_window(const uint32_t* __restrict__ w, int j, int k) {
     int q = j >> 5, r = j & 31;
@@ -25,10 +27,18 @@ __device__ __forceinline__ uint32_t plane_window(const uint32_t* __restrict__ w,
 
 __device__ __forceinline__ uint32_t brev_k(uint32_t x, int k) { return __brev(x) >> (32 - k); }
 
+// The three masks of a hash PARTITION the k low bits -- every position uses exactly one projection (build_hash_params refuses any
+// other coder entry) -- so "(p0 & m0) | (p1 & m1) | (p2 & m2)" is two bit-selects (m ? a : b) instead of three ANDs and
+// two ORs, and the forward word's three complements become one XOR with the k-bit mask at the end (the windows have no bit above k):
+// 6 vector instructions per hash instead of 14 in the round-2 form.  The masks are kernel arguments, i.e. scalar registers.
+// (written as (a & m) | (b & ~m) the compiler makes an AND and an AND-OR of it, with ~m kept in a scalar register: the gfx950
+// three-input bit operation does it in one; truth table 0xCA = m ? a : b)
+__device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
 __device__ __forceinline__ uint32_t hash_from_windows(uint32_t whi, uint32_t wlo, uint32_t rhi, uint32_t rlo,
                                                       const uint32_t* __restrict__ m) {
-    uint32_t fwd = (~(whi ^ wlo) & m[0]) | (~whi & m[1]) | (~wlo & m[2]);
-    uint32_t rc = (~(rhi ^ rlo) & m[0]) | (rhi & m[1]) | (rlo & m[2]);
+    const uint32_t kmask = m[0] | m[1] | m[2];
+    const uint32_t fwd = bit_select(m[0], whi ^ wlo, bit_select(m[1], whi, wlo)) ^ kmask;        // = (~(whi^wlo) & m0) | (~whi & m1) | (~wlo & m2)
+    const uint32_t rc = bit_select(m[0], ~(rhi ^ rlo), bit_select(m[1], rhi, rlo));              // = (~(rhi^rlo) & m0) | (rhi & m1) | (rlo & m2)
     return fwd < rc ? fwd : rc;
 }
 

@@ -829,6 +829,15 @@ def secondary_workloads(eng, args, wl, local, extra_traffic, mall):
             d.update(workload=f"configs[2]'s bases and reads, the reference cut into {len(cuts) - 1} pieces of a catalogue-like length distribution (localhgt_amd.synth.ragged_cuts)")
             out["uhgg_ragged_reference"] = d
             eng.pairs_clear()
+            # ... and the ragged catalogue under the deep focused sample (100 M pairs from 300 Mbase of it, about 2700 of its contigs):
+            # what a real run on a real catalogue looks like -- contig ends are peaks only where the sample covers them
+            eng.synth_options(0, 20, 300)
+            eng.synth_pairs(1, 2, args.contigs, args.contig_len, 0, args.pairs, L)
+            d = leg(eng, args.pairs, recall=False)
+            d.update(workload="the ragged catalogue under the deep focused sample: 100 M pairs drawn from the first 300 Mbase of its base stream (100x), sample=1")
+            out["uhgg_ragged_deep_focused"] = d
+            eng.synth_options(0, 20, 0)
+            eng.pairs_clear()
             eng.synth_reference(1, args.contigs, args.contig_len)
             if args.ref_form == "index":
                 # the headline workload once more with the reference resident as packed bases (3/8 byte per base instead of the

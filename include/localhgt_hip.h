@@ -43,6 +43,10 @@ int lhgt_device_count(int* n);
  * table of 2^k slots in HBM (replaces `new char[2^k]` + memset, E:1375-1376,1416). */
 int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out);
 int lhgt_ctx_destroy(lhgt_ctx* ctx);
+/* lhgt_ctx_destroy keeps one peak_kmer table of 4 GiB or more (16 GiB at k = 32) per device and size for the next context of the
+ * process -- a process that handles sample after sample would free and allocate it every time, and that allocation was measured
+ * to take anything from 0 to 2 s.  lhgt_pool_trim frees what is kept. */
+int lhgt_pool_trim(void);
 
 /* ---- R: glibc rand() stream and the position coder (host side, private random_r state) */
 int lhgt_rng_seed(lhgt_ctx* ctx, unsigned seed);                       /* srand(seed), E:1386 */
@@ -55,6 +59,11 @@ int lhgt_sampling_get(lhgt_ctx* ctx, float* out, long n);              /* first 
  * will see at most n_reads reads per file (from the line count) needs only that many entries; the loaders refuse a read beyond
  * them.  0 (default) = all 5*10^7.  Call before lhgt_sampling_init. */
 int lhgt_sampling_reserve(lhgt_ctx* ctx, long n_reads);
+/* get_random started early, on a host thread of its own: the draws depend on nothing but the seed and the coder's draws before
+ * them (E:1386-1422), so they can run next to the line count of the FASTQ files and the reference load.  Assumes ratio < 100;
+ * lhgt_sampling_init(ratio) joins the fill (lhgt_sampling_reserve before it cuts it short) and drops the array when ratio >= 100,
+ * where nothing observes the draws.  Same array as the synchronous lhgt_sampling_init. */
+int lhgt_sampling_begin(lhgt_ctx* ctx);
 
 /* ---- H: hash of every k-mer of one sequence (parity probe for E:1052-1081 / 786-811).
  * out_hash[(j*e)+i], out_valid[j]; runs the same device code as every phase. */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "lhgt_sampling_init": [_vp, _d],
     "lhgt_sampling_get": [_vp, _fp, _l],
     "lhgt_sampling_reserve": [_vp, _l],
+    "lhgt_sampling_begin": [_vp],
+    "lhgt_pool_trim": [],
     "lhgt_hash_sequence": [_vp, _cs, _l, _u32p, _u8p],
     "lhgt_index_build": [_vp, _cs, _cs, _cs, _lp, _lp],
     "lhgt_index_load": [_vp, _cs, _lp, _lp],

@@ -29,6 +29,35 @@ __global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, ui
 }
 }  // namespace lhgt
 
+#include <mutex>
+namespace lhgt {
+namespace {
+struct BigBuf { int device; size_t bytes; void* p; };
+std::mutex g_big_mu;
+std::vector<BigBuf> g_big;
+}  // namespace
+void* big_take(int device, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    for (size_t i = 0; i < g_big.size(); i++)
+        if (g_big[i].device == device && g_big[i].bytes == bytes) {
+            void* p = g_big[i].p;
+            g_big.erase(g_big.begin() + (long)i);
+            return p;
+        }
+    return nullptr;
+}
+void big_give(int device, size_t bytes, void* p) {
+    if (!p) return;
+    if (bytes >= BIG_BUFFER_MIN) {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        bool have = false;
+        for (const BigBuf& b : g_big) have |= b.device == device && b.bytes == bytes;
+        if (!have) { g_big.push_back({device, bytes, p}); return; }
+    }
+    hipFree(p);
+}
+}  // namespace lhgt
+
 extern "C" {
 
 int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
@@ -117,6 +146,7 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
 
 int lhgt_ctx_destroy(lhgt_ctx* c) {
     if (!c) return LHGT_OK;
+    lhgt::sampling_join(c);
     if (c->device < 0) { free(c->rng); delete c; return LHGT_OK; }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -124,10 +154,11 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt::ingest_free(c);
     lhgt_ingest_pool_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
-                    (void*)c->d_peak_kmer, (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
+                    (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],
                     (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_revote, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest})
         if (p) hipFree(p);
+    lhgt::big_give(c->device, ((size_t)1 << c->k) * 4, c->d_peak_kmer);   // kept for the next context of this process, or freed
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev2) hipEventDestroy(c->ev2);
@@ -136,6 +167,23 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     free(c->rng);
     delete c;
+    return LHGT_OK;
+}
+
+int lhgt_pool_trim(void) {
+    for (;;) {
+        void* p = nullptr;
+        int dev = 0;
+        {
+            std::lock_guard<std::mutex> lk(lhgt::g_big_mu);
+            if (lhgt::g_big.empty()) break;
+            p = lhgt::g_big.back().p;
+            dev = lhgt::g_big.back().device;
+            lhgt::g_big.pop_back();
+        }
+        hipSetDevice(dev);
+        hipFree(p);
+    }
     return LHGT_OK;
 }
 

@@ -995,6 +995,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     if (!ctx || !fq1 || !fq2) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world || shard_block < 1)
         LHGT_FAIL(LHGT_E_ARG, "bad shard spec %d/%d block %ld", shard_rank, shard_world, shard_block);
+    lhgt::sampling_join(ctx);
     if (ratio_percent < 100.0 && (long)ctx->random_array.size() != LHGT_MAX_RANDOM)
         LHGT_FAIL(LHGT_E_STATE, "lhgt_sampling_init(ratio) must precede lhgt_pairs_load_fastq when ratio < 100");
     // a batch is closed at 4 Mi pairs (1 Mi with count-on-load, so that phase A of one batch hides behind the parsing of the next;

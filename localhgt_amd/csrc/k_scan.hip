@@ -12,6 +12,7 @@
 //   B5 register       peak_loci + peak_kmer[h] = max id (ids grow in write order) (E:247-267)
 // flags byte per reference position: bit0 single, bit1 trio, bit2 good window, bit3 peak (computed inside intervals only),
 // bit4 inside a good interval, bit5 selected (peak & interval), bit6 new peak.
+#include <chrono>
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
@@ -1123,7 +1124,14 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     ctx->n_selected = n_selected;
     if ((long)total > max_peak)
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
-    if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
+    if (!ctx->d_peak_kmer) {
+        const auto t0 = std::chrono::steady_clock::now();
+        ctx->d_peak_kmer = (uint32_t*)big_take(ctx->device, slots * 4);    // a closed context's table on this device, if the process has one
+        if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
+        if (getenv("LHGT_TRACE"))
+            fprintf(stderr, "[lhgt] peak_kmer: %.1f GiB taken or allocated in %.3f s\n", (double)(slots * 4) / (1ull << 30),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
     LHGT_HIP(hipMemsetAsync(ctx->d_peak_kmer, 0, slots * 4, ctx->stream));  // E:1458
     // vote prefilter (k_vote.hip): a bitmap over the low pf_bits address bits (exact when pf_bits = k, folded otherwise).
     // Sized at >= 16 bits per registered k-mer (false positives <= 6 %) but no larger: a 4 MiB bitmap does not stay

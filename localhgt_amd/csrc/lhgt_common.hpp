@@ -4,7 +4,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/localhgt_hip.h"
 
@@ -115,6 +117,11 @@ struct lhgt_ctx {
     std::vector<float> random_array;
     long sampling_reads = 0;     // lhgt_sampling_reserve: reads the run can look at (0 = unknown: all 5*10^7 entries are filled)
     long sampling_filled = 0;    // entries of random_array the last lhgt_sampling_init filled
+    // lhgt_sampling_begin: the fill on a host thread of its own, next to the line count and the reference load; it stops at
+    // fill_limit (lowered by lhgt_sampling_reserve / lhgt_sampling_init once the number of reads, or ratio >= 100, is known)
+    std::thread* fill_thread = nullptr;
+    std::atomic<long> fill_limit{0};
+    long fill_done = 0;          // written by the fill thread, read after the join
     double ratio = 100.0;
     // A
     uint32_t* d_counts = nullptr;  // 2-bit saturating counters, 16 per word
@@ -213,6 +220,13 @@ namespace lhgt {
 // host helpers implemented across the .cpp/.hip files
 int build_hash_params(const int16_t* cc, int k, int e, HashParams* hp);
 int rng_next(lhgt_ctx* ctx);  // one rand() draw from the private glibc stream
+void sampling_join(lhgt_ctx* ctx);   // waits for a fill started by lhgt_sampling_begin (host_rng.cpp)
+// peak_kmer of a closed context (16 GiB at k = 32) kept for the next context of this process on the same device (cabi.hip):
+// a process that runs sample after sample would otherwise free and allocate it every time, and hipMalloc of 16 GiB right after such a
+// free was measured to take 0 s or 2 s (profiles/r03/e2e_peak_kmer_alloc.txt).  One buffer per (device, size); lhgt_pool_trim frees them.
+void* big_take(int device, size_t bytes);
+void big_give(int device, size_t bytes, void* p);
+constexpr size_t BIG_BUFFER_MIN = (size_t)4 << 30;
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
                  long n_pairs, const uint8_t* pair_flags);
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index = 1);  // allocates d_index, tiles, flags

@@ -62,6 +62,10 @@ class Engine:
     def sampling_init(self, ratio_percent: float):
         _lib.check(self.lib.lhgt_sampling_init(self.h, float(ratio_percent)))
 
+    def sampling_begin(self):
+        """start filling the sampling array on a host thread (after the coder's draws); sampling_init(ratio) joins it"""
+        _lib.check(self.lib.lhgt_sampling_begin(self.h))
+
     def sampling_reserve(self, n_reads: int):
         """the run will see at most n_reads reads per file: sampling_init fills only that many entries of the sampling array"""
         _lib.check(self.lib.lhgt_sampling_reserve(self.h, int(n_reads)))

@@ -98,14 +98,6 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
         log(f"reproducing the reference's -t {a.threads} read partition and peak id ranges")
     log(f"kmer length is {a.k}\nseed is {a.seed}\nnum of hash functions is {a.e}")
     eng.rng_seed(a.seed)                                       # E:1386
-    plan1 = plan2 = None
-    if dist:                                                   # every rank counts the lines of 1/world of both files (dist.fastq_plan)
-        plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1)
-        plan2 = dist.fastq_plan(eng, a.fq2)
-    elif a.sample > 1:                                         # the CLI's default --sample 2000000000: the line count the loader needs
-        plan1, plan2 = eng.fastq_plan(a.fq1, True, other=a.fq2)   # anyway also yields cal_sam_ratio's base count (no extra pass over fq1)
-    ratio = eng.sam_ratio_from_plan(plan1, a.sample) if plan1 is not None else eng.sam_ratio(a.fq1, a.sample)   # E:1392-1398
-    log(f"down-sampling ratio: {ratio}%.")
     idx = index_name(a.fasta, a.k, a.e)
     if ref_form is None:
         ref_form = os.environ.get("LHGT_REF_FORM", "index")
@@ -119,6 +111,21 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
         built = dist.broadcast_flag(built)
     if built:
         eng.coder_generate()
+    # get_random's 5*10^7 draws (E:1422, 0.3 s of one host core) depend on nothing but the seed and the coder's draws: they start
+    # here, on a thread of their own, next to the line count and the reference load, and are joined by sampling_init below --
+    # which cuts them short once the number of reads is known, or drops them when the ratio turns out >= 100 % (nothing looks).
+    # With --sample 1 exactly the ratio is known to be 100 % and nothing is drawn.
+    if a.sample != 1 and os.environ.get("LHGT_SYNC_SAMPLING", "0") != "1":   # =1: draw them where the reference does (A/B timing)
+        eng.sampling_begin()
+    plan1 = plan2 = None
+    if dist:                                                   # every rank counts the lines of 1/world of both files (dist.fastq_plan)
+        plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1)
+        plan2 = dist.fastq_plan(eng, a.fq2)
+    elif a.sample > 1:                                         # the CLI's default --sample 2000000000: the line count the loader needs
+        plan1, plan2 = eng.fastq_plan(a.fq1, True, other=a.fq2)   # anyway also yields cal_sam_ratio's base count (no extra pass over fq1)
+    ratio = eng.sam_ratio_from_plan(plan1, a.sample) if plan1 is not None else eng.sam_ratio(a.fq1, a.sample)   # E:1392-1398
+    log(f"down-sampling ratio: {ratio}%.")
+    if built:
         if rank == 0 and not packed:
             log("Reference index not detected, start index...")
             eng.index_build(a.fasta, idx, a.fasta + ".genome.len.txt")

@@ -87,6 +87,44 @@ def test_sampling_array_matches_libc_rand_after_coder(oracle):
             assert got.max() < 100.0
 
 
+def test_sampling_array_begun_early_is_the_same_array():
+    """lhgt_sampling_begin fills on a host thread of its own (next to the line count and the reference load, extract_ref.run);
+    joined by sampling_init it is the synchronous array -- whole, cut short by sampling_reserve, or dropped when ratio >= 100"""
+    from localhgt_amd.engine import Engine
+    with Engine(24, 3, device=-1) as ref:
+        ref.rng_seed(9)
+        ref.coder_generate()
+        ref.sampling_init(37.5)
+        want = ref.sampling_get(50_000_000)
+    with Engine(24, 3, device=-1) as eng:
+        eng.rng_seed(9)
+        eng.coder_generate()
+        eng.sampling_begin()
+        eng.sampling_init(37.5)
+        assert (eng.sampling_get(50_000_000) == want).all()
+        # cut short: at least the reserved entries are the stream's, the rest are the stream's or still 0
+        eng.rng_seed(9)
+        eng.coder_generate()
+        eng.sampling_begin()
+        eng.sampling_reserve(1_000_000)
+        eng.sampling_init(37.5)
+        got = eng.sampling_get(50_000_000)
+        assert (got[:1_000_000] == want[:1_000_000]).all()
+        assert ((got == want) | (got == 0)).all()
+        # ratio >= 100: nobody looks at the draws, the array is dropped
+        eng.rng_seed(9)
+        eng.sampling_begin()
+        eng.sampling_init(100.0)
+        with pytest.raises(Exception):
+            eng.sampling_get(10)
+        # a new seed while a fill is in flight joins it first
+        eng.sampling_begin()
+        eng.rng_seed(9)
+        eng.coder_generate()
+        eng.sampling_init(37.5)
+        assert (eng.sampling_get(200_000) == want[:200_000]).all()
+
+
 def test_sam_ratio_matches_oracle(oracle, case_inputs):
     from localhgt_amd.engine import Engine
     fa, f1, f2, _ = case_inputs("k24_seed7")

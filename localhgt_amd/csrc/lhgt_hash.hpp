@@ -97,9 +97,10 @@ __host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
 __device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
     return (1u << (h & 31u)) | (pf2 ? 1u << ((h >> pf2) & 31u) : 0u);
 }
+// (both bits shifted down and ANDed: a variable shift takes its count modulo 32 by itself, so this is four vector instructions
+// where building the two-bit mask and comparing took eight; with pf2 = 0 the second shift picks the first bit again)
 __device__ __forceinline__ bool pf_pass(uint32_t word, uint32_t h, int pf2) {
-    const uint32_t m = pf_word_bits(h, pf2);
-    return (word & m) == m;
+    return ((word >> (h & 31u)) & (word >> ((h >> pf2) & 31u)) & 1u) != 0u;
 }
 
 }  // namespace lhgt

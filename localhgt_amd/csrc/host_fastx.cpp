@@ -498,6 +498,10 @@ static void parse_chunk(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1,
                            (have2 && sb <= size1 && sampled((g + lay.shift) / 4) ? PAIR_COUNT2 : 0));
         }
         if (!fl || (n / shard_block) % shard_world != shard_rank) continue;
+        // a mate no phase reads is kept empty: the reference does not touch such a line either -- its buffers are filled under
+        // `r < down_sam_ratio` only (E:1044, 404) -- so it may be longer than they are
+        if (!(fl & (PAIR_COUNT1 | PAIR_VOTE))) la = 0;
+        if (!(fl & (PAIR_COUNT2 | PAIR_VOTE))) lb = 0;
         if (la > LHGT_MAX_READ_LEN || lb > LHGT_MAX_READ_LEN) {
             out->rc = LHGT_E_FORMAT;
             out->err = "read " + std::to_string(n) + " longer than " + std::to_string(LHGT_MAX_READ_LEN) + " bases (the reference's buffers, E:1004)";

@@ -172,13 +172,15 @@ def write_fastq(mate: np.ndarray, path: str, suffix: str, header_pad: int = 0,
 def write_case(outdir: str, ref: SynthRef, reads: SynthReads, fq2_header_pad: int = 0,
                lowercase_every: int = 0, fq1_header_pad: int = 0, fq1_drop_tail: int = 0,
                fq1_trailing_blank: bool = False, fq2_stray_records: int = 0, fq2_drop_tail: int = 0,
-               fq2_last_line_bases_of=None) -> Tuple[str, str, str]:
+               fq2_last_line_bases_of=None, long_line=None) -> Tuple[str, str, str]:
     """fq1_drop_tail: fq1 loses its last records, so fq2 holds surplus ones (counted in phase A while they start inside
     size(fq1), E:1438-1445; never voted, E:356); fq1_trailing_blank: one empty line after fq1's last record;
     fq2_stray_records: that many records with foreign read IDs in front of fq2 (copies of its last reads), so the first IDs differ
     and phase C re-scans fq2 for fq1's (E:368-402); fq2_drop_tail: fq2 loses its last records, so phase C runs out of mate-2 lines
     (E:356-367); fq2_last_line_bases_of = r: fq2's last line (a quality line) holds the bases of mate 2 of read r and has no newline --
-    the line std::getline then leaves behind for every later read of fq1"""
+    the line std::getline then leaves behind for every later read of fq1; long_line = (file 1 or 2, read r, length): that read's
+    sequence and quality lines in that file are `length` characters long -- more than the reference's 500-entry buffers, which it
+    fills for sampled reads only (E:1004-1005, 1044)"""
     os.makedirs(outdir, exist_ok=True)
     fa = os.path.join(outdir, "ref.fa")
     f1 = os.path.join(outdir, "s.1.fq")
@@ -203,6 +205,15 @@ def write_case(outdir: str, ref: SynthRef, reads: SynthReads, fq2_header_pad: in
             body = stray + body
         with open(f2, "wb") as f:
             f.write(body)
+    if long_line is not None:
+        which, r, length = long_line
+        path = f1 if which == 1 else f2
+        lines = open(path, "rb").read().split(b"\n")
+        seq = lines[4 * r + 1]
+        lines[4 * r + 1] = (seq * (length // max(1, len(seq)) + 1))[:length]
+        lines[4 * r + 3] = b"I" * length
+        with open(path, "wb") as f:
+            f.write(b"\n".join(lines))
     return fa, f1, f2
 
 

@@ -273,6 +273,7 @@ typedef struct {
     const orc_seqs* seqs; long lo, hi;
     int k, e; const short* cc; const float* rnd; double ratio;
     uint8_t* table; long kept;
+    int too_long;   /* a SAMPLED read longer than the reference's buffers (E:1004-1005, filled only under `r < down_sam_ratio`, E:1044) */
 } orc_count_job;
 
 static void* orc_count_worker(void* arg) {
@@ -282,6 +283,7 @@ static void* orc_count_worker(void* arg) {
         if (!orc_keep(n, j->rnd, j->ratio)) continue;
         j->kept++;
         const orc_seq* q = &j->seqs->v[n];
+        if (q->len > ORC_MAX_READ) { j->too_long = 1; return NULL; }
         for (int p = 0; p + j->k <= q->len; p++) {
             if (!orc_hash_kmer(q->s + p, j->k, j->e, j->cc, h)) continue;
             for (int i = 0; i < j->e; i++) {
@@ -303,19 +305,19 @@ long orc_count_fastq(const char* fq, long byte_limit, int k, int e, const short*
     orc_buf b = orc_slurp(fq);
     if (b.n < 0) return -1;
     orc_seqs seqs = orc_scan_fastq(&b, byte_limit);
-    for (long n = 0; n < seqs.n; n++) if (seqs.v[n].len > ORC_MAX_READ) { free(seqs.v); free(b.p); return -3; }
     if (threads < 1) threads = 1;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     orc_count_job* jobs = (orc_count_job*)calloc((size_t)threads, sizeof(orc_count_job));
     for (int t = 0; t < threads; t++) {
-        orc_count_job jb = {&seqs, seqs.n * t / threads, seqs.n * (t + 1) / threads, k, e, cc, rnd, ratio, table, 0};
+        orc_count_job jb = {&seqs, seqs.n * t / threads, seqs.n * (t + 1) / threads, k, e, cc, rnd, ratio, table, 0, 0};
         jobs[t] = jb;
         pthread_create(&th[t], NULL, orc_count_worker, &jobs[t]);
     }
     long kept = 0;
-    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); kept += jobs[t].kept; }
+    int too_long = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); kept += jobs[t].kept; too_long |= jobs[t].too_long; }
     free(th); free(jobs); free(seqs.v); free(b.p);
-    return kept;
+    return too_long ? -3 : kept;   /* the reference overruns its stack buffers there: undefined, refused */
 }
 
 /* ---------------------------------------------------------------- phase B (E:888-979, 550-725, 239-301) */
@@ -490,6 +492,7 @@ typedef struct {
     const orc_seqs *s1, *s2; long lo, hi;
     int k, e; const short* cc; const float* rnd; double ratio;
     const uint32_t* peak_kmer; const int32_t* loci; uint8_t* peak_filter; long kept;
+    int too_long;   /* a sampled pair with a mate longer than the reference's buffers */
 } orc_vote_job;
 
 static void orc_vote_mate(orc_vote_state* S, const orc_seq* q, const orc_vote_job* j) {
@@ -506,6 +509,7 @@ static void* orc_vote_worker(void* arg) {
     for (long n = j->lo; n < j->hi; n++) {
         if (!orc_keep(n, j->rnd, j->ratio)) continue;
         j->kept++;
+        if (j->s1->v[n].len > ORC_MAX_READ || j->s2->v[n].len > ORC_MAX_READ) { j->too_long = 1; break; }
         S->n = 0; S->base_hits = 0;
         orc_vote_mate(S, &j->s1->v[n], j);
         orc_vote_mate(S, &j->s2->v[n], j);
@@ -536,7 +540,6 @@ long orc_vote(const char* fq1, const char* fq2, int k, int e, const short* cc, d
             return kept;
         }
     }
-    for (long n = 0; n < s1.n; n++) if (s1.v[n].len > ORC_MAX_READ || s2.v[n].len > ORC_MAX_READ) return -3;
     if (threads < 1) threads = 1;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     orc_vote_job* jobs = (orc_vote_job*)calloc((size_t)threads, sizeof(orc_vote_job));
@@ -547,9 +550,10 @@ long orc_vote(const char* fq1, const char* fq2, int k, int e, const short* cc, d
         pthread_create(&th[t], NULL, orc_vote_worker, &jobs[t]);
     }
     long kept = 0;
-    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); kept += jobs[t].kept; }
+    int too_long = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); kept += jobs[t].kept; too_long |= jobs[t].too_long; }
     free(th); free(jobs); free(s1.v); free(s2.v); free(b1.p); free(b2.p);
-    return kept;
+    return too_long ? -3 : kept;
 }
 
 /* ---------------------------------------------------------------- phase D (E:515-548) */

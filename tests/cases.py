@@ -43,6 +43,7 @@ class Case:
     fq2_stray_records: int = 0                  # foreign records in front of fq2: phase C re-scans fq2 for fq1's first read ID (E:368-402)
     fq2_drop_tail: int = 0                      # fq2 has that many records fewer than fq1 (E:356-367)
     fq2_last_line_bases_of: Optional[int] = None  # fq2's last line holds the bases of that read's mate 2 and has no newline
+    long_line: Optional[Tuple[int, int, int]] = None   # (file, read, length): a line longer than the reference's buffers (harmless while unsampled)
     threads: int = 1                            # -t of the run (parity contract of t > 1: oracle/_ref run on ONE core)
     lowercase_every: int = 0
     preexisting_index: bool = False             # run twice, keep outputs of the 2nd run (quirk Q3)
@@ -78,6 +79,12 @@ CASES: Dict[str, Case] = {c.name: c for c in [
          max_len=20000, short_contig_at=None, depth=10,
          notes="the same with no newline after fq2's last line, which holds bases: std::getline leaves that line in place, so the "
                "rest of fq1 is voted against it"),
+    Case("k24_long_line_fq2", sample=0.5, long_line=(2, 40, 620), ref_seed=93, reads_seed=94, n_contigs=5, min_len=12000, max_len=20000,
+         short_contig_at=None, depth=10,
+         notes="read 40 of fq2 is 620 characters long -- more than the reference's 500-entry buffers, which it fills for sampled reads "
+               "only (E:1004-1005, 1044): the read is not sampled, the run is defined (a sampled one ends in a stack overrun)"),
+    Case("k24_long_line_fq1", sample=0.5, long_line=(1, 101, 620), ref_seed=93, reads_seed=94, n_contigs=5, min_len=12000, max_len=20000,
+         short_contig_at=None, depth=10, notes="the same for read 101 of fq1"),
     # -t N: goldens from the reference with its threads run in creation order (oracle/seq_threads.c)
     Case("k24_t4", threads=4, notes="-t 4: thread chunks of the FASTQs, 2 contig groups, 4 sentinel lines"),
     Case("k24_t8_sample_half", threads=8, sample=0.5, notes="-t 8 with sampling: ordinals restart in every chunk (E:1037)"),
@@ -106,7 +113,7 @@ def materialise(case: Case, outdir: str):
                             lowercase_every=case.lowercase_every, fq1_header_pad=case.fq1_header_pad,
                             fq1_drop_tail=case.fq1_drop_tail, fq1_trailing_blank=case.fq1_trailing_blank,
                             fq2_stray_records=case.fq2_stray_records, fq2_drop_tail=case.fq2_drop_tail,
-                            fq2_last_line_bases_of=case.fq2_last_line_bases_of)
+                            fq2_last_line_bases_of=case.fq2_last_line_bases_of, long_line=case.long_line)
 
 
 def extract_ref_argv(case: Case, fq1: str, fq2: str, fa: str, interval: str):

@@ -81,7 +81,10 @@ def _make_case(idx, d, k_max=32):
     return k, e, seed, sample, hit, match, max_peak
 
 
-@pytest.mark.parametrize("idx", range(int(os.environ.get("LHGT_FUZZ_CASES", "40"))))   # LHGT_FUZZ_CASES=400 for a longer soak
+_FIRST = int(os.environ.get("LHGT_FUZZ_FIRST", "0"))          # LHGT_FUZZ_FIRST=800 LHGT_FUZZ_CASES=1000: cases 800 .. 1799 (continue a soak)
+
+
+@pytest.mark.parametrize("idx", range(_FIRST, _FIRST + int(os.environ.get("LHGT_FUZZ_CASES", "40"))))   # LHGT_FUZZ_CASES=400 for a longer soak
 def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     from localhgt_amd import _lib, extract_ref
     import shutil

@@ -107,6 +107,8 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     # every fifth case as `-t N` (N = 2 .. 10): the product emulates the reference's thread chunks by default and is compared with
     # the oracle's -t N restatement -- or, where the emulation refuses the input and falls back, with its -t 1 run
     threads = 2 + (idx // 5) % 9 if idx % 5 == 4 else 1
+    if os.environ.get("LHGT_FUZZ_ALL_THREADS", "0") == "1":   # a soak of the CLI's default path: every case as -t N
+        threads = 2 + idx % 9
     args = ["0", "0", "0", "0", repr(hit), repr(match), str(threads), str(k), str(max_peak), str(e), str(seed), repr(sample)]
     runs = 2 if idx % 3 == 0 else 1          # second run = cached index (RNG stream position differs, quirk Q3)
     # every fourth case with the reference resident as packed bases, loaded from the FASTA (no index file: one run, whose RNG
@@ -124,6 +126,12 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
         except _lib.LocalHGTError as ex:
             gpu_rc = ex.code
         o = (str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(hit)), float(np.float32(match)))
+        if gpu_rc not in (0, 6) and threads > 1:
+            # refused under -t N for a reason other than the emulation's own limits (those fall back to -t 1 inside run()): the
+            # -t N restatement must refuse too -- e.g. a read longer than the reference's buffers that THIS thread partition samples
+            rc_t, _ = oracle.run_threads(*o, threads, k, max_peak, e, seed, sample)
+            assert rc_t != 0, (gpu_rc, rc_t, k, e, sample, threads)
+            return
         if threads > 1 and rep is not None and rep["emulated_threads"] == threads:
             rc, orep = oracle.run_threads(*o, threads, k, max_peak, e, seed, sample)
         else:                                 # -t 1, or the emulation fell back to it (or the run failed: the -t 1 oracle says how)

@@ -114,3 +114,42 @@ def test_more_ranks_and_the_reference_corner_cases(case_inputs, tmp_path, name, 
         assert "warning" not in res.stdout
     share = _parsed_share(res.stderr, world)
     assert len(share) == world and sum(s[2] for s in share.values()) == share[0][3]
+
+
+@pytest.mark.parametrize("idx", range(int(os.environ.get("LHGT_WORLD_FUZZ_FIRST", "0")),
+                                      int(os.environ.get("LHGT_WORLD_FUZZ_FIRST", "0")) + int(os.environ.get("LHGT_WORLD_FUZZ_CASES", "6"))))
+def test_random_case_with_several_ranks_matches_oracle(oracle, tmp_path, idx):
+    """the random whole runs of tests/test_gpu_fuzz.py through 2-4 PROCESSES (replicated / reference-sharded / packed by turns, every
+    third case as `-t N`): the files must be the CPU restatement's -- its `-t N` form where the product emulated the thread chunks
+    (its log says so), the `-t 1` form otherwise.  LHGT_WORLD_FUZZ_CASES / LHGT_WORLD_FUZZ_FIRST lengthen / move the run."""
+    import numpy as np
+    from test_gpu_fuzz import _make_case
+    g, c = tmp_path / "gpu", tmp_path / "cpu"
+    g.mkdir()
+    k, e, seed, sample, hit, match, max_peak = _make_case(5000 + idx, str(g))
+    shutil.copytree(g, c, dirs_exist_ok=True)
+    world = 2 + idx % 3
+    mode = list(MODES)[idx % 3]
+    threads = 2 + idx % 7 if idx % 3 == 2 else 1
+    argv = [str(g / "s.1.fq"), str(g / "s.2.fq"), str(g / "ref.fa"), str(g / "i.txt"), repr(hit), repr(match), str(threads), str(k),
+            str(max_peak), str(e), str(seed), repr(sample)]
+    env = {kk: v for kk, v in os.environ.items() if kk not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "LHGT_EMULATE_THREADS",
+                                                                "LHGT_REF_FORM", "LHGT_SHARD_INDEX")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", LHGT_INGEST_CHUNK_BYTES="20000", **MODES[mode])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bin", "extract_ref")] + argv
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    o = (str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(hit)), float(np.float32(match)))
+    emulated = threads > 1 and "reproducing the reference's -t" in res.stdout and "giving the -t 1 result" not in res.stdout
+    if emulated:
+        rc, orep = oracle.run_threads(*o, threads, k, max_peak, e, seed, sample)
+    else:
+        rc, orep = oracle.run(*o, 1, k, max_peak, e, seed, sample)
+    if res.returncode != 0:                       # refused on the GPU side: the restatement of the same -t must refuse too
+        rc_t = oracle.run_threads(*o, threads, k, max_peak, e, seed, sample)[0] if threads > 1 else rc
+        assert rc != 0 or rc_t != 0, (res.returncode, rc, rc_t, mode, world, threads, k, e, sample, res.stderr[-1500:])
+        return
+    assert rc == 0, (rc, mode, world, threads, k, e, sample, res.stdout[-800:])
+    names = ("i.txt", "ref.fa.genome.len.txt") + (() if mode == "packed" else (f"ref.fa.k{k}.h{e}.index.dat",))
+    for name in names:
+        assert open(g / name, "rb").read() == open(c / name, "rb").read(), (name, mode, world, threads, k, e, seed, sample, hit, match)

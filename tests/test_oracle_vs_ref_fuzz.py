@@ -19,7 +19,10 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "extract_ref_z")
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/extract_ref_z not built (needs /root/reference)")
 
 
-@pytest.mark.parametrize("idx", range(16))
+N_CASES = int(os.environ.get("LHGT_REF_FUZZ_CASES", "16"))     # LHGT_REF_FUZZ_CASES=300 for a soak of the restatement against the binary
+
+
+@pytest.mark.parametrize("idx", range(N_CASES))
 def test_oracle_equals_reference_binary(oracle, tmp_path, idx):
     r, c = tmp_path / "ref", tmp_path / "cpu"
     r.mkdir()
@@ -49,7 +52,7 @@ SHIM = os.path.join(ROOT, "oracle", "_ref", "libseqthreads.so")
 
 
 @pytest.mark.skipif(not os.path.exists(SHIM), reason="oracle/_ref/libseqthreads.so not built")
-@pytest.mark.parametrize("idx", range(16))
+@pytest.mark.parametrize("idx", range(N_CASES))
 def test_oracle_thread_emulation_equals_reference_binary(oracle, tmp_path, idx):
     """-t N: the restatement's thread chunks, per-chunk sampling ordinals, contig groups, id ranges and
     per-thread sentinel lines against the reference run with its threads in creation order (oracle/seq_threads.c)"""

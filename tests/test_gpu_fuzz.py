@@ -81,6 +81,19 @@ def _make_case(idx, d, k_max=32):
     return k, e, seed, sample, hit, match, max_peak
 
 
+def _apply_variant(idx, d):
+    """every seventh case with "\\r\\n" line ends in all three files, every eleventh with empty lines between the contigs of the FASTA
+    (also used by tests/test_oracle_vs_ref_fuzz.py, which pins the restatement's handling of them on the reference binary)"""
+    for f in ("ref.fa", "s.1.fq", "s.2.fq"):
+        path = os.path.join(str(d), f)
+        body = open(path, "rb").read()
+        if idx % 7 == 6:
+            body = body.replace(b"\n", b"\r\n")
+        elif idx % 11 == 10 and f == "ref.fa":
+            body = body.replace(b"\n>", b"\n\n>")
+        open(path, "wb").write(body)
+
+
 _FIRST = int(os.environ.get("LHGT_FUZZ_FIRST", "0"))          # LHGT_FUZZ_FIRST=800 LHGT_FUZZ_CASES=1000: cases 800 .. 1799 (continue a soak)
 
 
@@ -96,13 +109,7 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     # every seventh case with "\r\n" line ends in all three files (std::getline keeps the '\r': one more non-base character per
     # line, E:761-880 and E:1014), every eleventh with empty lines between the contigs of the FASTA -- checked on the CPU against
     # the reference binary itself for the restatement (same files for -t 1 and -t 3) before they went in here
-    for f in ("ref.fa", "s.1.fq", "s.2.fq"):
-        body = open(g / f, "rb").read()
-        if idx % 7 == 6:
-            body = body.replace(b"\n", b"\r\n")
-        elif idx % 11 == 10 and f == "ref.fa":
-            body = body.replace(b"\n>", b"\n\n>")
-        open(g / f, "wb").write(body)
+    _apply_variant(idx, g)
     shutil.copytree(g, c, dirs_exist_ok=True)
     # every fifth case as `-t N` (N = 2 .. 10): the product emulates the reference's thread chunks by default and is compared with
     # the oracle's -t N restatement -- or, where the emulation refuses the input and falls back, with its -t 1 run

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from test_gpu_fuzz import _make_case
+from test_gpu_fuzz import _apply_variant, _make_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "extract_ref_z")
@@ -31,14 +31,17 @@ def test_oracle_equals_reference_binary(oracle, tmp_path, idx):
         max_peak = 100000
     if hit == 0.0 or match == 0.0:
         hit, match = max(hit, 0.05), max(match, 0.02)
+    _apply_variant(idx, r)                      # every seventh case in "\r\n" line ends, every eleventh with blank lines in the FASTA
     shutil.copytree(r, c, dirs_exist_ok=True)
     runs = 2 if idx % 3 == 0 else 1
     for _ in range(runs):
         res = subprocess.run([REF_BIN, "s.1.fq", "s.2.fq", "ref.fa", "i.txt", repr(hit), repr(match), "1", str(k), str(max_peak), str(e),
                               str(seed), repr(sample)], cwd=r, capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-500:]
         rc, orep = oracle.run(str(c / "s.1.fq"), str(c / "s.2.fq"), str(c / "ref.fa"), str(c / "i.txt"), float(np.float32(hit)),
                               float(np.float32(match)), 1, k, max_peak, e, seed, sample)
+        if idx % 7 == 6 and rc in (-4, -6):     # a SAMPLED line of more than 500 characters (500 bases + "\r"): the reference writes past
+            return                              # its stack buffers (by one entry it survives, by more it aborts), the restatement refuses
+        assert res.returncode == 0, res.stderr[-500:]
         assert rc == 0
     raw = re.findall(r"No\. of raw BKPs: (\d+)", res.stdout)   # absent when no contig is longer than k (no scan thread starts)
     assert (int(raw[-1]) if raw else 0) == orep.n_peaks

@@ -27,6 +27,17 @@ __global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, ui
     for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); nz += __shfl_xor(nz, d, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)acc); atomicAdd(out + 1, (unsigned long long)nz); }
 }
+// probes of phase B's lite / trio-first forms, read off the per-position probe-state bytes (k_scan.hip: pstate = hashes that read 3
+// in bits 0-2, hashes PROBED in bits 4-6): sum of popcount(bits 4-6) over the positions that have a k-mer
+__global__ void __launch_bounds__(256) pstate_probe_sum(const uint8_t* __restrict__ ps, uint64_t n, unsigned long long* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (; i < n; i += stride) acc += (unsigned long long)__popc((uint32_t)(ps[i] >> 4) & 7u);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
 }  // namespace lhgt
 
 #include <mutex>
@@ -45,6 +56,27 @@ void* big_take(int device, size_t bytes) {
             return p;
         }
     return nullptr;
+}
+bool big_release_all() {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    bool any = false;
+    for (;;) {
+        void* p = nullptr;
+        int dev = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_big_mu);
+            if (g_big.empty()) break;
+            p = g_big.back().p;
+            dev = g_big.back().device;
+            g_big.pop_back();
+        }
+        hipSetDevice(dev);
+        hipFree(p);
+        any = true;
+    }
+    if (any && have_cur) hipSetDevice(cur);
+    return any;
 }
 void big_give(int device, size_t bytes, void* p) {
     if (!p) return;
@@ -76,7 +108,7 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
     }
     out[0] = out[1] = 0;
     if (!p || !n) return LHGT_OK;
-    if (!ctx->d_digest) LHGT_HIP(hipMalloc(&ctx->d_digest, 16));     // one small scratch per context, freed with it
+    if (!ctx->d_digest) LHGT_HIP(lhgt::dev_malloc(&ctx->d_digest, 16));     // one small scratch per context, freed with it
     unsigned long long* d_out = ctx->d_digest;
     LHGT_HIP(hipMemsetAsync(d_out, 0, 16, ctx->stream));
     if (bytes == 1) hipLaunchKernelGGL((digest_kernel<uint8_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint8_t*)p, n, mask, d_out);
@@ -87,6 +119,48 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
     if (e1 != hipSuccess || e2 != hipSuccess) LHGT_FAIL(LHGT_E_HIP, "digest copy failed");
     out[0] = h[0];
     out[1] = h[1];
+    return LHGT_OK;
+}
+
+// Work counters for bench.py's "bytes the implemented algorithm must move" (DESIGN.md 5).  enable = 1: start counting from zero;
+// 0: stop; -1: leave as it is.  out (nullable) receives
+//   [0] keys routed by phase A (valid k-mers x e of the counted mates; the direct kernel reports the upper bound k-mer positions x e)
+//   [1] table probes of phase B's probe kernel in the LAST lhgt_ref_scan: e per position with a k-mer in the exact form, the hashes
+//       marked as probed in the per-position state bytes in the lite / trio-first forms (the fill of the few unsettled tiles included:
+//       an upper bound of ref_flags_lite / ref_flags_trio themselves)
+//   [3] probes that went on from the LDS fold to the L2 bitmap (vote_kernel_fold), [4] probes that went on from the bitmap to peak_kmer
+//       (vote_kernel_queued / vote_kernel_fold), [5] pairs voted in the lane-per-offset form after the filters (deferred / re-voted)
+//   [2], [6], [7] reserved (0).
+int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || enable < -1 || enable > 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (enable == 1) {
+        if (!ctx->d_stats) LHGT_HIP(lhgt::dev_malloc(&ctx->d_stats, 64));
+        LHGT_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
+        memset(ctx->stats_host, 0, sizeof ctx->stats_host);
+        ctx->stats_on = true;
+    } else if (enable == 0) ctx->stats_on = false;
+    if (!out) return LHGT_OK;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!ctx->d_stats) return LHGT_OK;
+    // phase B: from the state the last scan left behind
+    unsigned long long probes_b = 0;
+    if (ctx->n_peaks >= 0 && ctx->index_resident) {
+        if (ctx->scan_form == 0) {
+            for (const ContigDev& c : ctx->contigs) probes_b += (unsigned long long)(c.len >= (uint32_t)ctx->k ? c.len - ctx->k + 1 : 0) * ctx->e;
+        } else if (ctx->d_nzmask && ctx->n_pos) {
+            if (!ctx->d_digest) LHGT_HIP(lhgt::dev_malloc(&ctx->d_digest, 16));
+            LHGT_HIP(hipMemsetAsync(ctx->d_digest, 0, 16, ctx->stream));
+            hipLaunchKernelGGL(pstate_probe_sum, dim3(8192), dim3(256), 0, ctx->stream, ctx->d_nzmask, ctx->n_pos, ctx->d_digest);
+            LHGT_HIP(hipMemcpyAsync(&probes_b, ctx->d_digest, 8, hipMemcpyDeviceToHost, ctx->stream));
+            LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    unsigned long long h[8];
+    LHGT_HIP(hipMemcpyAsync(h, ctx->d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; i++) out[i] = h[i] + ctx->stats_host[i];
+    out[1] = probes_b;
     return LHGT_OK;
 }
 
@@ -132,7 +206,7 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     if (he == hipSuccess) he = hipEventCreate(&c->ev1);
     if (he == hipSuccess) he = hipEventCreate(&c->ev2);
     if (he == hipSuccess) he = hipEventCreate(&c->ev3);
-    if (he == hipSuccess) he = hipMalloc(&c->d_counts, c->counts_words * 4);
+    if (he == hipSuccess) he = lhgt::dev_malloc(&c->d_counts, c->counts_words * 4);
     if (he == hipSuccess) he = hipMemsetAsync(c->d_counts, 0, c->counts_words * 4, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) {
@@ -156,7 +230,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],
-                    (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_revote, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest})
+                    (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_revote, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest, (void*)c->d_stats})
         if (p) hipFree(p);
     lhgt::big_give(c->device, ((size_t)1 << c->k) * 4, c->d_peak_kmer);   // kept for the next context of this process, or freed
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -171,19 +245,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
 }
 
 int lhgt_pool_trim(void) {
-    for (;;) {
-        void* p = nullptr;
-        int dev = 0;
-        {
-            std::lock_guard<std::mutex> lk(lhgt::g_big_mu);
-            if (lhgt::g_big.empty()) break;
-            p = lhgt::g_big.back().p;
-            dev = lhgt::g_big.back().device;
-            lhgt::g_big.pop_back();
-        }
-        hipSetDevice(dev);
-        hipFree(p);
-    }
+    lhgt::big_release_all();
     return LHGT_OK;
 }
 

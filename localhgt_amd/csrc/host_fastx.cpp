@@ -1428,7 +1428,7 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
                 if (d_out) hipFree(d_out);
                 d_out = nullptr;
                 d_cap = out_words + out_words / 4;
-                LHGT_HIP(hipMalloc(&d_out, d_cap * 4));
+                LHGT_HIP(lhgt::dev_malloc(&d_out, d_cap * 4));
             }
             LHGT_TRY(hash_span_dev_ascii(ctx, d_bases, n_bases_span, coff, ow.data(), n_c, d_out));
             host.resize(out_words);

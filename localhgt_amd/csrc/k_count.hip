@@ -115,6 +115,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
         long blocks = (waves + 3) / 4;
         if (blocks > 256L * 8 * 4) blocks = 256L * 8 * 4;
         hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0);
+        if (ctx->stats_on) ctx->stats_host[0] += b.n_kmers * (unsigned long long)ctx->e;   // lhgt_work_stats: upper bound (k-mers with an N are skipped)
     }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -205,7 +206,7 @@ int lhgt_counts_export_u8(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, 
     if (first_slot + n_slots > total) LHGT_FAIL(LHGT_E_ARG, "slot range outside the table");
     const uint64_t CH = 1ull << 28;
     uint8_t* d_tmp;
-    LHGT_HIP(hipMalloc(&d_tmp, n_slots < CH ? n_slots : CH));
+    LHGT_HIP(lhgt::dev_malloc(&d_tmp, n_slots < CH ? n_slots : CH));
     for (uint64_t o = 0; o < n_slots; o += CH) {
         uint64_t n = n_slots - o < CH ? n_slots - o : CH;
         hipLaunchKernelGGL(counts_expand_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_counts,
@@ -222,7 +223,7 @@ int lhgt_counts_histogram(lhgt_ctx* ctx, uint64_t out[4]) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     unsigned long long* d_h;
-    LHGT_HIP(hipMalloc(&d_h, 32));
+    LHGT_HIP(lhgt::dev_malloc(&d_h, 32));
     LHGT_HIP(hipMemsetAsync(d_h, 0, 32, ctx->stream));
     uint64_t slots = 1ull << ctx->k;
     uint64_t in_last = slots % 16 ? slots % 16 : 16;

@@ -569,6 +569,15 @@ __global__ void __launch_bounds__(PA) part_apply(const void* __restrict__ keys_v
     for (int i = threadIdx.x; i < words; i += PA) T[i] = slice[i];
 }
 
+// lhgt_work_stats: keys the read scatter sent to the level-1 segments of this chunk (every key, also those that found their
+// region full and went straight to the table)
+__global__ void __launch_bounds__(256) part_sum_cursors(const uint32_t* __restrict__ cur1, int n, unsigned long long* __restrict__ out) {
+    unsigned long long v = (int)threadIdx.x < n ? cur1[threadIdx.x] : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
 }  // namespace lhgt
 
 using namespace lhgt;
@@ -594,12 +603,12 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         for (int i = 0; i < 2; i++) {
             if (ctx->d_part_keys[i]) hipFree(ctx->d_part_keys[i]);
             ctx->d_part_keys[i] = nullptr;
-            LHGT_HIP(hipMalloc(&ctx->d_part_keys[i], need * (i == 0 ? 4 : 2) + 64));   // level-1 keys are 32-bit, final keys 16-bit
+            LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_keys[i], need * (i == 0 ? 4 : 2) + 64));   // level-1 keys are 32-bit, final keys 16-bit
         }
         ctx->part_keys_cap = need;
     }
     const long chunk_pairs = want;
-    if (!ctx->d_part_meta) LHGT_HIP(hipMalloc(&ctx->d_part_meta, (size_t)(65536 + 256) * 4));
+    if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(65536 + 256) * 4));
     uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket
     uint32_t* cur1 = cur2 + 65536;         // keys sent to each level-1 segment
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
@@ -619,6 +628,8 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         } else
             hipLaunchKernelGGL(part_scatter_reads, dim3(grid), dim3(PT), 0, ctx->stream, b.d, p0, np, ctx->hp, g, reads_per_tile, pc, cur1,
                                ctx->d_part_keys[0], ctx->d_counts);
+        if (ctx->stats_on && ctx->d_stats)
+            hipLaunchKernelGGL(part_sum_cursors, dim3(1), dim3(256), 0, ctx->stream, cur1, g.nb1, ctx->d_stats);
         const size_t slice_bytes = (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4;
         if (g.b2 > 0) {
             if (ctx->k == 32)

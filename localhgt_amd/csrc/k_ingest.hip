@@ -211,12 +211,12 @@ int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words) {
     if (ascii_bytes > ctx->ws_ascii_cap) {
         if (ctx->d_ws_ascii) hipFree(ctx->d_ws_ascii);
         ctx->ws_ascii_cap = ascii_bytes + ascii_bytes / 4 + 4096;
-        LHGT_HIP(hipMalloc(&ctx->d_ws_ascii, ctx->ws_ascii_cap));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_ws_ascii, ctx->ws_ascii_cap));
     }
     if (plane_words > ctx->ws_words_cap) {
         if (ctx->d_ws_words) hipFree(ctx->d_ws_words);
         ctx->ws_words_cap = plane_words + plane_words / 4 + 1024;
-        LHGT_HIP(hipMalloc(&ctx->d_ws_words, ctx->ws_words_cap * 4));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_ws_words, ctx->ws_words_cap * 4));
     }
     return LHGT_OK;
 }
@@ -420,20 +420,20 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
     uint16_t* d_len;
     uint8_t* d_cnt = nullptr;
     uint64_t *d_start, *d_word_off;
-    LHGT_HIP(hipMalloc(&d_words, words * 4 + 16));
+    LHGT_HIP(lhgt::dev_malloc(&d_words, words * 4 + 16));
     b.alloc[0] = d_words;
-    LHGT_HIP(hipMalloc(&d_off32, (size_t)2 * n * 4));
+    LHGT_HIP(lhgt::dev_malloc(&d_off32, (size_t)2 * n * 4));
     b.alloc[1] = d_off32;
-    LHGT_HIP(hipMalloc(&d_len, (size_t)2 * n * 2));
+    LHGT_HIP(lhgt::dev_malloc(&d_len, (size_t)2 * n * 2));
     b.alloc[2] = d_len;
     if (pair_flags) {
-        LHGT_HIP(hipMalloc(&d_cnt, (size_t)n));
+        LHGT_HIP(lhgt::dev_malloc(&d_cnt, (size_t)n));
         b.alloc[3] = d_cnt;
         LHGT_HIP(hipMemcpyAsync(d_cnt, pair_flags, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     }
-    LHGT_HIP(hipMalloc(&d_start, (size_t)2 * n * 8));
+    LHGT_HIP(lhgt::dev_malloc(&d_start, (size_t)2 * n * 8));
     b.alloc[4] = d_start;
-    LHGT_HIP(hipMalloc(&d_word_off, (size_t)2 * n * 8));
+    LHGT_HIP(lhgt::dev_malloc(&d_word_off, (size_t)2 * n * 8));
     b.alloc[5] = d_word_off;
     LHGT_HIP(hipMemcpyAsync(d_start, start, (size_t)2 * n * 8, hipMemcpyHostToDevice, ctx->stream));
     LHGT_HIP(hipMemcpyAsync(d_word_off, word_off.data(), word_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -494,7 +494,7 @@ int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPair
     // one allocation per batch: words | offsets | lengths | flags (the allocator call is not free, and a file has dozens of batches)
     const size_t words_b = (n_words * 4 + 16 + 255) & ~(size_t)255, off_b = ((size_t)2 * n * 4 + 255) & ~(size_t)255, len_b = ((size_t)2 * n * 2 + 255) & ~(size_t)255;
     uint8_t* blk = nullptr;
-    LHGT_HIP(hipMalloc(&blk, words_b + off_b + len_b + (size_t)n));
+    LHGT_HIP(lhgt::dev_malloc(&blk, words_b + off_b + len_b + (size_t)n));
     b.alloc[0] = blk;
     uint32_t* d_words = (uint32_t*)blk;
     uint32_t* d_off32 = (uint32_t*)(blk + words_b);
@@ -505,7 +505,7 @@ int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPair
         if (ctx->d_ingest_start) hipFree(ctx->d_ingest_start);
         ctx->d_ingest_start = nullptr;
         ctx->ingest_start_cap = need + need / 4;
-        LHGT_HIP(hipMalloc(&ctx->d_ingest_start, (size_t)ctx->ingest_start_cap * 4));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_ingest_start, (size_t)ctx->ingest_start_cap * 4));
     }
     hipStream_t st = ctx->stream;
     ChunkDesc* d_desc = (ChunkDesc*)(ctx->d_ingest_start + 2 * n);
@@ -604,19 +604,19 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     if (ctx->contigs.empty()) return LHGT_OK;
     if (ctx->ref_packed) {
         ctx->ref_plane_words = (size_t)((flat + 31) / 32) + 2;    // a window is cut from two consecutive words
-        LHGT_HIP(hipMalloc(&ctx->d_ref_planes, 3 * ctx->ref_plane_words * 4));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_ref_planes, 3 * ctx->ref_plane_words * 4));
         LHGT_HIP(hipMemsetAsync(ctx->d_ref_planes, 0, 3 * ctx->ref_plane_words * 4, ctx->stream));
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
     } else {
-        LHGT_HIP(hipMalloc(&ctx->d_index, word * 4));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_index, word * 4));
     }
-    LHGT_HIP(hipMalloc(&ctx->d_contigs, ctx->contigs.size() * sizeof(ContigDev)));
-    LHGT_HIP(hipMalloc(&ctx->d_tiles, tiles.size() * sizeof(TileDev)));
-    LHGT_HIP(hipMalloc(&ctx->d_flags, flat));
-    LHGT_HIP(hipMalloc(&ctx->d_nzmask, flat));
-    LHGT_HIP(hipMalloc(&ctx->d_tile_good, tiles.size() + 8));
-    LHGT_HIP(hipMalloc(&ctx->d_active_tiles, (tiles.size() + 1) * 4));
-    LHGT_HIP(hipMalloc(&ctx->d_tile_count, (tiles.size() + 16) * 4));  // counts, total, then small counters (selected positions, active tiles, saturated lines)
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_contigs, ctx->contigs.size() * sizeof(ContigDev)));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_tiles, tiles.size() * sizeof(TileDev)));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_flags, flat));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_nzmask, flat));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_tile_good, tiles.size() + 8));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_active_tiles, (tiles.size() + 1) * 4));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_tile_count, (tiles.size() + 16) * 4));  // counts, total, then small counters (selected positions, active tiles, saturated lines)
     LHGT_HIP(hipMemcpyAsync(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice, ctx->copy_stream));
     LHGT_HIP(hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice, ctx->copy_stream));
     LHGT_HIP(hipStreamSynchronize(ctx->copy_stream));
@@ -712,8 +712,8 @@ int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* 
     if (nk <= 0) return LHGT_OK;
     uint32_t* d_out;
     uint8_t* d_valid;
-    LHGT_HIP(hipMalloc(&d_out, (size_t)nk * ctx->e * 4));
-    LHGT_HIP(hipMalloc(&d_valid, (size_t)nk));
+    LHGT_HIP(lhgt::dev_malloc(&d_out, (size_t)nk * ctx->e * 4));
+    LHGT_HIP(lhgt::dev_malloc(&d_valid, (size_t)nk));
     int rc = hash_contig_to_device(ctx, ascii, len, d_out, d_valid);
     if (rc == LHGT_OK) {
         hipMemcpyAsync(out_hash, d_out, (size_t)nk * ctx->e * 4, hipMemcpyDeviceToHost, ctx->stream);

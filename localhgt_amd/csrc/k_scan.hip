@@ -910,7 +910,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     const size_t n_lines = ctx->counts_words / 16;
     unsigned long long* d_nsat = (unsigned long long*)(ctx->d_tile_count + ((ctx->n_tiles + 2) & ~1L)) + 2;   // [2], then the need count
     if (n_lines >= 64 && !(ctx->debug & 64)) {
-        if (!ctx->d_satline) LHGT_HIP(hipMalloc(&ctx->d_satline, n_lines / 8 + 16));
+        if (!ctx->d_satline) LHGT_HIP(lhgt::dev_malloc(&ctx->d_satline, n_lines / 8 + 16));
         LHGT_HIP(hipMemsetAsync(d_nsat, 0, 16, ctx->stream));
         const size_t want = (n_lines + 255) / 256;
         hipLaunchKernelGGL(table_line_summary, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, ctx->stream, ctx->d_counts, n_lines,
@@ -1127,7 +1127,7 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     if (!ctx->d_peak_kmer) {
         const auto t0 = std::chrono::steady_clock::now();
         ctx->d_peak_kmer = (uint32_t*)big_take(ctx->device, slots * 4);    // a closed context's table on this device, if the process has one
-        if (!ctx->d_peak_kmer) LHGT_HIP(hipMalloc(&ctx->d_peak_kmer, slots * 4));
+        if (!ctx->d_peak_kmer) LHGT_HIP(lhgt::dev_malloc(&ctx->d_peak_kmer, slots * 4));
         if (getenv("LHGT_TRACE"))
             fprintf(stderr, "[lhgt] peak_kmer: %.1f GiB taken or allocated in %.3f s\n", (double)(slots * 4) / (1ull << 30),
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1152,8 +1152,8 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] peaks %u, registered positions %llu (%llu k-mers), prefilter 2^%d bits %s\n", total, n_selected, n_keys, pf_bits, ctx->prefilter_on ? "on" : "off");
     if (ctx->prefilter_on) {
         if (!ctx->d_prefilter) {
-            LHGT_HIP(hipMalloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
-            LHGT_HIP(hipMalloc(&ctx->d_prefilter_fold, (size_t)128 * 1024));
+            LHGT_HIP(lhgt::dev_malloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
+            LHGT_HIP(lhgt::dev_malloc(&ctx->d_prefilter_fold, (size_t)128 * 1024));
         }
         LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ((size_t)1 << pf_bits) / 8, ctx->stream));
     }
@@ -1161,8 +1161,8 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
         if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
         if (ctx->d_filter) { hipFree(ctx->d_filter); ctx->d_filter = nullptr; }
         ctx->peaks_cap = (long)total + 1 + total / 8;
-        LHGT_HIP(hipMalloc(&ctx->d_loci, (size_t)ctx->peaks_cap * 8));
-        LHGT_HIP(hipMalloc(&ctx->d_filter, (size_t)ctx->peaks_cap * 4));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_loci, (size_t)ctx->peaks_cap * 8));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_filter, (size_t)ctx->peaks_cap * 4));
     }
     LHGT_HIP(hipMemsetAsync(ctx->d_filter, 0, ((size_t)total + 1) * 4, ctx->stream));  // E:1457
     LHGT_HIP(hipMemsetAsync(ctx->d_loci, 0, ((size_t)total + 1) * 8, ctx->stream));
@@ -1273,13 +1273,13 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
         if (ctx->d_emit_loci) hipFree(ctx->d_emit_loci);
         ctx->d_emit_loci = nullptr;
         ctx->emit_loci_cap = need_loci + need_loci / 8;
-        LHGT_HIP(hipMalloc(&ctx->d_emit_loci, (size_t)ctx->emit_loci_cap * 8));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_emit_loci, (size_t)ctx->emit_loci_cap * 8));
     }
     if (need_regs > ctx->emit_regs_cap) {
         if (ctx->d_emit_regs) hipFree(ctx->d_emit_regs);
         ctx->d_emit_regs = nullptr;
         ctx->emit_regs_cap = need_regs + need_regs / 8;
-        LHGT_HIP(hipMalloc(&ctx->d_emit_regs, (size_t)ctx->emit_regs_cap * 8 + 8));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_emit_regs, (size_t)ctx->emit_regs_cap * 8 + 8));
     }
     unsigned long long* d_cnt = (unsigned long long*)(ctx->d_emit_regs + (size_t)ctx->emit_regs_cap * 2);
     LHGT_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));

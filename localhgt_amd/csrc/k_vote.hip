@@ -434,7 +434,8 @@ constexpr int VF_WAVES = 16;
 template <int EC>   // EC = 3: e known at compile time (no uniform branch per hash), 0: e <= 3 at run time
 __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                                   const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
-                                                                  int fold_words, uint32_t* __restrict__ revote, int debug, uint32_t pf_mask, int pf2) {
+                                                                  int fold_words, uint32_t* __restrict__ revote, int debug, uint32_t pf_mask, int pf2,
+                                                                  unsigned long long* __restrict__ stats /* nullable: lhgt_work_stats */) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = EC ? EC : hp.e, k = hp.k;
@@ -470,6 +471,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
     // (A pair deferred here AND by an overflow would be voted twice: an overflowing pair never enters this queue.)
     uint32_t pend_h = 0u, pend_p = 0u;
     int n_pend = 0;
+    unsigned long long st_l2 = 0, st_hbm = 0;   // wave-uniform: probes sent on to the L2 bitmap / to peak_kmer
     auto flush_pending = [&]() {
         const bool hit = lane < n_pend && peak_kmer[pend_h] != 0u;
         const unsigned long long hits = __ballot(hit);
@@ -547,6 +549,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
         if (T == 0) continue;
         bool defer = T > VF_Q;
         if (!defer) {
+            st_l2 += (unsigned long long)T;
             int slot = incl - c;
 #pragma unroll
             for (int s = 0; s < 4; s++)
@@ -575,6 +578,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             if (debug & 1024) T2 = 0;
             if (T2 > VF_Q2) defer = true;
             else if (T2 > 0) {
+                st_hbm += (unsigned long long)T2;
                 // third level, peak_kmer itself: not now -- that is one HBM round trip per pair in this wave's chain -- but from a
                 // wave-wide register queue of (hash, pair) that is probed when the next pair's survivors no longer fit
                 if (n_pend + T2 > 64) flush_pending();
@@ -589,6 +593,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
         if (defer && lane == 0) revote[1u + atomicAdd(revote, 1u)] = (uint32_t)p;
     }
     flush_pending();
+    if (stats && lane == 0) { atomicAdd(stats + 3, st_l2); atomicAdd(stats + 4, st_hbm); }
 }
 
 // Sparse path without the LDS fold (the usual one: bitmap exact for k <= 25, or too many k-mers for a 64 KiB fold).  One pair
@@ -605,11 +610,12 @@ constexpr int VQ_CAP = 1024, VQ_FLUSH = 512;
 __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                           const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
                                                           uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,
-                                                          uint32_t pf_mask, int pf2) {
+                                                          uint32_t pf_mask, int pf2, unsigned long long* __restrict__ stats /* nullable: lhgt_work_stats */) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
     if (wib >= waves_per_block) return;
+    unsigned long long st_hbm = 0, st_revote = 0;   // wave-uniform: probes sent on to peak_kmer, pairs voted in the lane-per-offset form
     // per wave: [queue hashes | queue tags | 64 dump words | 64 staging words of the scan] and, over the same words, the vote's
     // [events | 64 staging words]: by the time a pair is voted the queue is empty and the tags to vote sit in registers
     const int ev_words = max_ev * e * 2;
@@ -681,6 +687,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                         slot += (int)f1[s][i];
                     }
                 qn += T;
+                st_hbm += (unsigned long long)T;
             }
         }
         const bool direct = T > ((debug & 2048) ? 8 : VQ_CAP - VQ_FLUSH);   // not a sparse pair: vote it as it is (bit 11: test hook)
@@ -722,6 +729,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                 if (lane == 0) qi[nv] = it;
                 nv++;
             }
+            st_revote += (unsigned long long)nv;
             __builtin_amdgcn_wave_barrier();
             uint32_t vt[VQ_CAP / 64];   // the tags leave LDS: the events below are written over the queue
 #pragma unroll
@@ -789,6 +797,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
         }
         if (!live) break;
     }
+    if (stats && lane == 0) { atomicAdd(stats + 4, st_hbm); atomicAdd(stats + 5, st_revote); }
 }
 
 // fold of the 2^pf_bits-bit bitmap onto fold_words words (64 or 128 KiB): word w = OR of the bitmap words w, w + fold_words, ... (same low address bits)
@@ -799,6 +808,8 @@ __global__ void __launch_bounds__(256) fold_prefilter(const uint32_t* __restrict
     for (int j = w; j < words; j += fold_words) acc |= prefilter[j];
     fold[w] = acc;
 }
+
+__global__ void stats_add_u32(const uint32_t* __restrict__ v, unsigned long long* __restrict__ out) { atomicAdd(out, (unsigned long long)*v); }
 
 // phase D helper: peaks with at least MIN_READS (1, E:37) votes, as (id, contig, pos) in any order;
 // the host sorts the few survivors by id, which is the order count_filtered_peak walks them (E:525).
@@ -825,6 +836,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan must precede lhgt_vote");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    unsigned long long* d_stats = ctx->stats_on ? ctx->d_stats : nullptr;
     for (const ReadBatch& b : ctx->batches) {
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
@@ -871,7 +883,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (ctx->revote_cap < need) {
                 if (ctx->d_revote) LHGT_HIP(hipFree(ctx->d_revote));
                 ctx->d_revote = nullptr;
-                LHGT_HIP(hipMalloc(&ctx->d_revote, need * 4));
+                LHGT_HIP(lhgt::dev_malloc(&ctx->d_revote, need * 4));
                 ctx->revote_cap = need;
             }
             LHGT_HIP(hipMemsetAsync(ctx->d_revote, 0, 4, ctx->stream));
@@ -883,15 +895,16 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (fb > 256) fb = 256;             // one resident workgroup per CU
             if (ctx->e == 3)
                 hipLaunchKernelGGL(vote_kernel_fold<3>, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
-                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2);
+                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
             else
                 hipLaunchKernelGGL(vote_kernel_fold<0>, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
-                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2);
+                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
             // the deferred pairs, from scratch in the lane-per-offset form (hits in offset order for the judge); the list's length
             // is read on the device
             hipLaunchKernelGGL((vote_kernel<4, 1, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
                                ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2,
                                (const uint32_t*)ctx->d_revote);
+            if (d_stats) hipLaunchKernelGGL(stats_add_u32, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)ctx->d_revote, d_stats + 5);
             if (getenv("LHGT_TRACE")) {
                 uint32_t n_def = 0;
                 LHGT_HIP(hipMemcpyAsync(&n_def, ctx->d_revote, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -915,7 +928,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256L * 16) blocks = 256L * 16;
             hipLaunchKernelGGL(vote_kernel_queued, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                               ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2);
+                               ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);
@@ -978,7 +991,7 @@ int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
         for (int attempt = 0; attempt < 2; attempt++) {
             if (!ctx->d_voted) {
                 if (cap < 4096) cap = 4096;
-                LHGT_HIP(hipMalloc(&ctx->d_voted, (size_t)cap * 12 + 8));
+                LHGT_HIP(lhgt::dev_malloc(&ctx->d_voted, (size_t)cap * 12 + 8));
                 ctx->voted_cap = cap;
             }
             unsigned long long* d_cnt = (unsigned long long*)((char*)ctx->d_voted + (size_t)ctx->voted_cap * 12);

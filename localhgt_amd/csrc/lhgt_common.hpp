@@ -195,6 +195,11 @@ struct lhgt_ctx {
     bool count_compat = false;               // count_diff_kmer.cpp's bool coder (lhgt_set_count_compat)
     int count_mode = -1;       // -1 = by k (partition from k >= 26), 0 = direct CAS kernel, 1 = radix partition
     unsigned long long* d_digest = nullptr;   // 16 bytes: lhgt_digest's accumulator
+    // lhgt_work_stats: while enabled, phase A adds up the keys it routes and the sparse vote kernels the probes that go on to the next
+    // filter level (8 x u64 on the device; null = off, the kernels then issue no extra instruction but a scalar add per pair)
+    unsigned long long* d_stats = nullptr;
+    bool stats_on = false;
+    unsigned long long stats_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // contributions known on the host (direct count kernel: upper bound of its keys)
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // FASTQ loader (host_fastx.cpp): pinned slabs the parse threads write into (bases + per-pair records), pinned chunk descriptors of the open batch,
     // events that tell when a slab's copy has left the host
@@ -227,6 +232,18 @@ void sampling_join(lhgt_ctx* ctx);   // waits for a fill started by lhgt_samplin
 void* big_take(int device, size_t bytes);
 void big_give(int device, size_t bytes, void* p);
 constexpr size_t BIG_BUFFER_MIN = (size_t)4 << 30;
+bool big_release_all();   // frees every parked table; true if there was one
+// hipMalloc that returns the process's parked tables to the device before it reports out-of-memory (a 16 GiB table kept for a next
+// context must never be the reason a 156 GB index does not fit)
+template <class T>
+inline hipError_t dev_malloc(T** p, size_t bytes) {
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e == hipErrorOutOfMemory && big_release_all()) {
+        (void)hipGetLastError();
+        e = hipMalloc((void**)p, bytes);
+    }
+    return e;
+}
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
                  long n_pairs, const uint8_t* pair_flags);
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index = 1);  // allocates d_index, tiles, flags

@@ -22,6 +22,7 @@ methods stage every collective through host memory -- device buffer -> host -> g
 from __future__ import annotations
 
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -105,10 +106,15 @@ class Exchange:
         if backend is None:
             backend = os.environ.get("LHGT_DIST_BACKEND")
         n_dev = torch.cuda.device_count()
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
         if backend is None:
-            # RCCL wants one GPU per rank; ranks that share a GPU exchange through host memory over gloo
-            backend = "gloo" if n_dev == 0 or local_world > n_dev else "nccl"
+            # RCCL wants one GPU per rank; ranks that share a GPU exchange through host memory over gloo.  Only what the launcher
+            # really said counts: LOCAL_WORLD_SIZE when it is set (torchrun sets it; srun, mpirun or hand-set RANK/WORLD_SIZE do not,
+            # and WORLD_SIZE over several nodes says nothing about this node), or a LOCAL_RANK beyond the node's GPUs
+            shared = n_dev == 0 or local >= n_dev or ("LOCAL_WORLD_SIZE" in os.environ and int(os.environ["LOCAL_WORLD_SIZE"]) > n_dev)
+            backend = "gloo" if shared else "nccl"
+            if shared and n_dev and rank == 0:
+                print(f"localhgt_amd.dist: more ranks than GPUs on this node ({n_dev}): collectives staged through host memory over gloo "
+                      f"(results identical, exchanges much slower); LHGT_DIST_BACKEND=nccl to insist on RCCL", file=sys.stderr, flush=True)
         if n_dev:
             device = local % n_dev
         return cls(rank, world, local, backend, adapter, device=device)
@@ -231,7 +237,13 @@ class Exchange:
         emulated_threads > 1 (the reference's -t N, lhgt_set_thread_emulation): the contig groups of split_ref cut across the
         ranks' shards, so the per-group peak counts are summed over the ranks first -- they fix each thread's id range, the
         sentinel lines of the interval file and whether a peak holds the invisible id 0 (first_id)."""
-        n_new, n_sel = self.adapter.scan_local(eng, hit_ratio, match_ratio)
+        err = None
+        try:
+            n_new, n_sel = self.adapter.scan_local(eng, hit_ratio, match_ratio)
+        except Exception as e:                             # noqa: BLE001 -- a rank that failed alone must not leave the others in the gather below
+            err = e
+        if self.agree(1 if err else 0):
+            raise err if err else RuntimeError(f"reference-sharded scan failed on another rank (rank {self.rank} stops with it)")
         allc = self._gather_small([n_new, n_sel])
         news = [c[0] for c in allc]
         first_id = 0

@@ -16,6 +16,11 @@ def _ptr(a: np.ndarray, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+def pool_trim() -> None:
+    """free the tables that closed contexts left parked for reuse (include/localhgt_hip.h: lhgt_pool_trim)"""
+    _lib.check(_lib.load(require_gpu=False).lhgt_pool_trim())
+
+
 class Engine:
     def __init__(self, k: int, e: int, device: int = 0):
         self.lib = _lib.load(require_gpu=(device >= 0))  # device -1 = host-only context (RNG/coder rows)
@@ -26,6 +31,9 @@ class Engine:
         self.emulated_threads = 1
 
     def close(self):
+        """frees the context.  One thing outlives it: a peak_kmer table of 4 GiB or more (16 GiB at k = 32) is parked for the next
+        context of this process on the same device (hipMalloc of 16 GiB right after such a free took up to 2 s); it is handed back
+        by `localhgt_amd.engine.pool_trim()`, and by itself whenever a device allocation would otherwise run out of memory"""
         if getattr(self, "h", None):
             self.lib.lhgt_ctx_destroy(self.h)
             self.h = None
@@ -171,6 +179,8 @@ class Engine:
         _, counts, sums = plan
         line0 = np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else np.zeros(0, dtype=np.int64)
         bases = int(sums[np.arange(len(counts)), (1 - line0) % 4].sum()) if len(counts) else 0
+        if bases == 0:               # an empty fq1 (or only empty sequence lines): the reference divides by zero in floating point
+            return float("inf")      # (E:1266) and keeps every read; so does lhgt_fastq_sam_ratio
         return 100.0 * sample / (2.0 * bases)
 
     def pairs_load_fastq_planned(self, fq1: str, fq2: str, ratio_percent: float, plan1, plan2, part: int, parts: int) -> Tuple[int, int]:
@@ -223,8 +233,13 @@ class Engine:
                                                  None if host is None else _ptr(host, C.c_uint8)))
         return host
 
-    def synth_reference_shard(self, ref_seed: int, n_contigs: int, contig_len: int, rank: int, world: int):
-        _lib.check(self.lib.lhgt_synth_reference_shard(self.h, ref_seed, n_contigs, contig_len, rank, world, None))
+    def synth_reference_shard(self, ref_seed: int, n_contigs: int, contig_len: int, rank: int, world: int, want_host: bool = False):
+        """contigs [n_contigs*rank/world, n_contigs*(rank+1)/world) of the synthetic reference become the resident shard"""
+        n = n_contigs * (rank + 1) // world - n_contigs * rank // world
+        host = np.zeros(n * contig_len, dtype=np.uint8) if want_host else None
+        _lib.check(self.lib.lhgt_synth_reference_shard(self.h, ref_seed, n_contigs, contig_len, rank, world,
+                                                       None if host is None else _ptr(host, C.c_uint8)))
+        return host
 
     def synth_reference_cuts(self, ref_seed: int, n_contigs: int, contig_len: int, cuts: np.ndarray, want_host: bool = False):
         """the same base stream as synth_reference, cut into contigs at `cuts` (ascending, 0 .. n_contigs*contig_len)"""
@@ -341,6 +356,14 @@ class Engine:
         _lib.check(self.lib.lhgt_scan_info(self.h, C.byref(lite), C.byref(frac), C.byref(nt), C.byref(ne)))
         return {"lite": lite.value == 1, "form": ("exact", "single-first", "trio-first")[lite.value], "frac_slots_at_3": round(frac.value, 4),
                 "tiles": nt.value, "tiles_exact": ne.value}
+
+    WORK_STATS = ("count_keys", "scan_probes", None, "vote_l2_probes", "vote_hbm_probes", "vote_revoted_pairs", None, None)
+
+    def work_stats(self, enable: int = -1) -> dict:
+        """work counters of the phases run since work_stats(1) (include/localhgt_hip.h: lhgt_work_stats); measurement only"""
+        out = np.zeros(8, dtype=np.uint64)
+        _lib.check(self.lib.lhgt_work_stats(self.h, int(enable), _ptr(out, C.c_uint64)))
+        return {name: int(v) for name, v in zip(self.WORK_STATS, out) if name}
 
     def synchronize(self):
         _lib.check(self.lib.lhgt_synchronize(self.h))

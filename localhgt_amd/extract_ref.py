@@ -86,10 +86,17 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     produced (under sampling the kept reads, and with them the .bed, differ between -t 1 and -t N, E:1037).  Where the emulation
     refuses an input -- one on which the reference reads stale bytes or overruns a thread's id range -- the run falls back to
     the -t 1 result with one warning line."""
-    from ._lib import LocalHGTError
-    rank, world = (dist.rank, dist.world) if dist else (0, 1)
     t0 = time.time()
     eng = Engine(a.k, a.e, device)
+    try:
+        return _run(eng, a, t0, dist, log, emulate_threads, ref_form)
+    finally:
+        eng.close()      # also on an error: a long-lived caller must not keep a 16 GiB peak_kmer table (and the reads) per failed call
+
+
+def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form) -> dict:
+    from ._lib import LocalHGTError
+    rank, world = (dist.rank, dist.world) if dist else (0, 1)
     if emulate_threads is None:
         emulate_threads = os.environ.get("LHGT_EMULATE_THREADS", "1") != "0"
     emulating = bool(emulate_threads) and a.threads > 1
@@ -162,16 +169,25 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     state = {"seen": 0, "kept": 0, "t_reads": 0.0}
 
     def everywhere(fn):
-        """fn() on this rank; a refusal by the -t N emulation is taken on every rank or on none"""
-        err = None
+        """fn() on this rank -- rank-local work only, no collective inside -- and its outcome agreed over the ranks before anyone
+        goes on: 0 fine, 1 the -t N emulation refuses the input (returned: the caller falls back on every rank), 2 any other
+        error (raised on EVERY rank: one that failed alone -- an over-long read in its byte range, a HIP error -- would otherwise
+        leave the others waiting in the next collective until the backend's timeout)"""
+        err, mine = None, 0
         try:
             fn()
         except LocalHGTError as e:
-            if not (emulating and _emulation_refused(e)):
-                raise
-            err = e
-        refused = dist.agree(1 if err else 0) if dist else (1 if err else 0)
-        return err if err else (LocalHGTError(4, "-t N emulation: refused on another rank") if refused else None)
+            err, mine = e, (1 if emulating and _emulation_refused(e) else 2)
+        except Exception as e:                                 # noqa: BLE001 -- agreed on first, re-raised below
+            err, mine = e, 2
+        worst = dist.agree(mine) if dist else mine
+        if worst == 2:
+            if mine == 2:
+                raise err
+            raise LocalHGTError(5, f"another rank failed (rank {rank} stops with it)")
+        if worst == 1:
+            return err if mine == 1 else LocalHGTError(4, "-t N emulation: refused on another rank")
+        return None
 
     def load_and_count():
         t = time.time()
@@ -181,6 +197,8 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
             state["seen"], state["kept"] = eng.pairs_load_fastq(a.fq1, a.fq2, ratio)
         state["t_reads"] = time.time() - t
         eng.count_kmers()                                      # phase A, E:1426-1448
+
+    def merge_counts():                                        # the first collective of the run: entered only once every rank has loaded
         if dist:
             dist.merge_counts(eng)
 
@@ -196,7 +214,8 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     err = everywhere(load_and_count)
     if err:
         fall_back(err)
-        load_and_count()
+        everywhere(load_and_count)
+    merge_counts()
     t2 = time.time()
     log(f"K-mer counting is finished. It costs {t2 - t0:.2f} seconds.")
     scan = {}
@@ -207,10 +226,13 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
         else:
             scan["n"] = eng.ref_scan(a.hit_ratio, a.match_ratio, a.max_peak)
 
-    err = everywhere(scan_ref)
+    # (the sharded scan holds collectives itself and agrees inside dist.sharded_scan before its first exchange; the refusals of the
+    # -t N emulation there come from global sums, the same on every rank)
+    err = _collective(scan_ref, emulating, LocalHGTError) if shard_index else everywhere(scan_ref)
     if err:                                                    # a thread's peaks overflow its id range: reads again, as -t 1 keeps them
         fall_back(err)
-        load_and_count()
+        everywhere(load_and_count)
+        merge_counts()
         scan_ref()
     n_peaks = scan["n"]
     seen, kept = state["seen"], state["kept"]
@@ -233,8 +255,19 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
                reads_s=state["t_reads"], count_s=t2 - t_r0 - state["t_reads"], scan_s=t3 - t2,
                vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
                vote_kernel_ms=eng.phase_ms(2), world=world, staged_bytes=dist.staged_bytes if dist else 0)
-    eng.close()
     return rep
+
+
+def _collective(fn, emulating, LocalHGTError):
+    """fn() holds collectives itself (the reference-sharded scan): the refusal of the -t N emulation is returned, anything else
+    propagates"""
+    try:
+        fn()
+    except LocalHGTError as e:
+        if not (emulating and _emulation_refused(e)):
+            raise
+        return e
+    return None
 
 
 def main(argv=None) -> int:

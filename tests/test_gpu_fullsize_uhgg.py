@@ -115,6 +115,37 @@ def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_
         assert 1 <= contig.min() and contig.max() <= NC
 
 
+def test_oracle_scans_contigs_at_big_addresses(eng, oracle, tmp_path):
+    """an INDEPENDENT implementation at offsets >= 2^32.  Under the headline's 100 M pairs (noise peaks on every
+    contig) the CPU restatement scans the contigs whose flat positions / index words / index bytes straddle 2^30 .. 2^37 and the
+    first and last ones, with the count table exported from the GPU, on an index it built itself from the contigs' bases: every
+    single / trio / inside / peak flag, every peak position and every registered k-mer of those contigs is the GPU's (index form)."""
+    import bigaddr
+    eng.pairs_clear()
+    eng.synth_pairs(1, 2, NC, CL, 0, 100_000_000)
+    eng.counts_clear()
+    eng.count_kmers()
+    contigs = bigaddr.boundary_contigs(NC, CL, K, E, False)
+    assert max(contigs) == NC - 1 and 4294 in contigs and 11453 in contigs and 1431 in contigs     # flat 2^32, index byte 2^37, index word 2^32
+    assert eng.reference_info()["form"] == "index"
+    checked, n_peaks, _ = bigaddr.check_against_oracle(eng, oracle, str(tmp_path), NC, CL, K, E, contigs)
+    assert checked == 2 * len(contigs) * CL and n_peaks >= 5
+
+
+def test_oracle_revotes_a_subset_of_pairs_at_full_table_size(eng, oracle, tmp_path):
+    """phase C against the 16 GiB registry of the whole 13 Gbase reference: 200 000 pairs of the 300-genome sample voted by the CPU
+    restatement with the GPU's exported peak_kmer / peak_loci == the GPU's votes of the same pairs (votes are sums over pairs)"""
+    import bigaddr
+    eng.pairs_clear()
+    eng.synth_options(0, 20, 300)
+    eng.synth_pairs(1, 2, NC, CL, 0, 25_000_000)
+    eng.synth_options(0, 20, 0)
+    eng.counts_clear()
+    eng.count_kmers()
+    _, n_peaks, n_votes = bigaddr.check_against_oracle(eng, oracle, str(tmp_path), NC, CL, K, E, [0, 1, 89, 4294, NC - 1], vote_pairs=200_000)
+    assert n_peaks > 100 and n_votes >= 1
+
+
 from localhgt_amd.synth import ragged_cuts as _ragged_cuts  # noqa: E402
 
 
@@ -162,7 +193,7 @@ def test_ragged_reference_forms_agree(eng):
         eng.synth_reference(1, NC, CL)                               # the module's other tests expect the regular reference, index form
 
 
-def test_packed_reference_equals_index_form(eng):
+def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
     """SURVEY.md 8f rank 1 at full size: the 13 Gbase reference resident as bit-planes (4.9 GB) instead of the index file's
     hashes (156 GB), hashes recomputed inside every form of B1 and in the peak registry -- the same flags, loci, peak_kmer and
     votes, table by table"""
@@ -189,6 +220,10 @@ def test_packed_reference_equals_index_form(eng):
             assert got == expect, (dbg, sinfo, got, expect)
         assert _vote(eng, 0) == want_votes
         assert _vote(eng, 4) == want_votes
+        # ... and against the CPU restatement at the plane-word addresses of 13 Gbase (tests/bigaddr.py)
+        import bigaddr
+        checked, n_peaks, _ = bigaddr.check_against_oracle(eng, oracle, str(tmp_path), NC, CL, K, E, bigaddr.boundary_contigs(NC, CL, K, E, True))
+        assert checked > 0 and n_peaks > 100
     finally:
         eng.set_reference_form(False)
         eng.synth_reference(1, NC, CL)                               # the module's other tests expect the index form

@@ -29,7 +29,7 @@ def _vote(eng, debug):
 
 
 @pytest.mark.parametrize("k", [32, 21])
-def test_progenomes_scale_reference_on_one_gpu(k):
+def test_progenomes_scale_reference_on_one_gpu(k, oracle, tmp_path):
     """BASELINE configs[4] names a reference of more than 50 GB, whose index (12 bytes per base: 600 GB) only fits sharded over
     eight GPUs.  Packed, 50 Gbase are 19 GB: the whole reference, its per-position flags and the tables fit ONE GPU.  Forms of
     the scan and of the vote against each other, as at 13 Gbase, for both ends of the config's k = 21 / 32 sweep (at k = 21 the
@@ -59,3 +59,10 @@ def test_progenomes_scale_reference_on_one_gpu(k):
         loci, _ = e.peaks_export(n_peaks)
         contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
         assert (np.diff(contig * (1 << 32) + pos) > 0).all() and contig.max() <= nc and pos.max() < CL
+        # the CPU restatement on the contigs whose plane words straddle 2^31 / 2^32 and whose flat positions straddle 2^32 .. 2^35
+        # (tests/bigaddr.py): flags, peaks and registry of those contigs; at k = 32 also the votes of 100 000 pairs
+        import bigaddr
+        contigs = bigaddr.boundary_contigs(nc, CL, k, E, True)
+        assert 37438 in contigs and 18719 in contigs and 34359 in contigs
+        checked, n_peaks, n_votes = bigaddr.check_against_oracle(e, oracle, str(tmp_path), nc, CL, k, E, contigs, vote_pairs=100_000 if k == 32 else 0)
+        assert checked == 2 * len(contigs) * CL and n_peaks >= 1

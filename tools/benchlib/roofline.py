@@ -1,0 +1,138 @@
+"""Rooflines of the three kernel families of a step against the 8 TB/s HBM peak.
+
+Two byte models per kernel, both per bench step:
+  model   SURVEY.md 8d's algorithmic bytes -- one 64-B sector per probe of the REFERENCE's algorithm (714 probes per pair in
+          phases A and C, e per reference base in phase B).  The kernels as built avoid most of those probes (radix partition,
+          L2-resident bitmap, single-first / trio-first scan), so bytes_model / time can exceed the peak: `model_exceeded`.
+  needed  the bytes the algorithm AS BUILT must move: every stream read or written once, every random probe that goes to HBM
+          one 128-B line (tools/probe_shapes.hip: a random 4-byte load is a 128-B line fill on gfx950), probes answered on-chip
+          (LDS fold, L2-resident bitmap, partition slices in LDS) nothing.  The probe and key counts are the run's own
+          (lhgt_work_stats), so needed / time / peak <= 1 by construction up to counter noise: `frac_needed`; and
+          `overfetch` = fabric bytes the counters saw / needed -- what the implementation moves beyond what its own algorithm asks.
+"""
+from .pmc import FETCH_SIZE_SCALE
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+LINE = 128                       # bytes a random probe moves (one fabric read request)
+# request-rate ceilings of the memory system, measured by tools/probe_rates.hip (profiles/r01_probe_rates_microbench.txt,
+# profiles/r02/probe_shapes_microbench.txt): random 4-byte loads that miss to HBM / that hit in L2
+CEIL_HBM_GREQ, CEIL_L2_GREQ = 56.0, 254.0
+HBM_CEILING = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 1 GiB table, 128-B line fills/s")
+L2_CEILING = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table")
+
+
+def model_bytes_per_pair(L, k, e):
+    """one 64 B sector per probe + packed bases"""
+    return 2 * (L - k + 1) * e * 64 + (2 * L + 3) // 4
+
+
+def read_store_bytes(pairs, L):
+    """what a read-side kernel streams in per step: per read the three bit-planes (ceil(L/32) + 1 words each) and its
+    descriptor (u32 offset + u16 length)"""
+    return pairs * 2 * (3 * ((L + 31) // 32 + 1) * 4 + 6)
+
+
+def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitioned, scan_form, vote_form):
+    """{family: (bytes per step, formula)} for the algorithm as built; stats = Engine.work_stats() of one step"""
+    table = (1 << k) // 4                                   # 2-bit count table
+    reads = read_store_bytes(pairs, L)
+    keys = stats.get("count_keys") or pairs * 2 * (L - k + 1) * e
+    n_chunks = -(-pairs // (4 << 20))
+    out = {}
+    if partitioned:
+        out["count_A"] = (reads + 12 * keys + n_chunks * 2 * table,
+                          f"reads {reads} + 12 B x {keys} keys (4 written + 4 read + 2 written + 2 read over the three passes) + {n_chunks} chunks x 2 x {table} B of table slices in and out")
+    else:
+        out["count_A"] = (reads + 2 * table, f"reads {reads} + the cache-resident table in and out 2 x {table}")
+    n_pos = max(0, ref_bases - n_contigs * (k - 1))          # positions with a k-mer
+    probes = stats.get("scan_probes") or n_pos * e
+    stream = ref_bases * 3 // 8 if packed else n_pos * 4 * e
+    out["ref_flags"] = (probes * LINE + stream + 2 * ref_bases,
+                        f"{probes} table probes x {LINE} B ({scan_form}: {probes / max(1, n_pos):.3f} per position) + "
+                        f"{'packed planes' if packed else 'index words'} {stream} + flag and state bytes written 2 x {ref_bases}")
+    if vote_form in ("queued", "fold"):
+        hb = stats.get("vote_hbm_probes", 0)
+        out["vote_kernel"] = (reads + hb * LINE,
+                              f"reads {reads} + {hb} probes of peak_kmer x {LINE} B ({hb / max(1, pairs):.2f} per pair survive the "
+                              f"{'LDS fold and the ' if vote_form == 'fold' else ''}L2-resident bitmap, which costs no HBM byte)")
+    else:
+        out["vote_kernel"] = (reads + keys * LINE, f"reads {reads} + {keys} probes of peak_kmer x {LINE} B (no on-chip filter: dense peak set)")
+    return out
+
+
+def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec, source, ceiling):
+    """one kernel family against the HBM peak.  frac = frac_fabric = (2 x FETCH_SIZE + WRITE_SIZE) / time / peak (every fabric read
+    request of these kernels is a 128-B line fill tallied at 64 B; an estimate of fabric bytes, Infinity-Cache hits included);
+    frac_raw = the counters as they are; frac_model / frac_needed / overfetch: see the module header."""
+    ent = {"kernel": kernel, "what": desc, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(ms_step, 3),
+           "launches_per_step": launches, "launch_ms": round(ms_step / launches, 3) if launches else None,
+           "bytes_model": model_b}
+    s = ms_step * 1e-3
+    if s <= 0:
+        return ent
+    fm = model_b / s / 1e9 / HBM_PEAK_GBS
+    ent.update({"frac_model": round(fm, 4), "model_exceeded": bool(fm > 1.0)})
+    if needed:
+        ent.update({"bytes_needed": int(needed[0]), "needed_is": needed[1], "frac_needed": round(needed[0] / s / 1e9 / HBM_PEAK_GBS, 4)})
+    if traffic_rec:
+        b = traffic_rec["bytes"]
+        ach = b / s / 1e9
+        ent.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": b // max(1, launches or 1),
+                    "traffic_per_step": b, "fetch_size_scale": FETCH_SIZE_SCALE, "traffic_source": source})
+        if needed and needed[0]:
+            ent["overfetch"] = round(b / needed[0], 3)
+        if traffic_rec.get("bytes_raw"):
+            ent["frac_raw"] = round(traffic_rec["bytes_raw"] / s / 1e9 / HBM_PEAK_GBS, 4)
+        req = traffic_rec.get(ceiling[0])
+        if req:
+            g = req / s / 1e9
+            ent["request_rate"] = {"value": round(g, 1), "unit": "G requests/s", "counter": ceiling[1], "ceiling": ceiling[2],
+                                   "frac_of_ceiling": round(g / ceiling[2], 3), "ceiling_source": ceiling[3]}
+        for key in ("l2_hit_rate", "l2_hits", "l2_misses", "hbm_read_requests", "l2_read_requests"):
+            if traffic_rec.get(key) is not None:
+                ent[key] = traffic_rec[key]
+    else:
+        ent.update({"achieved": None, "frac": None, "traffic": None,
+                    "traffic_source": "none: the rocprofv3 --pmc passes failed and profiles/traffic_per_launch.json was measured on other sources"})
+    return ent
+
+
+def vote_form_of(scan, stats, n_peaks, k):
+    """which vote kernel lhgt_vote took, from what it counted"""
+    if stats.get("vote_l2_probes"):
+        return "fold"
+    if stats.get("vote_hbm_probes") or stats.get("vote_revoted_pairs"):
+        return "queued"
+    return "dense"
+
+
+def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peaks, traffic, src, stats):
+    """entries of the three kernel families of one workload (phase A's as one), and which one dominates the step.
+    per_ms = phase_ms(0..3): A, B, C, the ref_flags kernel alone"""
+    model_pairs = model_bytes_per_pair(L, k, e) * pairs
+    model_ref = ref_bases * (64 * e) + (ref_bases // 4 if packed else ref_bases * 4 * e)   # 204 B per base / 0.25 + 192
+    n_batches = -(-pairs // (16 << 20))
+    n_chunks = -(-pairs // (4 << 20))
+    partitioned = k >= 26
+    vform = vote_form_of(scan, stats or {}, n_peaks, k)
+    need = needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats or {}, partitioned, scan["form"], vform) if stats is not None else {}
+    kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
+    scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio"}.get(scan["form"], "ref_flags")
+    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
+    info = {
+        "count_A": ("part_scatter_reads_reg+part_scatter_keys16+part_apply" if partitioned else "count_direct",
+                    f"phase A kernel family, {n_chunks} chunks of <= 4 Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
+                    model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING),
+        "ref_flags": (scan_kernel, {"single-first": "phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base",
+                                    "trio-first": "phase B on a sparse table: probes per base until a hash does not read 3"}.get(
+                                        scan["form"], "phase B: e random 2-bit table probes per reference base") + "; 1 launch per step",
+                      model_ref, 1, HBM_CEILING),
+        "vote_kernel": (vote_kernel, f"phase C read re-scan, {2 * (L - k + 1) * e} probes per pair "
+                        + {"fold": "screened by a 128 KiB LDS fold, then the L2-resident bitmap, then peak_kmer",
+                           "queued": "answered by the L2-resident bitmap except for its survivors"}.get(vform, "into peak_kmer")
+                        + f"; {n_batches} launches per step", model_pairs, n_batches, HBM_CEILING if vform == "dense" else L2_CEILING),
+    }
+    roof = {ph: roofline_entry(info[ph][0], info[ph][1], kern[ph], info[ph][3], info[ph][2], need.get(ph), traffic.get(ph) if src else None, src, info[ph][4])
+            for ph in kern}
+    dominant = max(kern, key=kern.get)                      # over A (as one entry), B's probe kernel and C
+    return roof, dominant

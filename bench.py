@@ -86,6 +86,7 @@ def parse_args(argv=None):
     ap.add_argument("--full", action="store_true", help="also the slow extras: PMC of the ragged leg, the packed e2e legs, two samples side by side")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect HBM traffic with rocprofv3 --pmc child runs")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed picked-forms-vs-exact-forms check")
+    ap.add_argument("--no-stats", action="store_true", help="skip the untimed step that counts keys and probes (the PMC children: their counters must see the timed step alone)")
     ap.add_argument("--pmc-out", default=None, help="also write the PMC summary of the headline to this JSON file")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes")
     ap.add_argument("--quiet", action="store_true", help="(PMC children) no detail file")
@@ -218,7 +219,7 @@ def main():
     wl = Workload(eng, dist, rank, world, forms[0], out_path)
 
     verify, stats = None, None
-    if world == 1 and not args.debug and not args.force_dist:
+    if world == 1 and not args.debug and not args.force_dist and not args.no_stats:
         stats = wl.stats_step()                              # untimed: the run's own key and probe counts (needed-bytes model)
         if not args.no_verify:
             verify = verify_forms(eng)

@@ -270,8 +270,11 @@ int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sam
  * second filter level (stage timing, outputs wrong); bit11: the queued sparse vote kernel votes every pair with more than 8 bitmap
  * survivors directly (exercises that branch; outputs unchanged); bit12 / bit13 / bit14: lhgt_ref_scan takes the single-first (lite) / the exact /
  * the trio-first form of its first two steps whatever the table looks like (default for e <= 3: trio-first below 45 % of the slots at 3, lite from 90 %,
- * in between exact unless a trial on a few runs of tiles favours lite; outputs unchanged); bit15: where lhgt_vote keeps a fold of the
- * bitmap in LDS, round 2's 64 KiB fold kernel with its in-kernel judge instead of the 128 KiB fold with the deferred judge (outputs unchanged).
+ * in between exact unless a trial on a few runs of tiles favours lite; outputs unchanged); bit16: phase A's partition takes round 3's
+ * sorted-tile scatters (histogram pass, shared regions, global run cursors) instead of round 4's direct form (k = 32, e = 3; outputs
+ * unchanged); bit17 / bit18: the queued sparse vote kernel reads peak_kmer / the read records with plain instead of non-temporal
+ * loads (outputs unchanged); bit19: the generic vote kernel walks every pair with six hit offsets, without the bound that proves most
+ * pairs with long event lists unable to vote (k <= 23; outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts

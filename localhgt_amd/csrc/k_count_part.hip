@@ -569,10 +569,283 @@ __global__ void __launch_bounds__(PA) part_apply(const void* __restrict__ keys_v
     for (int i = threadIdx.x; i < words; i += PA) T[i] = slice[i];
 }
 
+// =====================================================================================================================
+// Round 4: the two scatters without a histogram pass, without a scan and without a global atomic ("direct" form; k = 32, e = 3).
+//
+// What round 3's counters said (profiles/r03/sq_phase_a_after.txt): both scatters spend a quarter of their wave cycles issuing and
+// half of them waiting -- a tile goes through hashing, histogram atomics, a scan, placement atomics and a copy-out that looks every
+// key's bucket up again, with workgroup barriers between stretches that are each bound by a different unit.  Here
+//   * a tile is 256 buckets x a FIXED number of slots (128 four-byte keys in the read scatter, 192 two-byte keys in the key
+//     scatter): a key takes its slot with ONE LDS atomic right after it is hashed or loaded -- no histogram, no scan, and the
+//     keys never wait in registers for a second pass (124 -> ~64 VGPRs).  A bucket that runs over its slots (+ 4 sigma; hot
+//     k-mers) sends the key straight to the table, like a full region always did: the result stays exact;
+//   * the level-1 digit is the key's MIDDLE byte (bits 16..23), not its top byte: a hash is min(forward, reverse complement),
+//     whose density falls linearly over the TOP bits, so top-byte buckets hold from twice the mean to nothing and no fixed slot
+//     count fits them; the middle byte is uniform.  The second level sorts by the top byte (192 slots hold twice the mean of a
+//     16 Ki-key tile + 5 sigma);
+//   * every (level-1 bucket, workgroup) pair owns a PIECE of the key buffer, and ONE workgroup scatters a whole level-1 segment
+//     (= the 256 pieces of its bucket) into the segment's 256 final buckets, which nobody else writes: run cursors live in LDS,
+//     no global atomicAdd anywhere (round 3: one per bucket and tile, issued early to hide its round trip).  Consecutive runs of
+//     a piece come from the same CU, so their partial lines meet in ONE L2 and leave as full lines;
+//   * the copy-out walks a bucket per wave with the bucket's count and cursor in scalar registers: two LDS reads and stores per
+//     64 keys instead of a (delta, limit) lookup per key.
+// part_apply is unchanged: final bucket q = key >> 16 owns region part_region(q) of the 16-bit key buffer.
+constexpr int D_S1 = 128;                     // slots per bucket of the read scatter's tile: 256 x 128 x 4 B = 128 KiB
+constexpr int D_RW = 4;                       // reads per wave and tile: 64 reads, <= 22.8 K keys, 89 per bucket: 128 is + 4 sigma
+constexpr int D_S2 = 192;                     // 16-bit slots per bucket of the key scatter's tile: 256 x 192 x 2 B = 96 KiB
+constexpr int D_KPT = 16;                     // keys per thread and tile of the key scatter: 16 Ki keys, 64 per bucket, 128 for the first
+constexpr int D_GRID = 256;                   // workgroups of both scatters = level-1 buckets = pieces per bucket
+// keys a piece holds: its expected share (1 / 65536 of the chunk's keys) + 1/16 + 512, a multiple of 32 keys (128 B)
+__host__ __device__ inline uint32_t piece_keys(unsigned long long n_keys) {
+    const unsigned long long mean = n_keys / (unsigned long long)(NBK * D_GRID);
+    return (uint32_t)((mean + mean / 16 + 512ull + 31ull) & ~31ull);
+}
+
+__global__ void __launch_bounds__(1024) part_reads_direct(ReadBatchDev b, long pair0, long npairs, HashParams hp, uint32_t piece,
+                                                          uint32_t* __restrict__ cnt1 /*[bucket][workgroup]*/, uint32_t* __restrict__ out,
+                                                          uint32_t* __restrict__ counts) {
+    __shared__ uint32_t tile[NBK * D_S1];
+    __shared__ uint32_t cnt[NBK], cur[NBK];
+    __shared__ uint32_t dump[128];           // per-lane dummy counter and dummy word of the branch-free placement
+    constexpr int STAGE_W = 20;              // <= 18 record words per read on this path (<= 159 bases) + the word a window may look past
+    __shared__ uint32_t stage_all[16 * D_RW * STAGE_W];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint32_t* stage = stage_all + wib * D_RW * STAGE_W;
+    const bool r_zero = (lane & 31) == 0;    // the window starts at a word boundary: v_alignbit by 32 would give the NEXT word
+    const uint32_t sh_win = 32u - (uint32_t)(lane & 31);
+    constexpr int k = 32;
+    const long n_reads = 2 * npairs;
+    constexpr int RPT = 16 * D_RW;           // reads per tile
+    const long n_tiles = (n_reads + RPT - 1) / RPT;
+    if (threadIdx.x < NBK) { cnt[threadIdx.x] = 0; cur[threadIdx.x] = 0; }
+    int lens[D_RW];
+    uint32_t offs[D_RW], recw[D_RW];
+    auto load_descriptors = [&](long t) {        // t >= n_tiles: every length 0
+        const long r0 = t * RPT, r1 = r0 + RPT < n_reads ? r0 + RPT : n_reads;
+#pragma unroll
+        for (int rr = 0; rr < D_RW; rr++) {
+            const long r = r0 + wib + rr * 16;
+            const long rc = r < r1 ? r : (n_reads > 0 ? n_reads - 1 : 0);
+            const long p = pair0 + (rc >> 1);
+            const int m = (int)(rc & 1);
+            const int len = b.len[m][p];
+            offs[rr] = b.off[m][p];
+            const bool counted = !b.flags || ((b.flags[p] >> m) & 1);   // quirk Q4, thread-chunk emulation
+            lens[rr] = r < r1 && counted ? len : 0;
+        }
+    };
+    auto load_records = [&] {
+#pragma unroll
+        for (int rr = 0; rr < D_RW; rr++) {
+            const int wpr = ((lens[rr] + 31) >> 5) + 1;
+            recw[rr] = b.words[offs[rr] + (lane < 3 * wpr ? lane : 0)];
+        }
+    };
+    if (n_reads > 0) {
+        load_descriptors(blockIdx.x);
+        load_records();
+    }
+    __syncthreads();
+    for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        // this tile's records go to the wave's staging words; the next tile's descriptors and records fly during the hashing
+        int cl[D_RW];
+#pragma unroll
+        for (int rr = 0; rr < D_RW; rr++) {
+            cl[rr] = lens[rr];
+            stage[rr * STAGE_W + (lane < STAGE_W ? lane : 0)] = recw[rr];   // lanes >= 3 wpr hold a repeat of word 0
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_descriptors(t + gridDim.x);
+        load_records();
+        bool over = false;
+#pragma unroll
+        for (int rr = 0; rr < D_RW; rr++) {
+            const int len = cl[rr];
+            const int nk = len - k + 1;
+            if (nk <= 0) continue;                                  // wave-uniform
+            const int wpr = ((len + 31) >> 5) + 1;
+            uint32_t key[2][3];
+            bool live[2];
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int j = it * 64 + lane;
+                auto window = [&](int plane) {
+                    const uint32_t* w = stage + rr * STAGE_W + plane * wpr + 2 * it + (lane >> 5);
+                    const uint32_t w0 = w[0], w1 = w[1];
+                    const uint32_t a = __builtin_amdgcn_alignbit(w0, w1, sh_win);
+                    return r_zero ? w0 : a;
+                };
+                live[it] = j < nk && window(2) == 0;
+                const uint32_t whi = window(0), wlo = window(1);
+                const uint32_t rhi = __brev(whi), rlo = __brev(wlo);
+#pragma unroll
+                for (int i = 0; i < 3; i++) key[it][i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+            }
+            // six keys, six tickets back to back, waited for once; a dead offset (beyond the read, a k-mer with an N) draws from a
+            // per-lane dummy counter and writes a per-lane dummy word: no branch per key
+            uint32_t pos[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const uint32_t kk = key[u / 3][u % 3];
+                uint32_t* ctr = live[u / 3] ? &cnt[(kk >> 16) & 0xffu] : &dump[lane];
+                pos[u] = atomicAdd(ctr, 1u);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const uint32_t kk = key[u / 3][u % 3];
+                const bool ok = live[u / 3] && pos[u] < (uint32_t)D_S1;
+                uint32_t* dst = ok ? &tile[((kk >> 16) & 0xffu) * D_S1 + pos[u]] : &dump[64 + lane];
+                *dst = kk;
+                over |= live[u / 3] && pos[u] >= (uint32_t)D_S1;
+            }
+            if (__ballot(over)) {                                   // a bucket ran over its slots (hot k-mers): those keys go to the table now
+#pragma unroll
+                for (int u = 0; u < 6; u++)
+                    if (live[u / 3] && pos[u] >= (uint32_t)D_S1) part_sat_inc(counts, key[u / 3][u % 3]);
+                over = false;
+            }
+        }
+        __syncthreads();
+        // copy-out: wave v takes buckets 16 v .. 16 v + 15, count and cursor of each in scalar registers
+        {
+            const int b0 = wib * 16;
+            const uint32_t my_n = lane < 16 ? cnt[b0 + lane] : 0u, my_c = lane < 16 ? cur[b0 + lane] : 0u;
+            const uint32_t my_have = my_n < (uint32_t)D_S1 ? my_n : (uint32_t)D_S1;      // keys that found a slot
+            const uint32_t my_room = piece > my_c ? piece - my_c : 0u;
+            const uint32_t my_put = my_have < my_room ? my_have : my_room;               // keys that fit the piece
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t have = (uint32_t)__builtin_amdgcn_readlane((int)my_have, i);
+                const uint32_t put = (uint32_t)__builtin_amdgcn_readlane((int)my_put, i);
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_c, i);
+                const uint32_t* src = tile + (b0 + i) * D_S1;
+                uint32_t* dst = out + (size_t)((uint32_t)(b0 + i) * (uint32_t)D_GRID + blockIdx.x) * piece + c;
+                const uint32_t k0 = src[lane], k1 = src[64 + lane];
+                if ((uint32_t)lane < put) dst[lane] = k0;
+                if ((uint32_t)lane + 64u < put) dst[64 + lane] = k1;
+                if (put < have) {                                   // piece full: the rest goes straight to the table (exact either way)
+                    if ((uint32_t)lane >= put && (uint32_t)lane < have) part_sat_inc(counts, k0);
+                    if ((uint32_t)lane + 64u >= put && (uint32_t)lane + 64u < have) part_sat_inc(counts, k1);
+                }
+            }
+            if (lane < 16) { cur[b0 + lane] = my_c + my_put; cnt[b0 + lane] = 0u; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < NBK) cnt1[threadIdx.x * D_GRID + blockIdx.x] = cur[threadIdx.x];
+}
+
+// level-1 segment m (= the 256 pieces of bucket m, one per workgroup of the read scatter) -> its 256 final buckets (top byte t,
+// middle byte m), as 16-bit keys.  ONE workgroup per segment: it alone writes those final buckets.
+__global__ void __launch_bounds__(1024) part_keys16_direct(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cnt1, uint32_t piece,
+                                                           PartCap pc, uint32_t* __restrict__ cur2, uint16_t* __restrict__ out,
+                                                           uint32_t* __restrict__ counts) {
+    __shared__ uint16_t tile[NBK * D_S2];
+    __shared__ uint32_t cnt[NBK], cur[NBK], rbase[NBK], rcap[NBK], hist[NBK], pref[NBK + 1], wsum[4];
+    __shared__ uint32_t dump[128];
+    const uint32_t m = blockIdx.x;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    if (threadIdx.x < NBK) {
+        const uint32_t c = cnt1[m * D_GRID + threadIdx.x];
+        hist[threadIdx.x] = c < piece ? c : piece;
+        cnt[threadIdx.x] = 0;
+        cur[threadIdx.x] = 0;
+        const uint32_t q = threadIdx.x * (uint32_t)NBK + m;                     // final bucket (top byte = threadIdx.x, middle byte = m)
+        rbase[threadIdx.x] = part_region(pc, q);
+        rcap[threadIdx.x] = part_region(pc, q + 1) - part_region(pc, q);
+    }
+    __syncthreads();
+    {
+        const uint32_t o = bucket_excl_scan(hist, NBK, wsum);
+        if (threadIdx.x < NBK) {
+            pref[threadIdx.x] = o;
+            if (threadIdx.x == NBK - 1) pref[NBK] = o + hist[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = pref[NBK];
+    constexpr uint32_t TK = 1024u * D_KPT;
+    // a thread's keys come in ascending stream order over the whole kernel: the piece it reads from only ever moves forward
+    uint32_t p = 0, lo = 0, hi = pref[1];
+    uint32_t key[D_KPT];
+    auto load_keys = [&](uint32_t tile0) {
+#pragma unroll
+        for (int u = 0; u < D_KPT; u++) {
+            const uint32_t g = tile0 + (uint32_t)u * 1024u + threadIdx.x;
+            uint32_t v = 0u;
+            if (g < total) {
+                while (g >= hi) { p++; lo = hi; hi = pref[p + 1]; }             // g < total = pref[256]: p stays below 256
+                v = in[(size_t)(m * (uint32_t)D_GRID + p) * piece + (g - lo)];
+            }
+            key[u] = v;
+        }
+    };
+    load_keys(0);
+    for (uint32_t tile0 = 0; tile0 < total; tile0 += TK) {
+        bool over = false;
+#pragma unroll
+        for (int u0 = 0; u0 < D_KPT; u0 += 8) {
+            uint32_t pos[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool lv = tile0 + (uint32_t)(u0 + u) * 1024u + threadIdx.x < total;
+                uint32_t* ctr = lv ? &cnt[key[u0 + u] >> 24] : &dump[lane];
+                pos[u] = atomicAdd(ctr, 1u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool lv = tile0 + (uint32_t)(u0 + u) * 1024u + threadIdx.x < total;
+                const bool ok = lv && pos[u] < (uint32_t)D_S2;
+                uint16_t* dst = ok ? &tile[(key[u0 + u] >> 24) * D_S2 + pos[u]] : (uint16_t*)&dump[64 + lane];
+                *dst = (uint16_t)key[u0 + u];
+                over |= lv && pos[u] >= (uint32_t)D_S2;
+            }
+            if (__ballot(over)) {
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (tile0 + (uint32_t)(u0 + u) * 1024u + threadIdx.x < total && pos[u] >= (uint32_t)D_S2) part_sat_inc(counts, key[u0 + u]);
+                over = false;
+            }
+        }
+        load_keys(tile0 + TK);                  // the next tile's keys fly during the copy-out (the registers are free)
+        __syncthreads();
+        {
+            const int b0 = wib * 16;
+            const uint32_t my_n = lane < 16 ? cnt[b0 + lane] : 0u, my_c = lane < 16 ? cur[b0 + lane] : 0u;
+            const uint32_t my_have = my_n < (uint32_t)D_S2 ? my_n : (uint32_t)D_S2;
+            const uint32_t my_cap = lane < 16 ? rcap[b0 + lane] : 0u, my_base = lane < 16 ? rbase[b0 + lane] : 0u;
+            const uint32_t my_room = my_cap > my_c ? my_cap - my_c : 0u;
+            const uint32_t my_put = my_have < my_room ? my_have : my_room;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t have = (uint32_t)__builtin_amdgcn_readlane((int)my_have, i);
+                const uint32_t put = (uint32_t)__builtin_amdgcn_readlane((int)my_put, i);
+                const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(my_base + my_c), i);
+                const uint16_t* src = tile + (b0 + i) * D_S2;
+                uint16_t* dst = out + at;
+                const uint16_t k0 = src[lane], k1 = src[64 + lane], k2 = src[128 + lane];
+                if ((uint32_t)lane < put) dst[lane] = k0;
+                if ((uint32_t)lane + 64u < put) dst[64 + lane] = k1;
+                if ((uint32_t)lane + 128u < put) dst[128 + lane] = k2;
+                if (put < have) {                                   // region full: count the rest now (see the header of this file)
+                    const uint32_t hi16 = ((uint32_t)(b0 + i) << 24) | (m << 16);
+                    if ((uint32_t)lane >= put && (uint32_t)lane < have) part_sat_inc(counts, hi16 | k0);
+                    if ((uint32_t)lane + 64u >= put && (uint32_t)lane + 64u < have) part_sat_inc(counts, hi16 | k1);
+                    if ((uint32_t)lane + 128u >= put && (uint32_t)lane + 128u < have) part_sat_inc(counts, hi16 | k2);
+                }
+            }
+            if (lane < 16) { cur[b0 + lane] = my_c + my_put; cnt[b0 + lane] = 0u; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < NBK) cur2[threadIdx.x * (uint32_t)NBK + m] = cur[threadIdx.x];
+}
+
 // lhgt_work_stats: keys the read scatter sent to the level-1 segments of this chunk (every key, also those that found their
 // region full and went straight to the table)
 __global__ void __launch_bounds__(256) part_sum_cursors(const uint32_t* __restrict__ cur1, int n, unsigned long long* __restrict__ out) {
-    unsigned long long v = (int)threadIdx.x < n ? cur1[threadIdx.x] : 0u;
+    unsigned long long v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += cur1[i];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
@@ -598,7 +871,11 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     };
     long want = b.d.n_pairs < (4L << 20) ? b.d.n_pairs : (4L << 20);
     while (want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
-    const size_t need = (size_t)need_of(want);
+    size_t need = (size_t)need_of(want);
+    {   // the direct form's level-1 buffer: 65536 pieces
+        const size_t need_pieces = (size_t)piece_keys(cap_of(want).n) * (size_t)(NBK * D_GRID) + 64;
+        if (ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && need_pieces > need) need = need_pieces;
+    }
     if (ctx->part_keys_cap < need) {
         for (int i = 0; i < 2; i++) {
             if (ctx->d_part_keys[i]) hipFree(ctx->d_part_keys[i]);
@@ -608,13 +885,27 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         ctx->part_keys_cap = need;
     }
     const long chunk_pairs = want;
-    if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(65536 + 256) * 4));
+    if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(65536 + 65536) * 4));
     uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket
-    uint32_t* cur1 = cur2 + 65536;         // keys sent to each level-1 segment
+    uint32_t* cur1 = cur2 + 65536;         // keys sent to each level-1 segment (direct form: to each (bucket, workgroup) piece)
+    // round 4's direct form of the two scatters (k = 32, e = 3, reads of <= 159 bases); LHGT_DEBUG bit 16: round 3's sorted tiles
+    const bool direct_form = ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && !(ctx->debug & 65536);
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
     for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
         const PartCap pc = cap_of(np);
+        if (direct_form) {
+            const uint32_t piece = piece_keys(pc.n);
+            hipLaunchKernelGGL(part_reads_direct, dim3(D_GRID), dim3(1024), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0], ctx->d_counts);
+            if (ctx->stats_on && ctx->d_stats)
+                hipLaunchKernelGGL(part_sum_cursors, dim3(1), dim3(256), 0, ctx->stream, cur1, NBK * D_GRID, ctx->d_stats);
+            hipLaunchKernelGGL(part_keys16_direct, dim3(D_GRID), dim3(1024), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, pc, cur2,
+                               (uint16_t*)ctx->d_part_keys[1], ctx->d_counts);
+            hipLaunchKernelGGL((part_apply<true>), dim3(g.nb), dim3(PA), (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4, ctx->stream,
+                               (const void*)ctx->d_part_keys[1], cur2, g, pc, ctx->d_counts);
+            LHGT_HIP(hipGetLastError());
+            continue;
+        }
         LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(65536 + 256) * 4, ctx->stream));
         if (max_nk <= 128 && ctx->e <= 3) {
             int rpt = (int)(TILE_KEYS1 / ((long)max_nk * ctx->e));

@@ -10,9 +10,6 @@
 
 namespace lhgt {
 
-constexpr int LF_BITS = 19;                 // LDS-resident fold of the vote prefilter: 2^19 bits = 64 KiB
-constexpr int LF_WORDS = (1 << LF_BITS) / 32;
-
 // Per-wave LDS: events[max_ev][e] of (peak id, contig); the contig of a hit is fetched by the lane
 // that found it.  judge_base then runs out of registers: lane l holds events l, l+64, .. of the
 // current 64-event chunk and entries l, l+64, .. of the contig table (TR registers deep); an event
@@ -132,7 +129,8 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
     if (wib >= waves_per_block) return;
-    uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64);
+    constexpr int BOUND_WORDS = TR >= 8 ? 512 : 0;   // long event lists (k <= 23, long reads): 1024 16-bit counters per wave for the bound below
+    uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64 + BOUND_WORDS);
     uint32_t* stage = ev + (size_t)max_ev * e * 2;   // 64 words: the current read's record, staged once per read
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
@@ -192,6 +190,38 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
         }
         if (n_ev < 6 || (debug & 1)) continue;  // base_hits = offsets with any hit (E:149-157, 496)
         __builtin_amdgcn_wave_barrier();
+        if (TR >= 8 && n_ev >= 32 && !(debug & (1 << 19))) {
+            // Round 4: bound the outcome before walking the events.  judge_base adds every hit offset to exactly ONE of the contigs its
+            // hashes point at (E:118-159), so a contig's final count is at most the number of (event, hash) entries that name it, and
+            // check_split votes only if TWO contigs reach six (E:161-202).  The entries' contigs are counted into 1024 hashed 16-bit
+            // counters: with at most one counter at six or more, and that one below twelve, at most one contig can reach six -- the
+            // pair cannot vote and its walk (one dependent chain over hundreds of events: 2.0 of the 2.3 s of a k = 21 step on a
+            // 50 Gbase reference, all of it for pairs that vote nothing) is skipped.  A pair the bound cannot clear is walked as before.
+            uint32_t* hist = stage + 64;
+#pragma unroll
+            for (int i = 0; i < BOUND_WORDS / 64; i++) hist[lane + 64 * i] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < n_ev * e; q += 64) {
+                const uint32_t id = ev[(size_t)q * 2], chr = ev[(size_t)q * 2 + 1];
+                if (id) {
+                    const uint32_t h = (chr * 2654435761u) >> 22;                       // 10 bits
+                    atomicAdd(&hist[h >> 1], 1u << ((h & 1u) * 16u));                   // <= 9 * max_ev entries: a half never carries
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            int n6 = 0, n12 = 0;
+#pragma unroll
+            for (int i = 0; i < BOUND_WORDS / 64; i++) {
+                const uint32_t w = hist[lane + 64 * i], lo = w & 0xffffu, hi = w >> 16;
+                n6 += (lo >= 6u) + (hi >= 6u);
+                n12 += (lo >= 12u) + (hi >= 12u);
+            }
+            int both = n6 | (n12 << 16);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) both += __shfl_xor(both, d, 64);
+            if ((both & 0xffff) <= 1 && (both >> 16) == 0) continue;
+            __builtin_amdgcn_wave_barrier();
+        }
         if (e == 3) judge_pair<TR, 3>(ev, n_ev, e, lane, filter);
         else judge_pair<TR, 0>(ev, n_ev, e, lane, filter);
         __builtin_amdgcn_wave_barrier();
@@ -207,221 +237,9 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// Sparse-path form (prefilter on, <= 128 k-mer offsets per mate, e <= 3).  The generic kernel walks a pair slice by slice
-// and every slice costs three dependent round trips.  Here a wave handles NP pairs per iteration with all their slices together:
-// records staged in LDS by one coalesced load each, all windows cut from LDS, all 12*NP first-level filter probes at once (a use of
-// a loaded word inside a lane-masked branch would make the compiler wait after every single load: only the loads sit under masks).
-// The survivors are then PACKED (wave prefix sum, LDS queue) and the next level probed with full-width gathers; only an iteration in
-// which some probe finds a peak (or a queue overflows) falls back to the lane-per-offset form below, which rebuilds the hits in
-// offset order for the judge.  Launched with PF = 2: a 64 KiB LDS fold of the bitmap in front of it, for peak sets small enough to
-// leave the fold mostly clear; everything else on the sparse path goes to vote_kernel_queued below (PF = 1, the bitmap as first
-// level, is kept for A/B runs).
-template <int PF, int NP>
-__global__ void __launch_bounds__(PF == 2 ? 1024 : 256) vote_kernel_sparse(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
-                                                                           const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
-                                                                           const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
-                                                                           int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int e = hp.e, k = hp.k;
-    const uint32_t* lfilter = lds;
-    if (PF == 2) {
-        for (int i = threadIdx.x; i < LF_WORDS; i += blockDim.x) lds[i] = lds_fold[i];
-        __syncthreads();
-    }
-    if (wib >= waves_per_block) return;
-    const int ev_words = max_ev * e * 2 > 64 * NP ? max_ev * e * 2 : 64 * NP;
-    uint32_t* ev = lds + (PF == 2 ? LF_WORDS : 0) + (size_t)wib * ev_words;   // events; the same words stage the records first
-    const long wave = (long)blockIdx.x * waves_per_block + wib;
-    const long n_waves = (long)gridDim.x * waves_per_block;
-    for (long p0 = wave; p0 < b.n_pairs; p0 += (long)NP * n_waves) {
-        long pp[NP];
-        bool live[NP];
-#pragma unroll
-        for (int u = 0; u < NP; u++) {
-            pp[u] = p0 + (long)u * n_waves;
-            live[u] = pp[u] < b.n_pairs;
-            if (!live[u]) pp[u] = p0;          // a duplicate keeps every load unconditional; its result is dropped
-            if (b.flags && !(b.flags[pp[u]] & PAIR_VOTE)) live[u] = false;
-        }
-        int nk[NP][2], wpr[NP][2];
-        const uint32_t* rec[NP][2];
-#pragma unroll
-        for (int u = 0; u < NP; u++)
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const int len = b.len[m][pp[u]];
-                nk[u][m] = len - k + 1;
-                wpr[u][m] = ((len + 31) >> 5) + 1;
-                rec[u][m] = b.words + b.off[m][pp[u]];
-            }
-        uint32_t* stage = ev;   // the event area is free until a compaction below
-        uint32_t rw[NP][2];
-#pragma unroll
-        for (int u = 0; u < NP; u++)
-#pragma unroll
-            for (int m = 0; m < 2; m++) rw[u][m] = lane < 3 * wpr[u][m] ? rec[u][m][lane] : 0u;   // all loads first, see w2 below
-#pragma unroll
-        for (int u = 0; u < NP; u++)
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-                if (lane < 32) stage[(u * 2 + m) * 32 + lane] = rw[u][m];
-        __builtin_amdgcn_wave_barrier();
-        uint32_t hs[NP][4][3], ids[NP][4][3];
-        bool ok[NP][4];
-#pragma unroll
-        for (int u = 0; u < NP; u++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
-                const uint32_t* q = stage + (u * 2 + m) * 32 + (j < nk[u][m] ? (j >> 5) : 0);
-                const int wp = wpr[u][m];
-                auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
-                const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
-                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
-                ok[u][s] = j < nk[u][m] && wnb == 0;
-#pragma unroll
-                for (int i = 0; i < 3; i++) hs[u][s][i] = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
-            }
-        __builtin_amdgcn_wave_barrier();
-        // first filter level for all hashes, then the second, then the table itself: each level only for survivors
-        const uint32_t m512 = (debug & 512) ? 0u : ~0u, m1024 = (debug & 1024) ? 0u : ~0u;   // stage ablation (tools/ablate_vote.py)
-        uint32_t f1[NP][4][3];
-#pragma unroll
-        for (int u = 0; u < NP; u++)
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const uint32_t h = hs[u][s][i];
-                    if (PF == 2) f1[u][s][i] = pf_pass(lfilter[(h & ((1u << LF_BITS) - 1u)) >> 5], h, pf2);
-                    else f1[u][s][i] = pf_pass(prefilter[(h & pf_mask) >> 5], h, pf2);
-                    if (!(ok[u][s] && i < e && live[u])) f1[u][s][i] = 0u;
-                    f1[u][s][i] &= m512;
-                }
-        {
-            const int qcap = (ev_words - 64) * 3 / 4, q2cap = ev_words - 64 - qcap;
-            uint32_t* Q = ev;
-            uint32_t* Q2 = PF == 2 ? ev + qcap : ev;
-            uint32_t* dump = ev + ev_words - 64;
-            int c = 0;
-#pragma unroll
-            for (int u = 0; u < NP; u++)
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-#pragma unroll
-                    for (int i = 0; i < 3; i++) c += (int)f1[u][s][i];
-            const int incl = wave_incl_scan(c, lane);
-            const int T = __shfl(incl, 63, 64);
-            if (T == 0) continue;
-            if (T <= qcap) {
-                int slot = incl - c;
-#pragma unroll
-                for (int u = 0; u < NP; u++)
-#pragma unroll
-                    for (int s = 0; s < 4; s++)
-#pragma unroll
-                        for (int i = 0; i < 3; i++) {
-                            uint32_t* dst = f1[u][s][i] ? Q + slot : dump + lane;   // no branch: dead candidates land in a scratch word
-                            *dst = hs[u][s][i];
-                            slot += (int)f1[u][s][i];
-                        }
-                __builtin_amdgcn_wave_barrier();
-                int T2 = T;
-                if (PF == 2) {
-                    T2 = 0;
-                    for (int q0 = 0; q0 < T; q0 += 128) {   // two gathers in flight per round
-                        const int qa = q0 + lane, qb = qa + 64;
-                        const uint32_t ha = qa < T ? Q[qa] : 0u, hb = qb < T ? Q[qb] : 0u;
-                        const uint32_t wa = qa < T ? prefilter[(ha & pf_mask) >> 5] : 0u;
-                        const uint32_t wb = qb < T ? prefilter[(hb & pf_mask) >> 5] : 0u;
-                        const bool pa = qa < T && pf_pass(wa, ha, pf2), pb = qb < T && pf_pass(wb, hb, pf2);
-                        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
-                        const int sa = T2 + __popcll(ba & ((1ull << lane) - 1ull));
-                        const int sb = T2 + __popcll(ba) + __popcll(bb & ((1ull << lane) - 1ull));
-                        if (pa && sa < q2cap) Q2[sa] = ha;
-                        if (pb && sb < q2cap) Q2[sb] = hb;
-                        T2 += __popcll(ba) + __popcll(bb);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                T2 &= (int)m1024;
-                if (T2 <= (PF == 2 ? q2cap : qcap)) {
-                    bool hit = false;
-                    for (int q0 = 0; q0 < T2; q0 += 64) {
-                        const int q = q0 + lane;
-                        if (q < T2) hit |= peak_kmer[Q2[q]] != 0u;
-                    }
-                    if (!__ballot(hit)) continue;   // the usual case on the sparse path: nothing of these pairs is a peak k-mer
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // lane-per-offset form: some probe hit (or a queue overflowed)
-        if (PF == 2) {
-            // only the load sits under the lane mask; the bit is cut out after all of them are in flight (a use inside the
-            // branch would make the compiler wait for each load on its own: 12 round trips in a row instead of one)
-            uint32_t w2[NP][4][3];
-#pragma unroll
-            for (int u = 0; u < NP; u++)
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-#pragma unroll
-                    for (int i = 0; i < 3; i++) w2[u][s][i] = f1[u][s][i] ? prefilter[(hs[u][s][i] & pf_mask) >> 5] : 0u;
-#pragma unroll
-            for (int u = 0; u < NP; u++)
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-#pragma unroll
-                    for (int i = 0; i < 3; i++) f1[u][s][i] = (f1[u][s][i] && pf_pass(w2[u][s][i], hs[u][s][i], pf2)) & m1024;
-        }
-        bool any[NP];
-#pragma unroll
-        for (int u = 0; u < NP; u++) {
-            any[u] = false;
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    ids[u][s][i] = f1[u][s][i] ? peak_kmer[hs[u][s][i]] : 0u;   // 0 = no peak (E:454)
-                    any[u] |= ids[u][s][i] != 0u;
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < NP; u++) {
-            if (!__ballot(any[u])) continue;
-            int n_ev = 0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {   // slices in offset order: mate 1 (0..63, 64..127), mate 2 (E:430-495)
-                bool hit = false;
-#pragma unroll
-                for (int i = 0; i < 3; i++) hit |= ids[u][s][i] != 0u;
-                const unsigned long long bal = __ballot(hit);
-                if (bal) {
-                    if (hit) {
-                        const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
-#pragma unroll
-                        for (int i = 0; i < 3; i++)
-                            if (i < e) {
-                                ev[((size_t)slot * e + i) * 2] = ids[u][s][i];
-                                ev[((size_t)slot * e + i) * 2 + 1] = ids[u][s][i] ? (uint32_t)loci[2 * (long)ids[u][s][i]] : 0u;
-                            }
-                    }
-                    n_ev += __popcll(bal);
-                }
-            }
-            if (n_ev < 6 || (debug & 1)) continue;
-            __builtin_amdgcn_wave_barrier();
-            if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
-            else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
 // Round 3: the LDS fold at 128 KiB and the judge DEFERRED.  An LDS probe costs a fraction of the L1 miss every bitmap probe is
-// (DESIGN.md 4), so what the first level screens out is nearly free -- and a fold screens by its bits per key.  vote_kernel_sparse
-// keeps 64 KiB of fold beside 16 event areas of 5.7 KiB for the lane-per-offset re-vote of the rare pair with a hit.  Here a wave
+// (DESIGN.md 4), so what the first level screens out is nearly free -- and a fold screens by its bits per key.  (Round 2's form --
+// 64 KiB of fold beside 16 event areas of 5.7 KiB for an in-kernel judge -- was removed in round 4.)  Here a wave
 // keeps queues only (480 words) and a pair with a peak k-mer among its survivors, or with more survivors than a queue holds, is
 // appended to a list that the generic kernel votes from scratch afterwards (vote_kernel<.., pair_list>): same hits in the same
 // offset order, the votes are sums.  That leaves 128 KiB for the fold: twice the bits per key -- 100 M pairs from 300 genomes
@@ -629,6 +447,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
     const long n_waves = (long)gridDim.x * waves_per_block;
     const uint32_t m512 = (debug & 512) ? 0u : 1u;   // stage ablation: stop after the bitmap / (1024) before the peak_kmer gathers
     const bool skip_gather = (debug & 1024) != 0;
+    const bool nt_probe = !(debug & (1 << 17)), nt_rec = !(debug & (1 << 18));   // A/B switches of the two non-temporal hints (bits set: plain loads)
     int qn = 0;
     uint32_t it = 0;
     for (long p = wave;; p += n_waves, it++) {
@@ -642,7 +461,10 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
             const uint32_t* rec1 = b.words + b.off[1][p];
             const int nk[2] = {len0 - k + 1, len1 - k + 1};
             const int wpr[2] = {((len0 + 31) >> 5) + 1, ((len1 + 31) >> 5) + 1};
-            const uint32_t rw[2] = {rec0[lane < 3 * wpr[0] ? lane : 3 * wpr[0] - 1], rec1[lane < 3 * wpr[1] ? lane : 3 * wpr[1] - 1]};
+            // (bit 18: the records as non-temporal loads -- they stream through once and should not push bitmap lines out of the L2)
+            const uint32_t* ra0 = rec0 + (lane < 3 * wpr[0] ? lane : 3 * wpr[0] - 1);
+            const uint32_t* ra1 = rec1 + (lane < 3 * wpr[1] ? lane : 3 * wpr[1] - 1);
+            const uint32_t rw[2] = {nt_rec ? __builtin_nontemporal_load(ra0) : *ra0, nt_rec ? __builtin_nontemporal_load(ra1) : *ra1};
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int m = 0; m < 2; m++)
@@ -703,7 +525,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                 const bool in = q < qn && !skip_gather;
                 tagv[u] = in ? qi[q] : 0xffffffffu;
                 idv[u] = 0u;
-                if (in) idv[u] = peak_kmer[qh[q]];
+                if (in) idv[u] = nt_probe ? __builtin_nontemporal_load(peak_kmer + qh[q]) : peak_kmer[qh[q]];
             }
 #pragma unroll
             for (int u = 0; u < VQ_CAP / 64; u++) {
@@ -842,7 +664,6 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (nk <= 0) continue;
         int max_ev = 2 * nk;
         size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words
-        size_t per_wave_sp = (size_t)std::max(max_ev * ctx->e * 2, 128) * 4;   // sparse kernel: staging (2 pairs x 64 words) inside the event area
         int wpb = (int)(65536 / per_wave);
         if (wpb > 4) wpb = 4;
         if (wpb < 1) wpb = 1;
@@ -859,24 +680,17 @@ int lhgt_vote(lhgt_ctx* ctx) {
                            ctx->debug, ctx->pf_mask, ctx->pf2, (const uint32_t*)nullptr);                                   \
     } while (0)
         const bool nt = ctx->k >= 28;
-        // sparse peak sets on a folded (k > PF_BITS) bitmap: 16-wave workgroups that keep a 64 KiB fold of it in LDS
-        const size_t lds2 = (size_t)LF_WORDS * 4 + 16 * per_wave_sp;
         const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
-#define LHGT_VOTE_SPARSE(PF_, THREADS_, LDS_)                                                                                  \
-    hipLaunchKernelGGL((vote_kernel_sparse<PF_, (PF_ == 2 ? 2 : 1)>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
-                       ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                       ctx->debug, ctx->pf_mask, ctx->pf2)
         // LDS first level while the fold still screens.  The 128 KiB fold with the judge deferred (vote_kernel_fold) up to 1.15 bit
         // insertions per fold bit: 47 % of foreign probes pass on to the L2 bitmap, a pair's survivors (333 +- 13 of 714) still fit
         // the wave's queue -- beyond that the overflowing pairs would flood the deferred list.  Round 2 kept a 64 KiB fold up to a
         // quarter insertion per bit; measured in round 3 on 100 M pairs from 300 genomes of the 13 Gbase reference (205 410 registered
         // k-mers): 296 ms without a fold, 146 ms with 64 KiB (0.78 insertions per bit), 128 KiB below.  2.3 M k-mers (configs[2])
-        // fill any fold that fits.  LHGT_DEBUG bit 15: the 64 KiB kernel with its in-kernel judge (up to one insertion per bit).
+        // fill any fold that fits.
         static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 0.0;   // bit insertions per fold bit (0 = the defaults)
         const double fold_ins = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1));
-        const bool old_fold = (ctx->debug & 32768) != 0;
-        const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : old_fold ? 1.0 : 1.15) * (double)(1ull << (old_fold ? LF_BITS : LF2_BITS));
-        if (sparse_ok && ctx->k > PF_BITS && fold_ok && !old_fold && !(ctx->debug & 16)) {
+        const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : 1.15) * (double)(1ull << LF2_BITS);
+        if (sparse_ok && ctx->k > PF_BITS && fold_ok && !(ctx->debug & 16)) {
             const int fold_words = (int)std::min<unsigned long long>(LF2_WORDS, (ctx->pf_mask + 1ull) / 32);
             const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
             const size_t need = (size_t)b.d.n_pairs + 1;
@@ -912,14 +726,6 @@ int lhgt_vote(lhgt_ctx* ctx) {
                 fprintf(stderr, "[lhgt] vote: 128 KiB fold (%.2f insertions per bit), %u of %ld pairs deferred to the lane-per-offset form\n",
                         fold_ins / (double)(1ull << LF2_BITS), n_def, b.d.n_pairs);
             }
-        } else if (sparse_ok && ctx->k > PF_BITS && fold_ok && old_fold && lds2 <= 160 * 1024 && !(ctx->debug & 16)) {
-            wpb = 16;
-            blocks = (b.d.n_pairs + wpb - 1) / wpb;
-            if (blocks > 256) blocks = 256;     // one resident workgroup per CU
-            // per device, not per process: the attribute belongs to the kernel's code object on the device that is current
-            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_sparse<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL(fold_prefilter, dim3(LF_WORDS / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32), ctx->d_prefilter_fold, LF_WORDS);
-            LHGT_VOTE_SPARSE(2, 1024, lds2);
         } else if (sparse_ok) {
             const size_t per_wave_q = (size_t)std::max(max_ev * ctx->e * 2 + 64, 2 * VQ_CAP + 128) * 4;
             wpb = (int)(65536 / per_wave_q);
@@ -933,17 +739,25 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);
             else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave * wpb);
-        } else if (max_ev <= 512) {   // a table row per 64 events: 8 rows instead of 16 (k = 21 with 150-base reads has 260 events)
-            if (ctx->prefilter_on) LHGT_VOTE(8, 1, false, 64 * wpb, per_wave * wpb);
-            else if (nt) LHGT_VOTE(8, 0, true, 64 * wpb, per_wave * wpb);
-            else LHGT_VOTE(8, 0, false, 64 * wpb, per_wave * wpb);
         } else {
-            if (ctx->prefilter_on) LHGT_VOTE(16, 1, false, 64 * wpb, per_wave * wpb);
-            else if (nt) LHGT_VOTE(16, 0, true, 64 * wpb, per_wave * wpb);
-            else LHGT_VOTE(16, 0, false, 64 * wpb, per_wave * wpb);
+            // long event lists: every wave also holds the 2 KiB of counters of the vote bound (vote_kernel, TR >= 8)
+            const size_t per_wave_b = per_wave + 512 * 4;
+            wpb = (int)(65536 / per_wave_b);
+            if (wpb > 4) wpb = 4;
+            if (wpb < 1) wpb = 1;
+            blocks = (b.d.n_pairs + wpb - 1) / wpb;
+            if (blocks > 256L * 16) blocks = 256L * 16;
+            if (max_ev <= 512) {   // a table row per 64 events: 8 rows instead of 16 (k = 21 with 150-base reads has 260 events)
+                if (ctx->prefilter_on) LHGT_VOTE(8, 1, false, 64 * wpb, per_wave_b * wpb);
+                else if (nt) LHGT_VOTE(8, 0, true, 64 * wpb, per_wave_b * wpb);
+                else LHGT_VOTE(8, 0, false, 64 * wpb, per_wave_b * wpb);
+            } else {
+                if (ctx->prefilter_on) LHGT_VOTE(16, 1, false, 64 * wpb, per_wave_b * wpb);
+                else if (nt) LHGT_VOTE(16, 0, true, 64 * wpb, per_wave_b * wpb);
+                else LHGT_VOTE(16, 0, false, 64 * wpb, per_wave_b * wpb);
+            }
         }
 #undef LHGT_VOTE
-#undef LHGT_VOTE_SPARSE
     }
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

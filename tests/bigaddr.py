@@ -49,7 +49,7 @@ def check_against_oracle(eng, oracle, tmp, nc, cl, k, e, contigs, vote_pairs=0, 
             f.write(bases.tobytes())
             f.write(b"\n")
     idx = fa + ".index.dat"
-    assert oracle.index_build(fa, idx, fa + ".genome.len.txt", k, e, cc) == 0
+    assert oracle.index_build(fa, idx, fa + ".genome.len.txt", k, e, cc) == len(contigs)
     n_sub = len(contigs) * cl
     flags_o = np.zeros(n_sub, dtype=np.uint8)
     pk_o = np.zeros(1 << k, dtype=np.uint32)

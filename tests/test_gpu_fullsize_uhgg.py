@@ -68,8 +68,7 @@ def _check_scans_and_votes(eng, expect_lite, tag):
     direct = _vote(eng, 2048)                          # queued kernel, pairs with > 8 bitmap survivors voted at once
     nofilter = _vote(eng, 4)                           # every probe goes to peak_kmer
     nofold = _vote(eng, 16)                            # never an LDS fold in front of the bitmap (the queued kernel)
-    oldfold = _vote(eng, 32768)                        # round 2's 64 KiB fold kernel with its in-kernel judge, where a fold is used at all
-    assert queued == generic == direct == nofilter == nofold == oldfold, (tag, queued, generic, direct, nofilter, nofold, oldfold)
+    assert queued == generic == direct == nofilter == nofold, (tag, queued, generic, direct, nofilter, nofold)
     return exact, info_t, queued
 
 

@@ -113,10 +113,9 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         _, pf_o = oracle.vote(f1, f2, k, e, cc, ratio, None, pk_o, loci_o, n_o)
         _, pf_g = eng.peaks_export(n_g)
         assert (pf_g == pf_o[:n_g]).all()
-        # every vote kernel (queued with its direct branch forced, generic with / without the bitmap, no LDS fold, round 2's 64 KiB
-        # fold kernel instead of the 128 KiB one with the deferred judge); the form of the scan the
+        # every vote kernel (queued with its direct branch forced, generic with / without the bitmap, no LDS fold); the form of the scan the
         # engine picks by itself (0), the single-first ("lite") form, also with no tile settled early, and the trio-first form
-        for flags in (0, 2048, 32, 4, 16, 32768, 4096, 4096 | 256, 16384, 16384 | 256):
+        for flags in (0, 2048, 32, 4, 16, 4096, 4096 | 256, 16384, 16384 | 256):
             eng.set_debug(flags)
             assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
             eng.vote()
@@ -338,6 +337,37 @@ def test_partitioned_count_equals_direct_count(Engine, k):
     assert (tables[0] == tables[1]).all()
 
 
+def test_direct_form_of_the_partition_equals_direct_count(Engine):
+    """round 4's scatters (k = 32, e = 3, reads of <= 159 bases: fixed-slot tiles, workgroup-private pieces, no histogram pass)
+    against the compare-and-swap kernel and against round 3's sorted-tile scatters (LHGT_DEBUG bit 16): whole-table digest,
+    histogram and the first 2^26 slots.  Hot k-mers (poly-A, poly-AC, one read repeated) overflow the 128 slots of a tile bucket,
+    the 192 of the second level and the pieces themselves -- those keys go straight to the table; ragged lengths, N's, reads
+    shorter than k, mates not counted (quirk Q4) and an odd number of reads exercise the tails."""
+    k, e = 32, 3
+    rng = np.random.default_rng(7)
+    acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    def rd(n):
+        return [acgt[rng.choice(5, size=int(rng.integers(0, 160)), p=[.248, .248, .248, .248, .008])].tobytes() for _ in range(n)]
+    hot = acgt[rng.choice(4, size=150)].tobytes()
+    reads1 = rd(20001) + [b"A" * 150, b"ACAC" * 37, hot] * 700 + rd(3000)
+    reads2 = rd(20001) + [b"T" * 150, b"GTGT" * 37, hot] * 700 + rd(3000)
+    c2 = (rng.random(len(reads1)) < 0.9).astype(np.uint8)
+    got = []
+    for mode, dbg in ((0, 0), (1, 0), (1, 65536)):
+        with Engine(k, e) as eng:
+            eng.rng_seed(11)
+            eng.coder_generate()
+            eng.set_count_mode(mode)
+            eng.set_debug(dbg)
+            eng.pairs_append(*_pairs(reads1, reads2), count_mate2=c2)
+            eng.count_kmers()
+            eng.count_kmers()          # twice: the second pass meets pre-filled slices
+            got.append((eng.digest(eng.DIGEST_COUNTS), tuple(int(x) for x in eng.counts_histogram()), eng.counts_export(0, 1 << 26)))
+    for other in got[1:]:
+        assert other[0] == got[0][0] and other[1] == got[0][1] and (other[2] == got[0][2]).all()
+    assert got[0][1][3] > 0 and sum(got[0][1]) == 1 << 32
+
+
 def test_count_diff_kmer_tool(oracle, case_inputs):
     """C-tool row: the printed rates are #(T==0)/2^k and #(T!=3)/2^k of phase A's table (count_diff_kmer.cpp:26-50)"""
     import io
@@ -370,7 +400,7 @@ def test_vote_prefilter_changes_nothing(Engine):
         eng.synth_pairs(3, 4, 16, 100_000, 0, 60_000)
         eng.count_kmers()
         votes = []
-        for flags in (0, 32768, 16, 32, 4, 128, 256, 16 | 2048):  # fold kernel (128 KiB, deferred judge), round 2's 64 KiB fold kernel, queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
+        for flags in (0, 16, 32, 4, 128, 256, 16 | 2048):  # fold kernel (128 KiB, deferred judge), queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
             eng.set_debug(flags)
             n = eng.ref_scan(0.1, 0.08, 10**7)
             eng.vote()

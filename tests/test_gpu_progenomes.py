@@ -54,7 +54,7 @@ def test_progenomes_scale_reference_on_one_gpu(k, oracle, tmp_path):
             got, sinfo = _scan(e, dbg)
             assert got == exact, (dbg, sinfo)
         votes = _vote(e, 0)
-        assert votes == _vote(e, 32) == _vote(e, 4) and (votes[1] >= 1 or k < 32), votes
+        assert votes == _vote(e, 32) == _vote(e, 4) == _vote(e, 1 << 19) and (votes[1] >= 1 or k < 32), votes   # bit 19: every pair walked, no bound
         n_peaks = e.ref_scan(0.1, 0.08, 300_000_000)
         loci, _ = e.peaks_export(n_peaks)
         contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)

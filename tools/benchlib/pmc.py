@@ -47,7 +47,7 @@ def source_stamp(names):
 def child_command(args):
     """bench.py on the same workload: one step, nothing but the timed path"""
     py = sys.executable if os.path.basename(sys.executable).startswith("python") else "python3"
-    return [py, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-verify",
+    return [py, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-verify", "--no-stats",
             "--quiet", "--workload", args.workload, "--pairs", str(args.pairs), "--contigs", str(args.contigs),
             "--contig-len", str(args.contig_len), "-k", str(args.k), "-e", str(args.e), "--count-mode", str(args.count_mode),
             "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs), "--snp", str(args.snp),

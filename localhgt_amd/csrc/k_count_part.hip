@@ -20,6 +20,7 @@
 // final bucket in a separate pass that hashed all reads once more: 69 ms of 534 on configs[2].)
 // HBM traffic is 4 + 4 + 2 + 2 = 12 B per key streamed plus one table sweep per chunk, instead of one random 128-byte line
 // (and its write-back) per key.  The result is the same table: min(3, count).
+#include <algorithm>
 #include "lhgt_hash.hpp"
 
 namespace lhgt {
@@ -574,112 +575,184 @@ __global__ void __launch_bounds__(PA) part_apply(const void* __restrict__ keys_v
 //
 // What round 3's counters said (profiles/r03/sq_phase_a_after.txt): both scatters spend a quarter of their wave cycles issuing and
 // half of them waiting -- a tile goes through hashing, histogram atomics, a scan, placement atomics and a copy-out that looks every
-// key's bucket up again, with workgroup barriers between stretches that are each bound by a different unit.  Here
-//   * a tile is 256 buckets x a FIXED number of slots (128 four-byte keys in the read scatter, 192 two-byte keys in the key
+// key's bucket up again, with workgroup barriers between stretches that are each bound by a different unit (vector issue, LDS
+// atomics, the store path), one 1024-thread workgroup per CU: the stretches ADD UP (stage ablation, profiles/r04/).  Here
+//   * a tile is 256 buckets x a FIXED number of slots (64 four-byte keys in the read scatter, 128 two-byte keys in the key
 //     scatter): a key takes its slot with ONE LDS atomic right after it is hashed or loaded -- no histogram, no scan, and the
-//     keys never wait in registers for a second pass (124 -> ~64 VGPRs).  A bucket that runs over its slots (+ 4 sigma; hot
-//     k-mers) sends the key straight to the table, like a full region always did: the result stays exact;
+//     keys never wait in registers for a second pass.  A bucket that runs over its slots (+ 5 sigma; hot k-mers) sends the key
+//     straight to the table, like a full region always did: the result stays exact;
+//   * tiles are 64 KiB and workgroups 512 threads, so TWO workgroups share a CU and drift apart: one hashes (vector issue) or takes
+//     tickets (LDS atomics) while the other copies out (LDS reads, stores);
 //   * the level-1 digit is the key's MIDDLE byte (bits 16..23), not its top byte: a hash is min(forward, reverse complement),
 //     whose density falls linearly over the TOP bits, so top-byte buckets hold from twice the mean to nothing and no fixed slot
-//     count fits them; the middle byte is uniform.  The second level sorts by the top byte (192 slots hold twice the mean of a
-//     16 Ki-key tile + 5 sigma);
-//   * every (level-1 bucket, workgroup) pair owns a PIECE of the key buffer, and ONE workgroup scatters a whole level-1 segment
-//     (= the 256 pieces of its bucket) into the segment's 256 final buckets, which nobody else writes: run cursors live in LDS,
-//     no global atomicAdd anywhere (round 3: one per bucket and tile, issued early to hide its round trip).  Consecutive runs of
-//     a piece come from the same CU, so their partial lines meet in ONE L2 and leave as full lines;
-//   * the copy-out walks a bucket per wave with the bucket's count and cursor in scalar registers: two LDS reads and stores per
-//     64 keys instead of a (delta, limit) lookup per key.
-// part_apply is unchanged: final bucket q = key >> 16 owns region part_region(q) of the 16-bit key buffer.
-constexpr int D_S1 = 128;                     // slots per bucket of the read scatter's tile: 256 x 128 x 4 B = 128 KiB
-constexpr int D_RW = 4;                       // reads per wave and tile: 64 reads, <= 22.8 K keys, 89 per bucket: 128 is + 4 sigma
-constexpr int D_S2 = 192;                     // 16-bit slots per bucket of the key scatter's tile: 256 x 192 x 2 B = 96 KiB
-constexpr int D_KPT = 16;                     // keys per thread and tile of the key scatter: 16 Ki keys, 64 per bucket, 128 for the first
-constexpr int D_GRID = 256;                   // workgroups of both scatters = level-1 buckets = pieces per bucket
-// keys a piece holds: its expected share (1 / 65536 of the chunk's keys) + 1/16 + 512, a multiple of 32 keys (128 B)
-__host__ __device__ inline uint32_t piece_keys(unsigned long long n_keys) {
-    const unsigned long long mean = n_keys / (unsigned long long)(NBK * D_GRID);
+//     count fits them; the middle byte is uniform.  The second level sorts by the top byte (128 slots hold twice the mean of a
+//     10 Ki-key tile + 5 sigma);
+//   * every (level-1 bucket, workgroup) pair owns a PIECE of the key buffer, and the 512 pieces of a level-1 bucket (a segment)
+//     are scattered by TWO workgroups (256 pieces each) into their own halves of the segment's 256 final-bucket regions, which
+//     nobody else writes: run cursors live in LDS, no global atomicAdd anywhere (round 3: one per bucket and tile, issued early to
+//     hide its round trip).  Consecutive runs of a piece come from the same CU, so their lines meet in ONE L2;
+//   * the copy-out moves 16 bytes per lane (ds_read_b128 -> global_store_dwordx4, four buckets per wave instruction, every store
+//     16-byte aligned): a bucket only ever writes a multiple of 4 (8) keys, the remainder is CARRIED to the head of its row for
+//     the next tile and flushed key by key once, at the end.
+// part_apply2 is part_apply over the two half regions of a final bucket q = key >> 16.
+// Two geometries of the same kernels (LHGT_PART_GEOM picks one at run time; the table is the same):
+//   Small  512-thread workgroups with 64 KiB tiles, two per CU; two workgroups per level-1 segment in the key scatter
+//   Big    1024-thread workgroups with 128 KiB tiles, one per CU
+struct GeomSmall {
+    static constexpr int T = 512;      // threads per workgroup of both scatters
+    static constexpr int S1 = 64;      // slots per bucket of the read scatter's tile: 256 x 64 x 4 B = 64 KiB
+    static constexpr int RW = 3;       // reads per wave and tile: 24 reads, <= 8.6 K keys, 33.5 per bucket: 64 is + 5 sigma
+    static constexpr int S2 = 128;     // 16-bit slots per bucket of the key scatter's tile: 256 x 128 x 2 B = 64 KiB
+    static constexpr int KPT = 20;     // keys per thread and tile of the key scatter: 10 Ki keys, 40 per bucket, 80 for the first (+ 5 sigma = 125)
+    static constexpr int GRID = 512;   // workgroups of the read scatter = pieces per level-1 bucket
+    static constexpr int HALVES = 2;   // workgroups per level-1 segment in the key scatter, each with its own part of every final region
+};
+struct GeomBig {
+    static constexpr int T = 1024;
+    static constexpr int S1 = 128;     // 256 x 128 x 4 B = 128 KiB
+    static constexpr int RW = 4;       // 64 reads, <= 22.8 K keys, 89 per bucket: 128 is + 4 sigma
+    static constexpr int S2 = 256;     // 256 x 256 x 2 B = 128 KiB
+    static constexpr int KPT = 16;     // 16 Ki keys, 64 per bucket, 128 for the first (+ 5 sigma = 185)
+    static constexpr int GRID = 256;
+    static constexpr int HALVES = 1;
+};
+// keys a piece holds: its expected share of the chunk's keys + 1/16 + 512, a multiple of 32 keys (128 B)
+__host__ __device__ inline uint32_t piece_keys(unsigned long long n_keys, int grid) {
+    const unsigned long long mean = n_keys / (unsigned long long)(NBK * grid);
     return (uint32_t)((mean + mean / 16 + 512ull + 31ull) & ~31ull);
 }
+// The 16-bit key buffer of the direct form, SEGMENT-major: the 256 final buckets (top byte t) of segment m (middle byte) lie side by
+// side -- the 256 streams a workgroup of the key scatter writes stay within 23 MB -- each sized by the expected load of its top byte
+// (part_region over nb = 256 buckets and 1/256 of the chunk's keys) and split into two half regions, one per workgroup of the segment.
+__host__ __device__ inline PartCap seg_cap(unsigned long long n_keys) { return PartCap{n_keys / NBK + NBK, (uint32_t)NBK}; }
+__host__ __device__ inline uint32_t seg_size(const PartCap& sc) { return part_region(sc, NBK); }
+__host__ __device__ inline uint32_t half_region(const PartCap& sc, uint32_t t, int halves) { return ((part_region(sc, t + 1) - part_region(sc, t)) / (uint32_t)halves) & ~7u; }
+__host__ __device__ inline size_t final_region(const PartCap& sc, uint32_t m, uint32_t t, uint32_t half, int halves) {
+    return (size_t)m * seg_size(sc) + part_region(sc, t) + (size_t)half * half_region(sc, t, halves);
+}
 
-__global__ void __launch_bounds__(1024) part_reads_direct(ReadBatchDev b, long pair0, long npairs, HashParams hp, uint32_t piece,
-                                                          uint32_t* __restrict__ cnt1 /*[bucket][workgroup]*/, uint32_t* __restrict__ out,
-                                                          uint32_t* __restrict__ counts) {
-    __shared__ uint32_t tile[NBK * D_S1];
+template <class G>
+__global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long pair0, long npairs, HashParams hp, uint32_t piece,
+                                                         uint32_t* __restrict__ cnt1 /*[bucket][workgroup]*/, uint32_t* __restrict__ out,
+                                                         uint32_t* __restrict__ counts, int ablate /* stage timing (LHGT_PART_ABLATE), results wrong: 1 no stores, 2 no placement */) {
+    __shared__ __align__(16) uint32_t tile[NBK * G::S1];
     __shared__ uint32_t cnt[NBK], cur[NBK];
     __shared__ uint32_t dump[128];           // per-lane dummy counter and dummy word of the branch-free placement
     constexpr int STAGE_W = 20;              // <= 18 record words per read on this path (<= 159 bases) + the word a window may look past
-    __shared__ uint32_t stage_all[16 * D_RW * STAGE_W];
+    constexpr int NW = G::T / 64;
+    __shared__ uint32_t stage_all[NW * G::RW * STAGE_W];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    uint32_t* stage = stage_all + wib * D_RW * STAGE_W;
+    uint32_t* stage = stage_all + wib * G::RW * STAGE_W;
     const bool r_zero = (lane & 31) == 0;    // the window starts at a word boundary: v_alignbit by 32 would give the NEXT word
     const uint32_t sh_win = 32u - (uint32_t)(lane & 31);
     constexpr int k = 32;
     const long n_reads = 2 * npairs;
-    constexpr int RPT = 16 * D_RW;           // reads per tile
+    constexpr int RPT = NW * G::RW;           // reads per tile (even)
     const long n_tiles = (n_reads + RPT - 1) / RPT;
     if (threadIdx.x < NBK) { cnt[threadIdx.x] = 0; cur[threadIdx.x] = 0; }
-    int lens[D_RW];
-    uint32_t offs[D_RW], recw[D_RW];
-    auto load_descriptors = [&](long t) {        // t >= n_tiles: every length 0
+    // A wave's reads of a tile are r0 + wave + 8 rr with r0 even: their mate (r & 1) is the parity of the wave's number, the same
+    // for every read the wave will ever see -- the descriptor arrays of that mate are picked ONCE (indexing b.len[m] with a
+    // run-time m made the compiler fetch the pointer from the kernel-argument block with a vector load and wait for it, read by
+    // read: a chain of dependent round trips at the top of every tile).
+    const int mate = wib & 1;
+    const uint16_t* __restrict__ len_m = mate ? b.len[1] : b.len[0];
+    const uint32_t* __restrict__ off_m = mate ? b.off[1] : b.off[0];
+    // (every load unconditional -- without per-pair flags the flag byte is read from the length array and ignored: a load under
+    // `if (b.flags)` is followed by its own s_waitcnt vmcnt(0), which also waits for the record loads issued just before)
+    const bool have_flags = b.flags != nullptr;
+    const uint8_t* __restrict__ flag_m = have_flags ? b.flags : (const uint8_t*)len_m;
+    // Three tiles are in flight per wave: the one being hashed (its lengths in dA, its records in LDS), the next one (descriptors
+    // arrived in dB, records on their way into recB) and the one after (descriptors on their way into dC) -- two dependent round
+    // trips to memory, each given a whole tile's time.
+    struct Desc { int len[G::RW]; uint32_t off[G::RW]; };
+    auto load_descriptors = [&](long t, Desc& d) {        // t >= n_tiles: every length 0
         const long r0 = t * RPT, r1 = r0 + RPT < n_reads ? r0 + RPT : n_reads;
+        int len[G::RW];
+        uint32_t fl[G::RW];
 #pragma unroll
-        for (int rr = 0; rr < D_RW; rr++) {
-            const long r = r0 + wib + rr * 16;
-            const long rc = r < r1 ? r : (n_reads > 0 ? n_reads - 1 : 0);
+        for (int rr = 0; rr < G::RW; rr++) {
+            const long r = r0 + wib + rr * NW;
+            const long rc = r < r1 ? r : (n_reads > 0 ? n_reads - 2 + mate : 0);   // clamped to the last read of this wave's mate
             const long p = pair0 + (rc >> 1);
-            const int m = (int)(rc & 1);
-            const int len = b.len[m][p];
-            offs[rr] = b.off[m][p];
-            const bool counted = !b.flags || ((b.flags[p] >> m) & 1);   // quirk Q4, thread-chunk emulation
-            lens[rr] = r < r1 && counted ? len : 0;
+            len[rr] = len_m[p];
+            d.off[rr] = off_m[p];
+            fl[rr] = flag_m[p];
         }
-    };
-    auto load_records = [&] {
 #pragma unroll
-        for (int rr = 0; rr < D_RW; rr++) {
-            const int wpr = ((lens[rr] + 31) >> 5) + 1;
-            recw[rr] = b.words[offs[rr] + (lane < 3 * wpr ? lane : 0)];
+        for (int rr = 0; rr < G::RW; rr++) {
+            const long r = r0 + wib + rr * NW;
+            const bool counted = !have_flags || ((fl[rr] >> mate) & 1u);   // quirk Q4, thread-chunk emulation
+            d.len[rr] = r < r1 && counted ? len[rr] : 0;
         }
     };
+    auto load_records = [&](const Desc& d, uint32_t (&rec)[G::RW]) {
+#pragma unroll
+        for (int rr = 0; rr < G::RW; rr++) {
+            const int wpr = ((d.len[rr] + 31) >> 5) + 1;
+            rec[rr] = b.words[d.off[rr] + (lane < 3 * wpr ? lane : 0)];
+        }
+    };
+    Desc dA, dB, dC;
+    uint32_t recA[G::RW], recB[G::RW];
     if (n_reads > 0) {
-        load_descriptors(blockIdx.x);
-        load_records();
+        load_descriptors(blockIdx.x, dA);
+        load_descriptors((long)blockIdx.x + gridDim.x, dB);
+        load_records(dA, recA);
     }
     __syncthreads();
+    // piece (bucket, workgroup) = piece number workgroup * 256 + bucket: the 256 streams a workgroup writes lie side by side in 25 MB of
+    // the buffer (a dozen 2 MiB pages) -- bucket-major, they were 50 MB apart and every store instruction missed the CU's TLB
+    uint32_t* const my_out = out + (size_t)blockIdx.x * NBK * piece;
+    const size_t bucket_stride = (size_t)piece;
     for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        // this tile's records go to the wave's staging words; the next tile's descriptors and records fly during the hashing
-        int cl[D_RW];
+        // this tile's records go to the wave's staging words; the next tile's records and the descriptors of the one after are
+        // requested now and not looked at before the next iteration
+        int cl[G::RW];
 #pragma unroll
-        for (int rr = 0; rr < D_RW; rr++) {
-            cl[rr] = lens[rr];
-            stage[rr * STAGE_W + (lane < STAGE_W ? lane : 0)] = recw[rr];   // lanes >= 3 wpr hold a repeat of word 0
+        for (int rr = 0; rr < G::RW; rr++) {
+            cl[rr] = dA.len[rr];
+            stage[rr * STAGE_W + (lane < STAGE_W ? lane : 0)] = recA[rr];   // lanes >= 3 wpr hold a repeat of word 0
         }
         __builtin_amdgcn_wave_barrier();
-        load_descriptors(t + gridDim.x);
-        load_records();
+        load_records(dB, recB);
+        load_descriptors(t + 2L * gridDim.x, dC);
         bool over = false;
 #pragma unroll
-        for (int rr = 0; rr < D_RW; rr++) {
+        for (int rr = 0; rr < G::RW; rr++) {
             const int len = cl[rr];
             const int nk = len - k + 1;
             if (nk <= 0) continue;                                  // wave-uniform
             const int wpr = ((len + 31) >> 5) + 1;
             uint32_t key[2][3];
             bool live[2];
+            // all six window word pairs of the read first (unconditional: the staging words behind a short read are there, just not
+            // meant), ONE wait, then the arithmetic -- `j < nk && window(2) == 0` put the not-a-base window into a lane-masked region
+            // with its own s_waitcnt: four exposed LDS round trips per read with four waves per SIMD to hide them
+            uint32_t ww[2][3][2];
+#pragma unroll
+            for (int it = 0; it < 2; it++)
+#pragma unroll
+                for (int plane = 0; plane < 3; plane++) {
+                    const uint32_t* w = stage + rr * STAGE_W + plane * wpr + 2 * it + (lane >> 5);
+                    ww[it][plane][0] = w[0];
+                    ww[it][plane][1] = w[1];
+                }
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int j = it * 64 + lane;
                 auto window = [&](int plane) {
-                    const uint32_t* w = stage + rr * STAGE_W + plane * wpr + 2 * it + (lane >> 5);
-                    const uint32_t w0 = w[0], w1 = w[1];
-                    const uint32_t a = __builtin_amdgcn_alignbit(w0, w1, sh_win);
-                    return r_zero ? w0 : a;
+                    const uint32_t a = __builtin_amdgcn_alignbit(ww[it][plane][0], ww[it][plane][1], sh_win);
+                    return r_zero ? ww[it][plane][0] : a;
                 };
-                live[it] = j < nk && window(2) == 0;
+                live[it] = (j < nk) & (window(2) == 0);
                 const uint32_t whi = window(0), wlo = window(1);
                 const uint32_t rhi = __brev(whi), rlo = __brev(wlo);
 #pragma unroll
                 for (int i = 0; i < 3; i++) key[it][i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+            }
+            if (ablate & 2) {                                       // stage timing: the hashes only (kept alive through the dummy words)
+                dump[64 + lane] = key[0][0] ^ key[0][1] ^ key[0][2] ^ key[1][0] ^ key[1][1] ^ key[1][2];
+                continue;
             }
             // six keys, six tickets back to back, waited for once; a dead offset (beyond the read, a k-mer with an N) draws from a
             // per-lane dummy counter and writes a per-lane dummy word: no branch per key
@@ -693,66 +766,90 @@ __global__ void __launch_bounds__(1024) part_reads_direct(ReadBatchDev b, long p
 #pragma unroll
             for (int u = 0; u < 6; u++) {
                 const uint32_t kk = key[u / 3][u % 3];
-                const bool ok = live[u / 3] && pos[u] < (uint32_t)D_S1;
-                uint32_t* dst = ok ? &tile[((kk >> 16) & 0xffu) * D_S1 + pos[u]] : &dump[64 + lane];
+                const bool ok = live[u / 3] && pos[u] < (uint32_t)G::S1;
+                const uint32_t bk = (kk >> 16) & 0xffu;
+                // rows start at bank 0 and all buckets fill at the same pace: unrotated, a wave's stores crowd into the few banks of
+                // `pos`; row b is rotated by 4 (b & 7) slots (whole 16-byte groups, so the copy-out still moves aligned uint4s)
+                uint32_t* dst = ok ? &tile[bk * G::S1 + ((pos[u] + 4u * (bk & 7u)) & (uint32_t)(G::S1 - 1))] : &dump[64 + lane];
                 *dst = kk;
-                over |= live[u / 3] && pos[u] >= (uint32_t)D_S1;
+                over |= live[u / 3] && pos[u] >= (uint32_t)G::S1;
             }
             if (__ballot(over)) {                                   // a bucket ran over its slots (hot k-mers): those keys go to the table now
 #pragma unroll
                 for (int u = 0; u < 6; u++)
-                    if (live[u / 3] && pos[u] >= (uint32_t)D_S1) part_sat_inc(counts, key[u / 3][u % 3]);
+                    if (live[u / 3] && pos[u] >= (uint32_t)G::S1) part_sat_inc(counts, key[u / 3][u % 3]);
                 over = false;
             }
         }
         __syncthreads();
-        // copy-out: wave v takes buckets 16 v .. 16 v + 15, count and cursor of each in scalar registers
-        {
-            const int b0 = wib * 16;
-            const uint32_t my_n = lane < 16 ? cnt[b0 + lane] : 0u, my_c = lane < 16 ? cur[b0 + lane] : 0u;
-            const uint32_t my_have = my_n < (uint32_t)D_S1 ? my_n : (uint32_t)D_S1;      // keys that found a slot
-            const uint32_t my_room = piece > my_c ? piece - my_c : 0u;
-            const uint32_t my_put = my_have < my_room ? my_have : my_room;               // keys that fit the piece
+        // copy-out: a row is LPR lanes x 4 keys, a wave instruction covers 64 / LPR buckets; a bucket writes a multiple of four keys and
+        // carries the rest to the head of its row
+        constexpr int LPR = G::S1 / 4, BPI = 64 / LPR;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t have = (uint32_t)__builtin_amdgcn_readlane((int)my_have, i);
-                const uint32_t put = (uint32_t)__builtin_amdgcn_readlane((int)my_put, i);
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_c, i);
-                const uint32_t* src = tile + (b0 + i) * D_S1;
-                uint32_t* dst = out + (size_t)((uint32_t)(b0 + i) * (uint32_t)D_GRID + blockIdx.x) * piece + c;
-                const uint32_t k0 = src[lane], k1 = src[64 + lane];
-                if ((uint32_t)lane < put) dst[lane] = k0;
-                if ((uint32_t)lane + 64u < put) dst[64 + lane] = k1;
-                if (put < have) {                                   // piece full: the rest goes straight to the table (exact either way)
-                    if ((uint32_t)lane >= put && (uint32_t)lane < have) part_sat_inc(counts, k0);
-                    if ((uint32_t)lane + 64u >= put && (uint32_t)lane + 64u < have) part_sat_inc(counts, k1);
+        for (int g = 0; g < NBK / (NW * BPI); g++) {
+            const int bq = wib * (NBK / NW) + g * BPI + lane / LPR;
+            const uint32_t j = (uint32_t)(lane % LPR) * 4u;
+            const uint32_t n_all = cnt[bq], c = cur[bq];
+            const uint32_t have = n_all < (uint32_t)G::S1 ? n_all : (uint32_t)G::S1;       // keys that found a slot
+            const uint32_t full = have & ~3u;
+            const uint32_t room = piece > c ? piece - c : 0u;                            // piece and c are multiples of 4
+            const uint32_t put = full < room ? full : room;
+            const uint32_t rot = 4u * ((uint32_t)bq & 7u);                                 // the row's rotation (see the placement)
+            const uint4 v = *(const uint4*)&tile[bq * G::S1 + ((j + rot) & (uint32_t)(G::S1 - 1))];
+            if (!(ablate & 1)) {
+                if (j < put) *(uint4*)(my_out + (size_t)bq * bucket_stride + c + j) = v;
+                else if (j < full) {                                // piece full: the rest goes straight to the table (exact either way)
+                    part_sat_inc(counts, v.x); part_sat_inc(counts, v.y); part_sat_inc(counts, v.z); part_sat_inc(counts, v.w);
                 }
-            }
-            if (lane < 16) { cur[b0 + lane] = my_c + my_put; cnt[b0 + lane] = 0u; }
+            } else if (v.x + v.y == 0x12345u && v.z == v.w) my_out[c + j] = v.x;
+            if (j == full && have > full) *(uint4*)&tile[bq * G::S1 + rot] = v;           // the carry (its first have - full words) to logical slot 0
+            if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = have - full; }
         }
         __syncthreads();
+        dA = dB;
+        dB = dC;
+#pragma unroll
+        for (int rr = 0; rr < G::RW; rr++) recA[rr] = recB[rr];
     }
-    if (threadIdx.x < NBK) cnt1[threadIdx.x * D_GRID + blockIdx.x] = cur[threadIdx.x];
+    // the carried keys (fewer than four per bucket), one by one
+    if (threadIdx.x < NBK) {
+        const int bq = threadIdx.x;
+        uint32_t c = cur[bq];
+        const uint32_t rem = cnt[bq];
+        for (uint32_t i = 0; i < rem; i++) {
+            const uint32_t kk = tile[bq * G::S1 + ((i + 4u * ((uint32_t)bq & 7u)) & (uint32_t)(G::S1 - 1))];
+            if (c < piece) my_out[(size_t)bq * bucket_stride + c++] = kk;
+            else part_sat_inc(counts, kk);
+        }
+        cnt1[bq * G::GRID + blockIdx.x] = c;
+    }
 }
 
-// level-1 segment m (= the 256 pieces of bucket m, one per workgroup of the read scatter) -> its 256 final buckets (top byte t,
-// middle byte m), as 16-bit keys.  ONE workgroup per segment: it alone writes those final buckets.
-__global__ void __launch_bounds__(1024) part_keys16_direct(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cnt1, uint32_t piece,
-                                                           PartCap pc, uint32_t* __restrict__ cur2, uint16_t* __restrict__ out,
-                                                           uint32_t* __restrict__ counts) {
-    __shared__ uint16_t tile[NBK * D_S2];
-    __shared__ uint32_t cnt[NBK], cur[NBK], rbase[NBK], rcap[NBK], hist[NBK], pref[NBK + 1], wsum[4];
+// level-1 segment m (= the 512 pieces of bucket m, one per workgroup of the read scatter) -> its 256 final buckets (top byte t,
+// middle byte m), as 16-bit keys.  Two workgroups per segment (256 pieces each), each writing its own half of every final region.
+template <class G>
+__global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cnt1, uint32_t piece,
+                                                          PartCap pc, uint32_t* __restrict__ cur2 /*[half][final bucket]*/, uint16_t* __restrict__ out,
+                                                          uint32_t* __restrict__ counts, int ablate /* 1 no stores, 2 no placement */) {
+    __shared__ __align__(16) uint16_t tile[NBK * G::S2];
+    __shared__ uint32_t cnt[NBK], cur[NBK], rbase[NBK], rcap[NBK], hist[NBK], pref[NBK + 1], pcnt[NBK], wsum[4];
     __shared__ uint32_t dump[128];
-    const uint32_t m = blockIdx.x;
+    const uint32_t m = blockIdx.x / (uint32_t)G::HALVES, half = blockIdx.x % (uint32_t)G::HALVES;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    constexpr int NW = G::T / 64;
+    constexpr int PPW = G::GRID / G::HALVES;                        // pieces per workgroup (= 256)
+    static_assert(PPW == NBK, "a workgroup of the key scatter walks 256 pieces");
+    const uint32_t w0 = half * (uint32_t)PPW;                      // first piece of this part
+    constexpr uint32_t TK = (uint32_t)G::T * G::KPT;
     if (threadIdx.x < NBK) {
-        const uint32_t c = cnt1[m * D_GRID + threadIdx.x];
-        hist[threadIdx.x] = c < piece ? c : piece;
+        const uint32_t c0 = cnt1[m * G::GRID + w0 + threadIdx.x];
+        const uint32_t c = c0 < piece ? c0 : piece;
+        pcnt[threadIdx.x] = c;
+        hist[threadIdx.x] = (c + TK - 1u) / TK;                  // tiles of this piece
         cnt[threadIdx.x] = 0;
         cur[threadIdx.x] = 0;
-        const uint32_t q = threadIdx.x * (uint32_t)NBK + m;                     // final bucket (top byte = threadIdx.x, middle byte = m)
-        rbase[threadIdx.x] = part_region(pc, q);
-        rcap[threadIdx.x] = part_region(pc, q + 1) - part_region(pc, q);
+        rbase[threadIdx.x] = (uint32_t)final_region(pc, m, threadIdx.x, half, G::HALVES);   // final bucket (top byte = threadIdx.x, middle byte = m); pc = seg_cap
+        rcap[threadIdx.x] = half_region(pc, threadIdx.x, G::HALVES);
     }
     __syncthreads();
     {
@@ -763,82 +860,164 @@ __global__ void __launch_bounds__(1024) part_keys16_direct(const uint32_t* __res
         }
     }
     __syncthreads();
-    const uint32_t total = pref[NBK];
-    constexpr uint32_t TK = 1024u * D_KPT;
-    // a thread's keys come in ascending stream order over the whole kernel: the piece it reads from only ever moves forward
-    uint32_t p = 0, lo = 0, hi = pref[1];
-    uint32_t key[D_KPT];
-    auto load_keys = [&](uint32_t tile0) {
+    const uint32_t n_tiles = pref[NBK];                           // pref[w] = tiles before piece w
+    // A tile is TK consecutive slots of ONE piece (its last tile is short): every load of the kernel is unconditional, from one
+    // base pointer per tile, on a clamped index -- so that the compiler can count them (s_waitcnt vmcnt(N)).  Loads under a
+    // lane-dependent branch, or issued on only one side of a uniform one, are waited for with vmcnt(0), which also waits for the
+    // NEXT tile's loads issued just before: no prefetch at all (the first version, which walked the pieces as one stream: load,
+    // placement and copy-out times simply added up).
+    uint32_t pw = 0;                                              // piece of the tile being loaded (uniform, only moves forward)
+    uint32_t key[G::KPT], knext[G::KPT];
+    auto load_keys = [&](uint32_t tl, uint32_t (&kk)[G::KPT]) -> uint32_t {   // returns the tile's number of keys (0 past the end)
+        const uint32_t tc = tl < n_tiles ? tl : n_tiles - 1u;    // past the end: the last tile once more, ignored
+        while (tc >= pref[pw + 1]) pw++;                          // uniform; tc < n_tiles = pref[256]
+        const uint32_t o = (tc - pref[pw]) * TK, left = pcnt[pw] - o;
+        const uint32_t nv = left < TK ? left : TK;
+        const uint32_t* const base = in + ((size_t)(w0 + pw) * NBK + m) * piece + o;   // piece (bucket m, workgroup w) = piece number w * 256 + m
 #pragma unroll
-        for (int u = 0; u < D_KPT; u++) {
-            const uint32_t g = tile0 + (uint32_t)u * 1024u + threadIdx.x;
-            uint32_t v = 0u;
-            if (g < total) {
-                while (g >= hi) { p++; lo = hi; hi = pref[p + 1]; }             // g < total = pref[256]: p stays below 256
-                v = in[(size_t)(m * (uint32_t)D_GRID + p) * piece + (g - lo)];
-            }
-            key[u] = v;
+        for (int u = 0; u < G::KPT; u++) {
+            const uint32_t i = (uint32_t)u * (uint32_t)G::T + threadIdx.x;
+            kk[u] = base[i < nv ? i : nv - 1u];
         }
+        return tl < n_tiles ? nv : 0u;
     };
-    load_keys(0);
-    for (uint32_t tile0 = 0; tile0 < total; tile0 += TK) {
+    if (n_tiles == 0) {
+        if (threadIdx.x < NBK) cur2[half * (uint32_t)(NBK * NBK) + threadIdx.x * (uint32_t)NBK + m] = 0u;
+        return;
+    }
+    uint32_t nv_cur = load_keys(0, key);
+    for (uint32_t tl = 0; tl < n_tiles; tl++) {
+        const uint32_t nv_next = load_keys(tl + 1, knext);       // the next tile's keys: requested before this tile is placed, first looked at a whole tile later
         bool over = false;
+        if (ablate & 2) {
+            uint32_t x = 0;
 #pragma unroll
-        for (int u0 = 0; u0 < D_KPT; u0 += 8) {
-            uint32_t pos[8];
+            for (int u = 0; u < G::KPT; u++) x ^= key[u];
+            dump[64 + lane] = x;
+        } else {
+        constexpr int PG = G::KPT / 2;          // tickets taken back to back
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const bool lv = tile0 + (uint32_t)(u0 + u) * 1024u + threadIdx.x < total;
+        for (int u0 = 0; u0 < G::KPT; u0 += PG) {
+            uint32_t pos[PG];
+#pragma unroll
+            for (int u = 0; u < PG; u++) {
+                const bool lv = (uint32_t)(u0 + u) * (uint32_t)G::T + threadIdx.x < nv_cur;
                 uint32_t* ctr = lv ? &cnt[key[u0 + u] >> 24] : &dump[lane];
                 pos[u] = atomicAdd(ctr, 1u);
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const bool lv = tile0 + (uint32_t)(u0 + u) * 1024u + threadIdx.x < total;
-                const bool ok = lv && pos[u] < (uint32_t)D_S2;
-                uint16_t* dst = ok ? &tile[(key[u0 + u] >> 24) * D_S2 + pos[u]] : (uint16_t*)&dump[64 + lane];
+            for (int u = 0; u < PG; u++) {
+                const bool lv = (uint32_t)(u0 + u) * (uint32_t)G::T + threadIdx.x < nv_cur;
+                const bool ok = lv && pos[u] < (uint32_t)G::S2;
+                const uint32_t bk = key[u0 + u] >> 24;
+                uint16_t* dst = ok ? &tile[bk * G::S2 + ((pos[u] + 8u * (bk & 7u)) & (uint32_t)(G::S2 - 1))] : (uint16_t*)&dump[64 + lane];   // rows rotated by whole 16-byte groups, as in the read scatter
                 *dst = (uint16_t)key[u0 + u];
-                over |= lv && pos[u] >= (uint32_t)D_S2;
+                over |= lv && pos[u] >= (uint32_t)G::S2;
             }
             if (__ballot(over)) {
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (tile0 + (uint32_t)(u0 + u) * 1024u + threadIdx.x < total && pos[u] >= (uint32_t)D_S2) part_sat_inc(counts, key[u0 + u]);
+                for (int u = 0; u < PG; u++)
+                    if ((uint32_t)(u0 + u) * (uint32_t)G::T + threadIdx.x < nv_cur && pos[u] >= (uint32_t)G::S2) part_sat_inc(counts, key[u0 + u]);
                 over = false;
             }
         }
-        load_keys(tile0 + TK);                  // the next tile's keys fly during the copy-out (the registers are free)
-        __syncthreads();
-        {
-            const int b0 = wib * 16;
-            const uint32_t my_n = lane < 16 ? cnt[b0 + lane] : 0u, my_c = lane < 16 ? cur[b0 + lane] : 0u;
-            const uint32_t my_have = my_n < (uint32_t)D_S2 ? my_n : (uint32_t)D_S2;
-            const uint32_t my_cap = lane < 16 ? rcap[b0 + lane] : 0u, my_base = lane < 16 ? rbase[b0 + lane] : 0u;
-            const uint32_t my_room = my_cap > my_c ? my_cap - my_c : 0u;
-            const uint32_t my_put = my_have < my_room ? my_have : my_room;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t have = (uint32_t)__builtin_amdgcn_readlane((int)my_have, i);
-                const uint32_t put = (uint32_t)__builtin_amdgcn_readlane((int)my_put, i);
-                const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(my_base + my_c), i);
-                const uint16_t* src = tile + (b0 + i) * D_S2;
-                uint16_t* dst = out + at;
-                const uint16_t k0 = src[lane], k1 = src[64 + lane], k2 = src[128 + lane];
-                if ((uint32_t)lane < put) dst[lane] = k0;
-                if ((uint32_t)lane + 64u < put) dst[64 + lane] = k1;
-                if ((uint32_t)lane + 128u < put) dst[128 + lane] = k2;
-                if (put < have) {                                   // region full: count the rest now (see the header of this file)
-                    const uint32_t hi16 = ((uint32_t)(b0 + i) << 24) | (m << 16);
-                    if ((uint32_t)lane >= put && (uint32_t)lane < have) part_sat_inc(counts, hi16 | k0);
-                    if ((uint32_t)lane + 64u >= put && (uint32_t)lane + 64u < have) part_sat_inc(counts, hi16 | k1);
-                    if ((uint32_t)lane + 128u >= put && (uint32_t)lane + 128u < have) part_sat_inc(counts, hi16 | k2);
-                }
-            }
-            if (lane < 16) { cur[b0 + lane] = my_c + my_put; cnt[b0 + lane] = 0u; }
         }
         __syncthreads();
+        // copy-out: a row is LPR lanes x 8 keys (16 bytes); multiples of eight keys leave, the rest is carried
+        constexpr int LPR = G::S2 / 8, BPI = 64 / LPR;
+#pragma unroll
+        for (int g = 0; g < NBK / (NW * BPI); g++) {
+            const int bq = wib * (NBK / NW) + g * BPI + lane / LPR;
+            const uint32_t j = (uint32_t)(lane % LPR) * 8u;
+            const uint32_t n_all = cnt[bq], c = cur[bq];
+            const uint32_t have = n_all < (uint32_t)G::S2 ? n_all : (uint32_t)G::S2;
+            const uint32_t full = have & ~7u;
+            const uint32_t room = rcap[bq] > c ? rcap[bq] - c : 0u;                      // both multiples of 8
+            const uint32_t put = full < room ? full : room;
+            const uint32_t rot = 8u * ((uint32_t)bq & 7u);
+            const uint4 v = *(const uint4*)&tile[bq * G::S2 + ((j + rot) & (uint32_t)(G::S2 - 1))];
+            if (!(ablate & 1)) {
+                if (j < put) *(uint4*)(out + rbase[bq] + c + j) = v;
+                else if (j < full) {                                // region full: count those keys now (see the header of this file)
+                    const uint32_t hi16 = ((uint32_t)bq << 24) | (m << 16);
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 8; q++) part_sat_inc(counts, hi16 | ((w4[q >> 1] >> ((q & 1) * 16)) & 0xffffu));
+                }
+            } else if (v.x + v.y == 0x12345u && v.z == v.w) out[c + j] = (uint16_t)v.x;
+            if (j == full && have > full) *(uint4*)&tile[bq * G::S2 + rot] = v;           // the carry (its first have - full keys) to logical slot 0
+            if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = have - full; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < G::KPT; u++) key[u] = knext[u];
+        nv_cur = nv_next;
     }
-    if (threadIdx.x < NBK) cur2[threadIdx.x * (uint32_t)NBK + m] = cur[threadIdx.x];
+    if (threadIdx.x < NBK) {
+        const int bq = threadIdx.x;
+        uint32_t c = cur[bq];
+        const uint32_t rem = cnt[bq];
+        for (uint32_t i = 0; i < rem; i++) {
+            const uint16_t kk = tile[bq * G::S2 + ((i + 8u * ((uint32_t)bq & 7u)) & (uint32_t)(G::S2 - 1))];
+            if (c < rcap[bq]) out[rbase[bq] + c++] = kk;
+            else part_sat_inc(counts, ((uint32_t)bq << 24) | (m << 16) | kk);
+        }
+        cur2[half * (uint32_t)(NBK * NBK) + (uint32_t)bq * (uint32_t)NBK + m] = c;   // [part][final bucket = top byte * 256 + middle byte]
+    }
+}
+
+// part_apply<true> over the two half regions of a final bucket
+template <int HALVES>
+__global__ void __launch_bounds__(PA) part_apply2(const uint16_t* __restrict__ keys, const uint32_t* __restrict__ n_keys /*[2][nb]*/, PartGeom g,
+                                                  PartCap pc, uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t slice[];   // 2^16 / 16 words
+    const uint32_t fb = blockIdx.x;                                 // slice of the table = key >> 16 = (top byte, middle byte)
+    const uint32_t hr = half_region(pc, fb >> 8, HALVES), r0 = (uint32_t)final_region(pc, fb & 0xffu, fb >> 8, 0, HALVES);   // pc = seg_cap
+    uint32_t nh[HALVES], n_all = 0;
+#pragma unroll
+    for (int h = 0; h < HALVES; h++) {
+        const uint32_t n = n_keys[(uint32_t)h * (uint32_t)g.nb + fb];
+        nh[h] = n < hr ? n : hr;
+        n_all += nh[h];
+    }
+    if (n_all == 0) return;               // untouched slice: nothing to read or write
+    const int words = ((1 << g.slot_bits) + 15) >> 4;
+    uint32_t* T = counts + (size_t)fb * words;
+    for (int i = threadIdx.x; i < words; i += PA) slice[i] = T[i];
+    __syncthreads();
+    auto sat_inc_lds = [&](uint32_t s) {          // if (T[h] < 3) T[h]++  (E:1082-1084), race-free
+        uint32_t* w = slice + (s >> 4);
+        const uint32_t sh = (s & 15u) * 2u;
+        uint32_t o = *(volatile uint32_t*)w;
+        while (((o >> sh) & 3u) != 3u) {
+            const uint32_t seen = atomicCAS(w, o, o + (1u << sh));
+            if (seen == o) break;
+            o = seen;
+        }
+    };
+    constexpr int U = 2;              // 16-byte groups in flight per thread
+#pragma unroll
+    for (int h = 0; h < HALVES; h++) {
+        const uint32_t k0 = r0 + (uint32_t)h * hr, k1 = k0 + nh[h];
+        for (uint32_t base = k0; base < k1; base += U * PA * 8) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + (u * PA + threadIdx.x) * 8;
+                v[u] = i < k1 ? *(const uint4*)(keys + i) : make_uint4(0, 0, 0, 0);   // the group is inside the half region even when k1 cuts it
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + (u * PA + threadIdx.x) * 8;
+                const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i + q < k1) sat_inc_lds((w4[q >> 1] >> ((q & 1) * 16)) & 0xffffu);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < words; i += PA) T[i] = slice[i];
 }
 
 // lhgt_work_stats: keys the read scatter sent to the level-1 segments of this chunk (every key, also those that found their
@@ -873,8 +1052,10 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     while (want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
     size_t need = (size_t)need_of(want);
     {   // the direct form's level-1 buffer: 65536 pieces
-        const size_t need_pieces = (size_t)piece_keys(cap_of(want).n) * (size_t)(NBK * D_GRID) + 64;
-        if (ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && need_pieces > need) need = need_pieces;
+        const size_t need_pieces = std::max((size_t)piece_keys(cap_of(want).n, GeomBig::GRID) * (size_t)(NBK * GeomBig::GRID),
+                                            (size_t)piece_keys(cap_of(want).n, GeomSmall::GRID) * (size_t)(NBK * GeomSmall::GRID)) + 64;   // either geometry
+        const size_t need_final = (size_t)seg_size(seg_cap(cap_of(want).n)) * NBK + 64;
+        if (ctx->k == 32 && ctx->e == 3 && max_nk <= 128) need = std::max(need, std::max(need_pieces, need_final));
     }
     if (ctx->part_keys_cap < need) {
         for (int i = 0; i < 2; i++) {
@@ -885,9 +1066,9 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         ctx->part_keys_cap = need;
     }
     const long chunk_pairs = want;
-    if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(65536 + 65536) * 4));
-    uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket
-    uint32_t* cur1 = cur2 + 65536;         // keys sent to each level-1 segment (direct form: to each (bucket, workgroup) piece)
+    if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(2 * 65536 + NBK * 512) * 4));
+    uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket (direct form: to each half of its region)
+    uint32_t* cur1 = cur2 + 2 * 65536;     // keys sent to each level-1 segment (direct form: to each (bucket, workgroup) piece)
     // round 4's direct form of the two scatters (k = 32, e = 3, reads of <= 159 bases); LHGT_DEBUG bit 16: round 3's sorted tiles
     const bool direct_form = ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && !(ctx->debug & 65536);
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
@@ -895,18 +1076,28 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
         const PartCap pc = cap_of(np);
         if (direct_form) {
-            const uint32_t piece = piece_keys(pc.n);
-            hipLaunchKernelGGL(part_reads_direct, dim3(D_GRID), dim3(1024), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0], ctx->d_counts);
-            if (ctx->stats_on && ctx->d_stats)
-                hipLaunchKernelGGL(part_sum_cursors, dim3(1), dim3(256), 0, ctx->stream, cur1, NBK * D_GRID, ctx->d_stats);
-            hipLaunchKernelGGL(part_keys16_direct, dim3(D_GRID), dim3(1024), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, pc, cur2,
-                               (uint16_t*)ctx->d_part_keys[1], ctx->d_counts);
-            hipLaunchKernelGGL((part_apply<true>), dim3(g.nb), dim3(PA), (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4, ctx->stream,
-                               (const void*)ctx->d_part_keys[1], cur2, g, pc, ctx->d_counts);
+            static const int ablate = getenv("LHGT_PART_ABLATE") ? atoi(getenv("LHGT_PART_ABLATE")) : 0;   // bits 0-1: the read scatter, bits 4-5: the key scatter
+            static const int geom = getenv("LHGT_PART_GEOM") ? atoi(getenv("LHGT_PART_GEOM")) : 1;          // 0 = Small (two 64 KiB workgroups per CU), 1 = Big
+            const PartCap sc = seg_cap(pc.n);
+            const size_t slice_bytes = (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4;
+            auto run = [&](auto G_) {
+                using G = decltype(G_);
+                const uint32_t piece = piece_keys(pc.n, G::GRID);
+                hipLaunchKernelGGL(part_reads_direct<G>, dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
+                                   ctx->d_counts, ablate & 3);
+                hipLaunchKernelGGL(part_keys16_direct<G>, dim3(G::HALVES * NBK), dim3(G::T), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, sc, cur2,
+                                   (uint16_t*)ctx->d_part_keys[1], ctx->d_counts, (ablate >> 4) & 3);
+                if (ctx->stats_on && ctx->d_stats)    // keys that reached a final bucket's region (the few sent straight to the table are not in it)
+                    hipLaunchKernelGGL(part_sum_cursors, dim3(1), dim3(256), 0, ctx->stream, cur2, G::HALVES * g.nb, ctx->d_stats);
+                hipLaunchKernelGGL(part_apply2<G::HALVES>, dim3(g.nb), dim3(PA), slice_bytes, ctx->stream, (const uint16_t*)ctx->d_part_keys[1], cur2, g, sc,
+                                   ctx->d_counts);
+            };
+            if (geom == 0) run(GeomSmall{});
+            else run(GeomBig{});
             LHGT_HIP(hipGetLastError());
             continue;
         }
-        LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(65536 + 256) * 4, ctx->stream));
+        LHGT_HIP(hipMemsetAsync(ctx->d_part_meta, 0, (size_t)(2 * 65536 + 256) * 4, ctx->stream));   // cur2, and cur1 behind its 2 x 65536 entries
         if (max_nk <= 128 && ctx->e <= 3) {
             int rpt = (int)(TILE_KEYS1 / ((long)max_nk * ctx->e));
             if (rpt > (PT1 / 64) * RW) rpt = (PT1 / 64) * RW;

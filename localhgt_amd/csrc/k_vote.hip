@@ -819,7 +819,7 @@ int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
             if (nf <= ctx->voted_cap) break;
             hipFree(ctx->d_voted);      // more voted peaks than room: grow once and redo
             ctx->d_voted = nullptr;
-            cap = nf + nf / 8;
+            cap = (nf + nf / 8 + 1) & ~1L;   // even: the 64-bit counter sits behind cap 12-byte records and must be 8-byte aligned (round 4: an odd cap faulted on the first sample with more than 4096 voted peaks)
         }
         rec.resize((size_t)nf * 3);
         if (nf) LHGT_HIP(hipMemcpyAsync(rec.data(), ctx->d_voted, (size_t)nf * 12, hipMemcpyDeviceToHost, ctx->stream)); LHGT_HIP(hipStreamSynchronize(ctx->stream));

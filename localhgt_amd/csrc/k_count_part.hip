@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
     uint32_t nv_cur = load_keys(0, key);
     for (uint32_t tl = 0; tl < n_tiles; tl++) {
         const uint32_t nv_next = load_keys(tl + 1, knext);       // the next tile's keys: requested before this tile is placed, first looked at a whole tile later
-        bool over = false;
+        uint32_t ovmask = 0;
         if (ablate & 2) {
             uint32_t x = 0;
 #pragma unroll
@@ -912,13 +912,7 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
                 const uint32_t bk = key[u0 + u] >> 24;
                 uint16_t* dst = ok ? &tile[bk * G::S2 + ((pos[u] + 8u * (bk & 7u)) & (uint32_t)(G::S2 - 1))] : (uint16_t*)&dump[64 + lane];   // rows rotated by whole 16-byte groups, as in the read scatter
                 *dst = (uint16_t)key[u0 + u];
-                over |= lv && pos[u] >= (uint32_t)G::S2;
-            }
-            if (__ballot(over)) {
-#pragma unroll
-                for (int u = 0; u < PG; u++)
-                    if ((uint32_t)(u0 + u) * (uint32_t)G::T + threadIdx.x < nv_cur && pos[u] >= (uint32_t)G::S2) part_sat_inc(counts, key[u0 + u]);
-                over = false;
+                if (lv && pos[u] >= (uint32_t)G::S2) ovmask |= 1u << (u0 + u);   // bucket over its slots: that key goes to the table (below)
             }
         }
         }
@@ -949,6 +943,13 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
             if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = have - full; }
         }
         __syncthreads();
+        // keys whose bucket was over its slots: straight to the table, HERE -- a global read-modify-write loop in the middle of the
+        // placement makes every later s_waitcnt a vmcnt(0), and the second group of tickets then waits for the NEXT tile's loads
+        if (__ballot(ovmask != 0u)) {
+#pragma unroll
+            for (int u = 0; u < G::KPT; u++)
+                if ((ovmask >> u) & 1u) part_sat_inc(counts, key[u]);
+        }
 #pragma unroll
         for (int u = 0; u < G::KPT; u++) key[u] = knext[u];
         nv_cur = nv_next;

@@ -291,8 +291,8 @@ int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_ti
 /* ---- work counters for the roofline's "bytes the implemented algorithm must move" (bench.py).  enable = 1: count from
  *      zero from now on; 0: stop; -1: leave as it is.  out (nullable, 8 values): [0] keys routed by phase A = valid k-mers x e of the
  *      counted mates (the direct kernel of k < 26 reports the upper bound k-mer positions x e); [1] count-table probes of phase B's
- *      probe kernel in the LAST lhgt_ref_scan (e per position with a k-mer in the exact form; the hashes marked as probed in the
- *      per-position state bytes in the single-first / trio-first forms, the fill of the few unsettled tiles included); [3] probes that
+ *      probe kernel in the last lhgt_ref_scan while counting was on (e per position with a k-mer in the exact form; the hashes
+ *      ref_flags_lite / ref_flags_trio marked as probed, summed before the fill of the unsettled tiles); [3] probes that
  *      went on from the LDS fold to the L2 bitmap; [4] probes that went on from the bitmap to peak_kmer; [5] pairs voted in the
  *      lane-per-offset form behind the filters; the others 0.  No reference counterpart: measurement only. */
 int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]);

@@ -27,17 +27,6 @@ __global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, ui
     for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); nz += __shfl_xor(nz, d, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)acc); atomicAdd(out + 1, (unsigned long long)nz); }
 }
-// probes of phase B's lite / trio-first forms, read off the per-position probe-state bytes (k_scan.hip: pstate = hashes that read 3
-// in bits 0-2, hashes PROBED in bits 4-6): sum of popcount(bits 4-6) over the positions that have a k-mer
-__global__ void __launch_bounds__(256) pstate_probe_sum(const uint8_t* __restrict__ ps, uint64_t n, unsigned long long* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long acc = 0;
-    for (; i < n; i += stride) acc += (unsigned long long)__popc((uint32_t)(ps[i] >> 4) & 7u);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
-}
 }  // namespace lhgt
 
 #include <mutex>
@@ -125,9 +114,9 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
 // Work counters for bench.py's "bytes the implemented algorithm must move" (DESIGN.md 5).  enable = 1: start counting from zero;
 // 0: stop; -1: leave as it is.  out (nullable) receives
 //   [0] keys routed by phase A (valid k-mers x e of the counted mates; the direct kernel reports the upper bound k-mer positions x e)
-//   [1] table probes of phase B's probe kernel in the LAST lhgt_ref_scan: e per position with a k-mer in the exact form, the hashes
-//       marked as probed in the per-position state bytes in the lite / trio-first forms (the fill of the few unsettled tiles included:
-//       an upper bound of ref_flags_lite / ref_flags_trio themselves)
+//   [1] table probes of phase B's probe kernel in the LAST lhgt_ref_scan while counting was on: e per position with a k-mer in the
+//       exact form; in the single-first / trio-first forms the hashes ref_flags_lite / ref_flags_trio marked as probed in the
+//       per-position state bytes (summed right behind that kernel; the fill of the unsettled tiles comes later and is not in it)
 //   [3] probes that went on from the LDS fold to the L2 bitmap (vote_kernel_fold), [4] probes that went on from the bitmap to peak_kmer
 //       (vote_kernel_queued / vote_kernel_fold), [5] pairs voted in the lane-per-offset form after the filters (deferred / re-voted)
 //   [2], [6], [7] reserved (0).
@@ -143,24 +132,16 @@ int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]) {
     if (!out) return LHGT_OK;
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (!ctx->d_stats) return LHGT_OK;
-    // phase B: from the state the last scan left behind
-    unsigned long long probes_b = 0;
-    if (ctx->n_peaks >= 0 && ctx->index_resident) {
-        if (ctx->scan_form == 0) {
-            for (const ContigDev& c : ctx->contigs) probes_b += (unsigned long long)(c.len >= (uint32_t)ctx->k ? c.len - ctx->k + 1 : 0) * ctx->e;
-        } else if (ctx->d_nzmask && ctx->n_pos) {
-            if (!ctx->d_digest) LHGT_HIP(lhgt::dev_malloc(&ctx->d_digest, 16));
-            LHGT_HIP(hipMemsetAsync(ctx->d_digest, 0, 16, ctx->stream));
-            hipLaunchKernelGGL(pstate_probe_sum, dim3(8192), dim3(256), 0, ctx->stream, ctx->d_nzmask, ctx->n_pos, ctx->d_digest);
-            LHGT_HIP(hipMemcpyAsync(&probes_b, ctx->d_digest, 8, hipMemcpyDeviceToHost, ctx->stream));
-            LHGT_HIP(hipStreamSynchronize(ctx->stream));
-        }
-    }
+    // phase B, exact form: e probes per position with a k-mer (the single-first / trio-first forms count theirs on the device, right
+    // behind the probe kernel and before the fill of the unsettled tiles: k_scan.hip)
+    unsigned long long probes_exact = 0;
+    if (ctx->n_peaks >= 0 && ctx->index_resident && ctx->scan_form == 0)
+        for (const ContigDev& c : ctx->contigs) probes_exact += (unsigned long long)(c.len >= (uint32_t)ctx->k ? c.len - ctx->k + 1 : 0) * ctx->e;
     unsigned long long h[8];
     LHGT_HIP(hipMemcpyAsync(h, ctx->d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 8; i++) out[i] = h[i] + ctx->stats_host[i];
-    out[1] = probes_b;
+    if (ctx->scan_form == 0) out[1] = probes_exact;
     return LHGT_OK;
 }
 

@@ -68,6 +68,18 @@ __global__ void __launch_bounds__(256) table_line_summary(const uint32_t* __rest
     }
 }
 
+// lhgt_work_stats: probes of the single-first / trio-first probe kernels, read off the per-position probe-state bytes they leave
+// (pstate = hashes that read 3 in bits 0-2, hashes PROBED in bits 4-6): sum of popcount(bits 4-6)
+__global__ void __launch_bounds__(256) pstate_probe_sum(const uint8_t* __restrict__ ps, uint64_t n, unsigned long long* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (; i < n; i += stride) acc += (unsigned long long)__popc((uint32_t)(ps[i] >> 4) & 7u);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 // ---- B1
 template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
@@ -118,7 +130,8 @@ template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const RefSource rs, const uint32_t* __restrict__ counts,
                                                      int k, int e, uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
-                                                     const uint32_t* __restrict__ satline, const uint32_t* __restrict__ list /* nullable */, long n_blk) {
+                                                     const uint32_t* __restrict__ satline, const uint32_t* __restrict__ list /* nullable */, long n_blk,
+                                                     int stride /* every stride-th position is probed completely */) {
     const long blk = block2d();
     if (blk >= n_blk) return;
     const TileDev t = tiles[list ? list[blk] : blk];
@@ -134,7 +147,7 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
             uint32_t h[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
-            const bool sample = (j & 7) == 0;
+            const bool sample = (j % stride) == 0;
             uint32_t known = 0, is3 = 0;
 #pragma unroll
             for (int i = 0; i < 3; i++)
@@ -903,6 +916,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     int three_min = (int)(WINDOW * match_ratio);
     const dim3 grid = blocks2d(ctx->n_tiles), blk(BT);
     const long nt = ctx->n_tiles;
+    static const int lite_stride_env = getenv("LHGT_LITE_STRIDE") ? atoi(getenv("LHGT_LITE_STRIDE")) : 0;
+    const int lite_stride = lite_stride_env >= 2 && lite_stride_env <= 64 ? lite_stride_env : 8;
     // summary of the count table (one streaming pass, ~0.3 ms per GiB): saturated 64-byte lines (their bitmap is consulted first
     // when at least half the lines are) and slots holding 3 (a nearly full table takes the lite form of B1/B2)
     bool use_sat = false;
@@ -949,7 +964,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipMemcpyAsync(d_list, pl.data(), pl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LHGT_HIP(hipMemcpyAsync(d_list + pl.size(), pw.data(), pw.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ref_flags_lite<false>, dim3((unsigned)pl.size()), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts,
-                           k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list, (long)pl.size());
+                           k, e, ctx->d_flags, ctx->d_nzmask, ctx->d_satline, d_list, (long)pl.size(), lite_stride);
         hipLaunchKernelGGL(window_lite, dim3((unsigned)((pw.size() + 3) / 4)), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags,
                            ctx->d_tile_good, (uint32_t*)nullptr, d_cnt, d_list + pl.size(), (long)pw.size());
         unsigned int n_not = 0;
@@ -967,6 +982,10 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                            ctx->d_nzmask, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
+        if (ctx->stats_on && ctx->d_stats) {
+            LHGT_HIP(hipMemsetAsync(ctx->d_stats + 1, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(pstate_probe_sum, dim3(8192), dim3(256), 0, ctx->stream, ctx->d_nzmask, ctx->n_pos, ctx->d_stats + 1);
+        }
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(window_trio, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count, nt);   // tile_count: free until the id scan
@@ -986,11 +1005,15 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     } else if (ctx->scan_lite) {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr, nt);
+                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr, nt, lite_stride);
         else
             hipLaunchKernelGGL(ref_flags_lite<false>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
-                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr, nt);
+                               ctx->d_nzmask, ctx->d_satline, (const uint32_t*)nullptr, nt, lite_stride);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
+        if (ctx->stats_on && ctx->d_stats) {
+            LHGT_HIP(hipMemsetAsync(ctx->d_stats + 1, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(pstate_probe_sum, dim3(8192), dim3(256), 0, ctx->stream, ctx->d_nzmask, ctx->n_pos, ctx->d_stats + 1);
+        }
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(window_lite, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
@@ -1136,10 +1159,18 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     // vote prefilter (k_vote.hip): a bitmap over the low pf_bits address bits (exact when pf_bits = k, folded otherwise).
     // Sized at >= 16 bits per registered k-mer (false positives <= 6 %) but no larger: a 4 MiB bitmap does not stay
     // resident in a 4 MiB L2 next to the read stream (21 % of its probes missed), a 256 KiB one does.
-    const int pf_max = ctx->k < PF_BITS ? ctx->k : PF_BITS;
+    static const int pf_cap = getenv("LHGT_PF_BITS") ? atoi(getenv("LHGT_PF_BITS")) : PF_BITS;   // A/B: a smaller bitmap (24 = 2 MiB: half an XCD's L2)
+    const int pf_lim = pf_cap >= 19 && pf_cap < PF_BITS ? pf_cap : PF_BITS;
+    const int pf_max = ctx->k < pf_lim ? ctx->k : pf_lim;
     const unsigned long long n_keys = n_selected * (unsigned long long)ctx->e;
+    // Round 4 (profiles/r04/vote_l2_variants.txt): a 4 MiB bitmap is the WHOLE L2 of an XCD -- 3.3 % of its probes miss, and every
+    // peak_kmer probe that follows costs its own line plus 2.2 more bitmap misses (75 fabric reads per pair where 16 are needed);
+    // at 2 MiB the bitmap is resident (0.3 % misses, the level 296 instead of 331 ms per 100 M pairs) and lets 41 instead of 16
+    // probes per pair through: 371 instead of 385 ms.  So the last doubling, from half of the L2 to all of it, needs more reason
+    // than the others: >= 6 bits per key suffice for 2^24, 16 per key are asked for below that as before.
     int pf_bits = 19;
     while (pf_bits < pf_max && (1ull << pf_bits) < 16 * n_keys) pf_bits++;
+    if (pf_bits == PF_BITS && PF_BITS == 25 && (1ull << 24) >= 6 * n_keys && !getenv("LHGT_PF_BITS")) pf_bits = 24;
     if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
     ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key

@@ -25,7 +25,7 @@ KERNEL_SOURCES = {   # which sources a kernel's measured traffic depends on (sta
 }
 COMMON_SOURCES = ("lhgt_hash.hpp", "lhgt_common.hpp", "k_ingest.hip", "k_synth.hip")
 PHASE_KERNELS = {
-    "count_A": ("part_scatter_reads", "part_scatter_keys", "part_apply", "count_direct"),
+    "count_A": ("part_scatter_reads", "part_scatter_keys", "part_reads_direct", "part_keys16_direct", "part_apply", "count_direct"),
     "ref_flags": ("ref_flags=", "ref_flags_lite=", "ref_flags_trio="),      # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
     "vote_kernel": ("vote_kernel",),
 }

@@ -120,7 +120,7 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio"}.get(scan["form"], "ref_flags")
     vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
     info = {
-        "count_A": ("part_scatter_reads_reg+part_scatter_keys16+part_apply" if partitioned else "count_direct",
+        "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if (k, e, L) == (32, 3, 150) else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
                     f"phase A kernel family, {n_chunks} chunks of <= 4 Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
                     model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING),
         "ref_flags": (scan_kernel, {"single-first": "phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base",

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bench
+from benchlib.legs import Workload
 from test_gpu_fullsize_uhgg import _ragged_cuts, NC, CL
 from localhgt_amd.engine import Engine
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
@@ -28,7 +29,7 @@ for name in ("13000 x 1 Mbp", "ragged"):
     setup = time.time() - t0
     if eng.pairs_count() == 0:
         eng.synth_pairs(1, 2, NC, CL, 0, pairs)
-    w = bench.Workload(eng, None, 0, 1, False, out)
+    w = Workload(eng, None, 0, 1, False, out)
     dt, ms, n_peaks, nf = w.run(3, 1)
     res[name] = dict(extra, index_setup_s=round(setup, 2), ms_per_step=round(dt / 3 * 1e3, 1), count_A=round(ms[0], 1), scan_B=round(ms[1], 1),
                      vote_C=round(ms[2], 1), ref_flags=round(ms[3], 1), scan_form=eng.scan_info(), raw_peaks=n_peaks, filtered=nf)

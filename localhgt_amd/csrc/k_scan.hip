@@ -814,8 +814,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                 if (nzmask && i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
-                        const uint32_t fb = h & pf_mask;
-                        atomicOr(&prefilter[fb >> 5], pf_word_bits(h, pf2));
+                        atomicOr(&prefilter[pf_word(h, pf_mask)], pf_word_bits(h, pf2));
                     }
                 }
             }
@@ -887,8 +886,7 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
         const uint32_t h = regs[2 * i], id = regs[2 * i + 1];
         atomicMax(&peak_kmer[h], id);
         if (prefilter) {
-            const uint32_t fb = h & pf_mask;
-            atomicOr(&prefilter[fb >> 5], pf_word_bits(h, pf2));
+            atomicOr(&prefilter[pf_word(h, pf_mask)], pf_word_bits(h, pf2));
         }
     }
 }
@@ -1165,12 +1163,18 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     const unsigned long long n_keys = n_selected * (unsigned long long)ctx->e;
     // Round 4 (profiles/r04/vote_l2_variants.txt): a 4 MiB bitmap is the WHOLE L2 of an XCD -- 3.3 % of its probes miss, and every
     // peak_kmer probe that follows costs its own line plus 2.2 more bitmap misses (75 fabric reads per pair where 16 are needed);
-    // at 2 MiB the bitmap is resident (0.3 % misses, the level 296 instead of 331 ms per 100 M pairs) and lets 41 instead of 16
-    // probes per pair through: 371 instead of 385 ms.  So the last doubling, from half of the L2 to all of it, needs more reason
-    // than the others: >= 6 bits per key suffice for 2^24, 16 per key are asked for below that as before.
+    // at 2 MiB the bitmap is resident (0.3 % misses, the level 296 instead of 331 ms per 100 M pairs) but lets 41 instead of 16
+    // probes per pair through: 371 instead of 385 ms; THREE quarters of the 4 MiB (lhgt_hash.hpp: PF_Q3) are still resident (298 ms)
+    // and let 20 through: 360 ms.  So where 16 bits per key ask for the last doubling and 6 bits per key fit 2^24, the bitmap is
+    // 3 MiB (LHGT_PF_Q3=0: 2 MiB; LHGT_PF_BITS=25: the whole 4 MiB).
     int pf_bits = 19;
     while (pf_bits < pf_max && (1ull << pf_bits) < 16 * n_keys) pf_bits++;
-    if (pf_bits == PF_BITS && PF_BITS == 25 && (1ull << 24) >= 6 * n_keys && !getenv("LHGT_PF_BITS")) pf_bits = 24;
+    static const bool q3_off = getenv("LHGT_PF_Q3") && !atoi(getenv("LHGT_PF_Q3"));
+    ctx->pf_q3 = false;
+    if (pf_bits == PF_BITS && PF_BITS == 25 && ctx->k > PF_BITS && (1ull << 24) >= 6 * n_keys && !getenv("LHGT_PF_BITS")) {
+        if (q3_off) pf_bits = 24;
+        else ctx->pf_q3 = true;
+    }
     if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
     ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key
@@ -1229,7 +1233,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -1349,7 +1353,7 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
         long blocks = (n_regs_all + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(replay_regs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_regs_all, n_regs_all,
-                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask, ctx->pf2);
+                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2);
         LHGT_HIP(hipGetLastError());
     }
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -161,8 +161,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                         if (i < e) {
                             const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
                             if (PF == 1) {
-                                const uint32_t fb = h & pf_mask;
-                                ids[i] = pf_pass(prefilter[fb >> 5], h, pf2) ? peak_kmer[h] : 0u;
+                                ids[i] = pf_pass(prefilter[pf_word(h, pf_mask)], h, pf2) ? peak_kmer[h] : 0u;
                             } else if (NT) {   // tables of 1 GiB and more (k >= 28): nothing to keep in the caches
                                 // `nt`: +11 % probe rate on a table far beyond the caches (profiles/r01_probe_policy_microbench.txt)
                                 ids[i] = __builtin_nontemporal_load(peak_kmer + h);
@@ -382,8 +381,8 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             for (int q0 = 0; q0 < T; q0 += 128) {   // second level, the L2 bitmap: two gathers in flight per round
                 const int qa = q0 + lane, qb = qa + 64;
                 const uint32_t ha = qa < T ? Q[qa] : 0u, hb = qb < T ? Q[qb] : 0u;
-                const uint32_t wa = qa < T ? prefilter[(ha & pf_mask) >> 5] : 0u;
-                const uint32_t wb = qb < T ? prefilter[(hb & pf_mask) >> 5] : 0u;
+                const uint32_t wa = qa < T ? prefilter[pf_word(ha, pf_mask)] : 0u;
+                const uint32_t wb = qb < T ? prefilter[pf_word(hb, pf_mask)] : 0u;
                 const bool pa = qa < T && pf_pass(wa, ha, pf2), pb = qb < T && pf_pass(wb, hb, pf2);
                 const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
                 const int sa = T2 + __popcll(ba & ((1ull << lane) - 1ull));
@@ -425,6 +424,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
 // per pair of a 2.3 M-k-mer peak set; a reference of 118 k ragged contigs registers 14 M k-mers, a third of the bitmap probes
 // pass, and 235 survivors per pair sent every pair down the direct path.)
 constexpr int VQ_CAP = 1024, VQ_FLUSH = 512;
+template <bool Q3>   // the bitmap is three quarters of the 4 MiB its mask spans (lhgt_hash.hpp: PF_Q3)
 __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                           const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
                                                           uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                     hs[s][i] = h;
                     // unconditional load (a dead lane probes word 0), masked afterwards: under `ok &&` every load would sit in its own
                     // lane-masked branch next to its use and be waited for singly
-                    const uint32_t pass = pf_pass(prefilter[(h & pf_mask) >> 5], h, pf2) ? 1u : 0u;
+                    const uint32_t pass = pf_pass(prefilter[pf_word_t<Q3>(h, pf_mask)], h, pf2) ? 1u : 0u;
                     f1[s][i] = (ok && i < e) ? (pass & m512) : 0u;
                 }
             }
@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                             for (int i = 0; i < 3; i++)
                                 if (i < e) {
                                     const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
-                                    ids[i] = pf_pass(prefilter[(h & pf_mask) >> 5], h, pf2) ? peak_kmer[h] : 0u;   // 0 = no peak (E:454)
+                                    ids[i] = pf_pass(prefilter[pf_word_t<Q3>(h, pf_mask)], h, pf2) ? peak_kmer[h] : 0u;   // 0 = no peak (E:454)
                                     hit |= ids[i] != 0u;
                                 }
 #pragma unroll
@@ -677,7 +677,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, PF_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                            ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                           ctx->debug, ctx->pf_mask, ctx->pf2, (const uint32_t*)nullptr);                                   \
+                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr);          \
     } while (0)
         const bool nt = ctx->k >= 28;
         const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
@@ -690,7 +690,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 0.0;   // bit insertions per fold bit (0 = the defaults)
         const double fold_ins = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1));
         const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : 1.15) * (double)(1ull << LF2_BITS);
-        if (sparse_ok && ctx->k > PF_BITS && fold_ok && !(ctx->debug & 16)) {
+        if (sparse_ok && ctx->k > PF_BITS && fold_ok && !ctx->pf_q3 && !(ctx->debug & 16)) {
             const int fold_words = (int)std::min<unsigned long long>(LF2_WORDS, (ctx->pf_mask + 1ull) / 32);
             const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
             const size_t need = (size_t)b.d.n_pairs + 1;
@@ -733,8 +733,12 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (wpb < 1) wpb = 1;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256L * 16) blocks = 256L * 16;
-            hipLaunchKernelGGL(vote_kernel_queued, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                               ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
+            if (ctx->pf_q3)
+                hipLaunchKernelGGL(vote_kernel_queued<true>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
+                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
+            else
+                hipLaunchKernelGGL(vote_kernel_queued<false>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
+                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);

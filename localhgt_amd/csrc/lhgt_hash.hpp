@@ -94,6 +94,18 @@ __host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
 // bitmap is a fold of the table (pf2 != 0: fewer address bits than k) a key also sets a second bit of the same word, chosen by
 // the address bits above the fold -- a one-load blocked Bloom filter: 2.3 M keys in 2^25 bits pass 1.6 % of foreign probes
 // instead of 6.9 %.  A clear bit is still an exact negative.
+// Word of the bitmap that key h sets / tests.  Bit 31 of the mask argument flags the three-quarter bitmap (3 MiB of the 4 MiB a 25-bit
+// mask spans: what an XCD's 4 MiB L2 can keep next to the streams that pass through it): the 2^20 word numbers fold onto 3 * 2^18.
+constexpr uint32_t PF_Q3 = 0x80000000u;
+template <bool Q3>
+__device__ __forceinline__ uint32_t pf_word_t(uint32_t h, uint32_t pf_mask) {
+    const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
+    return Q3 ? (w * 3u) >> 2 : w;
+}
+__device__ __forceinline__ uint32_t pf_word(uint32_t h, uint32_t pf_mask) {       // flag looked at at run time (the kernels that are not hot)
+    const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
+    return (pf_mask & PF_Q3) ? (w * 3u) >> 2 : w;
+}
 __device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
     return (1u << (h & 31u)) | (pf2 ? 1u << ((h >> pf2) & 31u) : 0u);
 }

@@ -225,6 +225,7 @@ def main():
             verify = verify_forms(eng)
     dt, per_ms, n_peaks, nf = wl.run(args.steps, args.warmup)
     scan = eng.scan_info()
+    vote_form = eng.vote_info()
     xch_main = dict(wl.xch)
     other_form = None
     if len(forms) > 1:                                   # the other form of phase B, a few steps, same reads
@@ -256,7 +257,7 @@ def main():
     if args.ragged:
         from localhgt_amd.synth import ragged_cuts
         n_contigs_here = len(ragged_cuts(args.contigs * args.contig_len)) - 1
-    roof, dominant = rooflines(k, e, L, args.pairs, ref_bases, n_contigs_here, args.ref_form == "packed", per_ms, scan, n_peaks, traffic, traffic_src, stats)
+    roof, dominant = rooflines(k, e, L, args.pairs, ref_bases, n_contigs_here, args.ref_form == "packed", per_ms, scan, n_peaks, traffic, traffic_src, stats, vote_form)
     # bytes a step cannot avoid: the packed reads twice (A and C), the resident index once, count table written and read,
     # peak_kmer cleared (E:1458) -- everything else is the price of random access
     read_store = args.pairs * 2 * 3 * ((L + 31) // 32 + 1) * 4
@@ -279,7 +280,7 @@ def main():
         "exchange_ms": xch_ms,
         "n1_equivalent_ms": round(step_s * 1e3 - sum(xch_ms.values()), 3) if xch_ms else round(step_s * 1e3, 3),
         "sharded_index" if (other_form and forms[1]) else "replicated_index": other_form,
-        "scan_B_form": scan, "work_stats": stats, "memory_plan_bytes": plan,
+        "scan_B_form": scan, "vote_form": vote_form, "work_stats": stats, "memory_plan_bytes": plan,
         "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
         "planted_transfers": interval_recall(out_path, planted_breakpoints(args.contigs, args.contig_len, args.sample_contigs)) if world == 1 and not args.ragged else None,
         "verify": verify,

@@ -274,7 +274,8 @@ int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sam
  * sorted-tile scatters (histogram pass, shared regions, global run cursors) instead of round 4's direct form (k = 32, e = 3; outputs
  * unchanged); bit17 / bit18: the queued sparse vote kernel reads peak_kmer / the read records with plain instead of non-temporal
  * loads (outputs unchanged); bit19: the generic vote kernel walks every pair with six hit offsets, without the bound that proves most
- * pairs with long event lists unable to vote (k <= 23; outputs unchanged).
+ * pairs with long event lists unable to vote (k <= 23; outputs unchanged); bit20: the vote bitmap takes its three-quarter (3 MiB) form whatever
+ * the number of registered k-mers (k > 25; outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts
@@ -288,6 +289,11 @@ int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the pha
  *      be settled from that); 2 trio-first, for a sparse table (probes until a hash does not read 3; complete probes only near
  *      windows that reach the trio threshold).  n_tiles_exact = tiles that got the exact treatment. */
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact);
+/* ---- which kernel the last lhgt_vote took (k_vote.hip): *form = 0 the generic kernel probing peak_kmer itself (dense peak sets), 1 the
+ *      generic kernel behind the L2-resident bitmap, 2 the queued sparse kernel behind the bitmap, 3 the 128 KiB LDS fold in front of
+ *      bitmap and peak_kmer; *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only
+ *      three quarters of them are used (3 MiB instead of 4).  Measurement only. */
+int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarter);
 /* ---- work counters for the roofline's "bytes the implemented algorithm must move" (bench.py).  enable = 1: count from
  *      zero from now on; 0: stop; -1: leave as it is.  out (nullable, 8 values): [0] keys routed by phase A = valid k-mers x e of the
  *      counted mates (the direct kernel of k < 26 reports the upper bound k-mer positions x e); [1] count-table probes of phase B's

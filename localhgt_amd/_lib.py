@@ -100,6 +100,7 @@ SIGNATURES = {
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_scan_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), _lp, _lp],
     "lhgt_work_stats": [_vp, _i, _u64p],
+    "lhgt_vote_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lhgt_stream": [_vp, C.POINTER(_vp)],
     "lhgt_synchronize": [_vp],
 }

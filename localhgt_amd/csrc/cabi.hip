@@ -293,6 +293,16 @@ int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_ti
     return LHGT_OK;
 }
 
+int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarter) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (form) *form = ctx->vote_form;
+    int bits = 0;
+    for (unsigned long long m = (unsigned long long)ctx->pf_mask + 1ull; m > 1; m >>= 1) bits++;
+    if (bitmap_bits) *bitmap_bits = ctx->prefilter_on ? bits : 0;
+    if (three_quarter) *three_quarter = ctx->prefilter_on && ctx->pf_q3 ? 1 : 0;
+    return LHGT_OK;
+}
+
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !hip_stream) LHGT_FAIL(LHGT_E_ARG, "null argument");

@@ -1175,6 +1175,7 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
         if (q3_off) pf_bits = 24;
         else ctx->pf_q3 = true;
     }
+    if ((ctx->debug & (1 << 20)) && ctx->k > PF_BITS) { ctx->pf_q3 = true; pf_bits = PF_BITS; }   // test hook: the three-quarter bitmap whatever the key count
     if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
     ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key

@@ -690,7 +690,9 @@ int lhgt_vote(lhgt_ctx* ctx) {
         static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 0.0;   // bit insertions per fold bit (0 = the defaults)
         const double fold_ins = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1));
         const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : 1.15) * (double)(1ull << LF2_BITS);
+        ctx->vote_form = ctx->prefilter_on ? 1 : 0;
         if (sparse_ok && ctx->k > PF_BITS && fold_ok && !ctx->pf_q3 && !(ctx->debug & 16)) {
+            ctx->vote_form = 3;
             const int fold_words = (int)std::min<unsigned long long>(LF2_WORDS, (ctx->pf_mask + 1ull) / 32);
             const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
             const size_t need = (size_t)b.d.n_pairs + 1;
@@ -727,6 +729,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
                         fold_ins / (double)(1ull << LF2_BITS), n_def, b.d.n_pairs);
             }
         } else if (sparse_ok) {
+            ctx->vote_form = 2;
             const size_t per_wave_q = (size_t)std::max(max_ev * ctx->e * 2 + 64, 2 * VQ_CAP + 128) * 4;
             wpb = (int)(65536 / per_wave_q);
             if (wpb > 4) wpb = 4;

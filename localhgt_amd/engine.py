@@ -365,6 +365,13 @@ class Engine:
         _lib.check(self.lib.lhgt_work_stats(self.h, int(enable), _ptr(out, C.c_uint64)))
         return {name: int(v) for name, v in zip(self.WORK_STATS, out) if name}
 
+    def vote_info(self) -> dict:
+        """which kernel the last vote() took and the size of its bitmap (include/localhgt_hip.h: lhgt_vote_info)"""
+        f, b, q = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.lhgt_vote_info(self.h, C.byref(f), C.byref(b), C.byref(q)))
+        mib = (1 << b.value) / 8 / (1 << 20) * (0.75 if q.value else 1.0) if b.value else 0.0
+        return {"form": ("dense", "bitmap", "queued", "fold")[f.value], "bitmap_MiB": round(mib, 3)}
+
     def synchronize(self):
         _lib.check(self.lib.lhgt_synchronize(self.h))
 

@@ -446,7 +446,7 @@ def test_vote_prefilter_changes_nothing(Engine):
         eng.synth_pairs(3, 4, 16, 100_000, 0, 60_000)
         eng.count_kmers()
         votes = []
-        for flags in (0, 16, 32, 4, 128, 256, 16 | 2048):  # fold kernel (128 KiB, deferred judge), queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
+        for flags in (0, 16, 32, 4, 128, 256, 16 | 2048, (1 << 20) | 16, (1 << 20) | 32, (1 << 20) | 16 | 2048):   # bit 20: the 3 MiB form of the bitmap (queued kernel, generic kernel, queued kernel's direct branch)  # fold kernel (128 KiB, deferred judge), queued kernel, generic kernel with bitmap, no prefilter, scan variants, queued kernel's direct branch
             eng.set_debug(flags)
             n = eng.ref_scan(0.1, 0.08, 10**7)
             eng.vote()

@@ -110,12 +110,12 @@ def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_co
     dt, per_ms, n_peaks, nf = w.run(steps, 0 if want_stats else 1)
     d = {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
          "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
-         "scan_B_form": engine.scan_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs,
+         "scan_B_form": engine.scan_info(), "vote_form": engine.vote_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs,
          "work_stats": stats}
     if recall:
         d["planted_transfers"] = interval_recall(out_path, planted_breakpoints(n_contigs, contig_len, sample_contigs))
     roof, dom = rooflines(k, e, 150, pairs, ref_bases or n_contigs * contig_len, n_contigs, packed, per_ms, d["scan_B_form"], n_peaks,
-                          traffic or {}, LIVE if traffic else None, stats)
+                          traffic or {}, LIVE if traffic else None, stats, d["vote_form"])
     d["roofline"] = roof[dom]
     d["roofline_other"] = {ph: r for ph, r in roof.items() if ph != dom}
     d["_shape"] = {"per_ms": per_ms, "k": k, "e": e, "ref_bases": ref_bases or n_contigs * contig_len, "n_contigs": n_contigs, "packed": packed}
@@ -126,7 +126,7 @@ def reroof(d, traffic):
     """a leg's rooflines again once its PMC traffic is known (the children run after the engine has let go of the GPU)"""
     s = d["_shape"]
     roof, dom = rooflines(s["k"], s["e"], 150, d["pairs"], s["ref_bases"], s["n_contigs"], s["packed"], s["per_ms"], d["scan_B_form"], d["raw_peaks"],
-                          traffic or {}, LIVE if traffic else None, d.get("work_stats"))
+                          traffic or {}, LIVE if traffic else None, d.get("work_stats"), d.get("vote_form"))
     d["roofline"] = roof[dom]
     d["roofline_other"] = {ph: r for ph, r in roof.items() if ph != dom}
 

@@ -97,8 +97,10 @@ def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec
     return ent
 
 
-def vote_form_of(scan, stats, n_peaks, k):
-    """which vote kernel lhgt_vote took, from what it counted"""
+def vote_form_of(vote, stats):
+    """which vote kernel lhgt_vote took: from Engine.vote_info(), else from what it counted"""
+    if vote:
+        return vote["form"] if vote["form"] in ("fold", "queued") else "dense"
     if stats.get("vote_l2_probes"):
         return "fold"
     if stats.get("vote_hbm_probes") or stats.get("vote_revoted_pairs"):
@@ -106,7 +108,7 @@ def vote_form_of(scan, stats, n_peaks, k):
     return "dense"
 
 
-def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peaks, traffic, src, stats):
+def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peaks, traffic, src, stats, vote=None):
     """entries of the three kernel families of one workload (phase A's as one), and which one dominates the step.
     per_ms = phase_ms(0..3): A, B, C, the ref_flags kernel alone"""
     model_pairs = model_bytes_per_pair(L, k, e) * pairs
@@ -114,7 +116,7 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     n_batches = -(-pairs // (16 << 20))
     n_chunks = -(-pairs // (4 << 20))
     partitioned = k >= 26
-    vform = vote_form_of(scan, stats or {}, n_peaks, k)
+    vform = vote_form_of(vote, stats or {})
     need = needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats or {}, partitioned, scan["form"], vform) if stats is not None else {}
     kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
     scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio"}.get(scan["form"], "ref_flags")

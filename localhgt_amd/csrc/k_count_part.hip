@@ -702,8 +702,11 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
     __syncthreads();
     // piece (bucket, workgroup) = piece number workgroup * 256 + bucket: the 256 streams a workgroup writes lie side by side in 25 MB of
     // the buffer (a dozen 2 MiB pages) -- bucket-major, they were 50 MB apart and every store instruction missed the CU's TLB
-    uint32_t* const my_out = out + (size_t)blockIdx.x * NBK * piece;
-    const size_t bucket_stride = (size_t)piece;
+    // Level-1 keys leave as 24 bits: inside piece (m, w) the middle byte IS m, so a key is (top byte << 16 | low 16 bits); four keys
+    // make three words (12 bytes per lane, global_store_dwordx3) -- 9 instead of 12 bytes per key through the level-1 buffer.
+    const size_t piece_words = (size_t)piece / 4 * 3;
+    uint32_t* const my_out = out + (size_t)blockIdx.x * NBK * piece_words;
+    const size_t bucket_stride = piece_words;
     for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         // this tile's records go to the wave's staging words; the next tile's records and the descriptors of the one after are
         // requested now and not looked at before the next iteration
@@ -716,18 +719,19 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         __builtin_amdgcn_wave_barrier();
         load_records(dB, recB);
         load_descriptors(t + 2L * gridDim.x, dC);
-        bool over = false;
-#pragma unroll
-        for (int rr = 0; rr < G::RW; rr++) {
+        // Software pipeline over the wave's reads: the tickets of read r are drawn (six LDS atomics issued back to back), then read
+        // r + 1 is HASHED while they are in flight, then the slots of read r are computed and stored.  (Hash, tickets, wait, stores
+        // read by read left the vector unit idle during every wait and the LDS idle during every hash: with all sixteen waves of the
+        // workgroup in the same stretch at the same time, the two times added up.)
+        uint32_t ovm = 0;                                           // bit u of read rr: key whose bucket was over its slots
+        uint32_t key[2][6], pos[6];
+        bool live[2][2];
+        auto hash_read = [&](int rr, uint32_t (&kk)[6], bool (&lv)[2]) {
             const int len = cl[rr];
-            const int nk = len - k + 1;
-            if (nk <= 0) continue;                                  // wave-uniform
+            const int nk = len - k + 1;                             // <= 0: a padding read, every offset dead
             const int wpr = ((len + 31) >> 5) + 1;
-            uint32_t key[2][3];
-            bool live[2];
             // all six window word pairs of the read first (unconditional: the staging words behind a short read are there, just not
-            // meant), ONE wait, then the arithmetic -- `j < nk && window(2) == 0` put the not-a-base window into a lane-masked region
-            // with its own s_waitcnt: four exposed LDS round trips per read with four waves per SIMD to hide them
+            // meant), ONE wait, then the arithmetic
             uint32_t ww[2][3][2];
 #pragma unroll
             for (int it = 0; it < 2; it++)
@@ -744,41 +748,53 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
                     const uint32_t a = __builtin_amdgcn_alignbit(ww[it][plane][0], ww[it][plane][1], sh_win);
                     return r_zero ? ww[it][plane][0] : a;
                 };
-                live[it] = (j < nk) & (window(2) == 0);
+                lv[it] = (j < nk) & (window(2) == 0);
                 const uint32_t whi = window(0), wlo = window(1);
                 const uint32_t rhi = __brev(whi), rlo = __brev(wlo);
 #pragma unroll
-                for (int i = 0; i < 3; i++) key[it][i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+                for (int i = 0; i < 3; i++) kk[it * 3 + i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
             }
-            if (ablate & 2) {                                       // stage timing: the hashes only (kept alive through the dummy words)
-                dump[64 + lane] = key[0][0] ^ key[0][1] ^ key[0][2] ^ key[1][0] ^ key[1][1] ^ key[1][2];
-                continue;
-            }
-            // six keys, six tickets back to back, waited for once; a dead offset (beyond the read, a k-mer with an N) draws from a
-            // per-lane dummy counter and writes a per-lane dummy word: no branch per key
-            uint32_t pos[6];
+        };
+        // six keys, six tickets back to back; a dead offset (beyond the read, a k-mer with an N) draws from a per-lane dummy counter
+        // and writes a per-lane dummy word: no branch per key
+        auto draw = [&](const uint32_t (&kk)[6], const bool (&lv)[2]) {
 #pragma unroll
             for (int u = 0; u < 6; u++) {
-                const uint32_t kk = key[u / 3][u % 3];
-                uint32_t* ctr = live[u / 3] ? &cnt[(kk >> 16) & 0xffu] : &dump[lane];
+                uint32_t* ctr = lv[u / 3] ? &cnt[(kk[u] >> 16) & 0xffu] : &dump[lane];
                 pos[u] = atomicAdd(ctr, 1u);
             }
+        };
+        auto place = [&](int rr, const uint32_t (&kk)[6], const bool (&lv)[2]) {
 #pragma unroll
             for (int u = 0; u < 6; u++) {
-                const uint32_t kk = key[u / 3][u % 3];
-                const bool ok = live[u / 3] && pos[u] < (uint32_t)G::S1;
-                const uint32_t bk = (kk >> 16) & 0xffu;
+                const bool ok = lv[u / 3] && pos[u] < (uint32_t)G::S1;
+                const uint32_t bk = (kk[u] >> 16) & 0xffu;
                 // rows start at bank 0 and all buckets fill at the same pace: unrotated, a wave's stores crowd into the few banks of
                 // `pos`; row b is rotated by 4 (b & 7) slots (whole 16-byte groups, so the copy-out still moves aligned uint4s)
                 uint32_t* dst = ok ? &tile[bk * G::S1 + ((pos[u] + 4u * (bk & 7u)) & (uint32_t)(G::S1 - 1))] : &dump[64 + lane];
-                *dst = kk;
-                over |= live[u / 3] && pos[u] >= (uint32_t)G::S1;
+                *dst = kk[u];
+                if (lv[u / 3] && pos[u] >= (uint32_t)G::S1) ovm |= 1u << (rr * 6 + u);
             }
-            if (__ballot(over)) {                                   // a bucket ran over its slots (hot k-mers): those keys go to the table now
+        };
+        if (ablate & 2) {                                           // stage timing: the hashes only (kept alive through the dummy words)
 #pragma unroll
-                for (int u = 0; u < 6; u++)
-                    if (live[u / 3] && pos[u] >= (uint32_t)G::S1) part_sat_inc(counts, key[u / 3][u % 3]);
-                over = false;
+            for (int rr = 0; rr < G::RW; rr++) {
+                hash_read(rr, key[0], live[0]);
+                dump[64 + lane] = key[0][0] ^ key[0][1] ^ key[0][2] ^ key[0][3] ^ key[0][4] ^ key[0][5];
+            }
+        } else {
+            hash_read(0, key[0], live[0]);
+#pragma unroll
+            for (int rr = 0; rr < G::RW; rr++) {
+                draw(key[rr & 1], live[rr & 1]);
+                if (rr + 1 < G::RW) hash_read(rr + 1, key[(rr + 1) & 1], live[(rr + 1) & 1]);
+                place(rr, key[rr & 1], live[rr & 1]);
+                // a bucket ran over its slots (hot k-mers): those keys go to the table now (the read's keys are still in registers)
+                if (__ballot((ovm >> (rr * 6)) & 63u)) {
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        if ((ovm >> (rr * 6 + u)) & 1u) part_sat_inc(counts, key[rr & 1][u]);
+                }
             }
         }
         __syncthreads();
@@ -797,8 +813,13 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
             const uint32_t rot = 4u * ((uint32_t)bq & 7u);                                 // the row's rotation (see the placement)
             const uint4 v = *(const uint4*)&tile[bq * G::S1 + ((j + rot) & (uint32_t)(G::S1 - 1))];
             if (!(ablate & 1)) {
-                if (j < put) *(uint4*)(my_out + (size_t)bq * bucket_stride + c + j) = v;
-                else if (j < full) {                                // piece full: the rest goes straight to the table (exact either way)
+                if (j < put) {
+                    const uint32_t k0 = ((v.x >> 24) << 16) | (v.x & 0xffffu), k1 = ((v.y >> 24) << 16) | (v.y & 0xffffu);
+                    const uint32_t k2 = ((v.z >> 24) << 16) | (v.z & 0xffffu), k3 = ((v.w >> 24) << 16) | (v.w & 0xffffu);
+                    uint32_t* dst = my_out + (size_t)bq * bucket_stride + (size_t)(c + j) / 4 * 3;
+                    const uint32_t w0 = k0 | (k1 << 24), w1 = (k1 >> 8) | (k2 << 16), w2 = (k2 >> 16) | (k3 << 8);
+                    *(uint3*)dst = make_uint3(w0, w1, w2);          // global_store_dwordx3
+                } else if (j < full) {                              // piece full: the rest goes straight to the table (exact either way)
                     part_sat_inc(counts, v.x); part_sat_inc(counts, v.y); part_sat_inc(counts, v.z); part_sat_inc(counts, v.w);
                 }
             } else if (v.x + v.y == 0x12345u && v.z == v.w) my_out[c + j] = v.x;
@@ -811,17 +832,13 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
 #pragma unroll
         for (int rr = 0; rr < G::RW; rr++) recA[rr] = recB[rr];
     }
-    // the carried keys (fewer than four per bucket), one by one
+    // the carried keys (fewer than four per bucket and workgroup: 10^5 of a launch's 3 * 10^9): straight to the table -- the pieces only
+    // hold whole groups of four
     if (threadIdx.x < NBK) {
         const int bq = threadIdx.x;
-        uint32_t c = cur[bq];
         const uint32_t rem = cnt[bq];
-        for (uint32_t i = 0; i < rem; i++) {
-            const uint32_t kk = tile[bq * G::S1 + ((i + 4u * ((uint32_t)bq & 7u)) & (uint32_t)(G::S1 - 1))];
-            if (c < piece) my_out[(size_t)bq * bucket_stride + c++] = kk;
-            else part_sat_inc(counts, kk);
-        }
-        cnt1[bq * G::GRID + blockIdx.x] = c;
+        for (uint32_t i = 0; i < rem; i++) part_sat_inc(counts, tile[bq * G::S1 + ((i + 4u * ((uint32_t)bq & 7u)) & (uint32_t)(G::S1 - 1))]);
+        cnt1[bq * G::GRID + blockIdx.x] = cur[bq];
     }
 }
 
@@ -868,16 +885,29 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
     // placement and copy-out times simply added up).
     uint32_t pw = 0;                                              // piece of the tile being loaded (uniform, only moves forward)
     uint32_t key[G::KPT], knext[G::KPT];
+    static_assert(G::KPT % 4 == 0, "a thread loads whole groups of four 24-bit keys");
+    const uint32_t hi_m = m << 16;                                // the middle byte every key of this segment has
     auto load_keys = [&](uint32_t tl, uint32_t (&kk)[G::KPT]) -> uint32_t {   // returns the tile's number of keys (0 past the end)
         const uint32_t tc = tl < n_tiles ? tl : n_tiles - 1u;    // past the end: the last tile once more, ignored
         while (tc >= pref[pw + 1]) pw++;                          // uniform; tc < n_tiles = pref[256]
-        const uint32_t o = (tc - pref[pw]) * TK, left = pcnt[pw] - o;
+        const uint32_t o = (tc - pref[pw]) * TK, left = pcnt[pw] - o;   // pcnt, o: multiples of 4
         const uint32_t nv = left < TK ? left : TK;
-        const uint32_t* const base = in + ((size_t)(w0 + pw) * NBK + m) * piece + o;   // piece (bucket m, workgroup w) = piece number w * 256 + m
+        // piece (bucket m, workgroup w) = piece number w * 256 + m, piece / 4 * 3 words each; group g of four keys = words 3 g .. 3 g + 2
+        const uint32_t* const base = in + ((size_t)(w0 + pw) * NBK + m) * ((size_t)piece / 4 * 3) + (size_t)o / 4 * 3;
+        const uint32_t ng = nv / 4;
 #pragma unroll
-        for (int u = 0; u < G::KPT; u++) {
-            const uint32_t i = (uint32_t)u * (uint32_t)G::T + threadIdx.x;
-            kk[u] = base[i < nv ? i : nv - 1u];
+        for (int u = 0; u < G::KPT / 4; u++) {
+            const uint32_t gi = (uint32_t)u * (uint32_t)G::T + threadIdx.x;
+            const uint32_t* q = base + (size_t)(gi < ng ? gi : ng - 1u) * 3;
+            const uint3 w3 = *(const uint3*)q;                    // global_load_dwordx3
+            const uint32_t w0_ = w3.x, w1_ = w3.y, w2_ = w3.z;
+            const uint32_t k0 = w0_ & 0xffffffu, k1 = (w0_ >> 24) | ((w1_ & 0xffffu) << 8), k2 = (w1_ >> 16) | ((w2_ & 0xffu) << 16), k3 = w2_ >> 8;
+            // back to the 32-bit key (top byte, this segment's middle byte, low 16 bits): what the tickets, the stores and the
+            // overflow path below work on
+            kk[4 * u + 0] = ((k0 >> 16) << 24) | hi_m | (k0 & 0xffffu);
+            kk[4 * u + 1] = ((k1 >> 16) << 24) | hi_m | (k1 & 0xffffu);
+            kk[4 * u + 2] = ((k2 >> 16) << 24) | hi_m | (k2 & 0xffffu);
+            kk[4 * u + 3] = ((k3 >> 16) << 24) | hi_m | (k3 & 0xffffu);
         }
         return tl < n_tiles ? nv : 0u;
     };
@@ -895,19 +925,19 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
             for (int u = 0; u < G::KPT; u++) x ^= key[u];
             dump[64 + lane] = x;
         } else {
-        constexpr int PG = G::KPT / 2;          // tickets taken back to back
+        constexpr int PG = G::KPT;              // all tickets of the tile back to back, then the stores
 #pragma unroll
         for (int u0 = 0; u0 < G::KPT; u0 += PG) {
             uint32_t pos[PG];
 #pragma unroll
             for (int u = 0; u < PG; u++) {
-                const bool lv = (uint32_t)(u0 + u) * (uint32_t)G::T + threadIdx.x < nv_cur;
+                const bool lv = 4u * ((uint32_t)((u0 + u) / 4) * (uint32_t)G::T + threadIdx.x) + (uint32_t)((u0 + u) % 4) < nv_cur;
                 uint32_t* ctr = lv ? &cnt[key[u0 + u] >> 24] : &dump[lane];
                 pos[u] = atomicAdd(ctr, 1u);
             }
 #pragma unroll
             for (int u = 0; u < PG; u++) {
-                const bool lv = (uint32_t)(u0 + u) * (uint32_t)G::T + threadIdx.x < nv_cur;
+                const bool lv = 4u * ((uint32_t)((u0 + u) / 4) * (uint32_t)G::T + threadIdx.x) + (uint32_t)((u0 + u) % 4) < nv_cur;
                 const bool ok = lv && pos[u] < (uint32_t)G::S2;
                 const uint32_t bk = key[u0 + u] >> 24;
                 uint16_t* dst = ok ? &tile[bk * G::S2 + ((pos[u] + 8u * (bk & 7u)) & (uint32_t)(G::S2 - 1))] : (uint16_t*)&dump[64 + lane];   // rows rotated by whole 16-byte groups, as in the read scatter

@@ -849,7 +849,8 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
                                                           PartCap pc, uint32_t* __restrict__ cur2 /*[half][final bucket]*/, uint16_t* __restrict__ out,
                                                           uint32_t* __restrict__ counts, int ablate /* 1 no stores, 2 no placement */) {
     __shared__ __align__(16) uint16_t tile[NBK * G::S2];
-    __shared__ uint32_t cnt[NBK], cur[NBK], rbase[NBK], rcap[NBK], hist[NBK], pref[NBK + 1], pcnt[NBK], wsum[4];
+    __shared__ uint32_t cnt[NBK], cur[NBK], rcap[NBK], hist[NBK], pref[NBK + 1], pcnt[NBK], wsum[4];
+    __shared__ size_t rbase[NBK];             // a chunk of 8 Mi pairs holds more than 2^32 final keys
     __shared__ uint32_t dump[128];
     const uint32_t m = blockIdx.x / (uint32_t)G::HALVES, half = blockIdx.x % (uint32_t)G::HALVES;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -865,7 +866,7 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
         hist[threadIdx.x] = (c + TK - 1u) / TK;                  // tiles of this piece
         cnt[threadIdx.x] = 0;
         cur[threadIdx.x] = 0;
-        rbase[threadIdx.x] = (uint32_t)final_region(pc, m, threadIdx.x, half, G::HALVES);   // final bucket (top byte = threadIdx.x, middle byte = m); pc = seg_cap
+        rbase[threadIdx.x] = final_region(pc, m, threadIdx.x, half, G::HALVES);   // final bucket (top byte = threadIdx.x, middle byte = m); pc = seg_cap
         rcap[threadIdx.x] = half_region(pc, threadIdx.x, G::HALVES);
     }
     __syncthreads();
@@ -1003,7 +1004,8 @@ __global__ void __launch_bounds__(PA) part_apply2(const uint16_t* __restrict__ k
                                                   PartCap pc, uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t slice[];   // 2^16 / 16 words
     const uint32_t fb = blockIdx.x;                                 // slice of the table = key >> 16 = (top byte, middle byte)
-    const uint32_t hr = half_region(pc, fb >> 8, HALVES), r0 = (uint32_t)final_region(pc, fb & 0xffu, fb >> 8, 0, HALVES);   // pc = seg_cap
+    const uint32_t hr = half_region(pc, fb >> 8, HALVES);
+    const size_t r0 = final_region(pc, fb & 0xffu, fb >> 8, 0, HALVES);   // pc = seg_cap
     uint32_t nh[HALVES], n_all = 0;
 #pragma unroll
     for (int h = 0; h < HALVES; h++) {
@@ -1029,13 +1031,14 @@ __global__ void __launch_bounds__(PA) part_apply2(const uint16_t* __restrict__ k
     constexpr int U = 2;              // 16-byte groups in flight per thread
 #pragma unroll
     for (int h = 0; h < HALVES; h++) {
-        const uint32_t k0 = r0 + (uint32_t)h * hr, k1 = k0 + nh[h];
-        for (uint32_t base = k0; base < k1; base += U * PA * 8) {
+        const uint16_t* const kh = keys + r0 + (size_t)h * hr;        // this part's keys: positions 0 .. nh[h]
+        const uint32_t k1 = nh[h];
+        for (uint32_t base = 0; base < k1; base += U * PA * 8) {
             uint4 v[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t i = base + (u * PA + threadIdx.x) * 8;
-                v[u] = i < k1 ? *(const uint4*)(keys + i) : make_uint4(0, 0, 0, 0);   // the group is inside the half region even when k1 cuts it
+                v[u] = i < k1 ? *(const uint4*)(kh + i) : make_uint4(0, 0, 0, 0);   // the group is inside the half region even when k1 cuts it
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -1079,14 +1082,18 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         const PartCap c = cap_of(np);
         return c.n + c.n / 16 + (unsigned long long)g.nb * 512ull + 64;
     };
-    long want = b.d.n_pairs < (4L << 20) ? b.d.n_pairs : (4L << 20);
-    while (want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
-    size_t need = (size_t)need_of(want);
-    {   // the direct form's level-1 buffer: 65536 pieces
+    // round 4's direct form of the two scatters (k = 32, e = 3, reads of <= 159 bases); LHGT_DEBUG bit 16: round 3's sorted tiles
+    const bool direct_form = ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && !(ctx->debug & 65536);
+    static const long chunk_env = getenv("LHGT_PART_CHUNK") ? atol(getenv("LHGT_PART_CHUNK")) : 0;   // pairs per chunk of the direct form (A/B)
+    const long chunk_max = direct_form ? (chunk_env > 0 ? chunk_env : (8L << 20)) : (4L << 20);   // the direct form addresses its buffers with 64 bits
+    long want = b.d.n_pairs < chunk_max ? b.d.n_pairs : chunk_max;
+    while (!direct_form && want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
+    size_t need = direct_form ? 0 : (size_t)need_of(want);
+    if (direct_form) {   // buffer 0 (need x 4 bytes) holds 65536 pieces of 24-bit keys, buffer 1 (need x 2 bytes) the final regions
         const size_t need_pieces = std::max((size_t)piece_keys(cap_of(want).n, GeomBig::GRID) * (size_t)(NBK * GeomBig::GRID),
                                             (size_t)piece_keys(cap_of(want).n, GeomSmall::GRID) * (size_t)(NBK * GeomSmall::GRID)) + 64;   // either geometry
         const size_t need_final = (size_t)seg_size(seg_cap(cap_of(want).n)) * NBK + 64;
-        if (ctx->k == 32 && ctx->e == 3 && max_nk <= 128) need = std::max(need, std::max(need_pieces, need_final));
+        need = std::max((need_pieces * 3 + 3) / 4, need_final);
     }
     if (ctx->part_keys_cap < need) {
         for (int i = 0; i < 2; i++) {
@@ -1100,8 +1107,6 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(2 * 65536 + NBK * 512) * 4));
     uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket (direct form: to each half of its region)
     uint32_t* cur1 = cur2 + 2 * 65536;     // keys sent to each level-1 segment (direct form: to each (bucket, workgroup) piece)
-    // round 4's direct form of the two scatters (k = 32, e = 3, reads of <= 159 bases); LHGT_DEBUG bit 16: round 3's sorted tiles
-    const bool direct_form = ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && !(ctx->debug & 65536);
     const int grid = 256 * 2;   // persistent-style grids: LDS admits two of these workgroups per CU
     for (long p0 = 0; p0 < b.d.n_pairs; p0 += chunk_pairs) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;

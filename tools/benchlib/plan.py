@@ -10,7 +10,8 @@ def memory_plan(pairs, ref_bases, n_contigs, k=32, e=3, L=150, packed=False, wor
     share = 1.0 / world if shard_index else 1.0
     n_pos = ref_bases * share
     wpr = (L + 31) // 32 + 1
-    chunk_pairs = min(pairs, 4 << 20)
+    direct = (k, e) == (32, 3) and L <= 159               # phase A's direct form: chunks of 8 Mi pairs, 24-bit level-1 keys
+    chunk_pairs = min(pairs, (8 if direct else 4) << 20)
     keys = chunk_pairs * 2 * (L - k + 1) * e
     nb = 1 << max(0, k - 16)
     plan = {
@@ -21,7 +22,9 @@ def memory_plan(pairs, ref_bases, n_contigs, k=32, e=3, L=150, packed=False, wor
         "count_table": (1 << k) / 4,
         "count_table_saturation_bitmap": (1 << k) / 4 / 64 / 8,
         "peak_kmer": (1 << k) * 4,
-        "partition_key_buffers": (keys + keys / 16 + nb * 512 + 64) * (4 + 2) + (65536 + 256) * 4 if k >= 26 else 0,
+        # two buffers of `need` x 4 and `need` x 2 bytes, need = keys + 1/16 + 512 per final bucket (the direct form's level-1 pieces
+        # hold 24-bit keys and use three quarters of the first)
+        "partition_key_buffers": (keys + keys / 16 + nb * 512 + 64) * (4 + 2) + (3 * 65536) * 4 if k >= 26 else 0,
         "vote_bitmap_fold_and_lists": (1 << 25) / 8 + 128 * 1024 + (min(pairs, 16 << 20) + 1) * 4,
         "exchange_buffers": 2 * (1 << k) / 4 if world > 1 else 0,     # all_to_all receive (world slices of 1/world) + the gathered slice's clone
         "synthetic_generator_staging": 0.5 * GB,

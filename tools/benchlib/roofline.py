@@ -40,8 +40,10 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
     n_chunks = -(-pairs // (4 << 20))
     out = {}
     if partitioned:
-        out["count_A"] = (reads + 12 * keys + n_chunks * 2 * table,
-                          f"reads {reads} + 12 B x {keys} keys (4 written + 4 read + 2 written + 2 read over the three passes) + {n_chunks} chunks x 2 x {table} B of table slices in and out")
+        direct = (k, e) == (32, 3) and L <= 159          # round 4's direct form: 24-bit level-1 keys
+        bpk = 10 if direct else 12
+        out["count_A"] = (reads + bpk * keys + n_chunks * 2 * table,
+                          f"reads {reads} + {bpk} B x {keys} keys ({'3 written + 3 read' if direct else '4 written + 4 read'} + 2 written + 2 read over the three passes) + {n_chunks} chunks x 2 x {table} B of table slices in and out")
     else:
         out["count_A"] = (reads + 2 * table, f"reads {reads} + the cache-resident table in and out 2 x {table}")
     n_pos = max(0, ref_bases - n_contigs * (k - 1))          # positions with a k-mer

@@ -26,11 +26,13 @@ What the line holds besides the contract's fields (all of it measured inside thi
   cpu_baseline  the CPU restatement on all host cores (kind "port": the checker, identical_to_gpu) and `reference`: the compiled
                 reference itself (oracle/_ref/extract_ref_raw, -t 10) run in the background on the same files
   secondary     one number per other regime: configs[1], the SNP 1 % sample, the CLI's default --sample 2e9, a ragged catalogue,
-                the packed reference, configs[4]-scale on one GPU (k = 32 / 21), and pairs/s from FASTQ files (e2e)
+                the packed reference, configs[4]-scale on one GPU (k = 32 / 21), and pairs/s from FASTQ files (e2e: last of all, in a
+                child process of its own -- 23 GB of files through the whole host pipeline must not be able to take the line along)
   at N > 1      value = the REPLICATED form (every rank scans the whole reference: per-GPU work fixed, which is what "weak" means);
                 sharded_index = the same step with phase B sharded over the ranks; exchange_ms; n1_equivalent_ms
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -91,6 +93,8 @@ def parse_args(argv=None):
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes")
     ap.add_argument("--quiet", action="store_true", help="(PMC children) no detail file")
     ap.add_argument("--make-cpu-files", default=None, metavar="DIR", help="(internal) write the CPU legs' FASTA/FASTQ/index into DIR and exit")
+    ap.add_argument("--e2e-child", default=None, metavar="JSON", help="(internal) run the from-FASTQ legs and write their record to JSON")
+    ap.add_argument("--device", type=int, default=0, help="(internal, with --e2e-child) the GPU to use")
     args = ap.parse_args(argv)
     wl_contigs, wl_pairs = (13000, 100_000_000) if args.workload == "uhgg" else (1000, 10_000_000)
     args.contigs = args.contigs or wl_contigs
@@ -103,10 +107,15 @@ def workload_key(args):
 
 
 def main():
+    faulthandler.enable()        # a native abort or fault leaves the Python frames it happened under on stderr
     args = parse_args()
     if args.make_cpu_files:
         from benchlib.cpu import make_files
         make_files(args.make_cpu_files, args.cpu_pairs)
+        return
+    if args.e2e_child:
+        from benchlib.secondary import e2e_child
+        e2e_child(args.e2e_child, args.k, args.e, args.device, args.full)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -319,6 +328,10 @@ def main():
             detail["cpu_baseline"] = {"error": str(ex)[:200]}
     if cpu_tmp:
         cpu_tmp.cleanup()
+    if extras and rank == 0 and world == 1:
+        from benchlib import secondary
+        emit(detail, "cpu baseline", detail_path)
+        secondary.run_e2e(detail, args, local, lambda stage: emit(detail, stage, detail_path))
     emit(detail, "final", detail_path)
     try:
         os.remove(out_path)

@@ -1,6 +1,8 @@
 import sys, time, json
-sys.path.insert(0, '/root/repo')
-import bench
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from benchlib.legs import Workload
 from localhgt_amd.engine import Engine
 nc, fp = 50_000, 25_000_000
 for kk in (21,):
@@ -9,7 +11,7 @@ for kk in (21,):
         e5.synth_reference(1, nc, 1_000_000)
         e5.synth_options(0, 20, 300)
         e5.synth_pairs(1, 2, nc, 1_000_000, 0, fp, 150)
-        w = bench.Workload(e5, None, 0, 1, False, '/tmp/iv.txt')
+        w = Workload(e5, None, 0, 1, False, '/tmp/iv.txt')
         dt, per_ms, n_peaks, nf = w.run(2, 1)
         print(kk, round(dt/2*1e3,1), [round(x,1) for x in per_ms], n_peaks, nf, e5.digest(e5.DIGEST_VOTES), flush=True)
         e5.set_debug(1)

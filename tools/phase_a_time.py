@@ -9,6 +9,7 @@ with Engine(32, 3) as g:
     g.rng_seed(1); g.coder_generate(); g.set_reference_form(True)
     g.synth_reference(1, 16, 1_000_000)           # the reads only need the generator's base stream
     g.synth_pairs(1, 2, 13000, 1_000_000, 0, pairs, 150)
+    g.set_debug(int(os.environ.get('PHASE_A_DEBUG', '0')))   # 65536 (bit 16): round 3's sorted-tile scatters
     for i in range(1 if os.environ.get('PHASE_A_ONLY') else 3):
         g.counts_clear(); g.count_kmers()
         print(f"partitioned count: {g.phase_ms(0):.1f} ms", flush=True)

@@ -27,5 +27,4 @@ with tempfile.TemporaryDirectory(prefix="lhgt_refcpu_") as tmp:
           f"({t_first:.1f} s building it); its own clock: counting (incl. 4 GiB memset + 50 M rand()) {count_s} s, whole run {total_s} s")
     print(f"=> {n_pairs / t_cached / 1e6:.4f} M pairs/s whole process, cached index")
     print("\n".join(l for l in out.splitlines() if "Slided" in l or "cost" in l.lower())[:1500])
-    cb = bench.cpu_baseline(32, 3, 20, 1_000_000, n_pairs, 0)
-    print("port:", cb)
+    print("(bench.py itself now times the reference binary and the port on every run: tools/benchlib/cpu.py)")

@@ -853,8 +853,8 @@ static int fasta_spans(lhgt_ctx* ctx, const Mapped& fa, const FastaIndex& fx, ui
         s0 = s1;
     }
     // Page-locking a span of the mapping costs about as much as copying it (~25 ms per GiB each, tools/h2d_rates.hip), so the
-    // NEXT span is locked on a helper thread while this one is copied, stripped and consumed, and the previous one is released
-    // there as well.  Locked ranges must not overlap: a span is locked from the first page boundary at or after the end of its
+    // NEXT span is locked on a helper thread while this one is copied, stripped and consumed, and the one before the previous one is
+    // released there as well.  Locked ranges must not overlap: a span is locked from the first page boundary at or after the end of its
     // predecessor's range; the few bytes before it travel as a small pageable copy.
     const uint64_t PAGE = 4096;
     std::vector<void*> locked(spans.size(), nullptr);
@@ -879,7 +879,10 @@ static int fasta_spans(lhgt_ctx* ctx, const Mapped& fa, const FastaIndex& fx, ui
     if (!spans.empty()) lock(0);
     for (size_t i = 0; i < spans.size() && rc == LHGT_OK; i++) {
         if (helper.joinable()) helper.join();
-        helper = std::thread([&, i] { if (i > 0) unlock(i - 1); if (i + 1 < spans.size()) lock(i + 1); });
+        // span i - 1 stays locked while span i is copied: span i's text starts inside the last page of that range, and the runtime must
+        // not be asked to copy from a registered range while another thread unregisters it (seen once as an abort inside the
+        // runtime: "pure virtual method called")
+        helper = std::thread([&, i] { if (i > 1) unlock(i - 2); if (i + 1 < spans.size()) lock(i + 1); });
         const Span& sp = spans[i];
         const size_t s0 = sp.s0, s1 = sp.s1;
         const uint64_t A = sp.A, B = sp.B, bases = sp.bases;

@@ -765,3 +765,38 @@ def test_odd_fasta_line_structure(Engine, oracle, tmp_path, name, text):
             eng.set_debug(0)
             res[packed] = (n, eng.peaks_export(n)[0].tolist() if n > 0 else [], eng.peak_kmer_export().tobytes())
         assert res[True] == res[False]
+
+
+def test_fasta_longer_than_one_upload_span(Engine, tmp_path):
+    """A FASTA is uploaded in spans (64 Mi bases for the index build, 256 Mi for the packed form) whose page-locking runs one span
+    ahead on a helper thread; a span's text starts inside the last locked page of its predecessor.  An index built over three
+    spans and loaded again, and the packed form loaded over two spans, against the same bases generated on the device (index
+    bytes against the restatement: test_odd_fasta_line_structure and the golden cases): same peaks, loci, registry and votes."""
+    import bench
+    k, e, cl = 32, 3, 1_000_000
+    fa = str(tmp_path / "ref.fa")
+    for packed, nc in ((False, 150), (True, 300)):
+        res = {}
+        for from_file in (False, True):
+            with Engine(k, e) as eng:
+                eng.rng_seed(1)
+                eng.coder_generate()
+                eng.set_reference_form(packed)
+                ref = eng.synth_reference(1, nc, cl, want_host=from_file)
+                if from_file:
+                    bench.write_fasta(fa, ref, nc, cl)
+                    del ref
+                    if packed:
+                        assert eng.reference_load_fasta(fa, None) == (nc, nc * cl)
+                    else:
+                        assert eng.index_build(fa, fa + ".idx", fa + ".len") == (nc, nc * cl)
+                        assert eng.index_load(fa + ".idx") == (nc, nc * cl)
+                        os.remove(fa + ".idx")
+                eng.synth_options(0, 20, 30)
+                eng.synth_pairs(1, 2, nc, cl, 0, 1_000_000, 150)
+                eng.counts_clear()
+                eng.count_kmers()
+                n = eng.ref_scan(0.1, 0.08, 3_000_000)
+                eng.vote()
+                res[from_file] = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_VOTES))
+        assert res[True] == res[False] and res[True][0] > 0, (packed, res)

@@ -160,7 +160,7 @@ def run_e2e(detail, args, local, emit, timeout_s=400):
     from . import ROOT
     with tempfile.TemporaryDirectory(prefix="lhgt_e2e_rec_") as tmp:
         rec = os.path.join(tmp, "e2e.json")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--e2e-child", rec, "--k", str(args.k), "--e", str(args.e), "--device", str(local)]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--e2e-child", rec, "-k", str(args.k), "-e", str(args.e), "--device", str(local)]
         if args.full:
             cmd.append("--full")
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",

@@ -635,16 +635,26 @@ template <class G>
 __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long pair0, long npairs, HashParams hp, uint32_t piece,
                                                          uint32_t* __restrict__ cnt1 /*[bucket][workgroup]*/, uint32_t* __restrict__ out,
                                                          uint32_t* __restrict__ counts, int ablate /* stage timing (LHGT_PART_ABLATE), results wrong: 1 no stores, 2 no placement */) {
-    __shared__ __align__(16) uint32_t tile[NBK * G::S1];
-    __shared__ uint32_t cnt[NBK], cur[NBK];
-    __shared__ uint32_t dump[128];           // per-lane dummy counter and dummy word of the branch-free placement
+    // Rows of S1 slots, RS1 = S1 + 4 words apart: every row starts 16 bytes further round the banks than the one before (all buckets
+    // fill at the same pace: with rows a multiple of the bank count apart a wave's stores would crowd into the few banks of the
+    // current position), and a slot's byte address is ONE multiply-add of bucket and ticket.  (Until the instruction counters of the
+    // 24-bit version were read -- profiles/r04/sq_phase_a_direct.txt: 42 lane-instructions per key, more than round 3's 38 -- rows
+    // were S1 apart and rotated by 4 (bucket & 7) slots: eight instructions per key for the address alone.)
+    constexpr int RS1 = G::S1 + 4;
+    constexpr uint32_t ROW_BYTES = RS1 * 4u, LIMIT = G::S1 * 4u;   // tickets count BYTES: a ticket is the slot's offset in its row
+    __shared__ __align__(16) uint32_t tile[NBK * RS1];
+    __shared__ uint32_t cnt[NBK], cur[NBK];  // cnt: bytes taken in the row (4 per key); cur: keys already in the piece
+    __shared__ uint32_t dump[G::T + 64];     // per-thread dummy counter (zeroed every tile: a dead offset's ticket never looks like an overflow), per-lane dummy word
     constexpr int STAGE_W = 20;              // <= 18 record words per read on this path (<= 159 bases) + the word a window may look past
     constexpr int NW = G::T / 64;
-    __shared__ uint32_t stage_all[NW * G::RW * STAGE_W];
+    __shared__ uint32_t stage_all[1 + NW * G::RW * STAGE_W];   // one word in front: the first window of a read looks at the word before it
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    uint32_t* stage = stage_all + wib * G::RW * STAGE_W;
-    const bool r_zero = (lane & 31) == 0;    // the window starts at a word boundary: v_alignbit by 32 would give the NEXT word
-    const uint32_t sh_win = 32u - (uint32_t)(lane & 31);
+    uint32_t* stage = stage_all + 1 + wib * G::RW * STAGE_W;
+    // window of offset j = bits j .. j + 31 of the plane = alignbit(W[q], W[q + 1], 32 - r) with q = j >> 5, r = j & 31 -- but a shift of
+    // 32 does not exist.  With q' = (j - 1) >> 5 and shift (32 - r) & 31 the same instruction gives W[q' + 1] = W[q] for r = 0 and is
+    // unchanged for r > 0: no select per window (the word in front of a read's first is read and shifted out)
+    const int wsel = ((lane + 31) >> 5) - 1;
+    const uint32_t sh_win = (32u - (uint32_t)(lane & 31)) & 31u;
     constexpr int k = 32;
     const long n_reads = 2 * npairs;
     constexpr int RPT = NW * G::RW;           // reads per tile (even)
@@ -723,9 +733,9 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         // r + 1 is HASHED while they are in flight, then the slots of read r are computed and stored.  (Hash, tickets, wait, stores
         // read by read left the vector unit idle during every wait and the LDS idle during every hash: with all sixteen waves of the
         // workgroup in the same stretch at the same time, the two times added up.)
-        uint32_t ovm = 0;                                           // bit u of read rr: key whose bucket was over its slots
         uint32_t key[2][6], pos[6];
         bool live[2][2];
+        dump[threadIdx.x] = 0u;
         auto hash_read = [&](int rr, uint32_t (&kk)[6], bool (&lv)[2]) {
             const int len = cl[rr];
             const int nk = len - k + 1;                             // <= 0: a padding read, every offset dead
@@ -737,22 +747,27 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
             for (int it = 0; it < 2; it++)
 #pragma unroll
                 for (int plane = 0; plane < 3; plane++) {
-                    const uint32_t* w = stage + rr * STAGE_W + plane * wpr + 2 * it + (lane >> 5);
+                    const uint32_t* w = stage + rr * STAGE_W + plane * wpr + 2 * it + wsel;
                     ww[it][plane][0] = w[0];
                     ww[it][plane][1] = w[1];
                 }
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int j = it * 64 + lane;
-                auto window = [&](int plane) {
-                    const uint32_t a = __builtin_amdgcn_alignbit(ww[it][plane][0], ww[it][plane][1], sh_win);
-                    return r_zero ? ww[it][plane][0] : a;
-                };
+                auto window = [&](int plane) { return __builtin_amdgcn_alignbit(ww[it][plane][0], ww[it][plane][1], sh_win); };
                 lv[it] = (j < nk) & (window(2) == 0);
                 const uint32_t whi = window(0), wlo = window(1);
                 const uint32_t rhi = __brev(whi), rlo = __brev(wlo);
+                const uint32_t fx = whi ^ wlo, rx = ~(rhi ^ rlo);
 #pragma unroll
-                for (int i = 0; i < 3; i++) kk[it * 3 + i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+                for (int i = 0; i < 3; i++) {
+                    // hash_from_windows at k = 32, where the three masks cover every bit: the final `^ kmask` is a NOT, folded into
+                    // the outer select's truth table (0x35 = ~0xCA)
+                    const uint32_t* mk = hp.mask[i];
+                    const uint32_t fwd = __builtin_amdgcn_bitop3_b32(mk[0], fx, bit_select(mk[1], whi, wlo), 0x35);
+                    const uint32_t rc = bit_select(mk[0], rx, bit_select(mk[1], rhi, rlo));
+                    kk[it * 3 + i] = fwd < rc ? fwd : rc;
+                }
             }
         };
         // six keys, six tickets back to back; a dead offset (beyond the read, a k-mer with an N) draws from a per-lane dummy counter
@@ -760,27 +775,27 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         auto draw = [&](const uint32_t (&kk)[6], const bool (&lv)[2]) {
 #pragma unroll
             for (int u = 0; u < 6; u++) {
-                uint32_t* ctr = lv[u / 3] ? &cnt[(kk[u] >> 16) & 0xffu] : &dump[lane];
-                pos[u] = atomicAdd(ctr, 1u);
+                uint32_t* ctr = lv[u / 3] ? &cnt[(kk[u] >> 16) & 0xffu] : &dump[threadIdx.x];
+                pos[u] = atomicAdd(ctr, 4u);
             }
         };
-        auto place = [&](int rr, const uint32_t (&kk)[6], const bool (&lv)[2]) {
+        // -> did a bucket of this read run over its slots?  (one maximum over the six tickets: a dead offset's are small)
+        auto place = [&](const uint32_t (&kk)[6], const bool (&lv)[2]) -> bool {
 #pragma unroll
             for (int u = 0; u < 6; u++) {
-                const bool ok = lv[u / 3] && pos[u] < (uint32_t)G::S1;
+                const bool ok = lv[u / 3] && pos[u] < LIMIT;
                 const uint32_t bk = (kk[u] >> 16) & 0xffu;
-                // rows start at bank 0 and all buckets fill at the same pace: unrotated, a wave's stores crowd into the few banks of
-                // `pos`; row b is rotated by 4 (b & 7) slots (whole 16-byte groups, so the copy-out still moves aligned uint4s)
-                uint32_t* dst = ok ? &tile[bk * G::S1 + ((pos[u] + 4u * (bk & 7u)) & (uint32_t)(G::S1 - 1))] : &dump[64 + lane];
+                uint32_t* dst = ok ? (uint32_t*)((char*)tile + (bk * ROW_BYTES + pos[u])) : &dump[G::T + lane];
                 *dst = kk[u];
-                if (lv[u / 3] && pos[u] >= (uint32_t)G::S1) ovm |= 1u << (rr * 6 + u);
             }
+            const uint32_t m0 = max(max(pos[0], pos[1]), pos[2]), m1 = max(max(pos[3], pos[4]), pos[5]);
+            return max(m0, m1) >= LIMIT;
         };
         if (ablate & 2) {                                           // stage timing: the hashes only (kept alive through the dummy words)
 #pragma unroll
             for (int rr = 0; rr < G::RW; rr++) {
                 hash_read(rr, key[0], live[0]);
-                dump[64 + lane] = key[0][0] ^ key[0][1] ^ key[0][2] ^ key[0][3] ^ key[0][4] ^ key[0][5];
+                dump[G::T + lane] = key[0][0] ^ key[0][1] ^ key[0][2] ^ key[0][3] ^ key[0][4] ^ key[0][5];
             }
         } else {
             hash_read(0, key[0], live[0]);
@@ -788,12 +803,12 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
             for (int rr = 0; rr < G::RW; rr++) {
                 draw(key[rr & 1], live[rr & 1]);
                 if (rr + 1 < G::RW) hash_read(rr + 1, key[(rr + 1) & 1], live[(rr + 1) & 1]);
-                place(rr, key[rr & 1], live[rr & 1]);
+                const bool over = place(key[rr & 1], live[rr & 1]);
                 // a bucket ran over its slots (hot k-mers): those keys go to the table now (the read's keys are still in registers)
-                if (__ballot((ovm >> (rr * 6)) & 63u)) {
+                if (__ballot(over)) {
 #pragma unroll
                     for (int u = 0; u < 6; u++)
-                        if ((ovm >> (rr * 6 + u)) & 1u) part_sat_inc(counts, key[rr & 1][u]);
+                        if (live[rr & 1][u / 3] && pos[u] >= LIMIT) part_sat_inc(counts, key[rr & 1][u]);
                 }
             }
         }
@@ -805,26 +820,26 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         for (int g = 0; g < NBK / (NW * BPI); g++) {
             const int bq = wib * (NBK / NW) + g * BPI + lane / LPR;
             const uint32_t j = (uint32_t)(lane % LPR) * 4u;
-            const uint32_t n_all = cnt[bq], c = cur[bq];
+            const uint32_t n_all = cnt[bq] >> 2, c = cur[bq];
             const uint32_t have = n_all < (uint32_t)G::S1 ? n_all : (uint32_t)G::S1;       // keys that found a slot
             const uint32_t full = have & ~3u;
             const uint32_t room = piece > c ? piece - c : 0u;                            // piece and c are multiples of 4
             const uint32_t put = full < room ? full : room;
-            const uint32_t rot = 4u * ((uint32_t)bq & 7u);                                 // the row's rotation (see the placement)
-            const uint4 v = *(const uint4*)&tile[bq * G::S1 + ((j + rot) & (uint32_t)(G::S1 - 1))];
+            const uint4 v = *(const uint4*)&tile[bq * RS1 + j];
             if (!(ablate & 1)) {
                 if (j < put) {
-                    const uint32_t k0 = ((v.x >> 24) << 16) | (v.x & 0xffffu), k1 = ((v.y >> 24) << 16) | (v.y & 0xffffu);
-                    const uint32_t k2 = ((v.z >> 24) << 16) | (v.z & 0xffffu), k3 = ((v.w >> 24) << 16) | (v.w & 0xffffu);
+                    // four keys (bytes: low 16 bits, middle byte, top byte) -> three words of 24-bit keys (low 16 bits, top byte): three
+                    // byte permutes (the shifts and masks they replace were twelve instructions)
                     uint32_t* dst = my_out + (size_t)bq * bucket_stride + (size_t)(c + j) / 4 * 3;
-                    const uint32_t w0 = k0 | (k1 << 24), w1 = (k1 >> 8) | (k2 << 16), w2 = (k2 >> 16) | (k3 << 8);
+                    const uint32_t w0 = __builtin_amdgcn_perm(v.y, v.x, 0x04030100u), w1 = __builtin_amdgcn_perm(v.z, v.y, 0x05040301u),
+                                   w2 = __builtin_amdgcn_perm(v.w, v.z, 0x07050403u);
                     *(uint3*)dst = make_uint3(w0, w1, w2);          // global_store_dwordx3
                 } else if (j < full) {                              // piece full: the rest goes straight to the table (exact either way)
                     part_sat_inc(counts, v.x); part_sat_inc(counts, v.y); part_sat_inc(counts, v.z); part_sat_inc(counts, v.w);
                 }
             } else if (v.x + v.y == 0x12345u && v.z == v.w) my_out[c + j] = v.x;
-            if (j == full && have > full) *(uint4*)&tile[bq * G::S1 + rot] = v;           // the carry (its first have - full words) to logical slot 0
-            if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = have - full; }
+            if (j == full && have > full) *(uint4*)&tile[bq * RS1] = v;                  // the carry (its first have - full words) to slot 0
+            if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = (have - full) << 2; }
         }
         __syncthreads();
         dA = dB;
@@ -836,8 +851,8 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
     // hold whole groups of four
     if (threadIdx.x < NBK) {
         const int bq = threadIdx.x;
-        const uint32_t rem = cnt[bq];
-        for (uint32_t i = 0; i < rem; i++) part_sat_inc(counts, tile[bq * G::S1 + ((i + 4u * ((uint32_t)bq & 7u)) & (uint32_t)(G::S1 - 1))]);
+        const uint32_t rem = cnt[bq] >> 2;
+        for (uint32_t i = 0; i < rem; i++) part_sat_inc(counts, tile[bq * RS1 + i]);
         cnt1[bq * G::GRID + blockIdx.x] = cur[bq];
     }
 }
@@ -848,10 +863,13 @@ template <class G>
 __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cnt1, uint32_t piece,
                                                           PartCap pc, uint32_t* __restrict__ cur2 /*[half][final bucket]*/, uint16_t* __restrict__ out,
                                                           uint32_t* __restrict__ counts, int ablate /* 1 no stores, 2 no placement */) {
-    __shared__ __align__(16) uint16_t tile[NBK * G::S2];
+    // rows of S2 two-byte slots, RS2 = S2 + 8 slots (16 bytes) apart; tickets count BYTES (2 per key): as in the read scatter
+    constexpr int RS2 = G::S2 + 8;
+    constexpr uint32_t ROW_BYTES = RS2 * 2u, LIMIT = G::S2 * 2u;
+    __shared__ __align__(16) uint16_t tile[NBK * RS2];
     __shared__ uint32_t cnt[NBK], cur[NBK], rcap[NBK], hist[NBK], pref[NBK + 1], pcnt[NBK], wsum[4];
     __shared__ size_t rbase[NBK];             // a chunk of 8 Mi pairs holds more than 2^32 final keys
-    __shared__ uint32_t dump[128];
+    __shared__ uint32_t dump[G::T + 64];      // per-thread dummy counter (zeroed every tile), per-lane dummy word
     const uint32_t m = blockIdx.x / (uint32_t)G::HALVES, half = blockIdx.x % (uint32_t)G::HALVES;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     constexpr int NW = G::T / 64;
@@ -888,6 +906,7 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
     uint32_t key[G::KPT], knext[G::KPT];
     static_assert(G::KPT % 4 == 0, "a thread loads whole groups of four 24-bit keys");
     const uint32_t hi_m = m << 16;                                // the middle byte every key of this segment has
+    auto key32 = [&](uint32_t k24) { return ((k24 >> 16) << 24) | hi_m | (k24 & 0xffffu); };
     auto load_keys = [&](uint32_t tl, uint32_t (&kk)[G::KPT]) -> uint32_t {   // returns the tile's number of keys (0 past the end)
         const uint32_t tc = tl < n_tiles ? tl : n_tiles - 1u;    // past the end: the last tile once more, ignored
         while (tc >= pref[pw + 1]) pw++;                          // uniform; tc < n_tiles = pref[256]
@@ -901,14 +920,12 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
             const uint32_t gi = (uint32_t)u * (uint32_t)G::T + threadIdx.x;
             const uint32_t* q = base + (size_t)(gi < ng ? gi : ng - 1u) * 3;
             const uint3 w3 = *(const uint3*)q;                    // global_load_dwordx3
-            const uint32_t w0_ = w3.x, w1_ = w3.y, w2_ = w3.z;
-            const uint32_t k0 = w0_ & 0xffffffu, k1 = (w0_ >> 24) | ((w1_ & 0xffffu) << 8), k2 = (w1_ >> 16) | ((w2_ & 0xffu) << 16), k3 = w2_ >> 8;
-            // back to the 32-bit key (top byte, this segment's middle byte, low 16 bits): what the tickets, the stores and the
-            // overflow path below work on
-            kk[4 * u + 0] = ((k0 >> 16) << 24) | hi_m | (k0 & 0xffffu);
-            kk[4 * u + 1] = ((k1 >> 16) << 24) | hi_m | (k1 & 0xffffu);
-            kk[4 * u + 2] = ((k2 >> 16) << 24) | hi_m | (k2 & 0xffffu);
-            kk[4 * u + 3] = ((k3 >> 16) << 24) | hi_m | (k3 & 0xffffu);
+            // three words -> four 24-bit keys (top byte << 16 | low 16 bits), kept that way: the ticket needs the top byte, the store the
+            // low half; only the overflow path wants the 32-bit key back (key32 below)
+            kk[4 * u + 0] = w3.x & 0xffffffu;
+            kk[4 * u + 1] = __builtin_amdgcn_perm(w3.y, w3.x, 0x0c050403u);
+            kk[4 * u + 2] = __builtin_amdgcn_perm(w3.z, w3.y, 0x0c040302u);
+            kk[4 * u + 3] = w3.z >> 8;
         }
         return tl < n_tiles ? nv : 0u;
     };
@@ -920,32 +937,38 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
     for (uint32_t tl = 0; tl < n_tiles; tl++) {
         const uint32_t nv_next = load_keys(tl + 1, knext);       // the next tile's keys: requested before this tile is placed, first looked at a whole tile later
         uint32_t ovmask = 0;
+        dump[threadIdx.x] = 0u;
         if (ablate & 2) {
             uint32_t x = 0;
 #pragma unroll
             for (int u = 0; u < G::KPT; u++) x ^= key[u];
-            dump[64 + lane] = x;
+            dump[G::T + lane] = x;
         } else {
-        constexpr int PG = G::KPT;              // all tickets of the tile back to back, then the stores
+            // all tickets of the tile back to back, then the stores.  A tile holds whole groups of four keys: one liveness test per group
+            const uint32_t ng_cur = nv_cur >> 2;
+            uint32_t pos[G::KPT];
+            bool lvg[G::KPT / 4];
 #pragma unroll
-        for (int u0 = 0; u0 < G::KPT; u0 += PG) {
-            uint32_t pos[PG];
+            for (int g4 = 0; g4 < G::KPT / 4; g4++) lvg[g4] = (uint32_t)g4 * (uint32_t)G::T + threadIdx.x < ng_cur;
 #pragma unroll
-            for (int u = 0; u < PG; u++) {
-                const bool lv = 4u * ((uint32_t)((u0 + u) / 4) * (uint32_t)G::T + threadIdx.x) + (uint32_t)((u0 + u) % 4) < nv_cur;
-                uint32_t* ctr = lv ? &cnt[key[u0 + u] >> 24] : &dump[lane];
-                pos[u] = atomicAdd(ctr, 1u);
+            for (int u = 0; u < G::KPT; u++) {
+                uint32_t* ctr = lvg[u / 4] ? &cnt[key[u] >> 16] : &dump[threadIdx.x];
+                pos[u] = atomicAdd(ctr, 2u);
             }
+            uint32_t mx = 0;
 #pragma unroll
-            for (int u = 0; u < PG; u++) {
-                const bool lv = 4u * ((uint32_t)((u0 + u) / 4) * (uint32_t)G::T + threadIdx.x) + (uint32_t)((u0 + u) % 4) < nv_cur;
-                const bool ok = lv && pos[u] < (uint32_t)G::S2;
-                const uint32_t bk = key[u0 + u] >> 24;
-                uint16_t* dst = ok ? &tile[bk * G::S2 + ((pos[u] + 8u * (bk & 7u)) & (uint32_t)(G::S2 - 1))] : (uint16_t*)&dump[64 + lane];   // rows rotated by whole 16-byte groups, as in the read scatter
-                *dst = (uint16_t)key[u0 + u];
-                if (lv && pos[u] >= (uint32_t)G::S2) ovmask |= 1u << (u0 + u);   // bucket over its slots: that key goes to the table (below)
+            for (int u = 0; u < G::KPT; u++) {
+                const bool ok = lvg[u / 4] && pos[u] < LIMIT;
+                uint16_t* dst = ok ? (uint16_t*)((char*)tile + ((key[u] >> 16) * ROW_BYTES + pos[u])) : (uint16_t*)&dump[G::T + lane];
+                *dst = (uint16_t)key[u];
+                mx = max(mx, pos[u]);
             }
-        }
+            // a bucket over its slots (a dead key's tickets are small: its counter starts every tile at 0): which keys, for the table below
+            if (__ballot(mx >= LIMIT)) {
+#pragma unroll
+                for (int u = 0; u < G::KPT; u++)
+                    if (lvg[u / 4] && pos[u] >= LIMIT) ovmask |= 1u << u;
+            }
         }
         __syncthreads();
         // copy-out: a row is LPR lanes x 8 keys (16 bytes); multiples of eight keys leave, the rest is carried
@@ -954,13 +977,12 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
         for (int g = 0; g < NBK / (NW * BPI); g++) {
             const int bq = wib * (NBK / NW) + g * BPI + lane / LPR;
             const uint32_t j = (uint32_t)(lane % LPR) * 8u;
-            const uint32_t n_all = cnt[bq], c = cur[bq];
+            const uint32_t n_all = cnt[bq] >> 1, c = cur[bq];
             const uint32_t have = n_all < (uint32_t)G::S2 ? n_all : (uint32_t)G::S2;
             const uint32_t full = have & ~7u;
             const uint32_t room = rcap[bq] > c ? rcap[bq] - c : 0u;                      // both multiples of 8
             const uint32_t put = full < room ? full : room;
-            const uint32_t rot = 8u * ((uint32_t)bq & 7u);
-            const uint4 v = *(const uint4*)&tile[bq * G::S2 + ((j + rot) & (uint32_t)(G::S2 - 1))];
+            const uint4 v = *(const uint4*)&tile[bq * RS2 + j];
             if (!(ablate & 1)) {
                 if (j < put) *(uint4*)(out + rbase[bq] + c + j) = v;
                 else if (j < full) {                                // region full: count those keys now (see the header of this file)
@@ -970,8 +992,8 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
                     for (int q = 0; q < 8; q++) part_sat_inc(counts, hi16 | ((w4[q >> 1] >> ((q & 1) * 16)) & 0xffffu));
                 }
             } else if (v.x + v.y == 0x12345u && v.z == v.w) out[c + j] = (uint16_t)v.x;
-            if (j == full && have > full) *(uint4*)&tile[bq * G::S2 + rot] = v;           // the carry (its first have - full keys) to logical slot 0
-            if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = have - full; }
+            if (j == full && have > full) *(uint4*)&tile[bq * RS2] = v;                  // the carry (its first have - full keys) to slot 0
+            if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = (have - full) << 1; }
         }
         __syncthreads();
         // keys whose bucket was over its slots: straight to the table, HERE -- a global read-modify-write loop in the middle of the
@@ -979,7 +1001,7 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
         if (__ballot(ovmask != 0u)) {
 #pragma unroll
             for (int u = 0; u < G::KPT; u++)
-                if ((ovmask >> u) & 1u) part_sat_inc(counts, key[u]);
+                if ((ovmask >> u) & 1u) part_sat_inc(counts, key32(key[u]));
         }
 #pragma unroll
         for (int u = 0; u < G::KPT; u++) key[u] = knext[u];
@@ -988,9 +1010,9 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
     if (threadIdx.x < NBK) {
         const int bq = threadIdx.x;
         uint32_t c = cur[bq];
-        const uint32_t rem = cnt[bq];
+        const uint32_t rem = cnt[bq] >> 1;
         for (uint32_t i = 0; i < rem; i++) {
-            const uint16_t kk = tile[bq * G::S2 + ((i + 8u * ((uint32_t)bq & 7u)) & (uint32_t)(G::S2 - 1))];
+            const uint16_t kk = tile[bq * RS2 + i];
             if (c < rcap[bq]) out[rbase[bq] + c++] = kk;
             else part_sat_inc(counts, ((uint32_t)bq << 24) | (m << 16) | kk);
         }

@@ -151,7 +151,9 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
             uint32_t known = 0, is3 = 0;
 #pragma unroll
             for (int i = 0; i < 3; i++)
-                if (i < e && (sample || is3 == 0u)) {
+                // a sampled position goes on until `single` AND `trio` are decided: a hash that reads 3 and one that does not settle
+                // both (round 4: before, all e hashes -- 3 probes where 2.5 do); any other position stops at the first 3
+                if (i < e && (is3 == 0u || (sample && known == is3))) {
                     uint32_t cnt = 0u;                                 // hash 0 = invalid (E:936-941)
                     if (h[i] != 0) {
                         if (SAT && ((satline[h[i] >> 13] >> ((h[i] >> 8) & 31u)) & 1u)) cnt = 3u;
@@ -160,8 +162,9 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
                     known |= 1u << i;
                     if (cnt == 3u) is3 |= 1u << i;                     // least_depth 3 (E:580)
                 }
-            const bool exact = known == full;
-            f = (uint8_t)((is3 != 0u) | ((exact && is3 == full) << 1) | (exact ? 0x80 : 0));
+            // both flags are exact once every hash was probed, or one read 3 (single) and one did not (no trio)
+            const bool exact = known == full || (is3 != 0u && known != is3);
+            f = (uint8_t)((is3 != 0u) | ((known == full && is3 == full) << 1) | (exact ? 0x80 : 0));
             ps = (uint8_t)(is3 | (known << 4));
         }
         flags[c.flat_base + j] = f;

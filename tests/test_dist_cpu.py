@@ -246,7 +246,7 @@ def test_bench_needed_bytes_model_and_memory_plan():
     from benchlib.roofline import needed_bytes, rooflines
     stats = {"count_keys": 71_000_000_000, "scan_probes": 16_800_000_000, "vote_l2_probes": 0, "vote_hbm_probes": 1_100_000_000, "vote_revoted_pairs": 10}
     need = needed_bytes(150, 32, 3, 100_000_000, 13_000_000_000, 13000, False, stats, True, "single-first", "queued")
-    assert abs(need["count_A"][0] - (100e6 * 2 * 78 + 10 * 71e9 + 24 * 2 * 2 ** 30)) < 1e9      # 24-bit level-1 keys: 3 + 3 + 2 + 2 B per key
+    assert abs(need["count_A"][0] - (100e6 * 2 * 78 + 10 * 71e9 + 12 * 2 * 2 ** 30)) < 1e9      # 24-bit level-1 keys: 3 + 3 + 2 + 2 B per key; 12 chunks of 8 Mi pairs
     assert abs(need["ref_flags"][0] - (16.8e9 * 128 + 12 * (13e9 - 13000 * 31) + 2 * 13e9)) < 1e9
     assert abs(need["vote_kernel"][0] - (100e6 * 2 * 78 + 1.1e9 * 128)) < 1e9
     scan = {"lite": True, "form": "single-first", "frac_slots_at_3": 0.8178, "tiles": 6500000, "tiles_exact": 13001}

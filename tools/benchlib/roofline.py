@@ -32,15 +32,26 @@ def read_store_bytes(pairs, L):
     return pairs * 2 * (3 * ((L + 31) // 32 + 1) * 4 + 6)
 
 
+def phase_a_chunks(pairs, direct):
+    """launches of each of phase A's three kernels per step: a batch of the read store holds 16 Mi pairs and is counted in chunks of
+    8 Mi pairs (round 4's direct form) or 4 Mi"""
+    batch, chunk = 16 << 20, (8 << 20) if direct else (4 << 20)
+    return (pairs // batch) * (batch // chunk) + -(-(pairs % batch) // chunk)
+
+
+def is_direct(k, e, L):
+    return (k, e) == (32, 3) and L <= 159
+
+
 def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitioned, scan_form, vote_form):
     """{family: (bytes per step, formula)} for the algorithm as built; stats = Engine.work_stats() of one step"""
     table = (1 << k) // 4                                   # 2-bit count table
     reads = read_store_bytes(pairs, L)
     keys = stats.get("count_keys") or pairs * 2 * (L - k + 1) * e
-    n_chunks = -(-pairs // (4 << 20))
     out = {}
     if partitioned:
-        direct = (k, e) == (32, 3) and L <= 159          # round 4's direct form: 24-bit level-1 keys
+        direct = is_direct(k, e, L)                      # round 4's direct form: 24-bit level-1 keys, chunks of 8 Mi pairs
+        n_chunks = phase_a_chunks(pairs, direct)
         bpk = 10 if direct else 12
         out["count_A"] = (reads + bpk * keys + n_chunks * 2 * table,
                           f"reads {reads} + {bpk} B x {keys} keys ({'3 written + 3 read' if direct else '4 written + 4 read'} + 2 written + 2 read over the three passes) + {n_chunks} chunks x 2 x {table} B of table slices in and out")
@@ -116,7 +127,8 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     model_pairs = model_bytes_per_pair(L, k, e) * pairs
     model_ref = ref_bases * (64 * e) + (ref_bases // 4 if packed else ref_bases * 4 * e)   # 204 B per base / 0.25 + 192
     n_batches = -(-pairs // (16 << 20))
-    n_chunks = -(-pairs // (4 << 20))
+    direct = is_direct(k, e, L)
+    n_chunks = phase_a_chunks(pairs, direct)
     partitioned = k >= 26
     vform = vote_form_of(vote, stats or {})
     need = needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats or {}, partitioned, scan["form"], vform) if stats is not None else {}
@@ -124,8 +136,8 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio"}.get(scan["form"], "ref_flags")
     vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
     info = {
-        "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if (k, e, L) == (32, 3, 150) else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
-                    f"phase A kernel family, {n_chunks} chunks of <= 4 Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
+        "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
+                    f"phase A kernel family, {n_chunks} chunks of <= {8 if direct else 4} Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
                     model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING),
         "ref_flags": (scan_kernel, {"single-first": "phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base",
                                     "trio-first": "phase B on a sparse table: probes per base until a hash does not read 3"}.get(

@@ -291,9 +291,8 @@ int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the pha
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact);
 /* ---- which kernel the last lhgt_vote took (k_vote.hip): *form = 0 the generic kernel probing peak_kmer itself (dense peak sets), 1 the
  *      generic kernel behind the L2-resident bitmap, 2 the queued sparse kernel behind the bitmap, 3 the 128 KiB LDS fold in front of
- *      bitmap and peak_kmer, 4 the queued kernel behind the XCD-sliced bitmap (k = 32: eight 3 MiB bitmaps, one per XCD's L2);
- *      *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only three quarters of them
- *      are used (3 MiB instead of 4), 8 when there are eight such bitmaps (24 MiB).  Measurement only. */
+ *      bitmap and peak_kmer; *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only
+ *      three quarters of them are used (3 MiB instead of 4).  Measurement only. */
 int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarter);
 /* ---- work counters for the roofline's "bytes the implemented algorithm must move" (bench.py).  enable = 1: count from
  *      zero from now on; 0: stop; -1: leave as it is.  out (nullable, 8 values): [0] keys routed by phase A = valid k-mers x e of the

@@ -299,7 +299,7 @@ int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarte
     int bits = 0;
     for (unsigned long long m = (unsigned long long)ctx->pf_mask + 1ull; m > 1; m >>= 1) bits++;
     if (bitmap_bits) *bitmap_bits = ctx->prefilter_on ? bits : 0;
-    if (three_quarter) *three_quarter = ctx->prefilter_on && ctx->pf_sliced ? 8 : ctx->prefilter_on && ctx->pf_q3 ? 1 : 0;
+    if (three_quarter) *three_quarter = ctx->prefilter_on && ctx->pf_q3 ? 1 : 0;
     return LHGT_OK;
 }
 

@@ -1180,31 +1180,21 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     }
     if ((ctx->debug & (1 << 20)) && ctx->k > PF_BITS) { ctx->pf_q3 = true; pf_bits = PF_BITS; }   // test hook: the three-quarter bitmap whatever the key count
     if (pf_bits > pf_max) pf_bits = pf_max;
-    // Round 4, the SLICED bitmap (lhgt_hash.hpp: PF_SLICED; k = 32): where one 3 MiB bitmap would hold fewer than 6 bits per key, eight
-    // of them -- one per XCD's L2 -- hold the keys by address bits 25..27.  LHGT_PF_SLICED=0 turns it off, =1 forces it (A/B); debug
-    // bit 21 forces it, bit 22 forbids it (tests).  Measured on a ragged 13 Gbase catalogue (14.3 M registered k-mers, 100 M pairs):
-    // see DESIGN.md 4.
-    static const int sliced_env = getenv("LHGT_PF_SLICED") ? atoi(getenv("LHGT_PF_SLICED")) : -1;
-    const bool sliced_fits = ctx->k == 32 && ctx->e <= 3 && PF_BITS == 25 && !getenv("LHGT_PF_BITS") && !(ctx->debug & (1 << 22)) &&
-                             2 * n_keys <= (unsigned long long)PF_SLICES * PF_SLICE_WORDS * 32ull;
-    ctx->pf_sliced = sliced_fits && ((ctx->debug & (1 << 21)) || sliced_env == 1 || (sliced_env != 0 && !ctx->pf_q3 && pf_bits == PF_BITS));
-    if (ctx->pf_sliced) { ctx->pf_q3 = true; pf_bits = PF_BITS; }
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
-    ctx->pf2 = ctx->pf_sliced ? PF2_SLICED : ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key
+    ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key
     // On while the bitmap still screens enough: with two bits per key, n_keys = 0.5 x 2^pf_bits leaves 63 % of the bits set and lets
     // 40 % of foreign probes through -- 285 of a pair's 714, which the queued kernel still holds in its queue -- and bitmap +
     // survivors (330 + 0.4 x 1430 ms per 100 M pairs) still beat 714 HBM probes per pair (1430 ms).  Round 1 stopped at 1/8 with a
     // queue for a dozen survivors: a ragged 13 Gbase reference (118 k contigs, 217 k peaks at their ends, 14 M registered k-mers)
     // fell off that cliff, 389 -> 1381 ms of phase C.
-    ctx->prefilter_on = !(ctx->debug & 4) && (ctx->pf_sliced || 2 * n_keys <= (1ull << pf_bits));
-    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] peaks %u, registered positions %llu (%llu k-mers), prefilter 2^%d bits%s %s\n", total, n_selected, n_keys, pf_bits, ctx->pf_sliced ? " x 3/4 x 8 slices" : ctx->pf_q3 ? " x 3/4" : "", ctx->prefilter_on ? "on" : "off");
+    ctx->prefilter_on = !(ctx->debug & 4) && 2 * n_keys <= (1ull << pf_bits);
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] peaks %u, registered positions %llu (%llu k-mers), prefilter 2^%d bits %s\n", total, n_selected, n_keys, pf_bits, ctx->prefilter_on ? "on" : "off");
     if (ctx->prefilter_on) {
-        const size_t sliced_bytes = (size_t)PF_SLICES * PF_SLICE_WORDS * 4;   // 24 MiB: room for the sliced form whatever form is taken
         if (!ctx->d_prefilter) {
-            LHGT_HIP(lhgt::dev_malloc(&ctx->d_prefilter, sliced_bytes));
+            LHGT_HIP(lhgt::dev_malloc(&ctx->d_prefilter, (size_t)(1u << PF_BITS) / 8));
             LHGT_HIP(lhgt::dev_malloc(&ctx->d_prefilter_fold, (size_t)128 * 1024));
         }
-        LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ctx->pf_sliced ? sliced_bytes : ((size_t)1 << pf_bits) / 8, ctx->stream));
+        LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ((size_t)1 << pf_bits) / 8, ctx->stream));
     }
     if ((long)total + 1 > ctx->peaks_cap) {     // grow-only: no allocator traffic in steady state
         if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
@@ -1247,7 +1237,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
-                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u) | (ctx->pf_sliced ? PF_SLICED : 0u), ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
+                       ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     LHGT_HIP(hipEventSynchronize(ctx->ev1));
@@ -1367,7 +1357,7 @@ int lhgt_peaks_install(lhgt_ctx* ctx, long n_peaks_total, long n_selected_total,
         long blocks = (n_regs_all + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(replay_regs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_regs_all, n_regs_all,
-                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u) | (ctx->pf_sliced ? PF_SLICED : 0u), ctx->pf2);
+                           ctx->d_peak_kmer, ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2);
         LHGT_HIP(hipGetLastError());
     }
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

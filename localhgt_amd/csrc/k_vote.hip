@@ -424,24 +424,15 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
 // per pair of a 2.3 M-k-mer peak set; a reference of 118 k ragged contigs registers 14 M k-mers, a third of the bitmap probes
 // pass, and 235 survivors per pair sent every pair down the direct path.)
 constexpr int VQ_CAP = 1024, VQ_FLUSH = 512;
-// SLICED (round 4; lhgt_hash.hpp: PF_SLICED): the bitmap is eight 3 MiB bitmaps, a key's slice = its address bits 25..27.  The
-// workgroups that share an XCD (equal blockIdx % 8: MI355X_MICROARCH.md, workgroup dispatch -- an observation used for speed only)
-// take ONE slice: every group walks ALL pairs and hashes all their k-mers (vector work, of which this kernel has to spare) but probes
-// only the keys of its slice -- a pair still costs 714 L2 probes over the chip, each XCD's L2 holds one slice, and the eight private
-// L2s act as one 24 MiB filter.  A pair's hits in peak_kmer are then spread over eight workgroups: each adds its count to hits[pair];
-// collect_revote lists the pairs with six or more for the generic kernel (as vote_kernel_fold defers them).
-template <bool Q3, bool SLICED>   // Q3: the bitmap is three quarters of the 4 MiB its mask spans (lhgt_hash.hpp: PF_Q3)
+template <bool Q3>   // the bitmap is three quarters of the 4 MiB its mask spans (lhgt_hash.hpp: PF_Q3)
 __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
-                                                          const uint32_t* __restrict__ prefilter_all, const int32_t* __restrict__ loci,
+                                                          const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
                                                           uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,
-                                                          uint32_t pf_mask, int pf2, unsigned long long* __restrict__ stats /* nullable: lhgt_work_stats */,
-                                                          uint32_t* __restrict__ hits /* SLICED: per pair of the batch, zeroed */) {
+                                                          uint32_t pf_mask, int pf2, unsigned long long* __restrict__ stats /* nullable: lhgt_work_stats */) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
     if (wib >= waves_per_block) return;
-    const uint32_t slice = SLICED ? (uint32_t)blockIdx.x & (PF_SLICES - 1u) : 0u;
-    const uint32_t* __restrict__ prefilter = prefilter_all + (size_t)slice * PF_SLICE_WORDS;
     unsigned long long st_hbm = 0, st_revote = 0;   // wave-uniform: probes sent on to peak_kmer, pairs voted in the lane-per-offset form
     // per wave: [queue hashes | queue tags | 64 dump words | 64 staging words of the scan] and, over the same words, the vote's
     // [events | 64 staging words]: by the time a pair is voted the queue is empty and the tags to vote sit in registers
@@ -452,8 +443,8 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
     uint32_t* stage = qh + 2 * VQ_CAP + 64;
     uint32_t* ev = qh;
     uint32_t* vstage = ev + ev_words;
-    const long wave = (long)(SLICED ? blockIdx.x / PF_SLICES : blockIdx.x) * waves_per_block + wib;
-    const long n_waves = (long)(SLICED ? gridDim.x / PF_SLICES : gridDim.x) * waves_per_block;
+    const long wave = (long)blockIdx.x * waves_per_block + wib;
+    const long n_waves = (long)gridDim.x * waves_per_block;
     const uint32_t m512 = (debug & 512) ? 0u : 1u;   // stage ablation: stop after the bitmap / (1024) before the peak_kmer gathers
     const bool skip_gather = (debug & 1024) != 0;
     const bool nt_probe = !(debug & (1 << 17)), nt_rec = !(debug & (1 << 18));   // A/B switches of the two non-temporal hints (bits set: plain loads)
@@ -495,10 +486,8 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                     hs[s][i] = h;
                     // unconditional load (a dead lane probes word 0), masked afterwards: under `ok &&` every load would sit in its own
                     // lane-masked branch next to its use and be waited for singly
-                    // (SLICED: a key of another slice probes word 0 of this one -- the lanes that do share one request)
-                    const bool mine = !SLICED || pf_slice(h) == slice;
-                    const uint32_t pass = pf_pass(prefilter[mine ? pf_word_t<Q3>(h, pf_mask) : 0u], h, pf2) ? 1u : 0u;
-                    f1[s][i] = (ok && i < e && mine) ? (pass & m512) : 0u;
+                    const uint32_t pass = pf_pass(prefilter[pf_word_t<Q3>(h, pf_mask)], h, pf2) ? 1u : 0u;
+                    f1[s][i] = (ok && i < e) ? (pass & m512) : 0u;
                 }
             }
             int c = 0;
@@ -549,88 +538,81 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
                     bal &= ~same;
                     if (t != cur) {
                         // base_hits >= 6 (E:496) needs six offsets with a hit, so at least six hit entries: fewer cannot vote
-                        if (SLICED) { if (cur_cnt > 0 && lane == 0) atomicAdd(hits + (wave + (long)cur * n_waves), (uint32_t)cur_cnt); }
-                        else if (cur_cnt >= 6) { if (lane == 0) qi[nv] = cur; nv++; }
+                        if (cur_cnt >= 6) { if (lane == 0) qi[nv] = cur; nv++; }
                         cur = t;
                         cur_cnt = 0;
                     }
                     cur_cnt += __popcll(same);
                 }
             }
-            if (SLICED) { if (cur_cnt > 0 && lane == 0) atomicAdd(hits + (wave + (long)cur * n_waves), (uint32_t)cur_cnt); }
-            else if (cur_cnt >= 6) { if (lane == 0) qi[nv] = cur; nv++; }
+            if (cur_cnt >= 6) { if (lane == 0) qi[nv] = cur; nv++; }
             qn = 0;
             if (direct) {
-                if (SLICED) { if (lane == 0) atomicAdd(hits + p, 6u); }   // more survivors in one slice than the queue takes: the generic kernel decides
-                else {
-                    if (lane == 0) qi[nv] = it;
-                    nv++;
-                }
+                if (lane == 0) qi[nv] = it;
+                nv++;
             }
-            if constexpr (!SLICED) {
-                st_revote += (unsigned long long)nv;
-                __builtin_amdgcn_wave_barrier();
-                uint32_t vt[VQ_CAP / 64];   // the tags leave LDS: the events below are written over the queue
+            st_revote += (unsigned long long)nv;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t vt[VQ_CAP / 64];   // the tags leave LDS: the events below are written over the queue
 #pragma unroll
-                for (int u = 0; u < VQ_CAP / 64; u++) vt[u] = u * 64 + lane < nv ? qi[u * 64 + lane] : 0u;
-                __builtin_amdgcn_wave_barrier();
-                // the generic kernel's treatment of those pairs: every offset, masked probes, hits compacted in offset order, judge
-                for (int v = 0; v < nv; v++) {
-                    uint32_t tv = 0;
+            for (int u = 0; u < VQ_CAP / 64; u++) vt[u] = u * 64 + lane < nv ? qi[u * 64 + lane] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            // the generic kernel's treatment of those pairs: every offset, masked probes, hits compacted in offset order, judge
+            for (int v = 0; v < nv; v++) {
+                uint32_t tv = 0;
 #pragma unroll
-                    for (int u = 0; u < VQ_CAP / 64; u++)
-                        if ((v >> 6) == u) tv = (uint32_t)__builtin_amdgcn_readlane((int)vt[u], v & 63);
-                    const long pv = wave + (long)tv * n_waves;
-                    int n_ev = 0;
+                for (int u = 0; u < VQ_CAP / 64; u++)
+                    if ((v >> 6) == u) tv = (uint32_t)__builtin_amdgcn_readlane((int)vt[u], v & 63);
+                const long pv = wave + (long)tv * n_waves;
+                int n_ev = 0;
 #pragma unroll
-                    for (int m = 0; m < 2; m++) {
-                        const int len = b.len[m][pv];
-                        const int nkm = len - k + 1;
-                        if (nkm <= 0) continue;
-                        const int wprm = ((len + 31) >> 5) + 1;
-                        const uint32_t* rec = b.words + b.off[m][pv];
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < 3 * wprm) vstage[lane] = rec[lane];
-                        __builtin_amdgcn_wave_barrier();
-                        for (int j0 = 0; j0 < nkm; j0 += 64) {
-                            const int j = j0 + lane;
-                            uint32_t ids[3] = {0u, 0u, 0u}, chrs[3] = {0u, 0u, 0u};
-                            bool hit = false;
-                            if (j < nkm && plane_window(vstage + 2 * wprm, j, k) == 0) {
-                                const uint32_t whi = plane_window(vstage, j, k), wlo = plane_window(vstage + wprm, j, k);
-                                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+                for (int m = 0; m < 2; m++) {
+                    const int len = b.len[m][pv];
+                    const int nkm = len - k + 1;
+                    if (nkm <= 0) continue;
+                    const int wprm = ((len + 31) >> 5) + 1;
+                    const uint32_t* rec = b.words + b.off[m][pv];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 3 * wprm) vstage[lane] = rec[lane];
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j0 = 0; j0 < nkm; j0 += 64) {
+                        const int j = j0 + lane;
+                        uint32_t ids[3] = {0u, 0u, 0u}, chrs[3] = {0u, 0u, 0u};
+                        bool hit = false;
+                        if (j < nkm && plane_window(vstage + 2 * wprm, j, k) == 0) {
+                            const uint32_t whi = plane_window(vstage, j, k), wlo = plane_window(vstage + wprm, j, k);
+                            const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+#pragma unroll
+                            for (int i = 0; i < 3; i++)
+                                if (i < e) {
+                                    const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
+                                    ids[i] = pf_pass(prefilter[pf_word_t<Q3>(h, pf_mask)], h, pf2) ? peak_kmer[h] : 0u;   // 0 = no peak (E:454)
+                                    hit |= ids[i] != 0u;
+                                }
+#pragma unroll
+                            for (int i = 0; i < 3; i++)
+                                if (i < e) chrs[i] = ids[i] ? (uint32_t)loci[2 * (long)ids[i]] : 0u;
+                        }
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            if (hit) {
+                                const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
                                 for (int i = 0; i < 3; i++)
                                     if (i < e) {
-                                        const uint32_t h = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
-                                        ids[i] = pf_pass(prefilter[pf_word_t<Q3>(h, pf_mask)], h, pf2) ? peak_kmer[h] : 0u;   // 0 = no peak (E:454)
-                                        hit |= ids[i] != 0u;
+                                        ev[((size_t)slot * e + i) * 2] = ids[i];
+                                        ev[((size_t)slot * e + i) * 2 + 1] = chrs[i];
                                     }
-#pragma unroll
-                                for (int i = 0; i < 3; i++)
-                                    if (i < e) chrs[i] = ids[i] ? (uint32_t)loci[2 * (long)ids[i]] : 0u;
                             }
-                            const unsigned long long bal = __ballot(hit);
-                            if (bal) {
-                                if (hit) {
-                                    const int slot = n_ev + __popcll(bal & ((1ull << lane) - 1ull));
-#pragma unroll
-                                    for (int i = 0; i < 3; i++)
-                                        if (i < e) {
-                                            ev[((size_t)slot * e + i) * 2] = ids[i];
-                                            ev[((size_t)slot * e + i) * 2 + 1] = chrs[i];
-                                        }
-                                }
-                                n_ev += __popcll(bal);
-                            }
+                            n_ev += __popcll(bal);
                         }
                     }
-                    if (n_ev >= 6 && !(debug & 1)) {   // base_hits = offsets with any hit (E:149-157, 496)
-                        __builtin_amdgcn_wave_barrier();
-                        if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
-                        else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                }
+                if (n_ev >= 6 && !(debug & 1)) {   // base_hits = offsets with any hit (E:149-157, 496)
+                    __builtin_amdgcn_wave_barrier();
+                    if (e == 3) judge_pair<4, 3>(ev, n_ev, e, lane, filter);
+                    else judge_pair<4, 0>(ev, n_ev, e, lane, filter);
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -650,19 +632,6 @@ __global__ void __launch_bounds__(256) fold_prefilter(const uint32_t* __restrict
 }
 
 __global__ void stats_add_u32(const uint32_t* __restrict__ v, unsigned long long* __restrict__ out) { atomicAdd(out, (unsigned long long)*v); }
-
-// sliced form: the pairs whose hit entries over the eight slices reach six (E:496), listed for the generic kernel ([0] = how many)
-__global__ void __launch_bounds__(256) collect_revote(const uint32_t* __restrict__ hits, long n_pairs, uint32_t* __restrict__ list) {
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool take = p < n_pairs && hits[p] >= 6u;
-    const unsigned long long bal = __ballot(take);
-    if (!bal) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(list, (uint32_t)__popcll(bal));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (take) list[1u + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)p;
-}
 
 // phase D helper: peaks with at least MIN_READS (1, E:37) votes, as (id, contig, pos) in any order;
 // the host sorts the few survivors by id, which is the order count_filtered_peak walks them (E:525).
@@ -708,7 +677,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, PF_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                            ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u) | (ctx->pf_sliced ? PF_SLICED : 0u), ctx->pf2, (const uint32_t*)nullptr); \
+                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr);          \
     } while (0)
         const bool nt = ctx->k >= 28;
         const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
@@ -759,38 +728,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
                 fprintf(stderr, "[lhgt] vote: 128 KiB fold (%.2f insertions per bit), %u of %ld pairs deferred to the lane-per-offset form\n",
                         fold_ins / (double)(1ull << LF2_BITS), n_def, b.d.n_pairs);
             }
-        } else if (sparse_ok && ctx->pf_sliced && !(ctx->debug & 16)) {
-            // the XCD-sliced bitmap: eight groups of workgroups (blockIdx % 8), each walking all pairs against its slice; then the pairs
-            // with six or more hit entries over all slices in the lane-per-offset form (as behind the LDS fold)
-            ctx->vote_form = 4;
-            const size_t need = 2 * (size_t)b.d.n_pairs + 2;       // [list: 1 + n_pairs][hits: n_pairs]
-            if (ctx->revote_cap < need) {
-                if (ctx->d_revote) LHGT_HIP(hipFree(ctx->d_revote));
-                ctx->d_revote = nullptr;
-                LHGT_HIP(lhgt::dev_malloc(&ctx->d_revote, need * 4));
-                ctx->revote_cap = need;
-            }
-            uint32_t* d_hits = ctx->d_revote + 1 + b.d.n_pairs;
-            LHGT_HIP(hipMemsetAsync(ctx->d_revote, 0, 4, ctx->stream));
-            LHGT_HIP(hipMemsetAsync(d_hits, 0, (size_t)b.d.n_pairs * 4, ctx->stream));
-            const size_t per_wave_s = (size_t)(2 * VQ_CAP + 128) * 4;
-            const int wps = 4;
-            long sb = ((b.d.n_pairs + wps - 1) / wps) * PF_SLICES;
-            if (sb > 256L * 16) sb = 256L * 16;                    // a multiple of 8 either way
-            hipLaunchKernelGGL((vote_kernel_queued<true, true>), dim3((unsigned)sb), dim3(64 * wps), per_wave_s * wps, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                               ctx->d_prefilter, ctx->d_loci, ctx->d_filter, 0, wps, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats, d_hits);
-            hipLaunchKernelGGL(collect_revote, dim3((unsigned)((b.d.n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_hits, b.d.n_pairs, ctx->d_revote);
-            hipLaunchKernelGGL((vote_kernel<4, 1, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                               ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask | PF_Q3 | PF_SLICED, ctx->pf2,
-                               (const uint32_t*)ctx->d_revote);
-            if (d_stats) hipLaunchKernelGGL(stats_add_u32, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)ctx->d_revote, d_stats + 5);
-            if (getenv("LHGT_TRACE")) {
-                uint32_t n_def = 0;
-                LHGT_HIP(hipMemcpyAsync(&n_def, ctx->d_revote, 4, hipMemcpyDeviceToHost, ctx->stream));
-                LHGT_HIP(hipStreamSynchronize(ctx->stream));
-                fprintf(stderr, "[lhgt] vote: sliced bitmap (8 x 3 MiB), %u of %ld pairs to the lane-per-offset form\n", n_def, b.d.n_pairs);
-            }
-        } else if (sparse_ok && !ctx->pf_sliced) {
+        } else if (sparse_ok) {
             ctx->vote_form = 2;
             const size_t per_wave_q = (size_t)std::max(max_ev * ctx->e * 2 + 64, 2 * VQ_CAP + 128) * 4;
             wpb = (int)(65536 / per_wave_q);
@@ -799,11 +737,11 @@ int lhgt_vote(lhgt_ctx* ctx) {
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256L * 16) blocks = 256L * 16;
             if (ctx->pf_q3)
-                hipLaunchKernelGGL((vote_kernel_queued<true, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(vote_kernel_queued<true>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
+                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
             else
-                hipLaunchKernelGGL((vote_kernel_queued<false, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(vote_kernel_queued<false>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
+                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);

@@ -165,9 +165,8 @@ struct lhgt_ctx {
     size_t revote_cap = 0;                 // words
     bool prefilter_on = false;
     uint32_t pf_mask = 0;             // low address bits indexing the prefilter
-    int vote_form = 0;                // which kernel the last lhgt_vote took: 0 generic on peak_kmer, 1 generic behind the bitmap, 2 queued behind the bitmap, 3 LDS fold + bitmap, 4 queued behind the XCD-sliced bitmap
+    int vote_form = 0;                // which kernel the last lhgt_vote took: 0 generic on peak_kmer, 1 generic behind the bitmap, 2 queued behind the bitmap, 3 LDS fold + bitmap
     bool pf_q3 = false;               // the bitmap is three quarters of what pf_mask spans (lhgt_hash.hpp: PF_Q3)
-    bool pf_sliced = false;           // eight such bitmaps, one per XCD's L2 (lhgt_hash.hpp: PF_SLICED)
     int pf2 = 0;                      // folded prefilter: shift of the address bits picking a key's second bit (0 = one bit per key)
     unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan
     // reference-sharded scan (k_scan.hip): this rank's new peaks / registrations as records for the exchange

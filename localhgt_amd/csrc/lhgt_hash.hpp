@@ -97,25 +97,14 @@ __host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
 // Word of the bitmap that key h sets / tests.  Bit 31 of the mask argument flags the three-quarter bitmap (3 MiB of the 4 MiB a 25-bit
 // mask spans: what an XCD's 4 MiB L2 can keep next to the streams that pass through it): the 2^20 word numbers fold onto 3 * 2^18.
 constexpr uint32_t PF_Q3 = 0x80000000u;
-// Bit 30 flags the SLICED bitmap (k = 32): eight three-quarter bitmaps of 3 MiB, slice = address bits 25..27 of the key.  An XCD's L2
-// holds ONE of them when the vote kernel lets the workgroups that share an XCD (equal blockIdx % 8) probe only the keys of one slice
-// (k_vote.hip: vote_kernel_queued<Q3, true>): the eight private L2s of the chip act as one 24 MiB filter -- 13 bits per key where a
-// ragged catalogue's 14 M registered k-mers have 1.8 in a single 3 MiB bitmap.  Any other kernel that probes it (the generic vote
-// of the deferred pairs, the registry) just sees a 24 MiB bitmap.
-constexpr uint32_t PF_SLICED = 0x40000000u;
-constexpr uint32_t PF_FLAGS = PF_Q3 | PF_SLICED;
-constexpr uint32_t PF_SLICE_WORDS = 3u << 18, PF_SLICES = 8;
-constexpr int PF2_SLICED = 27;            // second bit of a key in the sliced form: address bits 27..31
-__device__ __forceinline__ uint32_t pf_slice(uint32_t h) { return (h >> 25) & 7u; }
 template <bool Q3>
-__device__ __forceinline__ uint32_t pf_word_t(uint32_t h, uint32_t pf_mask) {   // inside the key's slice when the bitmap is sliced
-    const uint32_t w = (h & pf_mask & ~PF_FLAGS) >> 5;
+__device__ __forceinline__ uint32_t pf_word_t(uint32_t h, uint32_t pf_mask) {
+    const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
     return Q3 ? (w * 3u) >> 2 : w;
 }
-__device__ __forceinline__ uint32_t pf_word(uint32_t h, uint32_t pf_mask) {       // flags looked at at run time (the kernels that are not hot)
-    const uint32_t w = (h & pf_mask & ~PF_FLAGS) >> 5;
-    const uint32_t q = (pf_mask & PF_Q3) ? (w * 3u) >> 2 : w;
-    return (pf_mask & PF_SLICED) ? q + pf_slice(h) * PF_SLICE_WORDS : q;
+__device__ __forceinline__ uint32_t pf_word(uint32_t h, uint32_t pf_mask) {       // flag looked at at run time (the kernels that are not hot)
+    const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
+    return (pf_mask & PF_Q3) ? (w * 3u) >> 2 : w;
 }
 __device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
     return (1u << (h & 31u)) | (pf2 ? 1u << ((h >> pf2) & 31u) : 0u);

@@ -369,8 +369,8 @@ class Engine:
         """which kernel the last vote() took and the size of its bitmap (include/localhgt_hip.h: lhgt_vote_info)"""
         f, b, q = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.check(self.lib.lhgt_vote_info(self.h, C.byref(f), C.byref(b), C.byref(q)))
-        mib = (1 << b.value) / 8 / (1 << 20) * (0.75 * max(1, q.value) if q.value else 1.0) if b.value else 0.0
-        return {"form": ("dense", "bitmap", "queued", "fold", "sliced")[f.value], "bitmap_MiB": round(mib, 3)}
+        mib = (1 << b.value) / 8 / (1 << 20) * (0.75 if q.value else 1.0) if b.value else 0.0
+        return {"form": ("dense", "bitmap", "queued", "fold")[f.value], "bitmap_MiB": round(mib, 3)}
 
     def synchronize(self):
         _lib.check(self.lib.lhgt_synchronize(self.h))

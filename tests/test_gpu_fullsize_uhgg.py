@@ -68,14 +68,7 @@ def _check_scans_and_votes(eng, expect_lite, tag):
     direct = _vote(eng, 2048)                          # queued kernel, pairs with > 8 bitmap survivors voted at once
     nofilter = _vote(eng, 4)                           # every probe goes to peak_kmer
     nofold = _vote(eng, 16)                            # never an LDS fold in front of the bitmap (the queued kernel)
-    eng.set_debug(1 << 21)                             # the XCD-sliced bitmap whatever the key count (eight 3 MiB bitmaps, one per XCD's L2) ...
-    eng.ref_scan(0.1, 0.08, 300_000_000)
-    eng.vote()
-    sliced, form = eng.digest(eng.DIGEST_VOTES), eng.vote_info()
-    eng.set_debug(0)
-    assert form == {"form": "sliced", "bitmap_MiB": 24.0}, form
-    unsliced = _vote(eng, 1 << 22)                     # ... and never
-    assert queued == generic == direct == nofilter == nofold == sliced == unsliced, (tag, queued, generic, direct, nofilter, nofold, sliced, unsliced)
+    assert queued == generic == direct == nofilter == nofold, (tag, queued, generic, direct, nofilter, nofold)
     return exact, info_t, queued
 
 

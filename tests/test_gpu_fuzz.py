@@ -103,7 +103,7 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     import shutil
     # a third of the cases each: the form the engine picks, single-first, trio-first (when e <= 3); every fourth case with the vote
     # bitmap in its three-quarter form (bit 20; k > 25)
-    dbg = (0, 4096, 16384)[idx % 3] | ((1 << 20) if idx % 4 == 3 else 0) | ((1 << 21) if idx % 8 == 5 else 0)   # bit 21: the XCD-sliced bitmap (k = 32 only)
+    dbg = (0, 4096, 16384)[idx % 3] | ((1 << 20) if idx % 4 == 3 else 0)
     if dbg:
         monkeypatch.setenv("LHGT_DEBUG", str(dbg))
     g, c = tmp_path / "gpu", tmp_path / "cpu"

@@ -47,7 +47,7 @@ def _same_files(a, b, index=True):
         assert x.size == y.size and (x[:1198] == y[:1198]).all() and (x[1200:] == y[1200:]).all()   # bytes 1198-1199: the reference reads past its coder array
 
 
-def test_product_equals_the_cpu_restatement_at_k32_from_files(big, oracle, monkeypatch):
+def test_product_equals_the_cpu_restatement_at_k32_from_files(big, oracle):
     d_cpu = _copy_inputs(big["src"], os.path.join(big["base"], "cpu"))
     rc, rep = oracle.run(os.path.join(d_cpu, "s.1.fq"), os.path.join(d_cpu, "s.2.fq"), os.path.join(d_cpu, "ref.fa"), os.path.join(d_cpu, "i.txt"),
                          0.1, 0.08, os.cpu_count() or 1, K, 3_000_000, E, 1, 1.0)
@@ -59,13 +59,6 @@ def test_product_equals_the_cpu_restatement_at_k32_from_files(big, oracle, monke
     d_pk, rep_p = _product(big, "gpu_t1_packed", 1, ref_form="packed")
     assert not os.path.exists(os.path.join(d_pk, f"ref.fa.k{K}.h{E}.index.dat"))
     _same_files(d_cpu, d_pk, index=False)
-    # the vote behind the XCD-sliced bitmap (eight 3 MiB bitmaps, one per XCD's L2: taken by itself only for peak sets of millions
-    # of k-mers; LHGT_DEBUG bit 21 forces it): the same interval file
-    monkeypatch.setenv("LHGT_DEBUG", str(1 << 21))
-    d_sl, rep_s = _product(big, "gpu_t1_sliced", 1)
-    monkeypatch.delenv("LHGT_DEBUG")
-    assert (rep_s["n_peaks"], rep_s["n_filtered"]) == (rep.n_peaks, rep.n_filtered)
-    _same_files(d_cpu, d_sl)
     big["cpu_dir"] = d_cpu
 
 

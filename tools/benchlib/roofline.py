@@ -63,14 +63,7 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
     out["ref_flags"] = (probes * LINE + stream + 2 * ref_bases,
                         f"{probes} table probes x {LINE} B ({scan_form}: {probes / max(1, n_pos):.3f} per position) + "
                         f"{'packed planes' if packed else 'index words'} {stream} + flag and state bytes written 2 x {ref_bases}")
-    if vote_form == "sliced":
-        hb, rv = stats.get("vote_hbm_probes", 0), stats.get("vote_revoted_pairs", 0)
-        per_pair = 2 * (L - k + 1) * e
-        out["vote_kernel"] = (8 * reads + hb * LINE + rv * per_pair * LINE // 8,
-                              f"reads {reads} x 8 (every XCD's workgroups walk all pairs against their slice of the bitmap) + {hb} probes of peak_kmer x {LINE} B "
-                              f"({hb / max(1, pairs):.2f} per pair survive the sliced L2 bitmap) + {rv} pairs with six or more hits again in the "
-                              f"lane-per-offset form, an eighth of their {per_pair} probes counted as lines")
-    elif vote_form in ("queued", "fold"):
+    if vote_form in ("queued", "fold"):
         hb = stats.get("vote_hbm_probes", 0)
         out["vote_kernel"] = (reads + hb * LINE,
                               f"reads {reads} + {hb} probes of peak_kmer x {LINE} B ({hb / max(1, pairs):.2f} per pair survive the "
@@ -120,7 +113,7 @@ def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec
 def vote_form_of(vote, stats):
     """which vote kernel lhgt_vote took: from Engine.vote_info(), else from what it counted"""
     if vote:
-        return vote["form"] if vote["form"] in ("fold", "queued", "sliced") else "dense"
+        return vote["form"] if vote["form"] in ("fold", "queued") else "dense"
     if stats.get("vote_l2_probes"):
         return "fold"
     if stats.get("vote_hbm_probes") or stats.get("vote_revoted_pairs"):
@@ -141,7 +134,7 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     need = needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats or {}, partitioned, scan["form"], vform) if stats is not None else {}
     kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
     scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio"}.get(scan["form"], "ref_flags")
-    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued", "sliced": "vote_kernel_queued"}.get(vform, "vote_kernel")
+    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
     info = {
         "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
                     f"phase A kernel family, {n_chunks} chunks of <= {8 if direct else 4} Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
@@ -152,8 +145,7 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
                       model_ref, 1, HBM_CEILING),
         "vote_kernel": (vote_kernel, f"phase C read re-scan, {2 * (L - k + 1) * e} probes per pair "
                         + {"fold": "screened by a 128 KiB LDS fold, then the L2-resident bitmap, then peak_kmer",
-                           "queued": "answered by the L2-resident bitmap except for its survivors",
-                           "sliced": "answered by eight 3 MiB bitmaps, one per XCD's L2, except for their survivors"}.get(vform, "into peak_kmer")
+                           "queued": "answered by the L2-resident bitmap except for its survivors"}.get(vform, "into peak_kmer")
                         + f"; {n_batches} launches per step", model_pairs, n_batches, HBM_CEILING if vform == "dense" else L2_CEILING),
     }
     roof = {ph: roofline_entry(info[ph][0], info[ph][1], kern[ph], info[ph][3], info[ph][2], need.get(ph), traffic.get(ph) if src else None, src, info[ph][4])

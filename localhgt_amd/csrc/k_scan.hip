@@ -532,24 +532,49 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
     constexpr int NONE_LO = -(1 << 28), NONE_HI = 1 << 28;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) { n_new = 0; n_sel = 0; n_ins = 0; }
-    for (int w = wv; w < NW3; w += BT / 64) {
-        long pos = lo + 64L * w + lane;
-        bool g = pos >= 0 && pos < len && ((F[pos] >> 2) & 1);
-        unsigned long long bal = __ballot(g);
-        if (lane == 0) gw[w] = bal;
+    {
+        // all of a wave's flag bytes first (unconditional loads on an index clamped into the contig), then the ballots: a load and its
+        // wait per word made 28 dependent round trips of this loop -- most of a tile's 50 us (round 4; the ISA had
+        // global_load_ubyte / s_waitcnt vmcnt(0) back to back)
+        constexpr int WPW = (NW3 + BT / 64 - 1) / (BT / 64);
+        uint8_t fb[WPW];
+#pragma unroll
+        for (int q = 0; q < WPW; q++) {
+            const long pos = lo + 64L * (wv + q * (BT / 64)) + lane;
+            fb[q] = F[pos < 0 ? 0 : pos < len ? pos : len - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < WPW; q++) {
+            const int w = wv + q * (BT / 64);
+            const long pos = lo + 64L * w + lane;
+            const unsigned long long bal = __ballot(pos >= 0 && pos < len && ((fb[q] >> 2) & 1));
+            if (lane == 0 && w < NW3) gw[w] = bal;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int last = NONE_LO;
-        for (int w = 0; w < NW3; w++) {
-            if (gw[w]) last = 64 * w + 63 - __clzll((long long)gw[w]);
-            prevw[w] = last;
+    {
+        // prefix maximum of "last good index in word w" and suffix minimum of "first good index in word w" over the NW3 <= 128 words: two
+        // waves, shuffles (round 4: two single threads walked the words one LDS round trip at a time)
+        static_assert(NW3 <= 128 && BT >= 128, "two waves cover the ballot words");
+        const int w = threadIdx.x;
+        int pv = NONE_LO, nv = NONE_HI;
+        if (w < 128) {
+            const unsigned long long g = w < NW3 ? gw[w] : 0ull;
+            if (g) { pv = 64 * w + 63 - __clzll((long long)g); nv = 64 * w + __ffsll((long long)g) - 1; }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tp = __shfl_up(pv, d, 64), tn = __shfl_down(nv, d, 64);
+                if (lane >= d) pv = tp > pv ? tp : pv;
+                if (lane + d < 64) nv = tn < nv ? tn : nv;
+            }
+            if (w == 63) part[0] = pv;          // all of wave 0, for wave 1's prefix
+            if (w == 64) part[1] = nv;          // all of wave 1, for wave 0's suffix
         }
-    } else if (threadIdx.x == 64) {
-        int nxt = NONE_HI;
-        for (int w = NW3 - 1; w >= 0; w--) {
-            if (gw[w]) nxt = 64 * w + __ffsll((long long)gw[w]) - 1;
-            nextw[w] = nxt;
+        __syncthreads();
+        if (w < 128) {
+            if (wv == 1) pv = part[0] > pv ? part[0] : pv;
+            else nv = part[1] < nv ? part[1] : nv;
+            if (w < NW3) { prevw[w] = pv; nextw[w] = nv; }
         }
     }
     __syncthreads();
@@ -582,10 +607,20 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
         constexpr int CH = (N4 + BT - 1) / BT;
         const int b = threadIdx.x * CH, en = b + CH < N4 ? b + CH : N4;
         int s1 = 0;
-        for (int i = b; i < en; i++) {
-            long pos = lo4 + i;
-            s1 += (pos >= 0 && pos < len) ? (F[pos] & 1) : 0;
-            P1[i] = s1;
+        uint8_t f1[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q++) {                     // the bytes first, one wait (see the ballots above)
+            const long pos = lo4 + b + q;
+            f1[q] = F[pos < 0 ? 0 : pos < len ? pos : len - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const int i = b + q;
+            const long pos = lo4 + i;
+            if (i < en) {
+                s1 += (pos >= 0 && pos < len) ? (f1[q] & 1) : 0;
+                P1[i] = s1;
+            }
         }
         int o1 = block_excl_sum(s1, part);
         for (int i = b; i < en; i++) P1[i] += o1;
@@ -648,24 +683,37 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
         }
         __syncthreads();
     }
-    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
-        long j = (long)t.j0 + jj;
-        if (j >= len) break;
-        if (ins[jj]) {
-            const uint8_t s = sel[jj];
-            F[j] = (uint8_t)((F[j] & 7) | (s << 3) | (1 << 4) | (s << 5));   // peak (inside intervals only), inside, selected
-            if (s) atomicAdd(&n_sel, 1);
+    {
+        constexpr int PT4 = (TILE + BT - 1) / BT;
+        uint8_t fo[PT4];
+#pragma unroll
+        for (int q = 0; q < PT4; q++) {                    // the tile's own bytes first, then the stores (a load per store and its wait: 8 round trips)
+            const long j = (long)t.j0 + threadIdx.x + q * BT;
+            fo[q] = F[j < len ? j : len - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < PT4; q++) {
+            const int jj = threadIdx.x + q * BT;
+            const long j = (long)t.j0 + jj;
+            if (jj < TILE && j < len && ins[jj]) {
+                const uint8_t s = sel[jj];
+                F[j] = (uint8_t)((fo[q] & 7) | (s << 3) | (1 << 4) | (s << 5));   // peak (inside intervals only), inside, selected
+                if (s) atomicAdd(&n_sel, 1);
+            }
         }
     }
     __syncthreads();
-    // a selected position opens a new peak iff it is the first selected one of its 50-bp bucket (E:296)
-    for (int bk = threadIdx.x; bk < TILE / 50; bk += BT) {
-        for (int q = 0; q < 50; q++) {
-            int jj = bk * 50 + q;
-            if (sel[jj]) {
-                F[(long)t.j0 + jj] |= 1 << 6;
-                atomicAdd(&n_new, 1);
-                break;
+    // a selected position opens a new peak iff it is the first selected one of its 50-bp bucket (E:296); nothing selected (most tiles
+    // that get here): nothing to look for
+    if (n_sel) {
+        for (int bk = threadIdx.x; bk < TILE / 50; bk += BT) {
+            for (int q = 0; q < 50; q++) {
+                int jj = bk * 50 + q;
+                if (sel[jj]) {
+                    F[(long)t.j0 + jj] |= 1 << 6;
+                    atomicAdd(&n_new, 1);
+                    break;
+                }
             }
         }
     }

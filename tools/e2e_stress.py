@@ -1,6 +1,10 @@
+#!/usr/bin/env python3
+"""the whole drop-in call (localhgt_amd.extract_ref.run) back to back on the same files -- 4 M pairs and a large file set, --sample 1 /
+--sample 2e9 / packed reference -- in ONE process (how round 4 looked for the abort of the from-FASTQ legs, under rocgdb).
+usage: e2e_stress.py big_pairs iterations"""
 import sys, os, time, tempfile, faulthandler
 faulthandler.enable()
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from benchlib.files import synth_files, synth_files_sliced
 from localhgt_amd import extract_ref

@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""phase A of the direct form (k = 32, e = 3, reads of <= 159 bases) against the compare-and-swap kernel over random shapes: read counts
+1 .. 70 000, lengths 0 .. 159, N rates, hot k-mers that overflow tile rows and pieces, mates not counted.  usage: phase_a_soak.py first_seed end_seed"""
 import sys, os
 import numpy as np
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from localhgt_amd.engine import Engine
 acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)

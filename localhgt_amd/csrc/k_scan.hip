@@ -296,11 +296,20 @@ struct WavePlanes {
 // predicate is (f & m3) == m3 -- 0x02, or 0x82 where only completely probed positions count (lite form).
 __device__ __forceinline__ void wave_planes(const uint8_t* __restrict__ F, long lo, long len, int m3, int lane, uint8_t (&fs)[WL_WORDS], WavePlanes& P) {
     constexpr int NW = TILE + HL2;
+    if (lo >= 0 && lo + NW <= len) {
+        // a tile inside its contig with its whole look-back (all but the first and the last of a contig): ONE address and immediate
+        // offsets, no bounds test per byte (round 4: the tests and their 64-bit address arithmetic were a third of the kernel's vector
+        // instructions, and 134 registers held three waves per SIMD where this kernel lives on the tiles it has in flight)
+        const uint8_t* __restrict__ base = F + lo + lane;
 #pragma unroll
-    for (int r = 0; r < WL_WORDS; r++) {       // all loads in flight together
-        const int i = lane + 64 * r;
-        const long pos = lo + i;
-        fs[r] = (i < NW && pos >= 0 && pos < len) ? F[pos] : (uint8_t)0;
+        for (int r = 0; r < WL_WORDS; r++) fs[r] = (64 * r + 63 < NW || lane + 64 * r < NW) ? base[64 * r] : (uint8_t)0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < WL_WORDS; r++) {       // all loads in flight together
+            const int i = lane + 64 * r;
+            const long pos = lo + i;
+            fs[r] = (i < NW && pos >= 0 && pos < len) ? F[pos] : (uint8_t)0;
+        }
     }
 #pragma unroll
     for (int r = 0; r < WL_WORDS; r++) {
@@ -407,12 +416,22 @@ __global__ void __launch_bounds__(BT) window_good(const TileDev* __restrict__ ti
         // the good bits go through LDS so that the flags are written as they were read: lane = position mod 64, from registers
         P.G[lane] = good;
         __builtin_amdgcn_wave_barrier();
+        if (lo >= 0 && lo + NW <= len) {          // (see wave_planes)
+            uint8_t* __restrict__ base = F + lo + lane;
 #pragma unroll
-        for (int r = HL2 / 64; r < WL_WORDS; r++) {
-            const int i = lane + 64 * r, jj = i - HL2;
-            const long j = lo + i;
-            if (i < NW && j < len && ((P.G[jj >> 5] >> (jj & 31)) & 1u))
-                F[j] = (uint8_t)((fs[r] & 3) | 4 | (j >= 1 ? 16 : 0) | keep7);   // its own two flags, good window, inside (E:618)
+            for (int r = HL2 / 64; r < WL_WORDS; r++) {
+                const int jj = lane + 64 * r - HL2;
+                if ((64 * r + 63 < NW || lane + 64 * r < NW) && ((P.G[jj >> 5] >> (jj & 31)) & 1u))
+                    base[64 * r] = (uint8_t)((fs[r] & 3) | 4 | 16 | keep7);
+            }
+        } else {
+#pragma unroll
+            for (int r = HL2 / 64; r < WL_WORDS; r++) {
+                const int i = lane + 64 * r, jj = i - HL2;
+                const long j = lo + i;
+                if (i < NW && j < len && ((P.G[jj >> 5] >> (jj & 31)) & 1u))
+                    F[j] = (uint8_t)((fs[r] & 3) | 4 | (j >= 1 ? 16 : 0) | keep7);   // its own two flags, good window, inside (E:618)
+            }
         }
     }
     if (lane == 0) {
@@ -461,11 +480,18 @@ __global__ void __launch_bounds__(BT) window_lite(const TileDev* __restrict__ ti
         }
         return;
     }
+    if (lo >= 0 && lo + NW <= len) {              // (see wave_planes: every position exists, none is position 0)
+        uint8_t* __restrict__ base = F + lo + lane;
 #pragma unroll
-    for (int r = HL2 / 64; r < WL_WORDS; r++) {   // the tile's own positions: good window, inside (E:618), written from the registers
-        const int i = lane + 64 * r;
-        const long j = lo + i;
-        if (i < NW && j < len) F[j] = (uint8_t)(fs[r] | 4 | (j >= 1 ? 16 : 0));
+        for (int r = HL2 / 64; r < WL_WORDS; r++)
+            if (64 * r + 63 < NW || lane + 64 * r < NW) base[64 * r] = (uint8_t)(fs[r] | 4 | 16);
+    } else {
+#pragma unroll
+        for (int r = HL2 / 64; r < WL_WORDS; r++) {   // the tile's own positions: good window, inside (E:618), written from the registers
+            const int i = lane + 64 * r;
+            const long j = lo + i;
+            if (i < NW && j < len) F[j] = (uint8_t)(fs[r] | 4 | (j >= 1 ? 16 : 0));
+        }
     }
     if (lane == 0) {
         const int all_single = WavePlanes::rank(P.B1, P.R1, NW - 1) - WavePlanes::rank(P.B1, P.R1, HL2 - 1) == n_here;

@@ -106,13 +106,24 @@ __device__ __forceinline__ uint32_t pf_word(uint32_t h, uint32_t pf_mask) {     
     const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
     return (pf_mask & PF_Q3) ? (w * 3u) >> 2 : w;
 }
-__device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
-    return (1u << (h & 31u)) | (pf2 ? 1u << ((h >> pf2) & 31u) : 0u);
+// pf2 = shift of the address bits that pick a key's second bit (0: one bit per key) | PF_THREE when a key sets a THIRD bit (round 4: the
+// 3 MiB bitmap of configs[2] holds 11 bits per key, where three bits per key pass half as many foreign probes as two).  The third
+// index is a product hash of the twelve address bits that do not choose the word (0..4 and 25..31): it need not be independent of
+// the key's other two indices, only look random next to the bits OTHER keys set.
+constexpr int PF_THREE = 0x100;
+__device__ __forceinline__ uint32_t pf_third(uint32_t h) {
+    const uint32_t x = (h & 31u) | ((h >> 25) << 5);          // 12 bits
+    return (__umul24(x, 0x9E37u) >> 11) & 31u;
 }
-// (both bits shifted down and ANDed: a variable shift takes its count modulo 32 by itself, so this is four vector instructions
-// where building the two-bit mask and comparing took eight; with pf2 = 0 the second shift picks the first bit again)
+__device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
+    const uint32_t sh = (uint32_t)pf2 & 31u;
+    return (1u << (h & 31u)) | (sh ? 1u << ((h >> sh) & 31u) : 0u) | ((pf2 & PF_THREE) ? 1u << pf_third(h) : 0u);
+}
+// (the bits shifted down and ANDed: with pf2 = 0 the second shift picks the first bit again, and so does the third without PF_THREE.
+// A FOURTH bit was measured too: 23.4 -> 22.2 survivors per pair on configs[2] -- what is left are hits -- and no time.)
 __device__ __forceinline__ bool pf_pass(uint32_t word, uint32_t h, int pf2) {
-    return ((word >> (h & 31u)) & (word >> ((h >> pf2) & 31u)) & 1u) != 0u;
+    const uint32_t b1 = h & 31u, b3 = (pf2 & PF_THREE) ? pf_third(h) : b1;
+    return ((word >> b1) & (word >> ((h >> ((uint32_t)pf2 & 31u)) & 31u)) & (word >> b3) & 1u) != 0u;
 }
 
 }  // namespace lhgt

@@ -1256,10 +1256,8 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     if (pf_bits > pf_max) pf_bits = pf_max;
     ctx->pf_mask = (uint32_t)((1ull << pf_bits) - 1ull);
     ctx->pf2 = ctx->k - pf_bits >= 5 ? pf_bits : 0;   // five address bits above the fold: a second, independent bit per key
-    // ... and in the three-quarter form (6 to 16 bits per key; k = 32: seven address bits above the fold) a third one (lhgt_hash.hpp:
-    // PF_THREE; LHGT_PF_THREE=0: two bits, the A/B)
-    static const bool three_off = getenv("LHGT_PF_THREE") && !atoi(getenv("LHGT_PF_THREE"));
-    if (ctx->pf_q3 && ctx->pf2 && ctx->k - pf_bits >= 7 && !three_off) ctx->pf2 |= PF_THREE;
+    static const bool mixed_off = getenv("LHGT_PF_MIXED") && !atoi(getenv("LHGT_PF_MIXED"));   // A/B: two bits from the key's own address bits, on the new words
+    if (ctx->pf_q3 && !mixed_off) ctx->pf2 = PF_MIXED;   // the three-quarter form: three bits from the mixed key (lhgt_hash.hpp)
     // On while the bitmap still screens enough: with two bits per key, n_keys = 0.5 x 2^pf_bits leaves 63 % of the bits set and lets
     // 40 % of foreign probes through -- 285 of a pair's 714, which the queued kernel still holds in its queue -- and bitmap +
     // survivors (330 + 0.4 x 1430 ms per 100 M pairs) still beat 714 HBM probes per pair (1430 ms).  Round 1 stopped at 1/8 with a

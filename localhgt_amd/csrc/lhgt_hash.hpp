@@ -97,33 +97,41 @@ __host__ __device__ __forceinline__ uint32_t base_code(uint8_t c) {
 // Word of the bitmap that key h sets / tests.  Bit 31 of the mask argument flags the three-quarter bitmap (3 MiB of the 4 MiB a 25-bit
 // mask spans: what an XCD's 4 MiB L2 can keep next to the streams that pass through it): the 2^20 word numbers fold onto 3 * 2^18.
 constexpr uint32_t PF_Q3 = 0x80000000u;
+// Round 4, late: in the three-quarter form word and bits come from pf_mix(h) = h * an odd constant.  (1) The fold of 2^20 word numbers
+// onto 3 * 2^18 by (w * 3) >> 2 sent two of every four source words to one target: half of all probes met words with twice the keys,
+// and those words made most of the false positives; the product's HIGH word over the mixed key spreads the keys evenly over the
+// 786 432 words.  (2) Three bits per key instead of two (11 bits per key on configs[2]: 1.3 % instead of 2.8 % of foreign probes pass),
+// taken from the low twelve bits of the mixed key, which the word does not depend on.
+constexpr uint32_t PF_Q3_WORDS = 3u << 18;
+constexpr int PF_MIXED = 0x100;           // flag in pf2: the bits of a key in the three-quarter form (below)
+__device__ __forceinline__ uint32_t pf_mix(uint32_t h) { return h * 0x9E3779B1u; }
 template <bool Q3>
 __device__ __forceinline__ uint32_t pf_word_t(uint32_t h, uint32_t pf_mask) {
-    const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
-    return Q3 ? (w * 3u) >> 2 : w;
+    if (Q3) return __umulhi(pf_mix(h), PF_Q3_WORDS);
+    return (h & pf_mask & ~PF_Q3) >> 5;
 }
 __device__ __forceinline__ uint32_t pf_word(uint32_t h, uint32_t pf_mask) {       // flag looked at at run time (the kernels that are not hot)
-    const uint32_t w = (h & pf_mask & ~PF_Q3) >> 5;
-    return (pf_mask & PF_Q3) ? (w * 3u) >> 2 : w;
+    return (pf_mask & PF_Q3) ? __umulhi(pf_mix(h), PF_Q3_WORDS) : (h & pf_mask & ~PF_Q3) >> 5;
 }
-// pf2 = shift of the address bits that pick a key's second bit (0: one bit per key) | PF_THREE when a key sets a THIRD bit (round 4: the
-// 3 MiB bitmap of configs[2] holds 11 bits per key, where three bits per key pass half as many foreign probes as two).  The third
-// index is a product hash of the twelve address bits that do not choose the word (0..4 and 25..31): it need not be independent of
-// the key's other two indices, only look random next to the bits OTHER keys set.
-constexpr int PF_THREE = 0x100;
-__device__ __forceinline__ uint32_t pf_third(uint32_t h) {
-    const uint32_t x = (h & 31u) | ((h >> 25) << 5);          // 12 bits
-    return (__umul24(x, 0x9E37u) >> 11) & 31u;
-}
+// the word takes the mixed key's bits from ~12 up: a key's three positions come from the twelve below -- bits 0..4, 5..9, and a product
+// hash of all twelve (it need not be independent of the key's own other two positions, only look random next to the bits OTHER keys
+// set; (m >> 10) & 31 was tried: bits 12..14 are the same for all keys of a word, the third position then adds fill and screens nothing)
+__device__ __forceinline__ uint32_t pf_third_of(uint32_t m) { return (__umul24(m & 0xfffu, 0x9E37u) >> 11) & 31u; }
 __device__ __forceinline__ uint32_t pf_word_bits(uint32_t h, int pf2) {
-    const uint32_t sh = (uint32_t)pf2 & 31u;
-    return (1u << (h & 31u)) | (sh ? 1u << ((h >> sh) & 31u) : 0u) | ((pf2 & PF_THREE) ? 1u << pf_third(h) : 0u);
+    if (pf2 & PF_MIXED) {
+        const uint32_t m = pf_mix(h);
+        return (1u << (m & 31u)) | (1u << ((m >> 5) & 31u)) | (1u << pf_third_of(m));
+    }
+    return (1u << (h & 31u)) | (pf2 ? 1u << ((h >> pf2) & 31u) : 0u);
 }
-// (the bits shifted down and ANDed: with pf2 = 0 the second shift picks the first bit again, and so does the third without PF_THREE.
-// A FOURTH bit was measured too: 23.4 -> 22.2 survivors per pair on configs[2] -- what is left are hits -- and no time.)
+// (both bits shifted down and ANDed: a variable shift takes its count modulo 32 by itself, so this is four vector instructions
+// where building the two-bit mask and comparing took eight; with pf2 = 0 the second shift picks the first bit again)
 __device__ __forceinline__ bool pf_pass(uint32_t word, uint32_t h, int pf2) {
-    const uint32_t b1 = h & 31u, b3 = (pf2 & PF_THREE) ? pf_third(h) : b1;
-    return ((word >> b1) & (word >> ((h >> ((uint32_t)pf2 & 31u)) & 31u)) & (word >> b3) & 1u) != 0u;
+    if (pf2 & PF_MIXED) {
+        const uint32_t m = pf_mix(h);
+        return ((word >> (m & 31u)) & (word >> ((m >> 5) & 31u)) & (word >> pf_third_of(m)) & 1u) != 0u;
+    }
+    return ((word >> (h & 31u)) & (word >> ((h >> pf2) & 31u)) & 1u) != 0u;
 }
 
 }  // namespace lhgt

@@ -153,6 +153,9 @@ int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads);
 /* where thread i of `threads` enters a FASTQ (byte), the global index of its first line and the lines it consumes;
  * size_for_chunks = size of fq1 (also for fq2, E:1419), < 0 = this file's */
 int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, long* entry_byte, long* first_line, long* n_lines);
+/* get_fq_start (E:44-89) on text in memory: the byte at which a thread whose chunk starts at `start` enters the file, -1 where
+ * the reference's stream would hit EOF while looking (host only; the property test's handle on the restated scan) */
+long lhgt_fastq_thread_entry(const uint8_t* text, long n, long start);
 int lhgt_fastq_parse_digest_threads(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null,
                                     int shard_rank, int shard_world, long shard_block, int threads, long chunk_bytes,
                                     int emulate_threads, long* n_pairs_seen, long* n_pairs_kept, uint64_t* digest,

@@ -59,6 +59,7 @@ SIGNATURES = {
                                         _u64p, _lp],
     "lhgt_set_thread_emulation": [_vp, _i],
     "lhgt_fastq_thread_chunks": [_cs, _l, _i, _lp, _lp, _lp],
+    "lhgt_fastq_thread_entry": [_cs, _l, _l],
     "lhgt_fastq_parse_digest_threads": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _i, _lp, _lp, _u64p, _lp],
     "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
     "lhgt_pairs_append_flags": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
@@ -145,7 +146,7 @@ def load(require_gpu: bool = True):
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header and library out of sync
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "lhgt_last_error" else C.c_long if name == "lhgt_fastq_plan_chunk_bytes" else C.c_int
+            fn.restype = C.c_char_p if name == "lhgt_last_error" else C.c_long if name in ("lhgt_fastq_plan_chunk_bytes", "lhgt_fastq_thread_entry") else C.c_int
         _lib = lib
     if require_gpu:
         n = C.c_int(0)

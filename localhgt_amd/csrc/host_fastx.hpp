@@ -1,0 +1,235 @@
+// host_fastx.hpp -- what the host-side FASTA / FASTQ ingest shares between its translation units (host_fastx.cpp: the planned
+// two-pass loader, the FASTA loaders, the C-ABI entry points; host_fastq_stream.cpp: the single-pass FASTQ loader).
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include <time.h>
+#include <emmintrin.h>   // SSE2: part of the x86-64 baseline
+#include "lhgt_common.hpp"
+
+namespace lhgt {
+
+struct Mapped {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~Mapped() {
+        if (p && n) {
+            if (n > ((size_t)64 << 20)) {     // tearing down the page tables of a multi-GB mapping takes ~10 ms per GB: not on the caller's clock
+                const uint8_t* q = p;
+                const size_t m = n;
+                std::thread([q, m] { munmap((void*)q, m); }).detach();
+            } else munmap((void*)p, n);
+        }
+        if (fd >= 0) close(fd);
+    }
+    int open(const char* path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) LHGT_FAIL(LHGT_E_IO, "cannot open %s", path);
+        struct stat sb;
+        if (fstat(fd, &sb)) LHGT_FAIL(LHGT_E_IO, "cannot stat %s", path);
+        n = (size_t)sb.st_size;
+        if (n) {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) LHGT_FAIL(LHGT_E_IO, "cannot mmap %s", path);
+            p = (const uint8_t*)m;
+            const char* adv = getenv("LHGT_MMAP_ADVICE");     // experiment knob: seq (default) | none | willneed | hugepage
+            if (!adv || !strcmp(adv, "seq")) madvise((void*)p, n, MADV_SEQUENTIAL);
+            else if (!strcmp(adv, "willneed")) madvise((void*)p, n, MADV_WILLNEED);
+            else if (!strcmp(adv, "hugepage")) madvise((void*)p, n, MADV_HUGEPAGE);
+        }
+        return LHGT_OK;
+    }
+};
+
+// std::getline semantics: a trailing '\n' does not start another (empty) line
+struct LineCursor {
+    const uint8_t* p;
+    size_t n, cur = 0;
+    LineCursor(const Mapped& m) : p(m.p), n(m.n) {}
+    bool next(const uint8_t** s, size_t* len, size_t* start) {
+        if (cur >= n) return false;
+        const uint8_t* st = p + cur;
+        const uint8_t* nl = (const uint8_t*)memchr(st, '\n', n - cur);
+        *s = st;
+        *start = cur;
+        if (nl) { *len = (size_t)(nl - st); cur += *len + 1; }
+        else { *len = n - cur; cur = n; }
+        return true;
+    }
+};
+
+// get_read_ID (E:303-311): cut at the first '/', then at the first ' ', then at the first '\t'
+inline size_t read_id_len(const uint8_t* s, size_t len) {
+    size_t n = len;
+    for (size_t i = 0; i < n; i++) if (s[i] == '/') { n = i; break; }
+    for (size_t i = 0; i < n; i++) if (s[i] == ' ') { n = i; break; }
+    for (size_t i = 0; i < n; i++) if (s[i] == '\t') { n = i; break; }
+    return n;
+}
+
+inline double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+inline bool ingest_trace() { static int t = getenv("LHGT_INGEST_TRACE") ? 1 : 0; return t != 0; }
+
+// A pool of equal slabs of pinned host memory (allocated by the GPU loader, absent for host-only callers).  A parse task
+// writes the bases it keeps straight into a slab -- mate 1 into its first half, mate 2 into the second -- so the upload is one
+// asynchronous copy per mate from page-locked memory (57 GB/s instead of 5.6 GB/s from pageable vectors, tools/h2d_rates.hip)
+// with no staging copy and no per-chunk registration.
+struct SlabPool {
+    uint8_t* base = nullptr;
+    size_t slab_bytes = 0, half_bytes = 0;   // a slab: [mate-1 bases: half][mate-2 bases: half][ChunkPairMeta x (CHUNK_META_CAP + 1)]
+    int k = 0;
+    std::vector<int> free_ids;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool closed = false;
+    void close() { { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_all(); }
+    void reopen() { std::lock_guard<std::mutex> lk(mu); closed = false; }
+    int acquire() {   // blocks until a slab is free; -1 once the pool is closed
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return closed || !free_ids.empty(); });
+        if (closed) return -1;
+        const int id = free_ids.back();
+        free_ids.pop_back();
+        return id;
+    }
+    void release(int id) {
+        { std::lock_guard<std::mutex> lk(mu); free_ids.push_back(id); }
+        cv.notify_one();
+    }
+};
+
+// per-pair record a parse thread leaves next to the bases in its slab: where the pair's mates start inside the chunk's two base
+// runs and inside its packed words; entry n (one past the last pair) holds the totals.  The GPU turns (chunk bases + these) into
+// the batch's start / length / word-offset arrays (k_ingest.hip: expand_chunk_meta), so the calling thread touches no pair.
+constexpr int CHUNK_META_CAP = 16384;      // pairs per chunk with in-slab metadata (2 MiB chunks hold ~6600 150-bp pairs); more: vectors
+
+struct ParsedChunk {
+    std::vector<uint8_t> s1, s2, flags;   // flags: PAIR_COUNT1 | PAIR_COUNT2 | PAIR_VOTE per kept pair
+    std::vector<uint64_t> o1, o2;
+    // with a slab: bases live in slab[0 .. n1) and slab[half .. half + n2) instead of s1 / s2, the per-pair records in meta[0 .. n_meta]
+    // instead of o1 / o2 / flags
+    uint8_t* slab = nullptr;
+    ChunkPairMeta* meta = nullptr;
+    size_t half = 0, n1 = 0, n2 = 0;
+    long n_meta = 0;
+    uint32_t words = 0;
+    uint64_t nkm = 0;
+    int max_len = 0, k = 0;
+    int slab_id = -1;
+    int rc = LHGT_OK;
+    std::string err;
+    const uint8_t* bases1() const { return slab ? slab : s1.data(); }
+    const uint8_t* bases2() const { return slab ? slab + half : s2.data(); }
+    size_t size1() const { return slab ? n1 : s1.size(); }
+    size_t size2() const { return slab ? n2 : s2.size(); }
+    long n_pairs() const { return slab ? n_meta : (long)o1.size() - 1; }
+    void spill() {   // unusual line structure (or more pairs than the slab's record area holds): continue in vectors
+        s1.assign(slab, slab + n1);
+        s2.assign(slab + half, slab + half + n2);
+        o1.assign(1, 0);
+        o2.assign(1, 0);
+        flags.clear();
+        for (long i = 0; i < n_meta; i++) {
+            o1.push_back(i + 1 < n_meta ? meta[i + 1].rel1 : n1);
+            o2.push_back(i + 1 < n_meta ? meta[i + 1].rel2 : n2);
+            flags.push_back((uint8_t)meta[i].flags);
+        }
+        slab = nullptr;
+        meta = nullptr;
+    }
+    void push(const uint8_t* a, size_t la, const uint8_t* b, size_t lb, uint8_t fl) {
+        if (slab && (n1 + la > half || n2 + lb > half || n_meta >= CHUNK_META_CAP)) spill();
+        if (slab) {
+            meta[n_meta++] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, fl};
+            memcpy(slab + n1, a, la); n1 += la;
+            memcpy(slab + half + n2, b, lb); n2 += lb;
+            words += 3u * (uint32_t)((la + 31) / 32 + 1) + 3u * (uint32_t)((lb + 31) / 32 + 1);
+            if ((int)la > max_len) max_len = (int)la;
+            if ((int)lb > max_len) max_len = (int)lb;
+            if ((int)la >= k) nkm += la - k + 1;
+            if ((int)lb >= k) nkm += lb - k + 1;
+        } else {
+            s1.insert(s1.end(), a, a + la);
+            s2.insert(s2.end(), b, b + lb);
+            o1.push_back(s1.size());
+            o2.push_back(s2.size());
+            flags.push_back(fl);
+        }
+    }
+    // slab chunks end as ONE contiguous block -- [mate-1 bases][mate-2 bases][pad to 16 bytes][n + 1 records] -- so the calling
+    // thread issues one copy per chunk
+    size_t block_bytes() const { return meta_off() + (size_t)(n_meta + 1) * sizeof(ChunkPairMeta); }
+    size_t meta_off() const { return (n1 + n2 + 15) & ~(size_t)15; }
+    void finish() {
+        if (!slab) return;
+        meta[n_meta] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, 0u};
+        memmove(slab + n1, slab + half, n2);
+        ChunkPairMeta* dst = (ChunkPairMeta*)(slab + meta_off());
+        memmove(dst, meta, (size_t)(n_meta + 1) * sizeof(ChunkPairMeta));   // the record area lies behind both halves: dst <= meta
+        half = n1;
+        meta = dst;
+    }
+};
+
+struct ChunkPlan {
+    std::vector<size_t> start;   // byte offset of the first line of each chunk, plus file size at the end
+    std::vector<long> line0;     // global index of that line, plus total line count at the end
+};
+
+inline size_t line_start_at_or_after(const uint8_t* p, size_t n, size_t from) {
+    if (from == 0) return 0;
+    if (from >= n) return n;
+    const uint8_t* nl = (const uint8_t*)memchr(p + from - 1, '\n', n - (from - 1));
+    return nl ? (size_t)(nl - p) + 1 : n;
+}
+
+// newlines in [q, end): 16 bytes at a time (compare, mask, popcount): ~4x a memchr per 60-150-byte line
+inline long count_nl(const uint8_t* q, const uint8_t* end) {
+    long c = 0;
+    const __m128i nl16 = _mm_set1_epi8('\n');
+    for (; q + 64 <= end; q += 64) {
+        const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)q), nl16));
+        const unsigned m1 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(q + 16)), nl16));
+        const unsigned m2 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(q + 32)), nl16));
+        const unsigned m3 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(q + 48)), nl16));
+        c += __builtin_popcountll((unsigned long long)m0 | ((unsigned long long)m1 << 16) | ((unsigned long long)m2 << 32) | ((unsigned long long)m3 << 48));
+    }
+    for (; q < end; q++) c += *q == '\n';
+    return c;
+}
+
+inline long count_lines(const uint8_t* p, size_t b0, size_t b1, size_t n) {
+    long c = count_nl(p + b0, p + b1);
+    if (b1 == n && n > b0 && p[n - 1] != '\n') c++;   // last line without a newline is still a line (std::getline)
+    return c;
+}
+
+template <class Fn>
+inline void parallel_for(long n, int threads, Fn fn) {
+    if (threads <= 1 || n <= 1) { for (long i = 0; i < n; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<long> next{0};
+    int t = (int)(n < threads ? n : threads);
+    for (int w = 0; w < t; w++) th.emplace_back([&]() { for (long i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& x : th) x.join();
+}
+
+inline size_t n_plan_chunks(size_t file_bytes, size_t chunk_bytes) { return file_bytes ? (file_bytes + chunk_bytes - 1) / chunk_bytes : 1; }
+
+}  // namespace lhgt

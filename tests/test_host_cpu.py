@@ -457,6 +457,30 @@ def test_thread_partition_matches_the_reference_log(lib, oracle, case_inputs, na
             assert lines[last_header].split(b" ")[0].decode() == rows[i][1]
 
 
+def test_thread_entry_equals_the_literal_scan_on_random_text(lib, oracle):
+    """the restated automaton of get_fq_start (host_fastx.cpp: thread_entry) against the oracle's literal double loop with its
+    persistent newline counter (orc_get_fq_start, E:44-89): byte soups over the five characters the scan tells apart, at newline
+    densities from FASTQ-like to hostile, every start offset of short texts and sampled ones of long texts"""
+    h = lib.load(require_gpu=False)
+    rng = np.random.default_rng(20261004)
+    checked = 0
+    for case in range(260):
+        n = int(rng.integers(1, 300)) if case < 200 else int(rng.integers(1500, 6000))
+        p_nl = (0.02, 0.1, 0.3, 0.6)[case % 4]
+        rest = (1 - p_nl) / 4
+        text = bytes(rng.choice(np.frombuffer(b"\n+@AI", dtype=np.uint8), size=n, p=[p_nl, rest, rest, rest, rest]).tolist())
+        if case % 5 == 0:                                  # real records in the soup, so that answers are found, not only refusals
+            rec = b"@r1/1\nACGT\n+\nIIII\n" * int(rng.integers(1, 40))
+            cut = int(rng.integers(0, len(text) + 1))
+            text = text[:cut] + rec + text[cut:]
+        n = len(text)
+        starts = range(0, n + 3) if n < 400 else [int(x) for x in rng.integers(0, n + 3, size=60)]
+        for start in starts:
+            assert h.lhgt_fastq_thread_entry(text, n, start) == oracle.get_fq_start(text, start), (case, start)
+            checked += 1
+    assert checked > 30000
+
+
 def test_thread_partition_flags_and_refusals(lib, oracle, case_inputs, tmp_path):
     """pairs_counted / mate-2 counts / voted pairs of the partitioned parse equal the oracle's -t N run; one thread = the plain
     parse; files too small for the thread count are refused like every input on which the reference reads stale bytes"""

@@ -153,6 +153,17 @@ int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads);
 /* where thread i of `threads` enters a FASTQ (byte), the global index of its first line and the lines it consumes;
  * size_for_chunks = size of fq1 (also for fq2, E:1419), < 0 = this file's */
 int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, long* entry_byte, long* first_line, long* n_lines);
+/* host-only rate probe of the FASTQ loader (tools/ingest_scaling.py): the parse as lhgt_pairs_load_fastq runs it -- worker threads
+ * filling slabs with kept bases and per-pair records -- into host memory, nothing uploaded.  start1 null: the whole files (single
+ * pass first, as in the loader); otherwise part `part` of `n_parts` of the planned parse (plans from lhgt_fastq_plan_part). */
+int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int threads, long chunk_bytes,
+                          int emulate_threads, const uint64_t* start1, const long* n_lines1, long n1, const uint64_t* start2,
+                          const long* n_lines2, long n2, int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept, long* n_bases,
+                          double* seconds);
+/* which way the calling thread's last FASTQ parse went: 1 = in one pass over the text (host_fastq_stream.cpp), 0 = line count, then
+ * parse (the planned loader: always with plans made elsewhere, or when the single pass met something only the planned loader decides
+ * -- `why`, nullable, says what), -1 = none yet.  The pairs are the same either way. */
+int lhgt_ingest_last_path(char* why, long cap);
 /* get_fq_start (E:44-89) on text in memory: the byte at which a thread whose chunk starts at `start` enters the file, -1 where
  * the reference's stream would hit EOF while looking (host only; the property test's handle on the restated scan) */
 long lhgt_fastq_thread_entry(const uint8_t* text, long n, long start);

@@ -409,16 +409,62 @@ static int parse_setup(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, 
 // 2 x threads chunks, in flight).  A chunk that used a slab keeps it until the consumer hands it back (pool->release), which it
 // does once its copy to the device has completed; idle(true/false) is called while the consumer waits for the next chunk so it
 // can poll for finished copies (and must free at least one slab when asked to block and every slab is out).
+// which way the last FASTQ parse of this thread went (lhgt_ingest_last_path): 1 = the single pass, 0 = the two planned passes, and why
+static thread_local int g_last_path = -1;
+static thread_local std::string g_last_path_why;
+
+// `reset` (nullable): drops everything consume() has been given so far.  With it, and without plans made elsewhere, the files first
+// go through the single-pass loader (host_fastq_stream.cpp); where that pass does not decide the input, the pairs it delivered
+// are dropped and the two passes below run as if it had not been tried.  LHGT_INGEST_STREAM=0 turns the first attempt off.
 template <class Consume, class Idle>
 static int parse_pairs(const char* fq1, const char* fq2, double ratio, const float* random_array, int shard_rank, int shard_world,
                        long shard_block, int threads, size_t chunk_bytes, int emulate_threads, long* n_pairs_seen, SlabPool* pool_in,
                        Consume consume, Idle idle, const std::function<int(SlabPool**)>& prepare = nullptr,
                        const std::function<int(const Mapped&, const Mapped&, ParseShare*, ChunkPlan*, ChunkPlan*)>& share_fn = nullptr,
-                       long sampling_filled = LHGT_MAX_RANDOM) {
+                       long sampling_filled = LHGT_MAX_RANDOM, const std::function<int()>& reset = nullptr) {
     Mapped m1, m2;
     LHGT_TRY(m1.open(fq1));
     LHGT_TRY(m2.open(fq2));
     if (threads < 1) threads = 1;
+    auto sampling_covers = [&](long lines1, long lines2) -> int {   // a sampling array filled for fewer reads than the files hold (lhgt_sampling_reserve) must fail loudly
+        if (ratio < 100.0 && sampling_filled < LHGT_MAX_RANDOM && (lines1 + 2) / 4 > sampling_filled)
+            LHGT_FAIL(LHGT_E_STATE, "the sampling array was filled for %ld reads (lhgt_sampling_reserve), %s holds %ld", sampling_filled, fq1, (lines1 + 2) / 4);
+        if (ratio < 100.0 && sampling_filled < LHGT_MAX_RANDOM && (lines2 + 2) / 4 > sampling_filled)
+            LHGT_FAIL(LHGT_E_STATE, "the sampling array was filled for %ld reads (lhgt_sampling_reserve), %s holds %ld", sampling_filled, fq2, (lines2 + 2) / 4);
+        return LHGT_OK;
+    };
+    const bool stream_on = !(getenv("LHGT_INGEST_STREAM") && atoi(getenv("LHGT_INGEST_STREAM")) == 0);
+    g_last_path = 0;
+    g_last_path_why = share_fn ? "plans made elsewhere" : !reset ? "the caller cannot take pairs back" : !stream_on ? "LHGT_INGEST_STREAM=0" : "";
+    if (reset && !share_fn && stream_on) {
+        ChunkPlan q1, q2;
+        std::string why;
+        const int src = parse_pairs_stream(m1, m2, fq1, fq2, ratio, random_array, shard_rank, shard_world, shard_block, threads, chunk_bytes,
+                                           emulate_threads, prepare, std::function<int(ParsedChunk&)>(consume), std::function<void(bool)>(idle), &q1, &q2, &why);
+        if (src == LHGT_OK) {
+            const long lines1 = q1.line0.back(), lines2 = q2.line0.back();
+            // fq2 longer than fq1: its surplus records are counted by phase A (quirk Q4), as below
+            if (lines2 > lines1) {
+                ParsedChunk tail;
+                const ThreadEmu* no_emu = nullptr;
+                ThreadEmu emu_store;
+                if (emulate_threads > 1) {               // the surplus is kept by fq2's thread chunks: by line numbers, now that the plans exist
+                    LHGT_TRY(thread_part(m1, q1, (long)m1.n, emulate_threads, fq1, &emu_store.f1, &emu_store.pos1));
+                    LHGT_TRY(thread_part(m2, q2, (long)m1.n, emulate_threads, fq2, &emu_store.f2));
+                    no_emu = &emu_store;
+                }
+                LHGT_TRY(parse_fq2_only(m1, m2, q2, lines1, lines2, ratio, random_array, shard_rank, shard_world, shard_block, no_emu, &tail));
+                if (tail.o1.size() > 1) LHGT_TRY(consume(tail));
+            }
+            if (n_pairs_seen) *n_pairs_seen = (lines1 + 2) / 4;
+            g_last_path = 1;
+            return sampling_covers(lines1, lines2);
+        }
+        if (src != STREAM_RETRY) return src;
+        g_last_path_why = why;
+        if (ingest_trace()) fprintf(stderr, "[lhgt ingest] the single pass leaves %s to the planned loader: %s\n", fq1, why.c_str());
+        LHGT_TRY(reset());
+    }
     double t0 = now_s();
     // the line count runs on helper threads; meanwhile the calling thread may allocate (prepare: pinned slabs, device staging)
     ChunkPlan p1s, p2s;
@@ -558,12 +604,7 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
                 share.part, share.n_parts, threads, c_lo, c_hi, nc_all, 1e-6 * (double)(p1.start[(size_t)c_hi] - p1.start[(size_t)c_lo]), 1e-6 * (double)m1.n, fq1,
                 t_plan, t_parse, t_consume);
     if (n_pairs_seen) *n_pairs_seen = (p1.line0.back() + 2) / 4;   // lines with index % 4 == 1
-    // a sampling array filled for fewer reads than the files hold (lhgt_sampling_reserve) must fail loudly
-    if (ratio < 100.0 && sampling_filled < LHGT_MAX_RANDOM && (p1.line0.back() + 2) / 4 > sampling_filled)
-        LHGT_FAIL(LHGT_E_STATE, "the sampling array was filled for %ld reads (lhgt_sampling_reserve), %s holds %ld", sampling_filled, fq1, (p1.line0.back() + 2) / 4);
-    if (ratio < 100.0 && sampling_filled < LHGT_MAX_RANDOM && (p2.line0.back() + 2) / 4 > sampling_filled)
-        LHGT_FAIL(LHGT_E_STATE, "the sampling array was filled for %ld reads (lhgt_sampling_reserve), %s holds %ld", sampling_filled, fq2, (p2.line0.back() + 2) / 4);
-    return LHGT_OK;
+    return sampling_covers(p1.line0.back(), p2.line0.back());
 }
 
 static int default_threads() {
@@ -921,6 +962,24 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         return rc;
     };
     std::vector<ChunkPairMeta> conv;     // records of a chunk that came in vectors (spilled, head / tail records of fq2, no pinned memory)
+    // taking back what the single-pass attempt delivered (parse_pairs): batches installed by this call, and -- count-on-load --
+    // what they added to the count table, which only a clear can undo: offered only while nothing else was counted before
+    const size_t batches_at_entry = ctx->batches.size();
+    const bool can_reset = !(ctx->count_on_load && ctx->counts_touched);
+    auto reset = [&]() -> int {
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (pool) while (out_head < out_slabs.size()) pool->release(out_slabs[out_head++]);
+        bool counted = false;
+        for (size_t i = batches_at_entry; i < ctx->batches.size(); i++) counted = counted || ctx->batches[i].counted;
+        lhgt::pairs_truncate(ctx, batches_at_entry);
+        if (counted) LHGT_TRY(lhgt_counts_clear(ctx));
+        for (hipEvent_t e : count_ev) hipEventDestroy(e);
+        count_ev.clear();
+        fill = 0; n_open = 0; kept = 0; n_desc = 0; n_batches = 0; words = 0; nkm = 0; max_len = 0;
+        used[0] = used[1] = false;
+        return LHGT_OK;
+    };
     int rc = parse_pairs(fq1, fq2, ratio_percent, ctx->random_array.data(), shard_rank, shard_world, shard_block, threads, CHUNK,
                          ctx->emu_threads, n_pairs_seen, (SlabPool*)nullptr,
                          [&](ParsedChunk& ch) -> int {
@@ -965,7 +1024,8 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                              if (n_open >= BATCH_PAIRS || fill >= BATCH_BYTES) return flush();
                              return LHGT_OK;
                          },
-                         [&](bool block) { reap(block); }, prepare, share_fn, ctx->random_array.empty() ? LHGT_MAX_RANDOM : ctx->sampling_filled);
+                         [&](bool block) { reap(block); }, prepare, share_fn, ctx->random_array.empty() ? LHGT_MAX_RANDOM : ctx->sampling_filled,
+                         can_reset ? std::function<int()>(reset) : std::function<int()>(nullptr));
     const double t_f0 = now_s();
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(cs);               // whatever happened: no copy may still read a slab,
@@ -1127,6 +1187,7 @@ int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double rat
     if (!fq1 || !fq2 || !digest || chunk_bytes < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if (ratio_percent < 100.0 && !random_array_or_null) LHGT_FAIL(LHGT_E_ARG, "sampling needs the random array");
     uint64_t h = chain ? *digest : 1469598103934665603ull;
+    const uint64_t h_start = h;
     ShareFn share_fn = nullptr;
     if (start1)
         share_fn = [&](const Mapped& m1, const Mapped& m2, ParseShare* sh, ChunkPlan* p1, ChunkPlan* p2) -> int {
@@ -1154,12 +1215,62 @@ int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double rat
                              kept += n;
                              return LHGT_OK;
                          },
-                         [](bool) {}, nullptr, share_fn);
+                         [](bool) {}, nullptr, share_fn, LHGT_MAX_RANDOM,
+                         [&]() -> int { h = h_start; kept = 0; cnt[0] = cnt[1] = cnt[2] = 0; return LHGT_OK; });
     if (rc != LHGT_OK) return rc;
     *digest = h;
     if (n_pairs_kept) *n_pairs_kept = kept;
     if (counts) for (int q = 0; q < 3; q++) counts[q] = cnt[q];
     return LHGT_OK;
+}
+
+// Host-only rate probe of the loader (tools/ingest_scaling.py): the parse exactly as lhgt_pairs_load_fastq runs it -- worker threads
+// writing kept bases and per-pair records into a pool of slabs -- with a consumer that only adds up what it is handed and gives the
+// slab back (no GPU, no copy).  Without plans (start1 null) the single pass is tried first, as in the loader; with plans the
+// caller's part of the planned parse runs.  seconds = wall time of the call (mapping the files included).
+int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int threads, long chunk_bytes,
+                          int emulate_threads, const uint64_t* start1, const long* n_lines1, long n1, const uint64_t* start2, const long* n_lines2,
+                          long n2, int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept, long* n_bases, double* seconds) {
+    if (!fq1 || !fq2 || chunk_bytes < 256 || threads < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (ratio_percent < 100.0 && !random_array_or_null) LHGT_FAIL(LHGT_E_ARG, "sampling needs the random array");
+    const double t0 = now_s();
+    ShareFn share_fn = nullptr;
+    if (start1)
+        share_fn = [&](const Mapped& m1, const Mapped& m2, ParseShare* sh, ChunkPlan* p1, ChunkPlan* p2) -> int {
+            if (!n_lines1 || !start2 || !n_lines2 || n1 < 1 || n2 < 1 || n_parts < 1 || part < 0 || part >= n_parts) LHGT_FAIL(LHGT_E_ARG, "bad FASTQ plan");
+            LHGT_TRY(plan_from_arrays(m1, start1, n_lines1, n1, p1));
+            LHGT_TRY(plan_from_arrays(m2, start2, n_lines2, n2, p2));
+            sh->p1 = p1; sh->p2 = p2; sh->part = part; sh->n_parts = n_parts;
+            return LHGT_OK;
+        };
+    const size_t HALF = (size_t)chunk_bytes + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);
+    const int n_slabs = threads + threads / 3 + 4;
+    std::unique_ptr<uint8_t[]> mem(new uint8_t[(size_t)n_slabs * SLAB]);
+    SlabPool pool;
+    pool.base = mem.get();
+    pool.slab_bytes = SLAB;
+    pool.half_bytes = HALF;
+    pool.k = 32;
+    for (int i = 0; i < n_slabs; i++) pool.free_ids.push_back(i);
+    long kept = 0, bases = 0;
+    int rc = parse_pairs(fq1, fq2, ratio_percent, random_array_or_null, 0, 1, 1, threads, (size_t)chunk_bytes, emulate_threads, n_pairs_seen, (SlabPool*)nullptr,
+                         [&](ParsedChunk& ch) -> int {
+                             kept += ch.n_pairs();
+                             bases += (long)(ch.size1() + ch.size2());
+                             if (ch.slab_id >= 0) pool.release(ch.slab_id);
+                             return LHGT_OK;
+                         },
+                         [](bool) {}, [&](SlabPool** out) -> int { *out = &pool; return LHGT_OK; }, share_fn, LHGT_MAX_RANDOM,
+                         [&]() -> int { kept = 0; bases = 0; return LHGT_OK; });
+    if (n_pairs_kept) *n_pairs_kept = kept;
+    if (n_bases) *n_bases = bases;
+    if (seconds) *seconds = now_s() - t0;
+    return rc;
+}
+
+int lhgt_ingest_last_path(char* why, long cap) {
+    if (why && cap > 0) { strncpy(why, lhgt::g_last_path_why.c_str(), (size_t)cap - 1); why[cap - 1] = 0; }
+    return lhgt::g_last_path;
 }
 
 long lhgt_fastq_thread_entry(const uint8_t* text, long n, long start) {

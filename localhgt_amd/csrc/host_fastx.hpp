@@ -232,4 +232,16 @@ inline void parallel_for(long n, int threads, Fn fn) {
 
 inline size_t n_plan_chunks(size_t file_bytes, size_t chunk_bytes) { return file_bytes ? (file_bytes + chunk_bytes - 1) / chunk_bytes : 1; }
 
+
+// host_fastx.cpp
+long thread_entry(const uint8_t* p, long n, long start);   // get_fq_start (E:44-89)
+// host_fastq_stream.cpp: the single-pass loader.  LHGT_OK: every pair of the files went through consume(), plan1 / plan2 hold the
+// line plans made on the way.  STREAM_RETRY (not an error code of the C-ABI): this pass does not decide the input -- *why says what
+// it met -- and whatever consume() has seen must be dropped and the files given to the planned loader.
+extern const int STREAM_RETRY;
+int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, const char* fq2, double ratio, const float* random_array,
+                       int shard_rank, int shard_world, long shard_block, int threads, size_t chunk_bytes, int emulate_threads,
+                       const std::function<int(SlabPool**)>& prepare, const std::function<int(ParsedChunk&)>& consume,
+                       const std::function<void(bool)>& idle, ChunkPlan* plan1, ChunkPlan* plan2, std::string* why);
+
 }  // namespace lhgt

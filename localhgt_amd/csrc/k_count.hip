@@ -106,6 +106,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
     // resident and saturates at once, so the direct kernel's pre-check load makes it read-mostly (45 vs 1021 ms at k = 21).
     const int mode = ctx->count_compat ? 0 : ctx->count_mode >= 0 ? ctx->count_mode : (ctx->k >= 26 ? 1 : 0);   // the compat coder lives in the direct kernel only
     for (ReadBatch& b : ctx->batches) {
+        ctx->counts_touched = true;
         if (b.counted) { b.counted = false; continue; }   // the loader counted it already (lhgt_set_count_on_load): skipped this once
         if (mode == 1) {
             LHGT_TRY(lhgt_count_batch_partitioned(ctx, b));
@@ -143,6 +144,7 @@ int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0,
     }
     LHGT_HIP(hipEventRecord(t1, ctx->stream));
     b.counted = true;
+    ctx->counts_touched = true;
     return LHGT_OK;
 }
 
@@ -172,12 +174,14 @@ int lhgt_counts_clear(lhgt_ctx* ctx) {
     LHGT_HIP(hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * 4, ctx->stream));
     for (ReadBatch& b : ctx->batches) b.counted = false;
     ctx->count_on_load_ms = 0.f;
+    ctx->counts_touched = false;
     return LHGT_OK;
 }
 
 int lhgt_counts_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !dev_ptr || !bytes) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    ctx->counts_touched = true;      // the caller may write through the pointer (the count-table exchange does)
     *dev_ptr = ctx->d_counts;
     *bytes = ctx->counts_words * 4;
     return LHGT_OK;
@@ -190,6 +194,7 @@ int lhgt_counts_merge(lhgt_ctx* ctx, const void* dev_other, size_t byte_offset, 
         LHGT_FAIL(LHGT_E_ARG, "merge range [%zu,+%zu) outside the table or not word aligned", byte_offset, bytes);
     size_t n = bytes / 4;
     if (!n) return LHGT_OK;
+    ctx->counts_touched = true;
     size_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(counts_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_counts + byte_offset / 4,

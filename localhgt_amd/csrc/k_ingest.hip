@@ -529,6 +529,14 @@ int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPair
     return LHGT_OK;
 }
 
+void pairs_truncate(lhgt_ctx* ctx, size_t n_batches) {
+    while (ctx->batches.size() > n_batches) {
+        ctx->n_pairs -= ctx->batches.back().d.n_pairs;
+        free_batch(ctx->batches.back());
+        ctx->batches.pop_back();
+    }
+}
+
 void ingest_free(lhgt_ctx* ctx) {
     for (hipEvent_t e : ctx->ingest_events) hipEventDestroy(e);
     ctx->ingest_events.clear();

@@ -126,6 +126,8 @@ struct lhgt_ctx {
     // A
     uint32_t* d_counts = nullptr;  // 2-bit saturating counters, 16 per word
     size_t counts_words = 0;
+    bool counts_touched = false;   // something may have been counted since the last lhgt_counts_clear (a loader that has to take back a
+                                   // count-on-load can only do so by clearing the table: allowed while this was false at its start)
     // I
     uint32_t* d_index = nullptr;
     size_t index_words = 0;
@@ -272,6 +274,7 @@ int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPair
 int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, const uint64_t* kept_before, long n_blocks,
                      const uint64_t* seg, long n_seg, uint8_t* d_out);
 void ingest_free(lhgt_ctx* ctx);
+void pairs_truncate(lhgt_ctx* ctx, size_t n_batches);   // frees the resident batches from number n_batches on
 int stage_ascii(lhgt_ctx* ctx, size_t dev_off, const uint8_t* src, size_t bytes);
 int upload_locked_ahead(lhgt_ctx* ctx, hipStream_t st, void* d_dst, const void* src, size_t bytes);   // file mapping -> device, page-locking one piece ahead
 }  // namespace lhgt

@@ -575,6 +575,114 @@ def test_thread_partition_fuzz_against_the_oracle(lib, oracle, tmp_path, idx):
         assert (cnt[0], cnt[1], cnt[2]) == (rep.pairs_counted, int(rep.t_count), rep.pairs_voted), (threads, k, e, sample)
 
 
+# ------------------------------------------------------------------ the single-pass loader == the planned loader (round 5)
+def _digest_full(lib, f1, f2, ratio=100.0, rnd=None, threads=3, chunk=20000, emulate=1, stream=True):
+    """(rc, seen, kept, digest, [mate 1 counted, mate 2 counted, voted], path, why) -- path 1 = the single pass did it"""
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(0)
+    cnt = (C.c_long * 3)()
+    rp = rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None
+    os.environ["LHGT_INGEST_STREAM"] = "1" if stream else "0"
+    try:
+        rc = h.lhgt_fastq_parse_digest_threads(f1.encode(), f2.encode(), float(ratio), rp, 0, 1, 4096, threads, chunk, emulate, C.byref(seen),
+                                               C.byref(kept), C.byref(dig), cnt)
+    finally:
+        os.environ.pop("LHGT_INGEST_STREAM", None)
+    why = C.create_string_buffer(256)
+    path = h.lhgt_ingest_last_path(why, 256)
+    return rc, seen.value, kept.value, dig.value, list(cnt), path, why.value.decode()
+
+
+def test_single_pass_loader_equals_the_planned_loader(lib, oracle, case_inputs, tmp_path):
+    """host_fastq_stream.cpp against host_fastx.cpp's two passes: the same pairs in the same order with the same flags (one digest)
+    for every golden pair of files and for files made to hurt -- no final newline, CRLF, blank tail, a record cut short, fq2
+    shorter / longer / with other header lengths (the chunks of the two files drift against each other), a line longer than a
+    chunk's margin, foreign records in front -- at chunk sizes from one record to the whole file, with sampling, with the
+    reference's -t N partition; and the single pass must really have been the one that ran wherever nothing forbids it"""
+    oracle.srand(11)
+    rnd = np.resize(oracle.sampling_array(1_000_000), 50_000_000)
+    files = {}
+    for name in ("k24_seed7", "k24_fq2_longer", "k24_fq2_surplus", "k24_fq2_stray2", "k24_fq2_short", "k24_fq2_short_nonl", "k24_t4", "k24_t10_sample_bases",
+                 "k24_t3_fq2_longer"):
+        fa, f1, f2, _ = case_inputs(name)
+        files[name] = (f1, f2)
+    raw1, raw2 = open(files["k24_seed7"][0], "rb").read(), open(files["k24_seed7"][1], "rb").read()
+    l1, l2 = raw1.split(b"\n"), raw2.split(b"\n")
+
+    def put(name, a, b):
+        p1, p2 = str(tmp_path / f"{name}.1.fq"), str(tmp_path / f"{name}.2.fq")
+        open(p1, "wb").write(a)
+        open(p2, "wb").write(b)
+        files[name] = (p1, p2)
+
+    put("nonl", raw1[:-1], raw2[:-1])
+    put("nonl2", raw1, raw2[:-1])
+    put("crlf", b"\r\n".join(l1[:4000]) + b"\r\n", b"\r\n".join(l2[:4000]) + b"\r\n")
+    put("blank_tail", raw1 + b"\n\n", raw2 + b"\n")
+    put("cut_record", b"\n".join(l1[:4002]) + b"\n", b"\n".join(l2[:4002]) + b"\n")
+    put("fq2_short", raw1, b"\n".join(l2[:2000]) + b"\n")
+    put("fq2_short_nonl", raw1, b"\n".join(l2[:2002]))
+    # longer headers in fq2 only: equal line counts, fq2 5 % larger -- the columns' chunks drift by lines
+    put("drift", raw1, b"\n".join((ln + b" extra:comment" if i % 4 == 0 and ln else ln) for i, ln in enumerate(l2)))
+    # ragged read lengths
+    rng = np.random.default_rng(5)
+    rag1, rag2 = [], []
+    for i in range(0, min(len(l1), len(l2)) - 4, 4):
+        a, b = int(rng.integers(30, 150)), int(rng.integers(30, 150))
+        rag1 += [l1[i], l1[i + 1][:a], b"+", l1[i + 3][:a]]
+        rag2 += [l2[i], l2[i + 1][:b], b"+", l2[i + 3][:b]]
+    put("ragged", b"\n".join(rag1) + b"\n", b"\n".join(rag2) + b"\n")
+    # a quality line of 70 000 characters: longer than the margin a chunk reads past its end
+    long1 = l1[:400] + [b"@long/1", b"ACGT" * 25, b"+", b"I" * 70000] + l1[400:]
+    long2 = l2[:400] + [b"@long/2", b"ACGT" * 25, b"+", b"I" * 70000] + l2[400:]
+    put("long_line", b"\n".join(long1), b"\n".join(long2))
+    put("foreign_front", raw1, b"@stray/2\nACGT\n+\nIIII\n" + raw2)
+    put("other_first_id", raw1, b"@other/2\n" + b"\n".join(l2[1:]))
+    taken, left = set(), {}
+    for name, (f1, f2) in files.items():
+        t = cases.CASES[name].threads if name in cases.CASES else 1
+        for emulate in sorted({1, t, 4}):
+            for ratio in (100.0, 35.0):
+                want = _digest_full(lib, f1, f2, ratio=ratio, rnd=rnd, threads=2, chunk=1 << 40, emulate=emulate, stream=False)
+                assert want[5] == 0
+                for threads, chunk in ((1, 1 << 22), (3, 50000), (5, 7777), (4, 640)):
+                    got = _digest_full(lib, f1, f2, ratio=ratio, rnd=rnd, threads=threads, chunk=chunk, emulate=emulate, stream=True)
+                    assert got[:5] == want[:5], (name, emulate, ratio, threads, chunk, got[5:], want[:3])
+                    if got[5] == 1:
+                        taken.add((name, emulate))
+                    else:
+                        left[(name, emulate)] = got[6]
+    # the plain files went through the single pass, also under the thread emulation where the reference's threads land on records
+    for name in ("k24_seed7", "k24_fq2_longer", "k24_fq2_surplus", "k24_fq2_short", "k24_fq2_short_nonl", "nonl", "nonl2", "crlf", "blank_tail", "cut_record",
+                 "fq2_short", "fq2_short_nonl", "drift", "ragged"):
+        assert (name, 1) in taken, (name, left.get((name, 1)))
+    assert ("k24_t4", 4) in taken and ("k24_seed7", 4) in taken, left
+    # ... and these did not, for the reason given
+    assert "first read IDs differ" in left[("k24_fq2_stray2", 1)] and "first read IDs differ" in left[("foreign_front", 1)]
+    assert "first read IDs differ" in left[("other_first_id", 1)]
+    assert "longer than a chunk's margin" in left[("long_line", 1)]
+
+
+@pytest.mark.parametrize("idx", range(24))
+def test_single_pass_loader_fuzz(lib, oracle, tmp_path, idx):
+    """random small inputs of the whole-run fuzz (ragged reads, N runs, padded fq2 headers, CRLF, sampling): single pass == planned
+    loader, plain and under -t 2..8, whichever of the two ends up doing the work"""
+    from test_gpu_fuzz import _make_case
+    d = tmp_path / "c"
+    d.mkdir()
+    k, e, seed, sample, hit, match, max_peak = _make_case(700 + idx, str(d), k_max=16)
+    f1, f2 = str(d / "s.1.fq"), str(d / "s.2.fq")
+    oracle.srand(seed)
+    rnd = np.resize(oracle.sampling_array(200_000), 50_000_000)
+    ratio = 100.0 * sample if sample <= 1 else 40.0
+    for emulate in (1, 2 + idx % 7):
+        want = _digest_full(lib, f1, f2, ratio=ratio, rnd=rnd, threads=2, chunk=1 << 40, emulate=emulate, stream=False)
+        for threads, chunk in ((3, 3000), (4, 500), (2, 1 << 22)):
+            got = _digest_full(lib, f1, f2, ratio=ratio, rnd=rnd, threads=threads, chunk=chunk, emulate=emulate, stream=True)
+            assert got[:5] == want[:5], (idx, emulate, threads, chunk, got[5:])
+
+
 def test_fasta_line_structure_on_the_host(lib, oracle, tmp_path):
     """the host half of the FASTA loaders ('>' lines by memchr, newline counts per 4 KiB block, lengths from the counts; the bases
     go to the GPU as text): genome.len.txt and the contig count against the restatement's read_ref on files with unusual line

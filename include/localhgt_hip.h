@@ -159,7 +159,7 @@ int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, 
 int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int threads, long chunk_bytes,
                           int emulate_threads, const uint64_t* start1, const long* n_lines1, long n1, const uint64_t* start2,
                           const long* n_lines2, long n2, int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept, long* n_bases,
-                          double* seconds);
+                          double* seconds, uint64_t* digest_or_null /* lhgt_fastq_parse_digest's digest, read back from the slabs */);
 /* which way the calling thread's last FASTQ parse went: 1 = in one pass over the text (host_fastq_stream.cpp), 0 = line count, then
  * parse (the planned loader: always with plans made elsewhere, or when the single pass met something only the planned loader decides
  * -- `why`, nullable, says what), -1 = none yet.  The pairs are the same either way. */

@@ -30,52 +30,86 @@ __global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, ui
 }  // namespace lhgt
 
 #include <mutex>
+#include <unordered_map>
 namespace lhgt {
 namespace {
-struct BigBuf { int device; size_t bytes; void* p; };
-std::mutex g_big_mu;
-std::vector<BigBuf> g_big;
+struct DevBlock { int device; size_t bytes; void* p; };
+std::mutex g_dev_mu;
+std::vector<DevBlock> g_dev_free;                                   // cached blocks, oldest first
+std::unordered_map<void*, std::pair<int, size_t>> g_dev_live;       // blocks handed out by dev_alloc_raw: device, class size
+size_t g_dev_cached = 0;
+const size_t DEV_CACHE_CAP = (size_t)96 << 30;                      // more than this is not kept (a context's tables, buffers and batches at configs[1]..[2] sizes)
+size_t size_class(size_t bytes) {                                   // next eighth-step of a power of two, steps of at most 256 MiB
+    size_t top = (size_t)1 << 26;                                   // (a 156 GB index must not grow by 16 GB for the sake of reuse)
+    while ((top << 1) <= bytes) top <<= 1;
+    const size_t step = std::min(top >> 3, (size_t)256 << 20);
+    return (bytes + step - 1) / step * step;
+}
 }  // namespace
-void* big_take(int device, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_big_mu);
-    for (size_t i = 0; i < g_big.size(); i++)
-        if (g_big[i].device == device && g_big[i].bytes == bytes) {
-            void* p = g_big[i].p;
-            g_big.erase(g_big.begin() + (long)i);
-            return p;
+hipError_t dev_alloc_raw(void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes < DEV_CACHE_MIN) {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipErrorOutOfMemory && big_release_all()) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+        return e;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const size_t cls = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        for (size_t i = 0; i < g_dev_free.size(); i++)
+            if (g_dev_free[i].device == dev && g_dev_free[i].bytes == cls) {
+                *p = g_dev_free[i].p;
+                g_dev_cached -= cls;
+                g_dev_free.erase(g_dev_free.begin() + (long)i);
+                g_dev_live[*p] = {dev, cls};
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e == hipErrorOutOfMemory && big_release_all()) { (void)hipGetLastError(); e = hipMalloc(p, cls); }
+    if (e == hipErrorOutOfMemory && cls > bytes) { (void)hipGetLastError(); e = hipMalloc(p, bytes); if (e == hipSuccess) return e; }   // no room for the rounding: an exact, uncached block
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_dev_mu); g_dev_live[*p] = {dev, cls}; }
+    return e;
+}
+hipError_t dev_free(void* p) {
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto it = g_dev_live.find(p);
+        if (it != g_dev_live.end()) {
+            const int dev = it->second.first;
+            const size_t cls = it->second.second;
+            g_dev_live.erase(it);
+            if (g_dev_cached + cls <= DEV_CACHE_CAP) {
+                g_dev_free.push_back({dev, cls, p});
+                g_dev_cached += cls;
+                return hipSuccess;
+            }
         }
-    return nullptr;
+    }
+    return hipFree(p);
 }
 bool big_release_all() {
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     bool any = false;
     for (;;) {
-        void* p = nullptr;
-        int dev = 0;
+        DevBlock b;
         {
-            std::lock_guard<std::mutex> lk(g_big_mu);
-            if (g_big.empty()) break;
-            p = g_big.back().p;
-            dev = g_big.back().device;
-            g_big.pop_back();
+            std::lock_guard<std::mutex> lk(g_dev_mu);
+            if (g_dev_free.empty()) break;
+            b = g_dev_free.back();
+            g_dev_free.pop_back();
+            g_dev_cached -= b.bytes;
         }
-        hipSetDevice(dev);
-        hipFree(p);
+        hipSetDevice(b.device);
+        hipFree(b.p);
         any = true;
     }
     if (any && have_cur) hipSetDevice(cur);
     return any;
-}
-void big_give(int device, size_t bytes, void* p) {
-    if (!p) return;
-    if (bytes >= BIG_BUFFER_MIN) {
-        std::lock_guard<std::mutex> lk(g_big_mu);
-        bool have = false;
-        for (const BigBuf& b : g_big) have |= b.device == device && b.bytes == bytes;
-        if (!have) { g_big.push_back({device, bytes, p}); return; }
-    }
-    hipFree(p);
 }
 }  // namespace lhgt
 
@@ -210,10 +244,10 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt_ingest_pool_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
-                    (void*)c->d_ws_ascii, (void*)c->d_ws_words, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1],
+                    (void*)c->d_ws_ascii, (void*)c->d_ws_words,
                     (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_revote, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest, (void*)c->d_stats})
-        if (p) hipFree(p);
-    lhgt::big_give(c->device, ((size_t)1 << c->k) * 4, c->d_peak_kmer);   // kept for the next context of this process, or freed
+        if (p) lhgt::dev_free(p);
+    for (void* p : {(void*)c->d_peak_kmer, (void*)c->d_part_keys[0], (void*)c->d_part_keys[1]}) lhgt::dev_free(p);   // large blocks stay with the process (lhgt_common.hpp: dev_free)
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev2) hipEventDestroy(c->ev2);

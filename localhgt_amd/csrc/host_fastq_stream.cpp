@@ -18,6 +18,8 @@
 // delivered and gives the input to the planned loader, whose refusals and messages are the contract.
 #include "host_fastx.hpp"
 #include <immintrin.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
 
 namespace lhgt {
 
@@ -51,6 +53,24 @@ static size_t scan_nl(const uint8_t* t, size_t n, uint32_t* out) {
 }
 
 namespace {
+
+// A word that is 0 until its owner publishes; waiters sleep in the kernel instead of spinning (the GPU boxes run under a CPU quota:
+// forty workers polling with sched_yield were measured to eat the quota the working ones needed -- the wait grew with the thread
+// count until it was two thirds of a worker's time)
+struct Gate {
+    std::atomic<uint32_t> open{0};
+    void wait(const std::atomic<bool>& stop) {
+        for (int i = 0; i < 64 && !open.load(std::memory_order_acquire); i++) _mm_pause();
+        while (!open.load(std::memory_order_acquire) && !stop.load()) {
+            struct timespec ts = {0, 2000000};      // 2 ms: a stop request wakes nobody
+            syscall(SYS_futex, (uint32_t*)&open, FUTEX_WAIT_PRIVATE, 0u, &ts, nullptr, 0);
+        }
+    }
+    void release() {
+        open.store(1, std::memory_order_release);
+        syscall(SYS_futex, (uint32_t*)&open, FUTEX_WAKE_PRIVATE, INT32_MAX, nullptr, nullptr, 0);
+    }
+};
 
 constexpr size_t MARGIN = (size_t)64 << 10;     // bytes read past a chunk's end to find the newline that closes its last line
 constexpr long DRIFT_MAX = 1L << 16;            // partner lines outside the fq2 chunk a column may walk to (per side)
@@ -195,6 +215,10 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     const size_t ch2 = std::max<size_t>((n2 + (size_t)ncols - 1) / (size_t)ncols, 64);
     const char* io = getenv("LHGT_INGEST_IO");                      // pread (default) | mmap
     const bool use_pread = !(io && !strcmp(io, "mmap"));
+    if (use_pread && getenv("LHGT_INGEST_NOREUSE")) {                // experiment knob: reads that do not touch the page cache's LRU state
+        (void)posix_fadvise(m1.fd, 0, 0, POSIX_FADV_NOREUSE);
+        (void)posix_fadvise(m2.fd, 0, 0, POSIX_FADV_NOREUSE);
+    }
     const double t0 = now_s();
     // ---- what can be decided from bytes alone, before the first column
     {
@@ -246,8 +270,10 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     }
     // ---- the columns
     std::unique_ptr<std::atomic<long>[]> P1(new std::atomic<long>[(size_t)ncols + 1]), P2(new std::atomic<long>[(size_t)ncols + 1]);
+    std::unique_ptr<Gate[]> gate(new Gate[(size_t)ncols + 1]);       // gate[c] opens when P1[c] and P2[c] are known
     for (long c = 0; c <= ncols; c++) { P1[(size_t)c].store(-1); P2[(size_t)c].store(-1); }
     P1[0].store(0); P2[0].store(0);
+    gate[0].release();
     std::vector<size_t> S1((size_t)ncols + 1, n1), S2((size_t)ncols + 1, n2);   // chunk starts, for the plans handed back
     std::vector<ParsedChunk> out((size_t)ncols);
     std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[(size_t)ncols]);
@@ -266,44 +292,45 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     };
     std::atomic<SlabPool*> pool_ptr{nullptr};
     std::atomic<bool> pool_known{false};
+    std::mutex stage_mu;
+    double stage_s[5] = {0, 0, 0, 0, 0};            // summed over the workers: slab wait, read + newline scan, chain wait, pairs, (unused)
     auto sampled = [&](long n) { return ratio >= 100.0 || (double)random_array[n % LHGT_MAX_RANDOM] < ratio; };
 
     auto worker = [&]() {
         Scratch sc;
         std::vector<std::pair<size_t, size_t>> before;     // partner lines in front of the fq2 chunk: (start, length)
-        while (!pool_known.load(std::memory_order_acquire)) { if (stop.load()) return; std::this_thread::yield(); }
+        double my_s[4] = {0, 0, 0, 0};
+        struct Sum { double* a; double* b; std::mutex* m; ~Sum() { std::lock_guard<std::mutex> lk(*m); for (int i = 0; i < 4; i++) a[i] += b[i]; } } sum{stage_s, my_s, &stage_mu};
+        while (!pool_known.load(std::memory_order_acquire)) { if (stop.load()) return; usleep(50); }
         SlabPool* pool = pool_ptr.load();
         for (;;) {
             int slab_id = -1;
+            double ta = now_s();
             if (pool) {                                  // before the column number: every earlier column already holds its slab
                 slab_id = pool->acquire();
                 if (slab_id < 0) return;
             }
             const long c = next.fetch_add(1);
             if (c >= ncols || stop.load()) { if (pool && slab_id >= 0) pool->release(slab_id); return; }
+            double tb = now_s();
+            my_s[0] += tb - ta;
             ParsedChunk& ch = out[(size_t)c];
-            if (pool) {
-                ch.slab = pool->base + (size_t)slab_id * pool->slab_bytes;
-                ch.half = pool->half_bytes;
-                ch.meta = (ChunkPairMeta*)(ch.slab + 2 * pool->half_bytes);
-                ch.slab_id = slab_id;
-                ch.k = pool->k;
-            }
+            if (pool) ch.use_slab(pool->base + (size_t)slab_id * pool->slab_bytes, pool->half_bytes, slab_id, pool->k);
+            ch.src_slack = use_pread;                    // the text buffers end in 64 spare bytes
             ch.o1.assign(1, 0);
             ch.o2.assign(1, 0);
             // 1. text and newline lists of both chunks
             ChunkView v1, v2;
             const bool seen = view_chunk(m1, ch1, c, use_pread, &sc, 0, &v1) && view_chunk(m2, ch2, c, use_pread, &sc, 1, &v2);
             if (!seen) give_up(1, "a line longer than a chunk's margin");
+            ta = now_s();
+            my_s[1] += ta - tb;
             // 2. the chain of line numbers: wait for this column's, publish the next one's
-            long g0, h0;
-            for (;;) {
-                g0 = P1[(size_t)c].load(std::memory_order_acquire);
-                h0 = P2[(size_t)c].load(std::memory_order_acquire);
-                if ((g0 >= 0 && h0 >= 0) || stop.load()) break;
-                std::this_thread::yield();
-            }
+            gate[(size_t)c].wait(stop);
+            long g0 = P1[(size_t)c].load(std::memory_order_acquire), h0 = P2[(size_t)c].load(std::memory_order_acquire);
             if (g0 < 0 || h0 < 0) { g0 = h0 = 0; }       // stopping: numbers no longer matter, the chain must still move
+            tb = now_s();
+            my_s[2] += tb - ta;
             S1[(size_t)c] = v1.S;
             S2[(size_t)c] = v2.S;
             if (emu && seen) {                           // threads that enter inside these chunks learn their first line's number
@@ -327,6 +354,7 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
             }
             P1[(size_t)c + 1].store(g0 + v1.lines, std::memory_order_release);
             P2[(size_t)c + 1].store(h0 + v2.lines, std::memory_order_release);
+            gate[(size_t)c + 1].release();
             // 3. the pairs of fq1's chunk
             if (seen && !stop.load() && v1.lines > 0) {
                 const long h1 = h0 + v2.lines;           // fq2's chunk holds lines [h0, h1)
@@ -377,7 +405,7 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                                        (have2 && bp2.keep(h, sb, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
                     else
                         fl = (uint8_t)((sampled(n) ? PAIR_COUNT1 | PAIR_VOTE : 0) | (have2 && sb <= n1 && sampled(h / 4) ? PAIR_COUNT2 : 0));   // quirk Q4
-                    if (!fl || (n / shard_block) % shard_world != shard_rank) continue;
+                    if (!fl || (shard_world > 1 && (n / shard_block) % shard_world != shard_rank)) continue;
                     if (!(fl & (PAIR_COUNT1 | PAIR_VOTE))) la = 0;
                     if (!(fl & (PAIR_COUNT2 | PAIR_VOTE))) lb = 0;
                     if (la > LHGT_MAX_READ_LEN || lb > LHGT_MAX_READ_LEN) { give_up(1, "a read longer than the reference's buffers"); ok = false; break; }
@@ -386,6 +414,7 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                 if (odd_entry.load()) give_up(1, "a thread enters a file off a record boundary");
             }
             ch.finish();
+            my_s[3] += now_s() - tb;
             { std::lock_guard<std::mutex> lk(mu); ready[(size_t)c].store(1); }
             cv_ready.notify_all();
         }
@@ -477,8 +506,10 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
         pl->start.push_back(n);
     }
     if (ingest_trace())
-        fprintf(stderr, "[lhgt ingest] one pass (%s): %d threads, %ld columns of %zu + %zu bytes, %.1f MB of %s: waited for columns %.3fs, consume(+upload) %.3fs, whole pass %.3fs\n",
-                use_pread ? "pread" : "mmap", nt, ncols, ch1, ch2, 1e-6 * (double)n1, fq1, t_wait, t_consume, now_s() - t0);
+        fprintf(stderr, "[lhgt ingest] one pass (%s): %d threads, %ld columns of %zu + %zu bytes, %.1f MB of %s: waited for columns %.3fs, consume(+upload) %.3fs, whole pass %.3fs; "
+                "per worker: slab wait %.3fs, read + newline scan %.3fs, chain wait %.3fs, pairs %.3fs\n",
+                use_pread ? "pread" : "mmap", nt, ncols, ch1, ch2, 1e-6 * (double)n1, fq1, t_wait, t_consume, now_s() - t0,
+                stage_s[0] / nt, stage_s[1] / nt, stage_s[2] / nt, stage_s[3] / nt);
     return LHGT_OK;
 }
 

@@ -527,13 +527,7 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
                 if (c >= nc || stop.load()) { if (pool && slab_id >= 0) pool->release(slab_id); return; }
                 in_flight.fetch_add(1);
                 ParsedChunk& ch = out[(size_t)c];
-                if (pool) {
-                    ch.slab = pool->base + (size_t)slab_id * pool->slab_bytes;
-                    ch.half = pool->half_bytes;
-                    ch.meta = (ChunkPairMeta*)(ch.slab + 2 * pool->half_bytes);
-                    ch.slab_id = slab_id;
-                    ch.k = pool->k;
-                }
+                if (pool) ch.use_slab(pool->base + (size_t)slab_id * pool->slab_bytes, pool->half_bytes, slab_id, pool->k);
                 parse_chunk(m1, m2, p1, p2, c_lo + c, ratio, random_array, shard_rank, shard_world, shard_block, emu, lay, &ch);
                 { std::lock_guard<std::mutex> lk(mu); ready[(size_t)c].store(1); }
                 cv_ready.notify_all();
@@ -607,11 +601,35 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
     return sampling_covers(p1.line0.back(), p2.line0.back());
 }
 
+// CPUs this process may use at once: the hardware threads, cut to the cgroup's quota where one is set (a container that is given
+// 16 CPUs of a 256-thread host sees 256 in /proc; threads beyond the quota only get the whole group throttled)
+static int usable_cpus() {
+    unsigned hc = std::thread::hardware_concurrency();
+    int n = hc == 0 ? 4 : (int)hc;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+    for (const char* path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+        FILE* f = fopen(path, "r");
+        if (!f) continue;
+        char a[64] = {0}, b[64] = {0};
+        const int got = fscanf(f, "%63s %63s", a, b);
+        fclose(f);
+        long quota = got >= 1 && strcmp(a, "max") ? atol(a) : -1, period = got >= 2 ? atol(b) : 100000;
+        if (got == 1) {                                  // cgroup v1: the period lives in its own file
+            FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (g) { if (fscanf(g, "%ld", &period) != 1) period = 100000; fclose(g); }
+        }
+        if (quota > 0 && period > 0) { const int q = (int)((quota + period - 1) / period); if (q >= 1 && q < n) n = q; }
+        break;
+    }
+    return n;
+}
+
 static int default_threads() {
     const char* e = getenv("LHGT_INGEST_THREADS");
     if (e && atoi(e) > 0) return atoi(e);
-    unsigned hc = std::thread::hardware_concurrency();
-    return hc == 0 ? 4 : (hc > 48 ? 48 : (int)hc);   // the parse is bound by host memory bandwidth well before that
+    static const int n = usable_cpus();
+    return n > 48 ? 48 : n;   // the parse is bound by host memory bandwidth well before that
 }
 
 // ---------------------------------------------------------------- FASTA by line structure, bases never touched on the host
@@ -848,15 +866,23 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         LHGT_FAIL(LHGT_E_STATE, "lhgt_sampling_init(ratio) must precede lhgt_pairs_load_fastq when ratio < 100");
     // a batch is closed at 4 Mi pairs (1 Mi with count-on-load, so that phase A of one batch hides behind the parsing of the next;
     // every batch costs phase A one sweep of the count table, which is why they are not smaller)
-    const long BATCH_PAIRS = ctx->count_on_load ? 1L << 20 : 4L << 20, META_CAP = BATCH_PAIRS + (1L << 18);
-    const size_t BATCH_BYTES = ctx->count_on_load ? (size_t)384 << 20 : (size_t)1 << 30, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes();
+    // (round 5: with count-on-load the limits GROW -- 1, 2, 4 Mi pairs -- so that a small input still overlaps its count with its
+    // parse while a large one pays 9 table sweeps per 32 M pairs instead of 32: at 1 Mi pairs per batch phase A on load took 0.2 s
+    // per 32 M pairs, which the single-pass parse no longer hides)
+    const long BATCH_PAIRS_MAX = 4L << 20, META_CAP = BATCH_PAIRS_MAX + (1L << 18);
+    const size_t BATCH_BYTES_MAX = (size_t)1280 << 20, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes();
+    long BATCH_PAIRS = ctx->count_on_load ? 1L << 20 : BATCH_PAIRS_MAX;
+    if (ctx->count_on_load) ctx->part_reserve_pairs = BATCH_PAIRS_MAX;     // phase A's key buffers: made once, for the largest batch
+    size_t BATCH_BYTES = ctx->count_on_load ? (size_t)320 << 20 : BATCH_BYTES_MAX;
     const size_t HALF = CHUNK + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);
     const long DESC_CAP = 1L << 16;                                       // chunks per batch
     // device staging of one batch: the chunks' blocks (bases + records) one after the other.  TWO of them: the copies of batch
     // b + 1 (on the copy stream) run while batch b is expanded, packed and counted (on the context's stream)
-    const size_t STAGE = (BATCH_BYTES + 2 * SLAB + (size_t)META_CAP * sizeof(ChunkPairMeta) + 255) & ~(size_t)255;
+    const size_t STAGE = (BATCH_BYTES_MAX + 2 * SLAB + (size_t)META_CAP * sizeof(ChunkPairMeta) + 255) & ~(size_t)255;
     const int threads = default_threads();
-    const int n_slabs = threads + threads / 3 + 4;
+    // slabs: one per parse thread plus what rides out the calling thread's pauses (a batch close allocates and launches; the first
+    // one allocates phase A's key buffers): with 25 slabs for 16 threads the workers stood still for half of the load
+    const int n_slabs = std::max(threads + threads / 3 + 4, (int)std::min<size_t>(4096, ((size_t)280 << 20) / SLAB));
     // staging, pinned slabs and the pinned chunk descriptors are allocated by `prepare` below, on this thread, while helper threads count lines
     SlabPool* pool = nullptr;
     ChunkDesc* desc_base = nullptr;
@@ -866,7 +892,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     auto prepare = [&](SlabPool** pool_out) -> int {
         const double t_a0 = now_s();
         LHGT_TRY(ws_reserve(ctx, 2 * STAGE, 0));
-        for (auto& e : buf_free) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : buf_free) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));   // waits sleep: the host's CPUs are the parse threads' 
         LHGT_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
         pool = (SlabPool*)ctx->ingest_pool;
         if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != 2 * DESC_CAP) {
@@ -894,7 +920,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             for (int i = 0; i < n_slabs; i++) pool->free_ids.push_back(i);
             ctx->ingest_pool = pool;
             ctx->ingest_events.resize((size_t)n_slabs);
-            for (auto& e : ctx->ingest_events) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : ctx->ingest_events) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
         }
         pool->k = ctx->k;
         desc_base = (ChunkDesc*)ctx->h_ingest_meta;
@@ -959,6 +985,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         reap(false);
         fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0; n_desc = 0;
         n_batches++;
+        if (BATCH_PAIRS < BATCH_PAIRS_MAX) { BATCH_PAIRS *= 2; BATCH_BYTES = std::min(BATCH_BYTES * 2, BATCH_BYTES_MAX); }
         return rc;
     };
     std::vector<ChunkPairMeta> conv;     // records of a chunk that came in vectors (spilled, head / tail records of fq2, no pinned memory)
@@ -978,6 +1005,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         count_ev.clear();
         fill = 0; n_open = 0; kept = 0; n_desc = 0; n_batches = 0; words = 0; nkm = 0; max_len = 0;
         used[0] = used[1] = false;
+        if (ctx->count_on_load) { BATCH_PAIRS = 1L << 20; BATCH_BYTES = (size_t)320 << 20; }
         return LHGT_OK;
     };
     int rc = parse_pairs(fq1, fq2, ratio_percent, ctx->random_array.data(), shard_rank, shard_world, shard_block, threads, CHUNK,
@@ -985,7 +1013,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                          [&](ParsedChunk& ch) -> int {
                              const long n = ch.n_pairs();
                              if (n <= 0) { if (ch.slab_id >= 0) pool->release(ch.slab_id); return LHGT_OK; }
-                             const size_t b1n = ch.size1(), b2n = ch.size2();
+                             const size_t b1n = ch.slab ? ch.n1 : ch.s1.size(), b2n = ch.slab ? 0 : ch.s2.size();
                              const size_t moff = (b1n + b2n + 15) & ~(size_t)15, block = moff + (size_t)(n + 1) * sizeof(ChunkPairMeta);
                              if (fill + block > STAGE || n_open + n > META_CAP || n_desc >= DESC_CAP) LHGT_TRY(flush());
                              if (block > STAGE || n > META_CAP) LHGT_FAIL(LHGT_E_FORMAT, "ingest: one chunk holds %ld pairs / %zu bases", n, b1n + b2n);
@@ -1010,11 +1038,12 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                                      if ((int)l2 >= k) nkm += l2 - k + 1;
                                  }
                                  conv[(size_t)n] = ChunkPairMeta{(uint32_t)ch.o1[n], (uint32_t)ch.o2[n], ch_words, 0u};
-                                 LHGT_TRY(stage_sync(fill, ch.bases1(), b1n));
-                                 LHGT_TRY(stage_sync(fill + b1n, ch.bases2(), b2n));
+                                 LHGT_TRY(stage_sync(fill, ch.s1.data(), b1n));
+                                 LHGT_TRY(stage_sync(fill + b1n, ch.s2.data(), b2n));
                                  LHGT_TRY(stage_sync(fill + moff, (const uint8_t*)conv.data(), (size_t)(n + 1) * sizeof(ChunkPairMeta)));
                              }
-                             desc()[n_desc++] = ChunkDesc{(uint32_t)n_open, (uint32_t)n, (uint32_t)fill, (uint32_t)(fill + b1n), (uint32_t)words,
+                             // slab chunks: one run of bases, mate 2 of a pair behind its mate 1 (b2 = CHUNK_INTERLEAVED); chunks from vectors: two runs
+                             desc()[n_desc++] = ChunkDesc{(uint32_t)n_open, (uint32_t)n, (uint32_t)fill, ch.slab ? lhgt::CHUNK_INTERLEAVED : (uint32_t)(fill + b1n), (uint32_t)words,
                                                           (uint32_t)((fill + moff) / sizeof(ChunkPairMeta))};
                              fill = (fill + block + 15) & ~(size_t)15;
                              words += ch_words;
@@ -1230,7 +1259,7 @@ int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double rat
 // caller's part of the planned parse runs.  seconds = wall time of the call (mapping the files included).
 int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent, const float* random_array_or_null, int threads, long chunk_bytes,
                           int emulate_threads, const uint64_t* start1, const long* n_lines1, long n1, const uint64_t* start2, const long* n_lines2,
-                          long n2, int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept, long* n_bases, double* seconds) {
+                          long n2, int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept, long* n_bases, double* seconds, uint64_t* digest_or_null) {
     if (!fq1 || !fq2 || chunk_bytes < 256 || threads < 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");
     if (ratio_percent < 100.0 && !random_array_or_null) LHGT_FAIL(LHGT_E_ARG, "sampling needs the random array");
     const double t0 = now_s();
@@ -1244,7 +1273,7 @@ int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent
             return LHGT_OK;
         };
     const size_t HALF = (size_t)chunk_bytes + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);
-    const int n_slabs = threads + threads / 3 + 4;
+    const int n_slabs = std::max(threads + threads / 3 + 4, (int)std::min<size_t>(4096, ((size_t)280 << 20) / SLAB));
     std::unique_ptr<uint8_t[]> mem(new uint8_t[(size_t)n_slabs * SLAB]);
     SlabPool pool;
     pool.base = mem.get();
@@ -1253,15 +1282,34 @@ int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent
     pool.k = 32;
     for (int i = 0; i < n_slabs; i++) pool.free_ids.push_back(i);
     long kept = 0, bases = 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
     int rc = parse_pairs(fq1, fq2, ratio_percent, random_array_or_null, 0, 1, 1, threads, (size_t)chunk_bytes, emulate_threads, n_pairs_seen, (SlabPool*)nullptr,
                          [&](ParsedChunk& ch) -> int {
                              kept += ch.n_pairs();
-                             bases += (long)(ch.size1() + ch.size2());
+                             bases += (long)ch.bases_bytes();
+                             if (digest_or_null) {          // lhgt_fastq_parse_digest's digest, read back from the slab's block as the device would
+                                                                  const long n = ch.n_pairs();
+                                 for (long i = 0; i < n; i++) {
+                                     const uint8_t *a, *b;
+                                     uint64_t l1, l2;
+                                     uint8_t fl;
+                                     if (ch.slab) {
+                                         const ChunkPairMeta r = ch.meta[i], q = ch.meta[i + 1];
+                                         a = ch.slab + r.rel1; l1 = r.rel2 - r.rel1; b = ch.slab + r.rel2; l2 = q.rel1 - r.rel2; fl = (uint8_t)r.flags;
+                                     } else {
+                                         a = ch.s1.data() + ch.o1[i]; l1 = ch.o1[i + 1] - ch.o1[i]; b = ch.s2.data() + ch.o2[i]; l2 = ch.o2[i + 1] - ch.o2[i]; fl = ch.flags[i];
+                                     }
+                                     mix((const uint8_t*)&l1, 8); mix(a, l1); mix((const uint8_t*)&l2, 8); mix(b, l2);
+                                     { const uint8_t c2 = (fl & PAIR_COUNT2) ? 1 : 0; mix(&c2, 1); if (!(fl & PAIR_VOTE)) mix(&fl, 1); }
+                                 }
+                             }
                              if (ch.slab_id >= 0) pool.release(ch.slab_id);
                              return LHGT_OK;
                          },
                          [](bool) {}, [&](SlabPool** out) -> int { *out = &pool; return LHGT_OK; }, share_fn, LHGT_MAX_RANDOM,
-                         [&]() -> int { kept = 0; bases = 0; return LHGT_OK; });
+                         [&]() -> int { kept = 0; bases = 0; h = 1469598103934665603ull; return LHGT_OK; });
+    if (digest_or_null) *digest_or_null = h;
     if (n_pairs_kept) *n_pairs_kept = kept;
     if (n_bases) *n_bases = bases;
     if (seconds) *seconds = now_s() - t0;
@@ -1343,7 +1391,7 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
             }
             if (out_words == 0) return LHGT_OK;
             if (out_words > d_cap) {
-                if (d_out) hipFree(d_out);
+                if (d_out) lhgt::dev_free(d_out);
                 d_out = nullptr;
                 d_cap = out_words + out_words / 4;
                 LHGT_HIP(lhgt::dev_malloc(&d_out, d_cap * 4));
@@ -1357,7 +1405,7 @@ int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_pa
             if (fwrite(host.data(), 4, out_words, idx) != out_words) LHGT_FAIL(LHGT_E_IO, "short write to %s", index_path);
             return LHGT_OK;
         });
-    if (d_out) hipFree(d_out);
+    if (d_out) lhgt::dev_free(d_out);
     fclose(idx);
     fclose(lenf);
     if (n_contigs) *n_contigs = contigs;

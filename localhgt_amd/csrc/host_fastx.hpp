@@ -92,7 +92,7 @@ inline bool ingest_trace() { static int t = getenv("LHGT_INGEST_TRACE") ? 1 : 0;
 // with no staging copy and no per-chunk registration.
 struct SlabPool {
     uint8_t* base = nullptr;
-    size_t slab_bytes = 0, half_bytes = 0;   // a slab: [mate-1 bases: half][mate-2 bases: half][ChunkPairMeta x (CHUNK_META_CAP + 1)]
+    size_t slab_bytes = 0, half_bytes = 0;   // a slab: [bases: 2 x half][ChunkPairMeta x (CHUNK_META_CAP + 1)]
     int k = 0;
     std::vector<int> free_ids;
     std::mutex mu;
@@ -122,43 +122,56 @@ constexpr int CHUNK_META_CAP = 16384;      // pairs per chunk with in-slab metad
 struct ParsedChunk {
     std::vector<uint8_t> s1, s2, flags;   // flags: PAIR_COUNT1 | PAIR_COUNT2 | PAIR_VOTE per kept pair
     std::vector<uint64_t> o1, o2;
-    // with a slab: bases live in slab[0 .. n1) and slab[half .. half + n2) instead of s1 / s2, the per-pair records in meta[0 .. n_meta]
-    // instead of o1 / o2 / flags
+    // with a slab: the kept bases lie in slab[0 .. n1), pair after pair, mate 1 then mate 2 (every base is written once, where the
+    // copy to the device takes it from; round 4 kept the mates in two halves and moved the second one up at the end), the per-pair
+    // records in meta[0 .. n_meta] instead of o1 / o2 / flags
     uint8_t* slab = nullptr;
     ChunkPairMeta* meta = nullptr;
-    size_t half = 0, n1 = 0, n2 = 0;
+    size_t cap = 0, n1 = 0;               // room for bases in the slab, bases written
     long n_meta = 0;
     uint32_t words = 0;
     uint64_t nkm = 0;
     int max_len = 0, k = 0;
     int slab_id = -1;
+    bool src_slack = false;               // 16 readable bytes follow every source line (a worker's own text buffer): copies in 16-byte steps
     int rc = LHGT_OK;
     std::string err;
-    const uint8_t* bases1() const { return slab ? slab : s1.data(); }
-    const uint8_t* bases2() const { return slab ? slab + half : s2.data(); }
-    size_t size1() const { return slab ? n1 : s1.size(); }
-    size_t size2() const { return slab ? n2 : s2.size(); }
+    void use_slab(uint8_t* base, size_t half_bytes, int id, int k_) {
+        slab = base;
+        cap = 2 * half_bytes;
+        meta = (ChunkPairMeta*)(base + cap);
+        slab_id = id;
+        k = k_;
+    }
+    size_t bases_bytes() const { return slab ? n1 : s1.size() + s2.size(); }
     long n_pairs() const { return slab ? n_meta : (long)o1.size() - 1; }
     void spill() {   // unusual line structure (or more pairs than the slab's record area holds): continue in vectors
-        s1.assign(slab, slab + n1);
-        s2.assign(slab + half, slab + half + n2);
+        s1.clear();
+        s2.clear();
         o1.assign(1, 0);
         o2.assign(1, 0);
         flags.clear();
         for (long i = 0; i < n_meta; i++) {
-            o1.push_back(i + 1 < n_meta ? meta[i + 1].rel1 : n1);
-            o2.push_back(i + 1 < n_meta ? meta[i + 1].rel2 : n2);
+            const size_t a = meta[i].rel1, m = meta[i].rel2, e = i + 1 < n_meta ? meta[i + 1].rel1 : n1;
+            s1.insert(s1.end(), slab + a, slab + m);
+            s2.insert(s2.end(), slab + m, slab + e);
+            o1.push_back(s1.size());
+            o2.push_back(s2.size());
             flags.push_back((uint8_t)meta[i].flags);
         }
         slab = nullptr;
         meta = nullptr;
     }
+    static void copy16(uint8_t* dst, const uint8_t* src, size_t n) {   // writes and reads up to 15 bytes past n: the callers own that slack
+        for (size_t i = 0; i < n; i += 16) _mm_storeu_si128((__m128i*)(dst + i), _mm_loadu_si128((const __m128i*)(src + i)));
+    }
     void push(const uint8_t* a, size_t la, const uint8_t* b, size_t lb, uint8_t fl) {
-        if (slab && (n1 + la > half || n2 + lb > half || n_meta >= CHUNK_META_CAP)) spill();
+        if (slab && (n1 + la + lb + 32 > cap || n_meta >= CHUNK_META_CAP)) spill();
         if (slab) {
-            meta[n_meta++] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, fl};
-            memcpy(slab + n1, a, la); n1 += la;
-            memcpy(slab + half + n2, b, lb); n2 += lb;
+            meta[n_meta++] = ChunkPairMeta{(uint32_t)n1, (uint32_t)(n1 + la), words, fl};
+            if (src_slack) { copy16(slab + n1, a, la); copy16(slab + n1 + la, b, lb); }
+            else { memcpy(slab + n1, a, la); memcpy(slab + n1 + la, b, lb); }
+            n1 += la + lb;
             words += 3u * (uint32_t)((la + 31) / 32 + 1) + 3u * (uint32_t)((lb + 31) / 32 + 1);
             if ((int)la > max_len) max_len = (int)la;
             if ((int)lb > max_len) max_len = (int)lb;
@@ -172,17 +185,14 @@ struct ParsedChunk {
             flags.push_back(fl);
         }
     }
-    // slab chunks end as ONE contiguous block -- [mate-1 bases][mate-2 bases][pad to 16 bytes][n + 1 records] -- so the calling
-    // thread issues one copy per chunk
+    // slab chunks end as ONE contiguous block -- [bases][pad to 16 bytes][n + 1 records] -- so the calling thread issues one copy per chunk
     size_t block_bytes() const { return meta_off() + (size_t)(n_meta + 1) * sizeof(ChunkPairMeta); }
-    size_t meta_off() const { return (n1 + n2 + 15) & ~(size_t)15; }
+    size_t meta_off() const { return (n1 + 15) & ~(size_t)15; }
     void finish() {
         if (!slab) return;
-        meta[n_meta] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n2, words, 0u};
-        memmove(slab + n1, slab + half, n2);
+        meta[n_meta] = ChunkPairMeta{(uint32_t)n1, (uint32_t)n1, words, 0u};
         ChunkPairMeta* dst = (ChunkPairMeta*)(slab + meta_off());
-        memmove(dst, meta, (size_t)(n_meta + 1) * sizeof(ChunkPairMeta));   // the record area lies behind both halves: dst <= meta
-        half = n1;
+        memmove(dst, meta, (size_t)(n_meta + 1) * sizeof(ChunkPairMeta));   // the record area lies behind the bases: dst <= meta
         meta = dst;
     }
 };

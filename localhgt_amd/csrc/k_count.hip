@@ -218,9 +218,9 @@ int lhgt_counts_export_u8(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, 
                            first_slot + o, n, d_tmp);
         hipError_t e1 = hipMemcpyAsync(out + o, d_tmp, n, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        if (e1 != hipSuccess || e2 != hipSuccess) { hipFree(d_tmp); LHGT_FAIL(LHGT_E_HIP, "export copy failed"); }
+        if (e1 != hipSuccess || e2 != hipSuccess) { lhgt::dev_free(d_tmp); LHGT_FAIL(LHGT_E_HIP, "export copy failed"); }
     }
-    hipFree(d_tmp);
+    lhgt::dev_free(d_tmp);
     return LHGT_OK;
 }
 
@@ -236,7 +236,7 @@ int lhgt_counts_histogram(lhgt_ctx* ctx, uint64_t out[4]) {
     unsigned long long h[4];
     LHGT_HIP(hipMemcpyAsync(h, d_h, 32, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(d_h);
+    lhgt::dev_free(d_h);
     for (int i = 0; i < 4; i++) out[i] = h[i];
     return LHGT_OK;
 }

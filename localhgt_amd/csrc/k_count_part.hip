@@ -1110,20 +1110,47 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     const long chunk_max = direct_form ? (chunk_env > 0 ? chunk_env : (8L << 20)) : (4L << 20);   // the direct form addresses its buffers with 64 bits
     long want = b.d.n_pairs < chunk_max ? b.d.n_pairs : chunk_max;
     while (!direct_form && want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
-    size_t need = direct_form ? 0 : (size_t)need_of(want);
-    if (direct_form) {   // buffer 0 (need x 4 bytes) holds 65536 pieces of 24-bit keys, buffer 1 (need x 2 bytes) the final regions
-        const size_t need_pieces = std::max((size_t)piece_keys(cap_of(want).n, GeomBig::GRID) * (size_t)(NBK * GeomBig::GRID),
-                                            (size_t)piece_keys(cap_of(want).n, GeomSmall::GRID) * (size_t)(NBK * GeomSmall::GRID)) + 64;   // either geometry
-        const size_t need_final = (size_t)seg_size(seg_cap(cap_of(want).n)) * NBK + 64;
-        need = std::max((need_pieces * 3 + 3) / 4, need_final);
-    }
+    // keys the two buffers must hold for chunks of np pairs: buffer 0 takes need x 4 bytes, buffer 1 need x 2
+    auto keys_for = [&](long np) -> size_t {
+        if (!direct_form) return (size_t)need_of(np);
+        // buffer 0 holds 65536 pieces of 24-bit keys, buffer 1 the final regions
+        const size_t need_pieces = std::max((size_t)piece_keys(cap_of(np).n, GeomBig::GRID) * (size_t)(NBK * GeomBig::GRID),
+                                            (size_t)piece_keys(cap_of(np).n, GeomSmall::GRID) * (size_t)(NBK * GeomSmall::GRID)) + 64;   // either geometry
+        const size_t need_final = (size_t)seg_size(seg_cap(cap_of(np).n)) * NBK + 64;
+        return std::max((need_pieces * 3 + 3) / 4, need_final);
+    };
+    size_t need = keys_for(want);
     if (ctx->part_keys_cap < need) {
+        // A loader that counts batch by batch says how large its batches will get (part_reserve_pairs): the buffers are made for
+        // that at once -- growing them batch after batch is a free and an allocation of tens of GB each time, and hipMalloc right
+        // after such a free was measured to take seconds (lhgt_common.hpp: dev_free).  Where the
+        // device has no room for the wish the chunk is halved until its buffers fit (the table and a 156 GB index come first).
+        long want_alloc = std::max(want, std::min(chunk_max, ctx->part_reserve_pairs));
+        while (!direct_form && want_alloc > want && (need_of(want_alloc) >= (1ull << 32) || cap_of(want_alloc).n >= (1ull << 32))) want_alloc /= 2;
         for (int i = 0; i < 2; i++) {
-            if (ctx->d_part_keys[i]) hipFree(ctx->d_part_keys[i]);
+            if (ctx->d_part_keys[i]) lhgt::dev_free(ctx->d_part_keys[i]);
             ctx->d_part_keys[i] = nullptr;
-            LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_keys[i], need * (i == 0 ? 4 : 2) + 64));   // level-1 keys are 32-bit, final keys 16-bit
         }
-        ctx->part_keys_cap = need;
+        ctx->part_keys_cap = 0;
+        for (;;) {
+            const size_t n_alloc = keys_for(want_alloc);
+            hipError_t err = hipSuccess;
+            for (int i = 0; i < 2 && err == hipSuccess; i++) {
+                const size_t bytes = n_alloc * (i == 0 ? 4 : 2) + 64;   // level-1 keys are 32-bit (24-bit in the direct form), final keys 16-bit
+                err = lhgt::dev_malloc(&ctx->d_part_keys[i], bytes);
+            }
+            if (err == hipSuccess) { ctx->part_keys_cap = n_alloc; break; }
+            (void)hipGetLastError();
+            for (int i = 0; i < 2; i++) {
+                if (ctx->d_part_keys[i]) lhgt::dev_free(ctx->d_part_keys[i]);
+                ctx->d_part_keys[i] = nullptr;
+            }
+            if (err != hipErrorOutOfMemory || want_alloc <= (64L << 10))
+                LHGT_FAIL(LHGT_E_HIP, "phase A: no room for the key buffers of %ld pairs (%zu keys): %s", want_alloc, n_alloc, hipGetErrorString(err));
+            want_alloc = want_alloc > want ? want : want_alloc / 2;      // first drop the wish, then halve the chunk
+            if (want_alloc < want) want = want_alloc;
+        }
+        need = keys_for(want);
     }
     const long chunk_pairs = want;
     if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(2 * 65536 + NBK * 512) * 4));

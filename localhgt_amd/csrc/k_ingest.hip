@@ -209,12 +209,12 @@ __global__ void __launch_bounds__(256) write_contig_lens(const ContigDev* __rest
 
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words) {
     if (ascii_bytes > ctx->ws_ascii_cap) {
-        if (ctx->d_ws_ascii) hipFree(ctx->d_ws_ascii);
+        if (ctx->d_ws_ascii) lhgt::dev_free(ctx->d_ws_ascii);
         ctx->ws_ascii_cap = ascii_bytes + ascii_bytes / 4 + 4096;
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_ws_ascii, ctx->ws_ascii_cap));
     }
     if (plane_words > ctx->ws_words_cap) {
-        if (ctx->d_ws_words) hipFree(ctx->d_ws_words);
+        if (ctx->d_ws_words) lhgt::dev_free(ctx->d_ws_words);
         ctx->ws_words_cap = plane_words + plane_words / 4 + 1024;
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_ws_words, ctx->ws_words_cap * 4));
     }
@@ -392,7 +392,7 @@ int upload_locked_ahead(lhgt_ctx* ctx, hipStream_t st, void* d_dst, const void* 
 
 // ---------------------------------------------------------------- resident pairs
 static void free_batch(ReadBatch& b) {
-    for (void*& p : b.alloc) if (p) { hipFree(p); p = nullptr; }
+    for (void*& p : b.alloc) if (p) { lhgt::dev_free(p); p = nullptr; }
 }
 
 // Install n pairs whose ASCII bases already sit in device memory: sequence r (r < n: mate 1 of pair r, else
@@ -446,8 +446,8 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
                        d_start, d_len, 0L, d_word_off, 2 * n, max_wpr, d_words);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(d_start);
-    hipFree(d_word_off);
+    lhgt::dev_free(d_start);
+    lhgt::dev_free(d_word_off);
     b.alloc[4] = b.alloc[5] = nullptr;
     b.d.words = d_words;
     b.d.off[0] = d_off32;
@@ -472,9 +472,10 @@ __global__ void __launch_bounds__(256) expand_chunk_meta(const ChunkDesc* __rest
     const ChunkDesc d = desc[lo];
     const ChunkPairMeta* r = meta + d.mo + (m - d.pair0);
     const ChunkPairMeta a = r[0], b = r[1];
-    const uint32_t l1 = b.rel1 - a.rel1, l2 = b.rel2 - a.rel2;
+    const bool il = d.b2 == CHUNK_INTERLEAVED;
+    const uint32_t l1 = il ? a.rel2 - a.rel1 : b.rel1 - a.rel1, l2 = il ? b.rel1 - a.rel2 : b.rel2 - a.rel2;
     start[m] = d.b1 + a.rel1;
-    start[n + m] = d.b2 + a.rel2;
+    start[n + m] = (il ? d.b1 : d.b2) + a.rel2;
     len[m] = (uint16_t)l1;
     len[n + m] = (uint16_t)l2;
     const uint32_t w1 = d.wbase + a.relw;
@@ -502,7 +503,7 @@ int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPair
     uint8_t* d_fl = blk + words_b + off_b + len_b;
     const long need = 2 * n + (n_desc * (long)sizeof(ChunkDesc) + 3) / 4;
     if (need > ctx->ingest_start_cap) {
-        if (ctx->d_ingest_start) hipFree(ctx->d_ingest_start);
+        if (ctx->d_ingest_start) lhgt::dev_free(ctx->d_ingest_start);
         ctx->d_ingest_start = nullptr;
         ctx->ingest_start_cap = need + need / 4;
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_ingest_start, (size_t)ctx->ingest_start_cap * 4));
@@ -542,7 +543,7 @@ void ingest_free(lhgt_ctx* ctx) {
     ctx->ingest_events.clear();
     if (ctx->h_ingest_slabs) { hipHostFree(ctx->h_ingest_slabs); ctx->h_ingest_slabs = nullptr; }
     if (ctx->h_ingest_meta) { hipHostFree(ctx->h_ingest_meta); ctx->h_ingest_meta = nullptr; }
-    if (ctx->d_ingest_start) { hipFree(ctx->d_ingest_start); ctx->d_ingest_start = nullptr; }
+    if (ctx->d_ingest_start) { lhgt::dev_free(ctx->d_ingest_start); ctx->d_ingest_start = nullptr; }
     ctx->ingest_meta_cap = ctx->ingest_start_cap = 0;
 }
 
@@ -583,7 +584,7 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index) {
     const int k = ctx->k, e = ctx->e;
     for (void* p : {(void*)ctx->d_index, (void*)ctx->d_ref_planes, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count})
-        if (p) hipFree(p);
+        if (p) lhgt::dev_free(p);
     ctx->d_ref_planes = nullptr; ctx->ref_plane_words = 0;
     ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr;
     ctx->contigs.clear();
@@ -728,8 +729,8 @@ int lhgt_hash_sequence(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* 
         if (out_valid) hipMemcpyAsync(out_valid, d_valid, (size_t)nk, hipMemcpyDeviceToHost, ctx->stream);
         hipStreamSynchronize(ctx->stream);
     }
-    hipFree(d_out);
-    hipFree(d_valid);
+    lhgt::dev_free(d_out);
+    lhgt::dev_free(d_valid);
     return rc;
 }
 

@@ -1224,8 +1224,7 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     if (!ctx->d_peak_kmer) {
         const auto t0 = std::chrono::steady_clock::now();
-        ctx->d_peak_kmer = (uint32_t*)big_take(ctx->device, slots * 4);    // a closed context's table on this device, if the process has one
-        if (!ctx->d_peak_kmer) LHGT_HIP(lhgt::dev_malloc(&ctx->d_peak_kmer, slots * 4));
+        LHGT_HIP(lhgt::dev_malloc(&ctx->d_peak_kmer, slots * 4));          // a closed context's table, if the process has kept one
         if (getenv("LHGT_TRACE"))
             fprintf(stderr, "[lhgt] peak_kmer: %.1f GiB taken or allocated in %.3f s\n", (double)(slots * 4) / (1ull << 30),
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1273,8 +1272,8 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
         LHGT_HIP(hipMemsetAsync(ctx->d_prefilter, 0, ((size_t)1 << pf_bits) / 8, ctx->stream));
     }
     if ((long)total + 1 > ctx->peaks_cap) {     // grow-only: no allocator traffic in steady state
-        if (ctx->d_loci) { hipFree(ctx->d_loci); ctx->d_loci = nullptr; }
-        if (ctx->d_filter) { hipFree(ctx->d_filter); ctx->d_filter = nullptr; }
+        if (ctx->d_loci) { lhgt::dev_free(ctx->d_loci); ctx->d_loci = nullptr; }
+        if (ctx->d_filter) { lhgt::dev_free(ctx->d_filter); ctx->d_filter = nullptr; }
         ctx->peaks_cap = (long)total + 1 + total / 8;
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_loci, (size_t)ctx->peaks_cap * 8));
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_filter, (size_t)ctx->peaks_cap * 4));
@@ -1385,13 +1384,13 @@ int lhgt_ref_scan_emit(lhgt_ctx* ctx, long id_base, void** d_loci, void** d_regs
     if (id_base < 0 || id_base + ctx->local_new > 0xffffffffL) LHGT_FAIL(LHGT_E_ARG, "peak ids overflow 32 bits");
     const long need_loci = ctx->local_new + 1, need_regs = (long)ctx->n_selected * ctx->e + 1;
     if (need_loci > ctx->emit_loci_cap) {
-        if (ctx->d_emit_loci) hipFree(ctx->d_emit_loci);
+        if (ctx->d_emit_loci) lhgt::dev_free(ctx->d_emit_loci);
         ctx->d_emit_loci = nullptr;
         ctx->emit_loci_cap = need_loci + need_loci / 8;
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_emit_loci, (size_t)ctx->emit_loci_cap * 8));
     }
     if (need_regs > ctx->emit_regs_cap) {
-        if (ctx->d_emit_regs) hipFree(ctx->d_emit_regs);
+        if (ctx->d_emit_regs) lhgt::dev_free(ctx->d_emit_regs);
         ctx->d_emit_regs = nullptr;
         ctx->emit_regs_cap = need_regs + need_regs / 8;
         LHGT_HIP(lhgt::dev_malloc(&ctx->d_emit_regs, (size_t)ctx->emit_regs_cap * 8 + 8));

@@ -697,7 +697,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
             const size_t need = (size_t)b.d.n_pairs + 1;
             if (ctx->revote_cap < need) {
-                if (ctx->d_revote) LHGT_HIP(hipFree(ctx->d_revote));
+                if (ctx->d_revote) LHGT_HIP(lhgt::dev_free(ctx->d_revote));
                 ctx->d_revote = nullptr;
                 LHGT_HIP(lhgt::dev_malloc(&ctx->d_revote, need * 4));
                 ctx->revote_cap = need;
@@ -824,7 +824,7 @@ int lhgt_write_intervals(lhgt_ctx* ctx, const char* path, long* n_filtered) {
             LHGT_HIP(hipStreamSynchronize(ctx->stream));
             nf = (long)cnt;
             if (nf <= ctx->voted_cap) break;
-            hipFree(ctx->d_voted);      // more voted peaks than room: grow once and redo
+            lhgt::dev_free(ctx->d_voted);      // more voted peaks than room: grow once and redo
             ctx->d_voted = nullptr;
             cap = (nf + nf / 8 + 1) & ~1L;   // even: the 64-bit counter sits behind cap 12-byte records and must be 8-byte aligned (round 4: an odd cap faulted on the first sample with more than 4096 voted peaks)
         }

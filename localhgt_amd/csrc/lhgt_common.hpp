@@ -183,6 +183,7 @@ struct lhgt_ctx {
     // partitioned count (k_count_part.hip): two key buffers and the bucket histogram/offset block
     uint32_t* d_part_keys[2] = {nullptr, nullptr};
     size_t part_keys_cap = 0;  // keys per buffer
+    long part_reserve_pairs = 0;          // a loader that counts batch by batch: the largest batch it will close (0 = no wish)
     uint32_t* d_part_meta = nullptr;
     int synth_snp_permille = 0, synth_n_permille = 20;   // k_synth.hip: lhgt_synth_options
     long synth_sample_contigs = 0;
@@ -230,24 +231,20 @@ namespace lhgt {
 int build_hash_params(const int16_t* cc, int k, int e, HashParams* hp);
 int rng_next(lhgt_ctx* ctx);  // one rand() draw from the private glibc stream
 void sampling_join(lhgt_ctx* ctx);   // waits for a fill started by lhgt_sampling_begin (host_rng.cpp)
-// peak_kmer of a closed context (16 GiB at k = 32) kept for the next context of this process on the same device (cabi.hip):
-// a process that runs sample after sample would otherwise free and allocate it every time, and hipMalloc of 16 GiB right after such a
-// free was measured to take 0 s or 2 s (profiles/r03/e2e_peak_kmer_alloc.txt).  One buffer per (device, size); lhgt_pool_trim frees them.
-void* big_take(int device, size_t bytes);
-void big_give(int device, size_t bytes, void* p);
-constexpr size_t BIG_BUFFER_MIN = (size_t)4 << 30;
-bool big_release_all();   // frees every parked table; true if there was one
-// hipMalloc that returns the process's parked tables to the device before it reports out-of-memory (a 16 GiB table kept for a next
-// context must never be the reason a 156 GB index does not fit)
+// Device memory through a process-wide cache of large blocks (cabi.hip).  The driver wipes freed VRAM before it hands it out
+// again, so a hipMalloc shortly after a large hipFree waits for that -- measured at seconds: 16 GiB "in 0 s or 2.2 s"
+// (profiles/r03/e2e_peak_kmer_alloc.txt), and in round 5 whichever allocation came first after a closed context's 10+ GB of
+// batches, staging and key buffers (phase A on load 1.4-2.7 s instead of 85 ms, the scan 2 s instead of 8 ms, at random).  A
+// process that runs sample after sample therefore keeps blocks of >= DEV_CACHE_MIN bytes when they are freed -- sizes rounded up
+// to eighth-steps of a power of two (256 MiB at most) so that a slightly different request still fits -- and hands them to the next request of
+// that class; lhgt_pool_trim frees them, and so does any allocation that would otherwise fail (a parked block must never be the
+// reason a 156 GB index does not fit).
+constexpr size_t DEV_CACHE_MIN = (size_t)64 << 20;
+hipError_t dev_alloc_raw(void** p, size_t bytes);
+hipError_t dev_free(void* p);          // blocks that came from dev_malloc go back to the cache; anything else to hipFree
+bool big_release_all();               // frees every cached block; true if there was one
 template <class T>
-inline hipError_t dev_malloc(T** p, size_t bytes) {
-    hipError_t e = hipMalloc((void**)p, bytes);
-    if (e == hipErrorOutOfMemory && big_release_all()) {
-        (void)hipGetLastError();
-        e = hipMalloc((void**)p, bytes);
-    }
-    return e;
-}
+inline hipError_t dev_malloc(T** p, size_t bytes) { return dev_alloc_raw((void**)p, bytes); }
 int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2, const uint64_t* off2,
                  long n_pairs, const uint8_t* pair_flags);
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index = 1);  // allocates d_index, tiles, flags
@@ -267,8 +264,11 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
 // the loader's form: the batch as a list of chunks.  Per chunk the bases of its mate-1 reads and of its mate-2 reads lie back to
 // back at b1 / b2 of d_ascii, and n + 1 records at d_meta + mo tell where every pair starts inside them (and inside the chunk's
 // packed words); the device expands (descriptor + record) into the batch's start / length / word-offset / flag arrays
+// (round 5: b2 = CHUNK_INTERLEAVED -- ONE run of bases at b1, the mates of a pair back to back: record i holds where mate 1 and mate 2
+// of pair i start in it, record i + 1's rel1 is where pair i ends)
 struct ChunkPairMeta { uint32_t rel1, rel2, relw, flags; };
 struct ChunkDesc { uint32_t pair0, n, b1, b2, wbase, mo; };
+constexpr uint32_t CHUNK_INTERLEAVED = 0xFFFFFFFFu;
 int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPairMeta* d_meta, const ChunkDesc* desc, long n_desc, long n,
                           uint64_t n_words, int max_len, uint64_t n_kmers);
 int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, const uint64_t* kept_before, long n_blocks,

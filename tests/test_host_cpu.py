@@ -664,6 +664,38 @@ def test_single_pass_loader_equals_the_planned_loader(lib, oracle, case_inputs, 
     assert "longer than a chunk's margin" in left[("long_line", 1)]
 
 
+def _digest_slabs(lib, f1, f2, ratio=100.0, rnd=None, threads=3, chunk=20000, emulate=1, stream=True):
+    """the same digest, but through the slab pool the GPU loader parses into (lhgt_fastq_parse_rate): bases and records read back from
+    the blocks that would be copied to the device"""
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    seen, kept, bases, dig, secs = C.c_long(0), C.c_long(0), C.c_long(0), C.c_uint64(0), C.c_double(0)
+    rp = rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None
+    os.environ["LHGT_INGEST_STREAM"] = "1" if stream else "0"
+    try:
+        rc = h.lhgt_fastq_parse_rate(f1.encode(), f2.encode(), float(ratio), rp, threads, chunk, emulate, None, None, 0, None, None, 0, 0, 1,
+                                     C.byref(seen), C.byref(kept), C.byref(bases), C.byref(secs), C.byref(dig))
+    finally:
+        os.environ.pop("LHGT_INGEST_STREAM", None)
+    return rc, seen.value, kept.value, dig.value
+
+
+def test_slab_blocks_hold_what_the_vector_parse_holds(lib, oracle, case_inputs, tmp_path):
+    """the loader's slab form (one run of bases per chunk, the mates of a pair back to back, records behind them) read back == the
+    digest of the vector form, for both loaders, sampling and the thread emulation included; chunks small enough to spill"""
+    oracle.srand(4)
+    rnd = np.resize(oracle.sampling_array(1_000_000), 50_000_000)
+    for name in ("k24_seed7", "k24_fq2_longer", "k24_fq2_short_nonl", "k24_t4", "k24_fq2_stray2"):
+        fa, f1, f2, _ = case_inputs(name)
+        for emulate in (1, 4):
+            for ratio in (100.0, 35.0):
+                want = _digest_full(lib, f1, f2, ratio=ratio, rnd=rnd, threads=2, chunk=1 << 40, emulate=emulate, stream=False)
+                for stream in (True, False):
+                    for threads, chunk in ((3, 50000), (4, 2000), (2, 1 << 22)):
+                        got = _digest_slabs(lib, f1, f2, ratio=ratio, rnd=rnd, threads=threads, chunk=chunk, emulate=emulate, stream=stream)
+                        assert got[0] == want[0] and (got[0] != 0 or got == want[:4]), (name, emulate, ratio, stream, threads, chunk)   # a refusal is a refusal either way
+
+
 @pytest.mark.parametrize("idx", range(24))
 def test_single_pass_loader_fuzz(lib, oracle, tmp_path, idx):
     """random small inputs of the whole-run fuzz (ragged reads, N runs, padded fq2 headers, CRLF, sampling): single pass == planned

@@ -53,7 +53,7 @@ def worker(argv):
     if step == "single":
         os.environ["LHGT_INGEST_STREAM"] = "1"
         rc = h.lhgt_fastq_parse_rate(fq1.encode(), fq2.encode(), 100.0, None, threads, CHUNK, emulate, None, None, 0, None, None, 0, 0, 1,
-                                     C.byref(seen), C.byref(kept), C.byref(bases), C.byref(secs))
+                                     C.byref(seen), C.byref(kept), C.byref(bases), C.byref(secs), None)
         why = C.create_string_buffer(200)
         path = h.lhgt_ingest_last_path(why, 200)
         print(json.dumps({"step": "single", "rc": rc, "s": secs.value, "kept": kept.value, "bases": bases.value, "single_pass": path, "why": why.value.decode()}), flush=True)
@@ -63,7 +63,7 @@ def worker(argv):
     s2, c2 = np.concatenate([x["s2"] for x in z]), np.concatenate([x["c2"] for x in z])
     u64, lp = C.POINTER(C.c_uint64), C.POINTER(C.c_long)
     rc = h.lhgt_fastq_parse_rate(fq1.encode(), fq2.encode(), 100.0, None, threads, CHUNK, emulate, s1.ctypes.data_as(u64), c1.ctypes.data_as(lp), len(s1),
-                                 s2.ctypes.data_as(u64), c2.ctypes.data_as(lp), len(s2), part, parts, C.byref(seen), C.byref(kept), C.byref(bases), C.byref(secs))
+                                 s2.ctypes.data_as(u64), c2.ctypes.data_as(lp), len(s2), part, parts, C.byref(seen), C.byref(kept), C.byref(bases), C.byref(secs), None)
     print(json.dumps({"step": "parse", "part": part, "rc": rc, "s": secs.value, "kept": kept.value, "bases": bases.value}), flush=True)
 
 

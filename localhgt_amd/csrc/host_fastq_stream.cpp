@@ -120,11 +120,15 @@ struct ByteParts {
     std::vector<long> pos, stop;
     std::unique_ptr<std::atomic<long>[]> first;
     std::atomic<bool>* odd = nullptr;      // set when a thread turns out to enter off a record boundary (the planned loader refuses that)
-    // the reference's keep test for the sequence line g that starts at byte sa (host_fastx.cpp: ThreadPart::keep)
-    int keep(long g, size_t sa, double ratio, const float* random_array) const {
-        const size_t i1 = (size_t)(std::upper_bound(pos.begin(), pos.end(), (long)sa) - pos.begin());
-        if (i1 == 0) return -1;
-        const size_t i = i1 - 1;
+    // the reference's keep test for the sequence line g that starts at byte sa (host_fastx.cpp: ThreadPart::keep).  *hint: the
+    // part the caller's previous line fell into -- a column's lines come in file order, so the search is a step or two
+    int keep(long g, size_t sa, double ratio, const float* random_array, size_t* hint) const {
+        size_t i = *hint < pos.size() ? *hint : 0;
+        if ((long)sa < pos[i]) i = (size_t)(std::upper_bound(pos.begin(), pos.end(), (long)sa) - pos.begin());   // (not in file order: a walk back in fq2)
+        else { while (i + 1 < pos.size() && pos[i + 1] <= (long)sa) i++; i++; }
+        if (i == 0) return -1;
+        i--;
+        *hint = i;
         if ((long)sa >= stop[i]) return -1;
         long f = first[i].load(std::memory_order_acquire);
         if (f < 0) {                     // not published yet (a partner line beyond this column's chunk): count back to the entry
@@ -373,6 +377,7 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                         std::reverse(before.begin(), before.end());   // before[j] = line g0 + j
                     }
                 }
+                size_t hint1 = 0, hint2 = 0;
                 LineCursor fwd(m2);                      // partner lines behind fq2's chunk
                 fwd.cur = v2.E;
                 long fwd_idx = h1, walked = 0;
@@ -401,8 +406,8 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                     const long n = g / 4;
                     uint8_t fl;
                     if (emu)
-                        fl = (uint8_t)((bp1.keep(g, sa, ratio, random_array) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
-                                       (have2 && bp2.keep(h, sb, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
+                        fl = (uint8_t)((bp1.keep(g, sa, ratio, random_array, &hint1) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
+                                       (have2 && bp2.keep(h, sb, ratio, random_array, &hint2) == 1 ? PAIR_COUNT2 : 0));
                     else
                         fl = (uint8_t)((sampled(n) ? PAIR_COUNT1 | PAIR_VOTE : 0) | (have2 && sb <= n1 && sampled(h / 4) ? PAIR_COUNT2 : 0));   // quirk Q4
                     if (!fl || (shard_world > 1 && (n / shard_block) % shard_world != shard_rank)) continue;

@@ -888,12 +888,16 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     ChunkDesc* desc_base = nullptr;
     double t_alloc = 0;
     std::vector<ChunkDesc> desc_pageable;     // only when the host refuses page-locked memory
-    hipEvent_t buf_free[2] = {nullptr, nullptr}, copied = nullptr;
+    hipEvent_t buf_free[2] = {nullptr, nullptr}, copied = nullptr, copied2 = nullptr;
+    hipStream_t cs2 = nullptr;         // a second copy stream: the chunks' copies alternate between two queues, so one copy's set-up hides behind the other's transfer
     auto prepare = [&](SlabPool** pool_out) -> int {
         const double t_a0 = now_s();
         LHGT_TRY(ws_reserve(ctx, 2 * STAGE, 0));
-        for (auto& e : buf_free) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));   // waits sleep: the host's CPUs are the parse threads' 
-        LHGT_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        // (prepare runs again when the single pass hands the files to the planned loader)
+        for (auto& e : buf_free) if (!e) LHGT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));   // waits sleep: the host's CPUs are the parse threads' 
+        if (!copied) LHGT_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        if (!copied2) LHGT_HIP(hipEventCreateWithFlags(&copied2, hipEventDisableTiming));
+        if (!cs2 && !getenv("LHGT_ONE_COPY_STREAM")) LHGT_HIP(hipStreamCreateWithFlags(&cs2, hipStreamNonBlocking));
         pool = (SlabPool*)ctx->ingest_pool;
         if (!pool || pool->slab_bytes != SLAB || (int)ctx->ingest_events.size() != n_slabs || ctx->ingest_meta_cap != 2 * DESC_CAP) {
             lhgt_ingest_pool_free(ctx);
@@ -954,6 +958,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         if (used[bi]) {
             LHGT_HIP(hipEventSynchronize(buf_free[bi]));           // host: the descriptors are rewritten
             LHGT_HIP(hipStreamWaitEvent(cs, buf_free[bi], 0));      // device: so is the staging buffer
+            if (cs2) LHGT_HIP(hipStreamWaitEvent(cs2, buf_free[bi], 0));
         }
         return LHGT_OK;
     };
@@ -969,6 +974,10 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         const int bi = (int)(n_batches & 1);
         LHGT_HIP(hipEventRecord(copied, cs));
         LHGT_HIP(hipStreamWaitEvent(ctx->stream, copied, 0));
+        if (cs2) {
+            LHGT_HIP(hipEventRecord(copied2, cs2));
+            LHGT_HIP(hipStreamWaitEvent(ctx->stream, copied2, 0));
+        }
         int rc = install_pairs_chunked(ctx, stage_base(), (const ChunkPairMeta*)stage_base(), desc(), n_desc, n_open, words, max_len, nkm);
         LHGT_HIP(hipEventRecord(buf_free[bi], ctx->stream));
         used[bi] = true;
@@ -995,6 +1004,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     const bool can_reset = !(ctx->count_on_load && ctx->counts_touched);
     auto reset = [&]() -> int {
         (void)hipStreamSynchronize(cs);
+        if (cs2) (void)hipStreamSynchronize(cs2);
         (void)hipStreamSynchronize(ctx->stream);
         if (pool) while (out_head < out_slabs.size()) pool->release(out_slabs[out_head++]);
         bool counted = false;
@@ -1020,8 +1030,9 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                              if (n_open == 0) LHGT_TRY(open_batch());
                              uint32_t ch_words = 0;
                              if (ch.slab) {
-                                 LHGT_HIP(hipMemcpyAsync(stage_base() + fill, ch.slab, block, hipMemcpyHostToDevice, cs));
-                                 LHGT_HIP(hipEventRecord(ctx->ingest_events[(size_t)ch.slab_id], cs));
+                                 hipStream_t q = cs2 && (n_desc & 1) ? cs2 : cs;
+                                 LHGT_HIP(hipMemcpyAsync(stage_base() + fill, ch.slab, block, hipMemcpyHostToDevice, q));
+                                 LHGT_HIP(hipEventRecord(ctx->ingest_events[(size_t)ch.slab_id], q));
                                  out_slabs.push_back(ch.slab_id);
                                  ch_words = ch.words;
                                  if (ch.max_len > max_len) max_len = ch.max_len;
@@ -1058,10 +1069,12 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     const double t_f0 = now_s();
     if (rc == LHGT_OK) rc = flush();
     (void)hipStreamSynchronize(cs);               // whatever happened: no copy may still read a slab,
+    if (cs2) { (void)hipStreamSynchronize(cs2); (void)hipStreamDestroy(cs2); }
     (void)hipStreamSynchronize(ctx->stream);      // no kernel the staging buffers
     if (ingest_trace()) fprintf(stderr, "[lhgt ingest] staging + pinned pool %.3fs (behind the line count), %ld batches, last batch + drain %.3fs\n", t_alloc, n_batches, now_s() - t_f0);
     for (auto& e : buf_free) if (e) (void)hipEventDestroy(e);
     if (copied) (void)hipEventDestroy(copied);
+    if (copied2) (void)hipEventDestroy(copied2);
     if (pool) {                                    // ... so every slab is free again, also one a failed chunk still held
         std::lock_guard<std::mutex> lk(pool->mu);
         pool->free_ids.clear();

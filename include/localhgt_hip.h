@@ -153,6 +153,10 @@ int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads);
 /* where thread i of `threads` enters a FASTQ (byte), the global index of its first line and the lines it consumes;
  * size_for_chunks = size of fq1 (also for fq2, E:1419), < 0 = this file's */
 int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, long* entry_byte, long* first_line, long* n_lines);
+/* the chunk sizes at which the two files of a pair should be planned (lhgt_fastq_plan_part) so that lhgt_pairs_load_fastq_planned can
+ * read its part like the single-pass loader does (host_fastq_stream.cpp: fq2 cut into as many chunks as fq1); plans made at any
+ * other size give the same pairs through the line-by-line chunk loop */
+int lhgt_fastq_pair_chunk_bytes(const char* fq1, const char* fq2, long* chunk1, long* chunk2);
 /* host-only rate probe of the FASTQ loader (tools/ingest_scaling.py): the parse as lhgt_pairs_load_fastq runs it -- worker threads
  * filling slabs with kept bases and per-pair records -- into host memory, nothing uploaded.  start1 null: the whole files (single
  * pass first, as in the loader); otherwise part `part` of `n_parts` of the planned parse (plans from lhgt_fastq_plan_part). */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lhgt_fastq_thread_chunks": [_cs, _l, _i, _lp, _lp, _lp],
     "lhgt_fastq_thread_entry": [_cs, _l, _l],
     "lhgt_ingest_last_path": [_cs, _l],
+    "lhgt_fastq_pair_chunk_bytes": [_cs, _cs, _lp, _lp],
     "lhgt_fastq_parse_rate": [_cs, _cs, _d, _fp, _i, _l, _i, _u64p, _lp, _l, _u64p, _lp, _l, _i, _i, _lp, _lp, _lp, _dp, _u64p],
     "lhgt_fastq_parse_digest_threads": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _i, _lp, _lp, _u64p, _lp],
     "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],

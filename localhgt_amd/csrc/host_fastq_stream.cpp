@@ -206,17 +206,63 @@ static bool line_before(const uint8_t* p, size_t n, size_t q, size_t* s, size_t*
 
 const int STREAM_RETRY = -1000;   // not an error code of the C-ABI: "give this input to the planned loader"
 
+// The column grid of two files: fq1 in chunks of ch1 bytes, fq2 cut into the same NUMBER of chunks, so that column c of either
+// file holds about the same lines.  false: no grid (an empty file, sizes a factor of two apart).
+bool stream_chunking(size_t n1, size_t n2, size_t chunk_bytes, size_t* ch1, size_t* ch2) {
+    if (n1 == 0 || n2 == 0 || n2 > 2 * n1 || n1 > 2 * n2 || chunk_bytes < 64) return false;
+    *ch1 = std::min<size_t>(chunk_bytes, (size_t)1 << 30);      // newline offsets inside a chunk are 32-bit
+    const size_t ncols = n_plan_chunks(n1, *ch1);
+    *ch2 = std::max<size_t>((n2 + ncols - 1) / ncols, 64);
+    return true;
+}
+
+// The line plan of chunks [c_lo, c_hi) of one file cut at multiples of ch -- first line start, number of lines, and (len_sums
+// non-null) the summed line lengths by line index inside the chunk mod 4 (cal_sam_ratio's base count, E:1244-1270, folded into
+// the count) -- read with pread and one SIMD sweep per chunk.  false: a chunk the sweep does not handle (a line longer than its
+// margin); the caller falls back to its line-by-line pass.
+bool plan_columns(const Mapped& m, size_t ch, size_t c_lo, size_t c_hi, int threads, uint64_t* start, long* count, long* len_sums) {
+    std::atomic<bool> ok{true};
+    const bool use_pread = !(getenv("LHGT_INGEST_IO") && !strcmp(getenv("LHGT_INGEST_IO"), "mmap"));
+    std::atomic<long> next{(long)c_lo};
+    auto work = [&]() {
+        Scratch sc;
+        for (long c; ok.load() && (c = next.fetch_add(1)) < (long)c_hi;) {
+            ChunkView v;
+            if (!view_chunk(m, ch, c, use_pread, &sc, 0, &v)) { ok.store(false); return; }
+            const size_t i = (size_t)c - c_lo;
+            start[i] = v.S;
+            count[i] = v.lines;
+            if (len_sums) {
+                long sums[4] = {0, 0, 0, 0};
+                size_t a = v.S;
+                for (long j = 0; j < v.lines; j++) {
+                    const size_t b = (v.tail_open && j == v.lines - 1) ? m.n : v.rb + v.nl[v.i_first + (size_t)j];
+                    sums[j & 3] += (long)(b - a);
+                    a = b + 1;
+                }
+                for (int r = 0; r < 4; r++) len_sums[4 * i + (size_t)r] = sums[r];
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    const long n = (long)(c_hi - c_lo);
+    for (int w = 1; w < threads && w < n; w++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return ok.load();
+}
+
 int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, const char* fq2, double ratio, const float* random_array,
                        int shard_rank, int shard_world, long shard_block, int threads, size_t chunk_bytes, int emulate_threads,
                        const std::function<int(SlabPool**)>& prepare, const std::function<int(ParsedChunk&)>& consume,
-                       const std::function<void(bool)>& idle, ChunkPlan* plan1, ChunkPlan* plan2, std::string* why) {
+                       const std::function<void(bool)>& idle, ChunkPlan* plan1, ChunkPlan* plan2, std::string* why, const StreamSeeds* seeds) {
     auto retry = [&](const char* reason) { *why = reason; return STREAM_RETRY; };
     const size_t n1 = m1.n, n2 = m2.n;
-    if (n1 == 0 || n2 == 0) return retry("an empty file");
-    if (n2 > 2 * n1 || n1 > 2 * n2) return retry("files of very different size");
-    const size_t ch1 = std::min<size_t>(chunk_bytes, (size_t)1 << 30);      // newline offsets inside a chunk are 32-bit
+    size_t ch1 = 0, ch2 = 0;
+    if (!stream_chunking(n1, n2, chunk_bytes, &ch1, &ch2)) return retry("an empty file, or files of very different size");
     const long ncols = (long)n_plan_chunks(n1, ch1);
-    const size_t ch2 = std::max<size_t>((n2 + (size_t)ncols - 1) / (size_t)ncols, 64);
+    const long col_lo = seeds ? seeds->col_lo : 0, col_hi = seeds ? seeds->col_hi : ncols, n_my = col_hi - col_lo;
+    if (seeds && (seeds->ncols != ncols || col_lo < 0 || col_hi > ncols || col_lo > col_hi)) return retry("plans off the column grid");
     const char* io = getenv("LHGT_INGEST_IO");                      // pread (default) | mmap
     const bool use_pread = !(io && !strcmp(io, "mmap"));
     if (use_pread && getenv("LHGT_INGEST_NOREUSE")) {                // experiment knob: reads that do not touch the page cache's LRU state
@@ -224,8 +270,8 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
         (void)posix_fadvise(m2.fd, 0, 0, POSIX_FADV_NOREUSE);
     }
     const double t0 = now_s();
-    // ---- what can be decided from bytes alone, before the first column
-    {
+    // ---- what can be decided from bytes alone, before the first column (with seeds the caller has decided all of it from its plans)
+    if (!seeds) {
         LineCursor a(m1), b(m2);
         const uint8_t *s1, *s2;
         size_t l1, l2, st;
@@ -235,12 +281,14 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     }
     const uint8_t* stale = m2.p;
     size_t stale_len = 0;
-    if (m2.p[n2 - 1] != '\n') { size_t s, l; line_before(m2.p, n2, n2, &s, &l); stale = m2.p + s; stale_len = l; }   // E:356-367
+    if (seeds) { stale = seeds->stale; stale_len = seeds->stale_len; }
+    else if (m2.p[n2 - 1] != '\n') { size_t s, l; line_before(m2.p, n2, n2, &s, &l); stale = m2.p + s; stale_len = l; }   // E:356-367
     std::atomic<bool> odd_entry{false};
     ByteParts bp1, bp2;
     std::unique_ptr<std::atomic<long>[]> g2_at;                            // line number of fq2 at the byte thread i enters fq1 at
     const bool emu = emulate_threads > 1;
-    if (emu) {
+    const ThreadEmu* emu_lines = seeds ? seeds->emu : nullptr;               // with seeds: the thread chunks by line numbers, from the plans
+    if (emu && !seeds) {
         const long each = (long)n1 / emulate_threads;
         for (int f = 0; f < 2; f++) {
             const Mapped& m = f ? m2 : m1;
@@ -275,14 +323,13 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     // ---- the columns
     std::unique_ptr<std::atomic<long>[]> P1(new std::atomic<long>[(size_t)ncols + 1]), P2(new std::atomic<long>[(size_t)ncols + 1]);
     std::unique_ptr<Gate[]> gate(new Gate[(size_t)ncols + 1]);       // gate[c] opens when P1[c] and P2[c] are known
-    for (long c = 0; c <= ncols; c++) { P1[(size_t)c].store(-1); P2[(size_t)c].store(-1); }
-    P1[0].store(0); P2[0].store(0);
-    gate[0].release();
+    for (long c = 0; c <= ncols; c++) { P1[(size_t)c].store(seeds ? seeds->P1[c] : -1); P2[(size_t)c].store(seeds ? seeds->P2[c] : -1); }
+    if (!seeds) { P1[0].store(0); P2[0].store(0); gate[0].release(); }
     std::vector<size_t> S1((size_t)ncols + 1, n1), S2((size_t)ncols + 1, n2);   // chunk starts, for the plans handed back
-    std::vector<ParsedChunk> out((size_t)ncols);
-    std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[(size_t)ncols]);
-    for (long c = 0; c < ncols; c++) ready[(size_t)c].store(0);
-    std::atomic<long> next{0};
+    std::vector<ParsedChunk> out((size_t)n_my);
+    std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[(size_t)n_my + 1]);
+    for (long c = 0; c < n_my; c++) ready[(size_t)c].store(0);
+    std::atomic<long> next{col_lo};
     std::atomic<bool> stop{false};
     std::atomic<int> fail{0};                       // 1 = retry with the planned loader, 2 = error in err_rc / err_msg
     std::mutex mu;
@@ -315,10 +362,10 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                 if (slab_id < 0) return;
             }
             const long c = next.fetch_add(1);
-            if (c >= ncols || stop.load()) { if (pool && slab_id >= 0) pool->release(slab_id); return; }
+            if (c >= col_hi || stop.load()) { if (pool && slab_id >= 0) pool->release(slab_id); return; }
             double tb = now_s();
             my_s[0] += tb - ta;
-            ParsedChunk& ch = out[(size_t)c];
+            ParsedChunk& ch = out[(size_t)(c - col_lo)];
             if (pool) ch.use_slab(pool->base + (size_t)slab_id * pool->slab_bytes, pool->half_bytes, slab_id, pool->k);
             ch.src_slack = use_pread;                    // the text buffers end in 64 spare bytes
             ch.o1.assign(1, 0);
@@ -330,14 +377,17 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
             ta = now_s();
             my_s[1] += ta - tb;
             // 2. the chain of line numbers: wait for this column's, publish the next one's
-            gate[(size_t)c].wait(stop);
+            if (!seeds) gate[(size_t)c].wait(stop);
             long g0 = P1[(size_t)c].load(std::memory_order_acquire), h0 = P2[(size_t)c].load(std::memory_order_acquire);
+            if (seeds && seen && (v1.lines != seeds->P1[c + 1] - g0 || v2.lines != seeds->P2[c + 1] - h0 || (v1.lines && v1.S != seeds->start1[c]) ||
+                                  (v2.lines && v2.S != seeds->start2[c])))
+                give_up(1, "the plans do not describe these columns");
             if (g0 < 0 || h0 < 0) { g0 = h0 = 0; }       // stopping: numbers no longer matter, the chain must still move
             tb = now_s();
             my_s[2] += tb - ta;
             S1[(size_t)c] = v1.S;
             S2[(size_t)c] = v2.S;
-            if (emu && seen) {                           // threads that enter inside these chunks learn their first line's number
+            if (emu && seen && !seeds) {                 // threads that enter inside these chunks learn their first line's number
                 for (int f = 0; f < 2; f++) {
                     const ChunkView& v = f ? v2 : v1;
                     ByteParts& bp = f ? bp2 : bp1;
@@ -356,9 +406,11 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                         g2_at[(size_t)i].store(h0 + v2.newlines_before(pos), std::memory_order_release);
                 }
             }
-            P1[(size_t)c + 1].store(g0 + v1.lines, std::memory_order_release);
-            P2[(size_t)c + 1].store(h0 + v2.lines, std::memory_order_release);
-            gate[(size_t)c + 1].release();
+            if (!seeds) {
+                P1[(size_t)c + 1].store(g0 + v1.lines, std::memory_order_release);
+                P2[(size_t)c + 1].store(h0 + v2.lines, std::memory_order_release);
+                gate[(size_t)c + 1].release();
+            }
             // 3. the pairs of fq1's chunk
             if (seen && !stop.load() && v1.lines > 0) {
                 const long h1 = h0 + v2.lines;           // fq2's chunk holds lines [h0, h1)
@@ -405,7 +457,10 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                     if (!have2) { b = stale; lb = stale_len; sb = n2; }       // fq2 has run out (E:356-367)
                     const long n = g / 4;
                     uint8_t fl;
-                    if (emu)
+                    if (emu_lines)
+                        fl = (uint8_t)((emu_lines->f1.keep(g, ratio, random_array) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
+                                       (have2 && emu_lines->f2.keep(h, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
+                    else if (emu)
                         fl = (uint8_t)((bp1.keep(g, sa, ratio, random_array, &hint1) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
                                        (have2 && bp2.keep(h, sb, ratio, random_array, &hint2) == 1 ? PAIR_COUNT2 : 0));
                     else
@@ -420,13 +475,13 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
             }
             ch.finish();
             my_s[3] += now_s() - tb;
-            { std::lock_guard<std::mutex> lk(mu); ready[(size_t)c].store(1); }
+            { std::lock_guard<std::mutex> lk(mu); ready[(size_t)(c - col_lo)].store(1); }
             cv_ready.notify_all();
         }
     };
     if (threads < 1) threads = 1;
     std::vector<std::thread> th;
-    const int nt = (int)(ncols < threads ? ncols : threads);
+    const int nt = (int)(n_my < threads ? n_my : threads);
     for (int w = 0; w < nt; w++) th.emplace_back(worker);
     // the calling thread allocates (pinned slabs, device staging) while the workers read and scan their first columns
     SlabPool* pool = nullptr;
@@ -437,7 +492,7 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     pool_known.store(true, std::memory_order_release);
     long n_consumed = 0;
     double t_wait = 0, t_consume = 0;
-    for (long c = 0; c < ncols && rc == LHGT_OK && !fail.load(); c++) {
+    for (long c = 0; c < n_my && rc == LHGT_OK && !fail.load(); c++) {
         const double t1 = now_s();
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -473,13 +528,20 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
     if (pool) pool->close();
     for (auto& t : th) t.join();
     if (pool) {
-        for (long c = n_consumed; c < ncols; c++)
+        for (long c = n_consumed; c < n_my; c++)
             if (out[(size_t)c].slab_id >= 0) pool->release(out[(size_t)c].slab_id);
         pool->reopen();
     }
     if (rc != LHGT_OK) LHGT_FAIL(rc, "%s", consume_err.c_str());
     if (fail.load() == 2) LHGT_FAIL(err_rc, "%s", err_msg.c_str());
     if (fail.load() == 1) return retry(fail_why.c_str());
+    if (seeds) {
+        if (ingest_trace())
+            fprintf(stderr, "[lhgt ingest] columns [%ld, %ld) of %ld on given line numbers (%s): %d threads, waited for columns %.3fs, consume(+upload) %.3fs, whole pass %.3fs; "
+                    "per worker: slab wait %.3fs, read + newline scan %.3fs, pairs %.3fs\n", col_lo, col_hi, ncols, use_pread ? "pread" : "mmap", nt, t_wait, t_consume,
+                    now_s() - t0, stage_s[0] / std::max(nt, 1), stage_s[1] / std::max(nt, 1), stage_s[3] / std::max(nt, 1));
+        return LHGT_OK;
+    }
     // ---- what only the whole pass can tell
     const long lines1 = P1[(size_t)ncols].load(), lines2 = P2[(size_t)ncols].load();
     if (emu) {

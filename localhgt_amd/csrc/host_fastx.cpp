@@ -153,22 +153,6 @@ long thread_entry(const uint8_t* p, long n, long start) {
     return 0;
 }
 
-struct ThreadPart {
-    std::vector<long> first, count;   // per thread chunk: global index of its first line, lines it consumes
-    // sequence line g: in which chunk, and is it kept there?  (-1 = no chunk consumes it)
-    int keep(long g, double ratio, const float* random_array) const {
-        size_t i = (size_t)(std::upper_bound(first.begin(), first.end(), g) - first.begin());
-        while (i > 0) {   // chunks are in file order; a later chunk never starts before an earlier one
-            i--;
-            if (g < first[i]) continue;
-            if (g >= first[i] + count[i]) return -1;
-            const long local = g - first[i];
-            if (local % 4 != 1) return -1;
-            return (ratio >= 100.0 || (double)random_array[(local / 4) % LHGT_MAX_RANDOM] < ratio) ? 1 : 0;
-        }
-        return -1;
-    }
-};
 
 static long line_index_of(const Mapped& m, const ChunkPlan& pl, size_t byte_pos) {
     if (byte_pos >= m.n) return pl.line0.back();
@@ -197,22 +181,7 @@ static int thread_part(const Mapped& m, const ChunkPlan& pl, long size_for_chunk
     return LHGT_OK;
 }
 
-struct ThreadEmu {
-    ThreadPart f1, f2;
-    std::vector<long> pos1;   // byte at which each thread enters fq1 (and seeks fq2 to, E:350-352)
-};
 
-// How phase C pairs the lines of the two files (E:350-402).  It reads both in lock-step, line g of fq1 with line g + shift of fq2:
-// shift is 0 when the first read IDs agree; otherwise the reference rewinds fq2 (to byte 1 at -t 1) and reads on until a line
-// carries fq1's first ID (E:376-397), and the lock-step continues from there.  Once fq2 has run out std::getline leaves the string
-// as it was: empty when fq2's last line ended with a newline, that last line otherwise (E:356-367) -- the `stale` partner.
-// Phase A reads each file on its own (E:1426-1448), so fq2's records in front of the shift and behind fq1's end are counted, not voted.
-struct PairLayout {
-    long shift = 0;
-    long lines1 = 0, lines2 = 0;
-    const uint8_t* stale = nullptr;
-    size_t stale_len = 0;
-};
 
 // line g of a planned file: its bytes (without the newline) and its start offset
 static bool line_at(const Mapped& m, const ChunkPlan& pl, long g, const uint8_t** s, size_t* len, size_t* start) {
@@ -340,13 +309,6 @@ static int parse_fq2_only(const Mapped& m1, const Mapped& m2, const ChunkPlan& p
     return LHGT_OK;
 }
 
-// Plans made elsewhere and the share of fq1's chunks this caller parses: the ranks of a multi-GPU run each count the lines of
-// 1/world of both files, exchange the pieces, and parse chunks [part * nc / n_parts, (part + 1) * nc / n_parts) (lhgt_pairs_load_fastq_planned)
-struct ParseShare {
-    const ChunkPlan* p1 = nullptr;
-    const ChunkPlan* p2 = nullptr;
-    int part = 0, n_parts = 1;
-};
 
 // everything the parse needs to know before the first chunk: plans, thread chunks, pairing layout.  Returns LHGT_E_FORMAT with
 // a message that starts with "-t N emulation" where only the emulation refuses the input (the caller may fall back to -t 1).
@@ -504,7 +466,49 @@ static int parse_pairs(const char* fq1, const char* fq2, double ratio, const flo
         LHGT_TRY(parse_fq2_only(m1, m2, p2, 0, lay.shift < lay.lines2 ? lay.shift : lay.lines2, ratio, random_array, shard_rank, shard_world, shard_block, emu, &head));
         if (head.o1.size() > 1) LHGT_TRY(consume(head));
     }
-    {
+    // Plans that lie on the column grid of the single-pass loader (fq1 cut at chunk_bytes, fq2 into as many chunks: what
+    // lhgt_fastq_pair_chunk_bytes tells the planner) let this part's columns be read with pread and cut from SIMD newline lists
+    // like there, all at once -- their line numbers are known.  Same pairs, same part of the chunks; where a column does not see
+    // what its plan says (or the files drift apart) the pairs are taken back and the loop below parses the part.
+    bool parsed = false;
+    if (share.raw_start1 && reset && stream_on && lay.shift == 0 && nc_all > 0) {
+        size_t ch1 = 0, ch2 = 0;
+        if (stream_chunking(m1.n, m2.n, chunk_bytes, &ch1, &ch2) && ch1 == chunk_bytes && share.raw_n1 == (long)n_plan_chunks(m1.n, ch1) &&
+            share.raw_n2 == (long)n_plan_chunks(m2.n, ch2)) {
+            const long ncols = share.raw_n1;
+            std::vector<long> P1((size_t)ncols + 1, 0), P2((size_t)ncols + 1, 0), ne;     // ne: columns whose fq1 chunk holds a byte (the chunks of p1)
+            std::vector<uint64_t> S1((size_t)ncols, m1.n), S2((size_t)ncols, m2.n);
+            for (long c = 0; c < ncols; c++) {
+                P1[(size_t)c + 1] = P1[(size_t)c] + share.raw_count1[c];
+                P2[(size_t)c + 1] = P2[(size_t)c] + (c < share.raw_n2 ? share.raw_count2[c] : 0);
+                S1[(size_t)c] = share.raw_start1[c];
+                if (c < share.raw_n2) S2[(size_t)c] = share.raw_start2[c];
+                if ((c + 1 < ncols ? share.raw_start1[c + 1] : (uint64_t)m1.n) > share.raw_start1[c]) ne.push_back(c);
+            }
+            if ((long)ne.size() == nc_all && P1[(size_t)ncols] == lay.lines1 && P2[(size_t)ncols] == lay.lines2) {
+                StreamSeeds seeds;
+                seeds.P1 = P1.data(); seeds.P2 = P2.data(); seeds.start1 = S1.data(); seeds.start2 = S2.data();
+                seeds.ncols = ncols;
+                seeds.col_lo = c_lo < nc_all ? ne[(size_t)c_lo] : ncols;
+                seeds.col_hi = c_hi < nc_all ? ne[(size_t)c_hi] : ncols;
+                seeds.emu = emu;
+                seeds.stale = lay.stale; seeds.stale_len = lay.stale_len;
+                ChunkPlan q1, q2;
+                std::string why;
+                const int src = parse_pairs_stream(m1, m2, fq1, fq2, ratio, random_array, shard_rank, shard_world, shard_block, threads, chunk_bytes,
+                                                   emulate_threads, [&](SlabPool** out) -> int { *out = pool; return LHGT_OK; },
+                                                   std::function<int(ParsedChunk&)>(consume), std::function<void(bool)>(idle), &q1, &q2, &why, &seeds);
+                if (src == LHGT_OK) { parsed = true; g_last_path = 2; }
+                else if (src != STREAM_RETRY) return src;
+                else {
+                    g_last_path_why = why;
+                    if (ingest_trace()) fprintf(stderr, "[lhgt ingest] part %d/%d: the columns leave the part to the chunk loop: %s\n", share.part, share.n_parts, why.c_str());
+                    LHGT_TRY(reset());
+                }
+            }
+        }
+    }
+    if (!parsed) {
         std::vector<ParsedChunk> out((size_t)nc);
         std::vector<std::atomic<int>> ready((size_t)nc);
         for (auto& r : ready) r.store(0);
@@ -1107,6 +1111,20 @@ long lhgt_fastq_plan_chunk_bytes(void) {   // LHGT_INGEST_CHUNK_BYTES: test hook
     return v >= 256 ? v : (long)((size_t)2 << 20);
 }
 
+// the chunk sizes at which the two files of a pair should be planned so that the planned parse can take the single-pass loader's
+// columns (fq2 is cut into as many chunks as fq1); both = lhgt_fastq_plan_chunk_bytes() where no such grid exists
+int lhgt_fastq_pair_chunk_bytes(const char* fq1, const char* fq2, long* chunk1, long* chunk2) {
+    if (!fq1 || !fq2 || !chunk1 || !chunk2) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    struct stat a, b;
+    if (stat(fq1, &a)) LHGT_FAIL(LHGT_E_IO, "cannot stat %s", fq1);
+    if (stat(fq2, &b)) LHGT_FAIL(LHGT_E_IO, "cannot stat %s", fq2);
+    const long ch = lhgt_fastq_plan_chunk_bytes();
+    size_t c1 = 0, c2 = 0;
+    *chunk1 = *chunk2 = ch;
+    if (stream_chunking((size_t)a.st_size, (size_t)b.st_size, (size_t)ch, &c1, &c2) && (long)c1 == ch) *chunk2 = (long)c2;
+    return LHGT_OK;
+}
+
 int lhgt_fastq_plan_part(const char* fq, long chunk_bytes, int part, int n_parts, uint64_t* start, long* n_lines, long cap, long* n_out,
                          long* n_chunks_total, long* len_sums) {
     if (!fq || chunk_bytes < 1 || n_parts < 1 || part < 0 || part >= n_parts || !n_out) LHGT_FAIL(LHGT_E_ARG, "bad argument");
@@ -1121,6 +1139,15 @@ int lhgt_fastq_plan_part(const char* fq, long chunk_bytes, int part, int n_parts
     std::vector<size_t> st;
     std::vector<long> cnt;
     const double t0 = now_s();
+    // pread + one SIMD sweep per chunk (host_fastq_stream.cpp), the line lengths for cal_sam_ratio from the same newline lists; a
+    // file with a line longer than a chunk's margin goes through the mapping, line by line, as before
+    if (!(getenv("LHGT_INGEST_STREAM") && atoi(getenv("LHGT_INGEST_STREAM")) == 0) && chunk_bytes >= 64 && chunk_bytes <= (1L << 30) &&
+        plan_columns(m, (size_t)chunk_bytes, c_lo, c_hi, default_threads(), start, n_lines, len_sums)) {
+        if (ingest_trace())
+            fprintf(stderr, "[lhgt ingest] part %d/%d: lines of chunks [%zu, %zu) of %zu of %s counted in %.3fs (pread + newline lists%s)\n", part, n_parts, c_lo, c_hi,
+                    nch, fq, now_s() - t0, len_sums ? ", with line lengths" : "");
+        return LHGT_OK;
+    }
     plan_range(m, (size_t)chunk_bytes, c_lo, c_hi, default_threads(), &st, &cnt);
     for (size_t i = 0; i < c_hi - c_lo; i++) { start[i] = st[i]; n_lines[i] = cnt[i]; }
     if (len_sums)      // cal_sam_ratio's pass (E:1244-1270) folded into the line count: line lengths by (line index inside the chunk) mod 4
@@ -1148,6 +1175,8 @@ int lhgt_pairs_load_fastq_planned(lhgt_ctx* ctx, const char* fq1, const char* fq
                                LHGT_TRY(plan_from_arrays(m1, start1, n_lines1, n1, p1));
                                LHGT_TRY(plan_from_arrays(m2, start2, n_lines2, n2, p2));
                                sh->p1 = p1; sh->p2 = p2; sh->part = part; sh->n_parts = n_parts;
+                               sh->raw_start1 = start1; sh->raw_count1 = n_lines1; sh->raw_n1 = n1;
+                               sh->raw_start2 = start2; sh->raw_count2 = n_lines2; sh->raw_n2 = n2;
                                return LHGT_OK;
                            });
 }
@@ -1237,6 +1266,8 @@ int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double rat
             LHGT_TRY(plan_from_arrays(m1, start1, n_lines1, n1, p1));
             LHGT_TRY(plan_from_arrays(m2, start2, n_lines2, n2, p2));
             sh->p1 = p1; sh->p2 = p2; sh->part = part; sh->n_parts = n_parts;
+            sh->raw_start1 = start1; sh->raw_count1 = n_lines1; sh->raw_n1 = n1;
+            sh->raw_start2 = start2; sh->raw_count2 = n_lines2; sh->raw_n2 = n2;
             return LHGT_OK;
         };
     long kept = 0;
@@ -1283,6 +1314,8 @@ int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent
             LHGT_TRY(plan_from_arrays(m1, start1, n_lines1, n1, p1));
             LHGT_TRY(plan_from_arrays(m2, start2, n_lines2, n2, p2));
             sh->p1 = p1; sh->p2 = p2; sh->part = part; sh->n_parts = n_parts;
+            sh->raw_start1 = start1; sh->raw_count1 = n_lines1; sh->raw_n1 = n1;
+            sh->raw_start2 = start2; sh->raw_count2 = n_lines2; sh->raw_n2 = n2;
             return LHGT_OK;
         };
     const size_t HALF = (size_t)chunk_bytes + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);

@@ -243,15 +243,75 @@ inline void parallel_for(long n, int threads, Fn fn) {
 inline size_t n_plan_chunks(size_t file_bytes, size_t chunk_bytes) { return file_bytes ? (file_bytes + chunk_bytes - 1) / chunk_bytes : 1; }
 
 
+// ---------------------------------------------------------------- the reference's -t N read partition, by line numbers (host_fastx.cpp)
+struct ThreadPart {
+    std::vector<long> first, count;   // per thread chunk: global index of its first line, lines it consumes
+    // sequence line g: in which chunk, and is it kept there?  (-1 = no chunk consumes it)
+    int keep(long g, double ratio, const float* random_array) const {
+        size_t i = (size_t)(std::upper_bound(first.begin(), first.end(), g) - first.begin());
+        while (i > 0) {   // chunks are in file order; a later chunk never starts before an earlier one
+            i--;
+            if (g < first[i]) continue;
+            if (g >= first[i] + count[i]) return -1;
+            const long local = g - first[i];
+            if (local % 4 != 1) return -1;
+            return (ratio >= 100.0 || (double)random_array[(local / 4) % LHGT_MAX_RANDOM] < ratio) ? 1 : 0;
+        }
+        return -1;
+    }
+};
+
+struct ThreadEmu {
+    ThreadPart f1, f2;
+    std::vector<long> pos1;   // byte at which each thread enters fq1 (and seeks fq2 to, E:350-352)
+};
+
+// How phase C pairs the lines of the two files (E:350-402).  It reads both in lock-step, line g of fq1 with line g + shift of fq2:
+// shift is 0 when the first read IDs agree; otherwise the reference rewinds fq2 (to byte 1 at -t 1) and reads on until a line
+// carries fq1's first ID (E:376-397), and the lock-step continues from there.  Once fq2 has run out std::getline leaves the string
+// as it was: empty when fq2's last line ended with a newline, that last line otherwise (E:356-367) -- the `stale` partner.
+// Phase A reads each file on its own (E:1426-1448), so fq2's records in front of the shift and behind fq1's end are counted, not voted.
+struct PairLayout {
+    long shift = 0;
+    long lines1 = 0, lines2 = 0;
+    const uint8_t* stale = nullptr;
+    size_t stale_len = 0;
+};
+
+// Plans made elsewhere and the share of fq1's chunks this caller parses: the ranks of a multi-GPU run each count the lines of
+// 1/world of both files, exchange the pieces, and parse chunks [part * nc / n_parts, (part + 1) * nc / n_parts) (lhgt_pairs_load_fastq_planned)
+struct ParseShare {
+    const ChunkPlan* p1 = nullptr;
+    const ChunkPlan* p2 = nullptr;
+    int part = 0, n_parts = 1;
+    // the plans as they came in (chunk by chunk, empty chunks included): lets the parse check whether they lie on the column grid of
+    // the single-pass loader (host_fastq_stream.cpp: seeded columns)
+    const uint64_t *raw_start1 = nullptr, *raw_start2 = nullptr;
+    const long *raw_count1 = nullptr, *raw_count2 = nullptr;
+    long raw_n1 = 0, raw_n2 = 0;
+};
+
 // host_fastx.cpp
 long thread_entry(const uint8_t* p, long n, long start);   // get_fq_start (E:44-89)
 // host_fastq_stream.cpp: the single-pass loader.  LHGT_OK: every pair of the files went through consume(), plan1 / plan2 hold the
 // line plans made on the way.  STREAM_RETRY (not an error code of the C-ABI): this pass does not decide the input -- *why says what
 // it met -- and whatever consume() has seen must be dropped and the files given to the planned loader.
 extern const int STREAM_RETRY;
+bool stream_chunking(size_t n1, size_t n2, size_t chunk_bytes, size_t* ch1, size_t* ch2);
+bool plan_columns(const Mapped& m, size_t ch, size_t c_lo, size_t c_hi, int threads, uint64_t* start, long* count, long* len_sums);
+// line numbers made elsewhere (the planned loader's plans, when they lie on the column grid): columns [col_lo, col_hi) are parsed
+// with no chain to wait for; emu / stale come from the caller's parse_setup
+struct StreamSeeds {
+    const long *P1 = nullptr, *P2 = nullptr;              // ncols + 1 entries each: lines in front of every column
+    const uint64_t *start1 = nullptr, *start2 = nullptr;  // first line start of every column (checked against what the columns see)
+    long ncols = 0, col_lo = 0, col_hi = 0;
+    const ThreadEmu* emu = nullptr;
+    const uint8_t* stale = nullptr;
+    size_t stale_len = 0;
+};
 int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, const char* fq2, double ratio, const float* random_array,
                        int shard_rank, int shard_world, long shard_block, int threads, size_t chunk_bytes, int emulate_threads,
                        const std::function<int(SlabPool**)>& prepare, const std::function<int(ParsedChunk&)>& consume,
-                       const std::function<void(bool)>& idle, ChunkPlan* plan1, ChunkPlan* plan2, std::string* why);
+                       const std::function<void(bool)>& idle, ChunkPlan* plan1, ChunkPlan* plan2, std::string* why, const StreamSeeds* seeds = nullptr);
 
 }  // namespace lhgt

@@ -181,9 +181,9 @@ class Exchange:
         return int(t.item())
 
     # ---- ingest: the line structure of a FASTQ, each rank counting 1/world of it
-    def fastq_plan(self, eng, path: str, want_len_sums: bool = False):
-        """(start u64[n], n_lines i64[n][, len_sums i64[n, 4]]) for ALL chunks of the file"""
-        st, cn, sums = eng.fastq_plan_part(path, self.rank, self.world, want_len_sums)
+    def fastq_plan(self, eng, path: str, want_len_sums: bool = False, chunk=None):
+        """(start u64[n], n_lines i64[n][, len_sums i64[n, 4]]) for ALL chunks of the file (chunk: bytes per chunk, default the loader's)"""
+        st, cn, sums = eng.fastq_plan_part(path, self.rank, self.world, want_len_sums, chunk=chunk)
         cols = [st.view(np.int64), cn] + ([sums[:, r].copy() for r in range(4)] if want_len_sums else [])
         flat = np.stack(cols, axis=1).reshape(-1) if len(st) else np.zeros(0, dtype=np.int64)
         allv = self.all_gather_var(torch.from_numpy(flat).to(self._dev())).cpu().numpy().reshape(-1, len(cols))

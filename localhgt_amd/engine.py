@@ -146,9 +146,15 @@ class Engine:
         return seen.value, kept.value
 
     # ---- multi-GPU ingest: every rank counts the lines of its share of a file, the pieces are exchanged (localhgt_amd/dist.py)
-    def fastq_plan_part(self, path: str, part: int, parts: int, want_len_sums: bool = False):
+    def fastq_pair_chunks(self, fq1: str, fq2: str) -> Tuple[int, int]:
+        """chunk sizes at which to plan the two files so that the planned parse can take the single-pass loader's columns"""
+        c1, c2 = C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_fastq_pair_chunk_bytes(fq1.encode(), fq2.encode(), C.byref(c1), C.byref(c2)))
+        return c1.value, c2.value
+
+    def fastq_plan_part(self, path: str, part: int, parts: int, want_len_sums: bool = False, chunk: Optional[int] = None):
         """(start[n] u64, n_lines[n] i64, len_sums[n, 4] i64 or None) of this part's chunks (include/localhgt_hip.h)"""
-        chunk = self.lib.lhgt_fastq_plan_chunk_bytes()
+        chunk = chunk or self.lib.lhgt_fastq_plan_chunk_bytes()
         n, tot = C.c_long(0), C.c_long(0)
         _lib.check(self.lib.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, None, None, 0, C.byref(n), C.byref(tot), None))
         st, cn = np.zeros(max(n.value, 1), dtype=np.uint64), np.zeros(max(n.value, 1), dtype=np.int64)
@@ -159,14 +165,15 @@ class Engine:
 
     def fastq_plan(self, path: str, want_len_sums: bool = False, other: Optional[str] = None):
         """the whole plan of one file made here (one rank); with `other`, that file's plan is made at the same time on a second
-        thread and (plan, plan_other) is returned"""
+        thread -- cut into as many chunks as `path` (fastq_pair_chunks) -- and (plan, plan_other) is returned"""
         if other is None:
             return self.fastq_plan_part(path, 0, 1, want_len_sums)
         import threading
         box = {}
-        t = threading.Thread(target=lambda: box.update(p2=self.fastq_plan_part(other, 0, 1, False)))
+        ch1, ch2 = self.fastq_pair_chunks(path, other)
+        t = threading.Thread(target=lambda: box.update(p2=self.fastq_plan_part(other, 0, 1, False, chunk=ch2)))
         t.start()
-        p1 = self.fastq_plan_part(path, 0, 1, want_len_sums)
+        p1 = self.fastq_plan_part(path, 0, 1, want_len_sums, chunk=ch1)
         t.join()
         return p1, box["p2"]
 

@@ -126,8 +126,9 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form) 
         eng.sampling_begin()
     plan1 = plan2 = None
     if dist:                                                   # every rank counts the lines of 1/world of both files (dist.fastq_plan)
-        plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1)
-        plan2 = dist.fastq_plan(eng, a.fq2)
+        ch1, ch2 = eng.fastq_pair_chunks(a.fq1, a.fq2)          # fq2 in as many chunks as fq1: the parse can then take whole columns
+        plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1, chunk=ch1)
+        plan2 = dist.fastq_plan(eng, a.fq2, chunk=ch2)
     elif a.sample > 1:                                         # the CLI's default --sample 2000000000: the line count the loader needs
         plan1, plan2 = eng.fastq_plan(a.fq1, True, other=a.fq2)   # anyway also yields cal_sam_ratio's base count (no extra pass over fq1)
     ratio = eng.sam_ratio_from_plan(plan1, a.sample) if plan1 is not None else eng.sam_ratio(a.fq1, a.sample)   # E:1392-1398

@@ -281,14 +281,14 @@ def _plan(lib, path, chunk, parts):
     return np.array(starts, dtype=np.uint64), np.array(counts, dtype=np.int64)
 
 
-def _digest_planned(lib, f1, f2, plan1, plan2, part, parts, state=None, ratio=100.0, rnd=None, threads=3, emulate=1):
+def _digest_planned(lib, f1, f2, plan1, plan2, part, parts, state=None, ratio=100.0, rnd=None, threads=3, emulate=1, chunk=1 << 40):
     import ctypes as C
     h = lib.load(require_gpu=False)
     seen, kept, dig = C.c_long(0), C.c_long(0), C.c_uint64(state or 0)
     cnt = (C.c_long * 3)()
     rp = rnd.ctypes.data_as(C.POINTER(C.c_float)) if rnd is not None else None
     u64, lp = C.POINTER(C.c_uint64), C.POINTER(C.c_long)
-    rc = h.lhgt_fastq_parse_digest_planned(f1.encode(), f2.encode(), float(ratio), rp, 0, 1, 1, threads, 1 << 40, emulate,
+    rc = h.lhgt_fastq_parse_digest_planned(f1.encode(), f2.encode(), float(ratio), rp, 0, 1, 1, threads, chunk, emulate,
                                            plan1[0].ctypes.data_as(u64), plan1[1].ctypes.data_as(lp), len(plan1[0]),
                                            plan2[0].ctypes.data_as(u64), plan2[1].ctypes.data_as(lp), len(plan2[0]),
                                            part, parts, 0 if state is None else 1, C.byref(seen), C.byref(kept), C.byref(dig), cnt)
@@ -662,6 +662,47 @@ def test_single_pass_loader_equals_the_planned_loader(lib, oracle, case_inputs, 
     assert "first read IDs differ" in left[("k24_fq2_stray2", 1)] and "first read IDs differ" in left[("foreign_front", 1)]
     assert "first read IDs differ" in left[("other_first_id", 1)]
     assert "longer than a chunk's margin" in left[("long_line", 1)]
+
+
+def test_planned_parse_takes_columns_when_the_plans_lie_on_the_grid(lib, oracle, case_inputs, tmp_path, monkeypatch):
+    """plans made at lhgt_fastq_pair_chunk_bytes' sizes (fq2 in as many chunks as fq1: what extract_ref plans under --sample > 1 and
+    in multi-rank runs) let every part be parsed column-wise with pread + newline lists (path 2): the parts' digests chain to the
+    digest of the line-by-line loader; plans at other sizes go through the chunk loop (path 0) with the same result"""
+    import ctypes as C
+    h = lib.load(require_gpu=False)
+    oracle.srand(9)
+    rnd = np.resize(oracle.sampling_array(1_000_000), 50_000_000)
+    seeded = 0
+    for name in ("k24_seed7", "k24_fq2_longer", "k24_fq2_short_nonl", "k24_t4", "k24_t10_sample_bases", "k24_fq2_stray2"):
+        fa, f1, f2, _ = case_inputs(name)
+        t = cases.CASES[name].threads
+        for emulate in sorted({1, t}):
+            for ratio in (100.0, 35.0):
+                want = _digest_full(lib, f1, f2, ratio=ratio, rnd=rnd, threads=2, chunk=1 << 40, emulate=emulate, stream=False)
+                for chunk, parts in ((50000, 1), (7777, 3), (300000, 2)):
+                    monkeypatch.setenv("LHGT_INGEST_CHUNK_BYTES", str(chunk))
+                    c1, c2 = C.c_long(0), C.c_long(0)
+                    assert h.lhgt_fastq_pair_chunk_bytes(f1.encode(), f2.encode(), C.byref(c1), C.byref(c2)) == 0 and c1.value == chunk
+                    for on_grid in (True, False):
+                        plan1, plan2 = _plan(lib, f1, c1.value, parts), _plan(lib, f2, c2.value if on_grid else c1.value + 13, parts)
+                        state, kept, cnt, paths = None, 0, [0, 0, 0], set()
+                        rc = 0
+                        for part in range(parts):
+                            rc, sn, kp, dg, c3 = _digest_planned(lib, f1, f2, plan1, plan2, part, parts, state=state if part else None, ratio=ratio, rnd=rnd,
+                                                                 emulate=emulate, chunk=c1.value)
+                            if rc:
+                                break
+                            state, kept, cnt = dg, kept + kp, [a + b for a, b in zip(cnt, c3)]
+                            paths.add(h.lhgt_ingest_last_path(None, 0))
+                        assert rc == want[0], (name, emulate, ratio, chunk, parts, on_grid)
+                        if rc == 0:
+                            assert (kept, state, cnt) == (want[2], want[3], want[4]), (name, emulate, ratio, chunk, parts, on_grid, paths)
+                            if on_grid and name != "k24_fq2_stray2":
+                                assert paths == {2}, (name, emulate, chunk, parts, paths)
+                                seeded += 1
+                            if not on_grid:
+                                assert 2 not in paths
+    assert seeded > 40
 
 
 def _digest_slabs(lib, f1, f2, ratio=100.0, rnd=None, threads=3, chunk=20000, emulate=1, stream=True):

@@ -26,11 +26,11 @@ from localhgt_amd import _lib                        # noqa: E402
 CHUNK = 2 << 20
 
 
-def plan_part(h, path, part, parts):
+def plan_part(h, path, part, parts, chunk):
     n, total = C.c_long(0), C.c_long(0)
-    assert h.lhgt_fastq_plan_part(path.encode(), CHUNK, part, parts, None, None, 0, C.byref(n), C.byref(total), None) == 0
+    assert h.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, None, None, 0, C.byref(n), C.byref(total), None) == 0
     st, cnt = np.zeros(n.value, np.uint64), np.zeros(n.value, np.int64)
-    rc = h.lhgt_fastq_plan_part(path.encode(), CHUNK, part, parts, st.ctypes.data_as(C.POINTER(C.c_uint64)), cnt.ctypes.data_as(C.POINTER(C.c_long)),
+    rc = h.lhgt_fastq_plan_part(path.encode(), chunk, part, parts, st.ctypes.data_as(C.POINTER(C.c_uint64)), cnt.ctypes.data_as(C.POINTER(C.c_long)),
                                 n.value, C.byref(n), C.byref(total), None)
     assert rc == 0
     return st, cnt
@@ -43,8 +43,10 @@ def worker(argv):
     h = _lib.load(require_gpu=False)
     t0 = time.time()
     if step == "plan":
-        a = plan_part(h, fq1, part, parts)
-        b = plan_part(h, fq2, part, parts)
+        c1, c2 = C.c_long(0), C.c_long(0)
+        assert h.lhgt_fastq_pair_chunk_bytes(fq1.encode(), fq2.encode(), C.byref(c1), C.byref(c2)) == 0      # fq2 in as many chunks as fq1
+        a = plan_part(h, fq1, part, parts, c1.value)
+        b = plan_part(h, fq2, part, parts, c2.value)
         dt = time.time() - t0
         np.savez(os.path.join(work, f"plan_{parts}_{part}.npz"), s1=a[0], c1=a[1], s2=b[0], c2=b[1])
         print(json.dumps({"step": "plan", "part": part, "s": dt}), flush=True)
@@ -64,7 +66,7 @@ def worker(argv):
     u64, lp = C.POINTER(C.c_uint64), C.POINTER(C.c_long)
     rc = h.lhgt_fastq_parse_rate(fq1.encode(), fq2.encode(), 100.0, None, threads, CHUNK, emulate, s1.ctypes.data_as(u64), c1.ctypes.data_as(lp), len(s1),
                                  s2.ctypes.data_as(u64), c2.ctypes.data_as(lp), len(s2), part, parts, C.byref(seen), C.byref(kept), C.byref(bases), C.byref(secs), None)
-    print(json.dumps({"step": "parse", "part": part, "rc": rc, "s": secs.value, "kept": kept.value, "bases": bases.value}), flush=True)
+    print(json.dumps({"step": "parse", "part": part, "rc": rc, "s": secs.value, "kept": kept.value, "bases": bases.value, "path": h.lhgt_ingest_last_path(None, 0)}), flush=True)
 
 
 def run_step(step, fq1, fq2, parts, threads, emulate, work):
@@ -99,21 +101,30 @@ def main():
     lines = [f"host-side FASTQ ingest alone (no GPU in the timed part), {n_pairs} pairs = {size / 1e9:.1f} GB of text in the page cache, {hw} hardware threads; "
              f"aggregate = pairs / (slowest rank's line count + slowest rank's parse)",
              "processes x threads each | line count s (max over ranks) | parse s (max) | aggregate M pairs/s | GB/s of text"]
+    quota = 0
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = 0 if q == "max" else int(q) // int(per)
+    except (OSError, ValueError):
+        pass
+    lines[0] += f"; CPU quota of this container: {quota or 'none'} CPUs"
+    base = quota or min(hw, 48)
     for emulate in (1, 10):
         for rep in range(2):
-            for t in (24, 48, 96):
+            for t in sorted({max(2, base // 2), base, base * 3 // 2}):
                 r = run_step("single", fq1, fq2, 1, t, emulate, work)[0]
                 lines.append(f"1 x {t:3d}, ONE PASS (-t {emulate:2d}{' emulated' if emulate > 1 else ''}) | - | {r['s']:.3f} | {n_pairs / r['s'] / 1e6:.1f} | {size / r['s'] / 1e9:.1f}"
                              f"   [single pass taken: {r['single_pass']} {r['why']}; kept {r['kept']}]")
                 print(lines[-1], flush=True)
     for parts in (1, 2, 4, 8):
-        for t in sorted({48, max(8, hw // parts // 2), max(8, hw // parts)}):
+        for t in sorted({max(2, base // parts), max(2, base * 3 // 2 // parts)}):
             for rep in range(2):
                 a = run_step("plan", fq1, fq2, parts, t, 1, work)
                 b = run_step("parse", fq1, fq2, parts, t, 1, work)
                 assert all(x["rc"] == 0 for x in b) and sum(x["kept"] for x in b) == n_pairs, b
                 tp, tq = max(x["s"] for x in a), max(x["s"] for x in b)
-                lines.append(f"{parts} x {t:3d}, planned (count, exchange, parse 1/{parts}) | {tp:.3f} | {tq:.3f} | {n_pairs / (tp + tq) / 1e6:.1f} | {size / (tp + tq) / 1e9:.1f}")
+                how = {2: "columns on the plans' line numbers", 0: "chunk loop"}.get(b[0].get("path"), "?")
+                lines.append(f"{parts} x {t:3d}, planned (count, exchange, parse 1/{parts}: {how}) | {tp:.3f} | {tq:.3f} | {n_pairs / (tp + tq) / 1e6:.1f} | {size / (tp + tq) / 1e9:.1f}")
                 print(lines[-1], flush=True)
     if out_path:
         open(out_path, "w").write("\n".join(lines) + "\n")

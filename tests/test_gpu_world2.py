@@ -87,7 +87,7 @@ def test_two_ranks_on_one_gpu_write_the_reference_files(case_inputs, tmp_path, n
         assert 0.3 * total_mb < share[r][0] < 0.7 * total_mb, share
     assert share[0][2] + share[1][2] == share[0][3]
     if mode == "sharded":
-        assert "lines of bytes" in res.stderr
+        assert "lines of bytes" in res.stderr or "lines of chunks" in res.stderr     # every rank counted its share of the lines (either planner)
 
 
 @pytest.mark.parametrize("name,world,mode", [

@@ -14,13 +14,13 @@ __device__ __forceinline__ uint64_t digest_mix(uint64_t i, uint64_t v) {
     return x ^ (x >> 31);
 }
 template <class T>
-__global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, uint64_t n, uint64_t mask, unsigned long long* __restrict__ out) {
+__global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, uint64_t n, uint64_t mask, uint64_t index_base, unsigned long long* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t acc = 0, nz = 0;
     for (; i < n; i += stride) {
         const uint64_t x = (uint64_t)v[i] & mask;
-        acc += digest_mix(i, x);
+        acc += digest_mix(index_base + i, x);
         nz += x != 0;
     }
 #pragma unroll
@@ -119,11 +119,15 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || !out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     const void* p = nullptr;
-    uint64_t n = 0;
+    uint64_t n = 0, index_base = 0;
     int bytes = 4;
     switch (what) {
         case 0: p = ctx->d_counts; n = ctx->counts_words; break;                                   // packed 2-bit table, as words
-        case 1: p = ctx->d_flags; n = ctx->n_pos; bytes = 1; break;                                // per reference position
+        case 1:                                                                                    // per reference position, numbered over ALL indexed
+            p = ctx->d_flags; n = ctx->n_pos; bytes = 1;                                           // contigs: the digests of a reference's shards add up
+            if (!ctx->all_lens.empty() && !ctx->contigs.empty())                                   // (mod 2^64) to the digest of the whole
+                for (uint32_t c = 0; c + 1 < ctx->contigs[0].ref_index && c < ctx->all_lens.size(); c++) index_base += ctx->all_lens[c];
+            break;
         case 2: p = ctx->d_peak_kmer; n = ctx->d_peak_kmer ? (1ull << ctx->k) : 0; break;
         case 3: p = ctx->d_loci; n = ctx->n_peaks > 0 ? 2ull * (uint64_t)ctx->id_end : 0; break;
         case 4: p = ctx->d_filter; n = ctx->n_peaks > 0 ? (uint64_t)ctx->id_end : 0; break;         // votes (u32, unclamped)
@@ -134,8 +138,8 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
     if (!ctx->d_digest) LHGT_HIP(lhgt::dev_malloc(&ctx->d_digest, 16));     // one small scratch per context, freed with it
     unsigned long long* d_out = ctx->d_digest;
     LHGT_HIP(hipMemsetAsync(d_out, 0, 16, ctx->stream));
-    if (bytes == 1) hipLaunchKernelGGL((digest_kernel<uint8_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint8_t*)p, n, mask, d_out);
-    else hipLaunchKernelGGL((digest_kernel<uint32_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint32_t*)p, n, mask, d_out);
+    if (bytes == 1) hipLaunchKernelGGL((digest_kernel<uint8_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint8_t*)p, n, mask, index_base, d_out);
+    else hipLaunchKernelGGL((digest_kernel<uint32_t>), dim3(8192), dim3(256), 0, ctx->stream, (const uint32_t*)p, n, mask, index_base, d_out);
     unsigned long long h[2] = {0, 0};
     hipError_t e1 = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
             uint32_t h[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
-            uint32_t known = 0, is3 = 0;
+            uint32_t known = 0, is3 = 0, stop_nz = 0;
             bool all3 = true;
 #pragma unroll
             for (int i = 0; i < 3; i++)
@@ -206,11 +206,13 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
                     const uint32_t cnt = h[i] != 0 ? count_of(counts, h[i]) : 0u;   // hash 0 = invalid (E:936-941)
                     known |= 1u << i;
                     if (cnt == 3u) is3 |= 1u << i;                                    // least_depth 3 (E:580)
-                    else all3 = false;
+                    else { all3 = false; stop_nz = cnt > 0u; }
                 }
             const bool exact = known == full || is3 != 0u;
             f = (uint8_t)((is3 != 0u) | ((is3 == full) << 1) | (exact ? 0x80 : 0));
-            ps = (uint8_t)(is3 | (known << 4));
+            // bit 3 (round 5): the count of the one probed hash that did not read 3 is > 0 -- what register_peaks asks of every hash
+            // of a selected position (E:250, 265); with it, and the fill's record below, it probes the table for unprobed hashes only
+            ps = (uint8_t)(is3 | (stop_nz << 3) | (known << 4));
         }
         flags[c.flat_base + j] = f;
         pstate[c.flat_base + j] = ps;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
 __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ list, const RefSource rs,
                                                      const uint32_t* __restrict__ counts, int k, int e, uint8_t* __restrict__ flags,
-                                                     uint8_t* __restrict__ pstate, long n_blk) {
+                                                     uint8_t* __restrict__ pstate, long n_blk, int record_nz /* the trio-first form: see below */) {
     const long blk = block2d();
     if (blk >= n_blk) return;
     const TileDev t = tiles[list[blk]];
@@ -234,7 +236,9 @@ __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__
         const uint8_t f = flags[c.flat_base + j];
         if (f & 0x80) continue;                     // already exact (a neighbouring workgroup may write the same values meanwhile)
         const uint8_t ps = pstate[c.flat_base + j];
-        uint32_t known = ps >> 4, is3 = ps & 7u;
+        if (ps & 0x80) continue;                    // ... and has written this byte already
+        uint32_t known = (ps >> 4) & 7u, is3 = ps & 7u;
+        uint32_t nz = is3 | (((ps >> 3) & 1u) ? (known & ~is3) : 0u);   // trio-first: the one probed hash that did not read 3 has its "> 0" in bit 3
         if (j < nk) {
             const RefKmer km = ref_kmer(rs, c, j, k, e);
 #pragma unroll
@@ -243,11 +247,15 @@ __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__
                     const uint32_t h = ref_hash(rs, km, i);
                     const uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;
                     if (cnt == 3u) is3 |= 1u << i;
+                    if (cnt > 0u) nz |= 1u << i;
                 }
         }
         known = full;
         flags[c.flat_base + j] = (uint8_t)((f & 0x7c) | (is3 != 0u) | ((is3 == full) << 1) | 0x80);
-        pstate[c.flat_base + j] = (uint8_t)(is3 | (known << 4));
+        // record_nz: every hash's count is known here, so bits 4-6 take "count > 0" per hash and bit 7 says so (register_peaks then
+        // probes nothing for this position).  The single-first form probes several hashes that do not read 3 without keeping their
+        // counts, so there the byte stays "probed" and register_peaks looks the counts up, as before.
+        pstate[c.flat_base + j] = record_nz ? (uint8_t)(is3 | (nz << 4) | 0x80) : (uint8_t)(is3 | (known << 4));
     }
 }
 
@@ -847,6 +855,7 @@ __global__ void __launch_bounds__(1024) tile_chunk_scan(uint32_t* __restrict__ v
 __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const RefSource rs, const uint32_t* __restrict__ counts,
                                                      const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
+                                                     const uint8_t* __restrict__ pstate /* trio-first form: the probe state with its "> 0" records */,
                                                      const uint32_t* __restrict__ tile_base,
                                                      int k, int e, int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer,
                                                      uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2,
@@ -884,11 +893,21 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
         }
         if (j < nk) {  // E:247,262; beyond nk the hit array is zero anyway
             const RefKmer km = ref_kmer(rs, c, j, k, e);
-            const uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u;
+            uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u, have = nzmask ? 0xffu : 0u;
+            if (pstate) {                 // trio-first form (e <= 3): what the probe kernels already know about "count > 0" per hash
+                const uint32_t ps = pstate[c.flat_base + j];
+                if (ps & 0x80u) { nz = (ps >> 4) & 7u; have = 7u; }                         // filled: every hash
+                else {
+                    const uint32_t known = (ps >> 4) & 7u, is3 = ps & 7u;
+                    nz = is3 | (((ps >> 3) & 1u) ? (known & ~is3) : 0u);
+                    have = known;                                                           // the others are looked up below
+                }
+            }
             for (int i = 0; i < e; i++) {
                 uint32_t h = ref_hash(rs, km, i);
-                // hit > 0 for this hash: the bit ref_flags recorded (hashes 8.., and all of them after the lite form, are probed again)
-                if (nzmask && i < 8 ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
+                // hit > 0 for this hash: the bit the probe kernels recorded, where they did (hashes 8.., and those the single-first /
+                // trio-first forms left unprobed or without a record, are probed again)
+                if (i < 8 && ((have >> i) & 1u) ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                     atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
                         atomicOr(&prefilter[pf_word(h, pf_mask)], pf_word_bits(h, pf2));
@@ -1073,7 +1092,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
-                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need);
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 1);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
@@ -1100,7 +1119,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
-                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need);
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 0);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
@@ -1311,7 +1330,9 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, max_peak + first_id));
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
-                       ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
+                       ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask,
+                       ctx->scan_form == 2 && !(ctx->debug & (1 << 20)) ? ctx->d_nzmask : nullptr /* debug bit 20: look every count up (A/B) */,
+                       ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
                        ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -236,6 +236,7 @@ def main():
     scan = eng.scan_info()
     vote_form = eng.vote_info()
     xch_main = dict(wl.xch)
+    moved_main = dict(dist.moved) if dist else None
     other_form = None
     if len(forms) > 1:                                   # the other form of phase B, a few steps, same reads
         load_reference(forms[1])
@@ -273,6 +274,13 @@ def main():
     compulsory = 2 * read_store + (ref_bases * 3 // 8 if args.ref_form == "packed" else ref_bases * 4 * e) + 2 * ((1 << k) // 4) + (1 << k) * 4
     step_s = dt / args.steps
     xch_ms = {kk: round(v / args.steps * 1e3, 3) for kk, v in xch_main.items()} if dist else None
+    xch_bytes = None
+    if dist:                     # what rank 0 sent + received per step in each exchange, and at what rate (host clock around the call: device work of the merge included)
+        xch_bytes = {kk: {"bytes_per_step": int(moved_main[kk] // args.steps), "GB_per_s": round(moved_main[kk] / max(xch_main[kk], 1e-9) / 1e9, 2) if xch_main[kk] > 0 else None}
+                     for kk in moved_main}
+        print("bench: exchanges of rank 0 per step (" + dist.backend + "): " + "; ".join(
+            f"{kk} {v['bytes_per_step'] / 1e6:.1f} MB in {xch_ms[kk]:.2f} ms" + (f" = {v['GB_per_s']} GB/s" if v["GB_per_s"] else "") for kk, v in xch_bytes.items()),
+            file=sys.stderr, flush=True)
     cfg_no = 2 if headline else 1 if workload_key(args) == (1000, 10_000_000, 0, False, 0) else "-"
     sample_txt = (f"drawn from {args.sample_contigs} of its contigs" if args.sample_contigs else "drawn from half of its contigs") + (f", SNP {args.snp / 10:g} %" if args.snp else "")
     detail = {
@@ -286,7 +294,7 @@ def main():
                    "parallelism": f"reads sharded x{world}" + (", index sharded" if forms[0] else ", phase B replicated on every GPU (per-GPU work fixed)" if world > 1 else "")},
         "world_size": torch.distributed.get_world_size() if dist else 1, "backend": dist.backend if dist else None,
         "phase_ms": {"count_A": round(per_ms[0], 3), "scan_B": round(per_ms[1], 3), "vote_C": round(per_ms[2], 3)},
-        "exchange_ms": xch_ms,
+        "exchange_ms": xch_ms, "exchange_bytes": xch_bytes,
         "n1_equivalent_ms": round(step_s * 1e3 - sum(xch_ms.values()), 3) if xch_ms else round(step_s * 1e3, 3),
         "sharded_index" if (other_form and forms[1]) else "replicated_index": other_form,
         "scan_B_form": scan, "vote_form": vote_form, "work_stats": stats, "memory_plan_bytes": plan,

@@ -87,12 +87,15 @@ class Exchange:
         self.device = local_rank if device is None else device     # the GPU this rank's engine lives on
         self.adapter = adapter or GpuAdapter()
         self.own_group = own_group
-        if own_group and not dist.is_initialized():
+        if own_group and not dist.is_initialized():       # (from_env has made the group already when it had to ask the ranks for the backend)
             if backend == "nccl":
                 torch.cuda.set_device(self.device)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
         self.backend = backend
         self.staged_bytes = 0       # bytes that went through host memory (gloo with device buffers)
+        # bytes THIS rank sent + received in each exchange since the last reset (bench.py: GB/s per exchange, so that the first run on
+        # a real 8-GPU node explains itself)
+        self.moved = {"merge_counts": 0, "sharded_scan": 0, "sum_votes": 0}
 
     @classmethod
     def from_env(cls, backend: Optional[str] = None, adapter=None):
@@ -107,13 +110,28 @@ class Exchange:
             backend = os.environ.get("LHGT_DIST_BACKEND")
         n_dev = torch.cuda.device_count()
         if backend is None:
-            # RCCL wants one GPU per rank; ranks that share a GPU exchange through host memory over gloo.  Only what the launcher
-            # really said counts: LOCAL_WORLD_SIZE when it is set (torchrun sets it; srun, mpirun or hand-set RANK/WORLD_SIZE do not,
-            # and WORLD_SIZE over several nodes says nothing about this node), or a LOCAL_RANK beyond the node's GPUs
-            shared = n_dev == 0 or local >= n_dev or ("LOCAL_WORLD_SIZE" in os.environ and int(os.environ["LOCAL_WORLD_SIZE"]) > n_dev)
+            # RCCL wants one GPU per rank; ranks that share a GPU exchange through host memory over gloo.  What ONE rank sees does
+            # not settle it: without LOCAL_WORLD_SIZE (srun, mpirun, hand-set RANK / WORLD_SIZE) rank 0 of two ranks on a one-GPU
+            # node sees nothing wrong (LOCAL_RANK 0 < 1 GPU) while rank 1 does, and two ranks that pick different backends hang in
+            # their first collective.  So the group is created with both backends -- "cpu:gloo,cuda:nccl": CPU tensors
+            # travel over gloo, device tensors over RCCL, whose communicator is only made by the first device collective -- every
+            # rank says what it sees, and the maximum decides for all.
+            mine = n_dev == 0 or local >= n_dev
+            for var in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE"):
+                v = os.environ.get(var, "")
+                if v.isdigit() and int(v) > n_dev:
+                    mine = True
+            if not dist.is_initialized():
+                if n_dev and not mine:
+                    torch.cuda.set_device(local % n_dev)
+                init_backend = os.environ.get("LHGT_DIST_INIT_BACKEND") or ("cpu:gloo,cuda:nccl" if n_dev else "gloo")   # (the variable: CPU tests that fake a GPU count)
+                dist.init_process_group(backend=init_backend, rank=rank, world_size=world)
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            shared = bool(flag.item())
             backend = "gloo" if shared else "nccl"
             if shared and n_dev and rank == 0:
-                print(f"localhgt_amd.dist: more ranks than GPUs on this node ({n_dev}): collectives staged through host memory over gloo "
+                print(f"localhgt_amd.dist: more ranks than GPUs on a node ({n_dev} here): collectives staged through host memory over gloo "
                       f"(results identical, exchanges much slower); LHGT_DIST_BACKEND=nccl to insist on RCCL", file=sys.stderr, flush=True)
         if n_dev:
             device = local % n_dev
@@ -203,6 +221,7 @@ class Exchange:
         self.adapter.sync(eng)
         recv = torch.empty(w * mine_n, dtype=table.dtype, device=table.device)
         self._all_to_all(recv, table, [mine_n] * w, sizes)   # recv[j*mine_n:(j+1)*mine_n] = rank j's copy of MY slice
+        self.moved["merge_counts"] += (n - mine_n) + (w - 1) * mine_n + (w - 1) * sl + (n - mine_n)   # all-to-all out + in, all-gather out + in
         self.adapter.sync(eng)                           # RCCL runs on torch's stream, the merge kernel on the engine's
         for j in range(w):
             if j != self.rank and mine_n:
@@ -237,13 +256,20 @@ class Exchange:
         emulated_threads > 1 (the reference's -t N, lhgt_set_thread_emulation): the contig groups of split_ref cut across the
         ranks' shards, so the per-group peak counts are summed over the ranks first -- they fix each thread's id range, the
         sentinel lines of the interval file and whether a peak holds the invisible id 0 (first_id)."""
-        err = None
+        from ._lib import LocalHGTError
+        err, mine = None, 0
         try:
             n_new, n_sel = self.adapter.scan_local(eng, hit_ratio, match_ratio)
+        except LocalHGTError as e:                         # 1: only the -t N emulation refuses (the caller falls back to -t 1 -- on EVERY rank), 2: anything else
+            err, mine = e, (1 if (e.code == 4 and "emulation:" in str(e)) or (e.code == 6 and "Too many peaks! thread" in str(e)) else 2)
         except Exception as e:                             # noqa: BLE001 -- a rank that failed alone must not leave the others in the gather below
-            err = e
-        if self.agree(1 if err else 0):
-            raise err if err else RuntimeError(f"reference-sharded scan failed on another rank (rank {self.rank} stops with it)")
+            err, mine = e, 2
+        worst = self.agree(mine)
+        if worst:                                          # the same class and code on every rank, so that all fall back or all stop (ADVICE r4)
+            if mine == worst:
+                raise err
+            raise LocalHGTError(4 if worst == 1 else 5, "-t N emulation: refused on another rank" if worst == 1 else
+                                f"reference-sharded scan failed on another rank (rank {self.rank} stops with it)")
         allc = self._gather_small([n_new, n_sel])
         news = [c[0] for c in allc]
         first_id = 0
@@ -256,6 +282,8 @@ class Exchange:
         self.adapter.sync(eng)
         loci_all = self.all_gather_var(loci)
         regs_all = self.all_gather_var(regs)
+        mine_words, all_words = loci.numel() + regs.numel(), loci_all.numel() + regs_all.numel()
+        self.moved["sharded_scan"] += 4 * ((self.world - 1) * mine_words + (all_words - mine_words))      # all-gather: mine to the others, theirs to me
         if first_id:                                     # no peak holds id 0: the loci table starts with an empty row
             loci_all = torch.cat([torch.zeros(2 * first_id, dtype=loci_all.dtype, device=loci_all.device), loci_all])
         self.adapter.sync(eng)
@@ -269,4 +297,5 @@ class Exchange:
         self.adapter.sync(eng)
         if t is not None and t.numel():
             self._all_reduce_sum(t)
+            self.moved["sum_votes"] += 2 * (2 * (self.world - 1) * t.numel() * t.element_size()) // self.world   # ring all-reduce: 2 (w - 1) / w of the buffer out, the same in
         self.adapter.sync(eng)

@@ -107,6 +107,31 @@ def test_exchange_world2_gloo(tmp_path, world, n_bytes):
         assert (np.load(tmp_path / f"votes_out_{r}.npy") == want_v).all()
 
 
+def _backend_worker(rank, world, port, tmp):
+    """two ranks on a node with ONE GPU, started without LOCAL_WORLD_SIZE (srun / mpirun / by hand): rank 0 alone sees nothing
+    wrong (LOCAL_RANK 0 < 1 GPU), rank 1 does -- both must end up staging through gloo (they picked nccl and gloo)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LHGT_DIST_INIT_BACKEND="gloo")
+    for var in ("LOCAL_WORLD_SIZE", "LHGT_DIST_BACKEND", "SLURM_NTASKS_PER_NODE", "OMPI_COMM_WORLD_LOCAL_SIZE"):
+        os.environ.pop(var, None)
+    torch.cuda.device_count = lambda: 1               # the node's one GPU
+    torch.cuda.set_device = lambda d: None
+    from localhgt_amd.dist import Exchange
+    ex = Exchange.from_env(adapter=NumpyAdapter())
+    assert ex.agree(rank) == world - 1                # the group works
+    open(os.path.join(tmp, f"backend_{rank}.txt"), "w").write(f"{ex.backend} {ex.device}")
+    ex.close()
+
+
+def test_ranks_agree_on_the_backend_when_only_one_of_them_sees_the_shared_gpu(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_backend_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [open(tmp_path / f"backend_{r}.txt").read() for r in range(2)]
+    assert got == ["gloo 0", "gloo 0"], got
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher starts its two ranks itself; --dry-run drives the launcher, the process
     group and every exchange on host tensors (gloo) and prints the one JSON line on rank 0"""
@@ -263,3 +288,9 @@ def test_bench_needed_bytes_model_and_memory_plan():
     with pytest.raises(SystemExit, match="needs 7"):
         check_fits(memory_plan(25_000_000, 50_000_000_000, 50000), what="50 Gbase as an index")
     check_fits(memory_plan(25_000_000, 50_000_000_000, 50000, packed=True))
+    # configs[3] as `bench.py --gpus 8 --ref-form packed` lays it out: 125 M pairs per GPU, the 13 Gbase reference whole on every
+    # GPU as 4.9 GB of planes; and configs[4]'s reference sharded over the eight as an index (75 GB each) fits where the whole does not
+    p3 = check_fits(memory_plan(125_000_000, 13_000_000_000, 13000, packed=True, world=8))
+    assert abs(p3["reference"] - 4.875e9) < 1e7 and p3["exchange_buffers"] == 2 * (1 << 32) // 4 and 100e9 < p3["total"] < 125e9
+    p4 = check_fits(memory_plan(25_000_000, 50_000_000_000, 50000, world=8, shard_index=True))
+    assert abs(p4["reference"] - 75e9) < 1e9

@@ -64,8 +64,9 @@ def compact_line(detail):
     cb = detail.get("cpu_baseline")
     if isinstance(cb, dict):
         c = {k: cb[k] for k in ("value", "unit", "cores", "kind", "identical_to_gpu", "error") if k in cb}
-        if "sample" in cb:
-            c["sample"] = cb["sample"][:110]
+        if "sample" in cb:                                  # cut at a word, and say that it was cut
+            smp = cb["sample"]
+            c["sample"] = smp if len(smp) <= 110 else smp[:107].rsplit(" ", 1)[0] + " ..."
         ref = cb.get("reference")
         if isinstance(ref, dict):
             c["reference"] = {k: ref[k] for k in ("value", "threads", "wall_s", "own_clock_s", "identical_to_gpu", "error") if k in ref}

@@ -57,6 +57,9 @@ class Workload:
         self.fence()
         for key in self.xch:
             self.xch[key] = 0.0
+        if self.dist:
+            for key in self.dist.moved:
+                self.dist.moved[key] = 0
         t0 = time.time()
         ms = [0.0, 0.0, 0.0, 0.0]
         seen = set()

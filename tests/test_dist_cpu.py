@@ -282,6 +282,11 @@ def test_bench_needed_bytes_model_and_memory_plan():
     for ent in roof.values():
         assert 0 < ent["frac_needed"] <= 1.0 and ent["overfetch"] >= 0.95      # needed bytes never exceed the peak; the counters never show less than needed
     assert roof["vote_kernel"]["model_exceeded"] and roof["vote_kernel"]["overfetch"] > 5
+    # what bounds each kernel (round 5): the queued vote by the L2's request rate (78.4 G requests in 384 ms = 204 G/s of the guide's
+    # 269.5), phase A by random LDS operations (6 per key), the probe kernel of phase B by the fabric's line rate
+    assert (roof["vote_kernel"]["bound"], roof["count_A"]["bound"], roof["ref_flags"]["bound"]) == ("l2_requests", "lds_random", "hbm_lines")
+    assert abs(roof["vote_kernel"]["frac_of_bound"] - 78.4 / 0.384 / 269.5) < 0.01 and roof["vote_kernel"]["frac"] < 0.35
+    assert abs(roof["count_A"]["frac_of_bound"] - 6 * 71e9 / 0.285 / 1e12 / 3.99) < 0.01
     plan = memory_plan(125_000_000, 13_000_000_000, 13000, world=8)
     assert 250e9 < plan["total"] < 0.95 * HBM_BYTES and abs(plan["reference"] - 156e9) < 1e9 and abs(plan["partition_key_buffers"] - 38.5e9) < 1e9
     check_fits(plan)

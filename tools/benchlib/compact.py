@@ -5,7 +5,7 @@ import json
 LIMIT = 4096
 
 ROOF_KEYS = ("kernel", "bound", "peak", "unit", "launch_ms", "launches_per_step", "traffic", "achieved", "frac", "frac_raw", "frac_model",
-             "model_exceeded", "frac_needed", "overfetch", "l2_hit_rate")
+             "model_exceeded", "frac_needed", "overfetch", "l2_hit_rate", "frac_of_bound")
 
 
 def _roof(r):
@@ -15,6 +15,9 @@ def _roof(r):
     rr = r.get("request_rate")
     if isinstance(rr, dict):
         out["request_rate"] = {"value": rr.get("value"), "ceiling": rr.get("ceiling"), "unit": "G req/s"}
+    bc = r.get("bound_ceiling")
+    if isinstance(bc, dict) and "value" in bc:              # what bounds the kernel: achieved / ceiling in the bound's own unit (frac_of_bound)
+        out["bound_ceiling"] = {"value": bc.get("value"), "ceiling": bc.get("ceiling"), "unit": bc.get("unit")}
     return out
 
 

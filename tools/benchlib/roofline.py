@@ -1,4 +1,5 @@
-"""Rooflines of the three kernel families of a step against the 8 TB/s HBM peak.
+"""Rooflines of the three kernel families of a step against the 8 TB/s HBM peak -- and, since round 5, against the resource that
+really bounds each of them (`bound`, `frac_of_bound`: BOUNDS below).
 
 Two byte models per kernel, both per bench step:
   model   SURVEY.md 8d's algorithmic bytes -- one 64-B sector per probe of the REFERENCE's algorithm (714 probes per pair in
@@ -19,6 +20,24 @@ LINE = 128                       # bytes a random probe moves (one fabric read r
 CEIL_HBM_GREQ, CEIL_L2_GREQ = 56.0, 254.0
 HBM_CEILING = ("hbm_read_requests", "TCC_EA0_RDREQ_sum", CEIL_HBM_GREQ, "tools/probe_shapes.hip: random 4-byte loads from a 1 GiB table, 128-B line fills/s")
 L2_CEILING = ("l2_read_requests", "TCP_TCC_READ_REQ_sum", CEIL_L2_GREQ, "tools/probe_rates.hip: random 4-byte loads from an L2-resident table")
+# What BOUNDS each kernel (round 5).  The HBM fractions above stay as they were; next to them `bound` names the
+# resource the kernel sits on and `frac_of_bound` how much of that resource's ceiling it uses:
+#   hbm_lines    ref_flags*, the dense vote: random probes, every one a 128-B line fill.  Ceiling = the fabric's line rate, 56 G
+#                fills/s = 7.2 TB/s (tools/probe_shapes.hip; the guide's HBM figures are for streams: 8 TB/s spec, 6.3 achievable)
+#   l2_requests  the queued and the fold vote: 714 bitmap probes per pair answered by the XCDs' L2s.  Ceiling = the guide's L2
+#                figure, 34.5 TB/s in 128-B requests = 269.5 G requests/s (MI355X_MICROARCH.md "L2 (per XCD)"); our own
+#                microbenchmark of random 4-byte loads from an L2-resident table stays in request_rate (254 G/s)
+#   lds_random   phase A: six random LDS operations per key over its three kernels (ticket + slot store, ticket + slot store, read +
+#                compare-and-swap).  Ceiling = 6.5 lane-operations per clock and CU -- the guide's bank model (32 banks, a wave's 64
+#                random lanes in two groups: 3.5 deep each) and what profiles/r04/phase_a_direct_ablation_final.txt measured -- x 256
+#                CUs x 2.4 GHz = 4.0 T operations/s
+L2_GUIDE_GREQ = 34.5e12 / LINE / 1e9
+LDS_RANDOM_TOPS = 6.5 * 256 * 2.4e9 / 1e12
+BOUNDS = {
+    "hbm_lines": {"unit": "G line fills/s", "ceiling": CEIL_HBM_GREQ, "ceiling_source": "tools/probe_shapes.hip (profiles/r02/probe_shapes_microbench.txt): the fabric's random 128-B line rate = 7.2 TB/s"},
+    "l2_requests": {"unit": "G requests/s", "ceiling": round(L2_GUIDE_GREQ, 1), "ceiling_source": "MI355X_MICROARCH.md, L2 (per XCD): 34.5 TB/s, in 128-B requests"},
+    "lds_random": {"unit": "T lane-operations/s", "ceiling": round(LDS_RANDOM_TOPS, 2), "ceiling_source": "6.5 random lane-operations per clock and CU (guide's LDS bank model; profiles/r04/phase_a_direct_ablation_final.txt) x 256 CUs x 2.4 GHz"},
+}
 
 
 def model_bytes_per_pair(L, k, e):
@@ -73,11 +92,11 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
     return out
 
 
-def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec, source, ceiling):
+def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec, source, ceiling, bound="hbm_lines", lds_ops=None):
     """one kernel family against the HBM peak.  frac = frac_fabric = (2 x FETCH_SIZE + WRITE_SIZE) / time / peak (every fabric read
     request of these kernels is a 128-B line fill tallied at 64 B; an estimate of fabric bytes, Infinity-Cache hits included);
     frac_raw = the counters as they are; frac_model / frac_needed / overfetch: see the module header."""
-    ent = {"kernel": kernel, "what": desc, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(ms_step, 3),
+    ent = {"kernel": kernel, "what": desc, "bound": bound, "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(ms_step, 3),
            "launches_per_step": launches, "launch_ms": round(ms_step / launches, 3) if launches else None,
            "bytes_model": model_b}
     s = ms_step * 1e-3
@@ -85,6 +104,10 @@ def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec
         return ent
     fm = model_b / s / 1e9 / HBM_PEAK_GBS
     ent.update({"frac_model": round(fm, 4), "model_exceeded": bool(fm > 1.0)})
+    ent["bound_ceiling"] = dict(BOUNDS[bound])
+    if bound == "lds_random" and lds_ops:                  # from the run's own key count, no counter needed
+        ent["bound_ceiling"]["value"] = round(lds_ops / s / 1e12, 3)
+        ent["frac_of_bound"] = round(lds_ops / s / 1e12 / LDS_RANDOM_TOPS, 3)
     if needed:
         ent.update({"bytes_needed": int(needed[0]), "needed_is": needed[1], "frac_needed": round(needed[0] / s / 1e9 / HBM_PEAK_GBS, 4)})
     if traffic_rec:
@@ -104,6 +127,10 @@ def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec
         for key in ("l2_hit_rate", "l2_hits", "l2_misses", "hbm_read_requests", "l2_read_requests"):
             if traffic_rec.get(key) is not None:
                 ent[key] = traffic_rec[key]
+        breq = traffic_rec.get({"hbm_lines": "hbm_read_requests", "l2_requests": "l2_read_requests"}.get(bound, ""))
+        if breq:
+            ent["bound_ceiling"]["value"] = round(breq / s / 1e9, 1)
+            ent["frac_of_bound"] = round(breq / s / 1e9 / BOUNDS[bound]["ceiling"], 3)
     else:
         ent.update({"achieved": None, "frac": None, "traffic": None,
                     "traffic_source": "none: the rocprofv3 --pmc passes failed and profiles/traffic_per_launch.json was measured on other sources"})
@@ -138,17 +165,20 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     info = {
         "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
                     f"phase A kernel family, {n_chunks} chunks of <= {8 if direct else 4} Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
-                    model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING),
+                    model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING, "lds_random" if partitioned else "hbm_lines"),
         "ref_flags": (scan_kernel, {"single-first": "phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base",
                                     "trio-first": "phase B on a sparse table: probes per base until a hash does not read 3"}.get(
                                         scan["form"], "phase B: e random 2-bit table probes per reference base") + "; 1 launch per step",
-                      model_ref, 1, HBM_CEILING),
+                      model_ref, 1, HBM_CEILING, "hbm_lines"),
         "vote_kernel": (vote_kernel, f"phase C read re-scan, {2 * (L - k + 1) * e} probes per pair "
                         + {"fold": "screened by a 128 KiB LDS fold, then the L2-resident bitmap, then peak_kmer",
                            "queued": "answered by the L2-resident bitmap except for its survivors"}.get(vform, "into peak_kmer")
-                        + f"; {n_batches} launches per step", model_pairs, n_batches, HBM_CEILING if vform == "dense" else L2_CEILING),
+                        + f"; {n_batches} launches per step", model_pairs, n_batches, HBM_CEILING if vform == "dense" else L2_CEILING,
+                        "hbm_lines" if vform == "dense" else "l2_requests"),
     }
-    roof = {ph: roofline_entry(info[ph][0], info[ph][1], kern[ph], info[ph][3], info[ph][2], need.get(ph), traffic.get(ph) if src else None, src, info[ph][4])
+    keys_a = (stats or {}).get("count_keys") or pairs * 2 * (L - k + 1) * e
+    roof = {ph: roofline_entry(info[ph][0], info[ph][1], kern[ph], info[ph][3], info[ph][2], need.get(ph), traffic.get(ph) if src else None, src, info[ph][4],
+                               bound=info[ph][5], lds_ops=6 * keys_a if ph == "count_A" else None)
             for ph in kern}
     dominant = max(kern, key=kern.get)                      # over A (as one entry), B's probe kernel and C
     return roof, dominant

@@ -280,6 +280,9 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
  * the "snp0.01" of the reference's test data), reads per thousand carrying one N (default 20), number of contigs the sample is
  * drawn from (0 = half of the reference; a metagenome holds far fewer of a catalogue's genomes). */
 int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sample_contigs);
+/* a share of the synthetic pairs (per thousand) gets reads of long_len bases instead of the read length lhgt_synth_pairs is
+ * called with: mixed batches, as a sample with reads of several lengths makes them (0 = none) */
+int lhgt_synth_read_mix(lhgt_ctx* ctx, int long_permille, int long_len);
 
 /* switches for profiling / A-B runs.  bit0: lhgt_vote skips judge_base (outputs wrong);
  * bit2: never use the vote prefilter; bit4: without its LDS-resident first level (the fold); bit5: generic vote kernel even on the

@@ -99,6 +99,7 @@ SIGNATURES = {
     "lhgt_synth_reference_cuts": [_vp, C.c_uint64, _l, _l, _u64p, _l, _u8p],
     "lhgt_synth_pairs": [_vp, C.c_uint64, C.c_uint64, _l, _l, _l, _l, _i, _u8p, _u8p],
     "lhgt_synth_options": [_vp, _i, _i, _l],
+    "lhgt_synth_read_mix": [_vp, _i, _i],
     "lhgt_set_debug": [_vp, _i],
     "lhgt_set_cu_mask": [_vp, _u32p, _i],
     "lhgt_phase_ms": [_vp, _i, _fp],

@@ -939,7 +939,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     const int k = ctx->k;
     hipStream_t cs = ctx->copy_stream;
     size_t fill = 0;
-    long n_open = 0, kept = 0, n_desc = 0, n_batches = 0;
+    long n_open = 0, kept = 0, n_desc = 0, n_batches = 0, n_long = 0;
     uint64_t words = 0, nkm = 0;
     int max_len = 0;
     bool used[2] = {false, false};
@@ -982,7 +982,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             LHGT_HIP(hipEventRecord(copied2, cs2));
             LHGT_HIP(hipStreamWaitEvent(ctx->stream, copied2, 0));
         }
-        int rc = install_pairs_chunked(ctx, stage_base(), (const ChunkPairMeta*)stage_base(), desc(), n_desc, n_open, words, max_len, nkm);
+        int rc = install_pairs_chunked(ctx, stage_base(), (const ChunkPairMeta*)stage_base(), desc(), n_desc, n_open, words, max_len, nkm, n_long);
         LHGT_HIP(hipEventRecord(buf_free[bi], ctx->stream));
         used[bi] = true;
         if (rc == LHGT_OK && ctx->count_on_load) {
@@ -996,7 +996,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
             }
         }
         reap(false);
-        fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0; n_desc = 0;
+        fill = 0; n_open = 0; words = 0; nkm = 0; max_len = 0; n_desc = 0; n_long = 0;
         n_batches++;
         if (BATCH_PAIRS < BATCH_PAIRS_MAX) { BATCH_PAIRS *= 2; BATCH_BYTES = std::min(BATCH_BYTES * 2, BATCH_BYTES_MAX); }
         return rc;
@@ -1017,7 +1017,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         if (counted) LHGT_TRY(lhgt_counts_clear(ctx));
         for (hipEvent_t e : count_ev) hipEventDestroy(e);
         count_ev.clear();
-        fill = 0; n_open = 0; kept = 0; n_desc = 0; n_batches = 0; words = 0; nkm = 0; max_len = 0;
+        fill = 0; n_open = 0; kept = 0; n_desc = 0; n_batches = 0; words = 0; nkm = 0; max_len = 0; n_long = 0;
         used[0] = used[1] = false;
         if (ctx->count_on_load) { BATCH_PAIRS = 1L << 20; BATCH_BYTES = (size_t)320 << 20; }
         return LHGT_OK;
@@ -1041,6 +1041,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                                  ch_words = ch.words;
                                  if (ch.max_len > max_len) max_len = ch.max_len;
                                  nkm += ch.nkm;
+                                 n_long += ch.n_long;
                              } else {                      // a chunk in pageable vectors: its records are made here, everything copied before it goes away
                                  conv.resize((size_t)n + 1);
                                  for (long i = 0; i < n; i++) {
@@ -1051,6 +1052,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
                                      if ((int)l2 > max_len) max_len = (int)l2;
                                      if ((int)l1 >= k) nkm += l1 - k + 1;
                                      if ((int)l2 >= k) nkm += l2 - k + 1;
+                                     n_long += ((int)l1 - k + 1 > FAST_NK) + ((int)l2 - k + 1 > FAST_NK);
                                  }
                                  conv[(size_t)n] = ChunkPairMeta{(uint32_t)ch.o1[n], (uint32_t)ch.o2[n], ch_words, 0u};
                                  LHGT_TRY(stage_sync(fill, ch.s1.data(), b1n));

@@ -131,6 +131,7 @@ struct ParsedChunk {
     long n_meta = 0;
     uint32_t words = 0;
     uint64_t nkm = 0;
+    long n_long = 0;                      // reads with more than FAST_NK k-mer offsets (lhgt_common.hpp: ReadBatch::n_long)
     int max_len = 0, k = 0;
     int slab_id = -1;
     bool src_slack = false;               // 16 readable bytes follow every source line (a worker's own text buffer): copies in 16-byte steps
@@ -177,6 +178,7 @@ struct ParsedChunk {
             if ((int)lb > max_len) max_len = (int)lb;
             if ((int)la >= k) nkm += la - k + 1;
             if ((int)lb >= k) nkm += lb - k + 1;
+            n_long += ((int)la - k + 1 > FAST_NK) + ((int)lb - k + 1 > FAST_NK);
         } else {
             s1.insert(s1.end(), a, a + la);
             s2.insert(s2.end(), b, b + lb);

@@ -692,7 +692,9 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         for (int rr = 0; rr < G::RW; rr++) {
             const long r = r0 + wib + rr * NW;
             const bool counted = !have_flags || ((fl[rr] >> mate) & 1u);   // quirk Q4, thread-chunk emulation
-            d.len[rr] = r < r1 && counted ? len[rr] : 0;
+            // a read of more than 159 bases (more than FAST_NK offsets: it would overrun its staging words and the tile's rows) is
+            // passed over: the batch's few long reads are counted by count_direct behind this kernel (lhgt_count_batch_partitioned)
+            d.len[rr] = r < r1 && counted && len[rr] - k + 1 <= FAST_NK ? len[rr] : 0;
         }
     };
     auto load_records = [&](const Desc& d, uint32_t (&rec)[G::RW]) {
@@ -1093,8 +1095,14 @@ using namespace lhgt;
 // Partitioned count of one resident batch; called by lhgt_count_kmers.  Key buffers live in ctx.
 int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     const PartGeom g = part_geom(ctx->k);
-    const int max_nk = b.max_len - ctx->k + 1;
-    if (max_nk <= 0) return LHGT_OK;
+    const int batch_nk = b.max_len - ctx->k + 1;
+    if (batch_nk <= 0) return LHGT_OK;
+    // A batch of short reads with a FEW long ones (at most an eighth of its reads longer than 159 bases at k = 32: a 150-base sample
+    // with some 250-base reads in it) keeps the direct form for the short ones -- part_reads_direct passes the long ones over -- and
+    // the long ones go through the direct compare-and-swap kernel behind it: the table is a set of saturating counters, the order of
+    // the increments does not matter.  (Round 4: one long read sent the whole batch through the generic scatter.)
+    const bool mixed = ctx->k == 32 && ctx->e == 3 && !(ctx->debug & 65536) && batch_nk > FAST_NK && b.n_long >= 0 && b.n_long * 8 <= 2 * b.d.n_pairs;
+    const int max_nk = mixed ? FAST_NK : batch_nk;
     const long keys_per_pair = 2L * max_nk * ctx->e;
     int reads_per_tile = (int)(TILE_KEYS / ((long)max_nk * ctx->e));
     if (reads_per_tile < 1) LHGT_FAIL(LHGT_E_ARG, "read of %d bases with e=%d exceeds the partition tile", b.max_len, ctx->e);
@@ -1212,5 +1220,6 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
                                ctx->d_counts);
         LHGT_HIP(hipGetLastError());
     }
+    if (mixed && b.n_long > 0) LHGT_TRY(lhgt_count_long_reads(ctx, b));   // the long reads, one wave each, straight into the table (k_count.hip)
     return LHGT_OK;
 }

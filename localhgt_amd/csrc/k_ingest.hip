@@ -403,6 +403,7 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
     std::vector<uint64_t> word_off(2 * n);
     uint64_t words = 0, nkm = 0;
     int max_len = 0;
+    long n_long = 0;
     for (long r = 0; r < 2 * n; r++) {
         uint64_t len = lens[r];
         if (len > LHGT_MAX_READ_LEN) LHGT_FAIL(LHGT_E_FORMAT, "read longer than %d bases", LHGT_MAX_READ_LEN);
@@ -410,12 +411,14 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
         words += 3 * ((len + 31) / 32 + 1);
         if ((int)len > max_len) max_len = (int)len;
         if ((long)len >= k) nkm += len - k + 1;
+        if ((long)len - k + 1 > FAST_NK) n_long++;
     }
     if (words >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "batch too large: %llu plane words (split the append)", (unsigned long long)words);
     ReadBatch b;
     b.n_words = words;
     b.max_len = max_len;
     b.n_kmers = nkm;
+    b.n_long = n_long;
     uint32_t *d_words, *d_off32;
     uint16_t* d_len;
     uint8_t* d_cnt = nullptr;
@@ -485,13 +488,14 @@ __global__ void __launch_bounds__(256) expand_chunk_meta(const ChunkDesc* __rest
 }
 
 int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPairMeta* d_meta, const ChunkDesc* desc, long n_desc, long n,
-                          uint64_t n_words, int max_len, uint64_t n_kmers) {
+                          uint64_t n_words, int max_len, uint64_t n_kmers, long n_long) {
     if (n <= 0) return LHGT_OK;
     if (n_words >= (1ull << 32)) LHGT_FAIL(LHGT_E_ARG, "batch too large: %llu plane words", (unsigned long long)n_words);
     ReadBatch b;
     b.n_words = n_words;
     b.max_len = max_len;
     b.n_kmers = n_kmers;
+    b.n_long = n_long;
     // one allocation per batch: words | offsets | lengths | flags (the allocator call is not free, and a file has dozens of batches)
     const size_t words_b = (n_words * 4 + 16 + 255) & ~(size_t)255, off_b = ((size_t)2 * n * 4 + 255) & ~(size_t)255, len_b = ((size_t)2 * n * 2 + 255) & ~(size_t)255;
     uint8_t* blk = nullptr;

@@ -28,7 +28,12 @@ struct SynthSpec {
     uint32_t snp_permille;  // positions of a sample genome that differ from the reference, per thousand (0; 10 = the "snp0.01" of the
                             // reference's test data, test/run_BKP_detection.sh)
     uint32_t n_sample;      // contigs the sample is made of (even; default: half of the reference)
+    uint32_t long_permille, long_len;   // pairs per thousand whose two reads have long_len bases instead of read_len (lhgt_synth_read_mix)
 };
+// the read length of pair p (both mates)
+__host__ __device__ __forceinline__ uint32_t pair_read_len(const SynthSpec& s, uint64_t p) {
+    return s.long_permille && mix64(s.reads_seed * 0x6A09E667ull ^ mix64(p ^ 0x5bd1e995ull)) % 1000 < s.long_permille ? s.long_len : s.read_len;
+}
 
 // donor cut position / recipient insert position of sample pair i
 __host__ __device__ __forceinline__ void transfer_sites(const SynthSpec& s, uint32_t i, uint64_t* r0, uint64_t* d0) {
@@ -69,15 +74,17 @@ __global__ void __launch_bounds__(256) synth_flat_ascii(SynthSpec s, uint64_t fl
     out[i] = "ACGT"[ref_code(s.ref_seed, (uint32_t)(x / s.contig_len), x % s.contig_len)];
 }
 
-// thread = one base of one mate; out1/out2 are [n][read_len] ASCII
+// thread = one base of one mate; out1/out2 are [n][stride] ASCII, stride = the longer of the two read lengths in use
 __global__ void __launch_bounds__(256) synth_pairs_ascii(SynthSpec s, uint64_t first_pair, uint64_t n_pairs,
                                                          uint8_t* __restrict__ out1, uint8_t* __restrict__ out2) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t L = s.read_len;
-    if (t >= n_pairs * L) return;
-    uint64_t pi = t / L;
-    uint32_t b = (uint32_t)(t % L);
+    const uint64_t stride = s.long_permille && s.long_len > s.read_len ? s.long_len : s.read_len;
+    if (t >= n_pairs * stride) return;
+    uint64_t pi = t / stride;
+    uint32_t b = (uint32_t)(t % stride);
     uint64_t p = first_pair + pi;
+    const uint64_t L = pair_read_len(s, p);
+    if (b >= L) { out1[pi * stride + b] = 'A'; out2[pi * stride + b] = 'A'; return; }   // behind a shorter read's end: never read
     uint64_t h = mix64(s.reads_seed ^ mix64(p));
     uint32_t g = (uint32_t)(h % s.n_sample);
     uint64_t h2 = mix64(h);
@@ -95,8 +102,8 @@ __global__ void __launch_bounds__(256) synth_pairs_ascii(SynthSpec s, uint64_t f
         uint32_t col = (uint32_t)((h4 >> 20) % L);
         if (col == b) { if ((h4 >> 40) & 1) c1 = 'N'; else c2 = 'N'; }
     }
-    out1[pi * L + b] = c1;
-    out2[pi * L + b] = c2;
+    out1[pi * stride + b] = c1;
+    out2[pi * stride + b] = c2;
 }
 
 static SynthSpec make_spec(const lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len, int read_len) {
@@ -106,6 +113,7 @@ static SynthSpec make_spec(const lhgt_ctx* ctx, uint64_t ref_seed, uint64_t read
     s.ref_seed = ref_seed; s.reads_seed = reads_seed;
     s.n_contigs = (uint32_t)n_contigs; s.contig_len = (uint64_t)contig_len;
     s.transfer_len = 3000; s.read_len = (uint32_t)read_len; s.frag_min = 300; s.frag_max = 500; s.n_permille = (uint32_t)ctx->synth_n_permille;
+    s.long_permille = (uint32_t)ctx->synth_long_permille; s.long_len = (uint32_t)ctx->synth_long_len;
     return s;
 }
 
@@ -203,6 +211,15 @@ int lhgt_synth_options(lhgt_ctx* ctx, int snp_permille, int n_permille, long sam
     return LHGT_OK;
 }
 
+// A share of the synthetic pairs with longer reads (both mates long_len bases; 0 = all read_len): the batches a real run sees when
+// a sample holds reads of more than one length.
+int lhgt_synth_read_mix(lhgt_ctx* ctx, int long_permille, int long_len) {
+    if (!ctx || long_permille < 0 || long_permille > 1000 || long_len < 0 || long_len > 300) LHGT_FAIL(LHGT_E_ARG, "bad read mix");
+    ctx->synth_long_permille = long_permille;
+    ctx->synth_long_len = long_len;
+    return LHGT_OK;
+}
+
 // Append pairs [first_pair, first_pair + n_pairs) of the synthetic sample to the resident store.
 // host_seq1/2 (optional, n_pairs*read_len bytes each) receive the bases for writing FASTQs.
 int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long n_contigs, long contig_len,
@@ -211,11 +228,13 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
     LHGT_DEVICE_ENTRY(ctx);
     if (n_contigs < 4 || contig_len < 16000 || read_len < 1 || read_len > 300 || n_pairs < 0) LHGT_FAIL(LHGT_E_ARG, "bad synthetic spec");
     SynthSpec s = make_spec(ctx, ref_seed, reads_seed, n_contigs, contig_len, read_len);
+    const int stride = s.long_permille && (int)s.long_len > read_len ? (int)s.long_len : read_len;
+    if ((host_seq1 || host_seq2) && stride != read_len) LHGT_FAIL(LHGT_E_ARG, "host copies of mixed-length synthetic reads are not laid out");
     long CH = 16L << 20;  // pairs per resident batch (one scan launch each)
-    while (CH * read_len >= (1L << 32)) CH >>= 1;   // synth_pairs_ascii: one work-item per base, a launch holds 2^32 - 1
+    while (CH * stride >= (1L << 32)) CH >>= 1;   // synth_pairs_ascii: one work-item per base, a launch holds 2^32 - 1
     for (long o = 0; o < n_pairs; o += CH) {
         long n = n_pairs - o < CH ? n_pairs - o : CH;
-        size_t bytes = (size_t)n * read_len;
+        size_t bytes = (size_t)n * stride;
         LHGT_TRY(ws_reserve(ctx, 2 * bytes + 32, 0));
         uint8_t *d1 = ctx->d_ws_ascii, *d2 = ctx->d_ws_ascii + bytes;
         hipLaunchKernelGGL(synth_pairs_ascii, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, s,
@@ -224,8 +243,9 @@ int lhgt_synth_pairs(lhgt_ctx* ctx, uint64_t ref_seed, uint64_t reads_seed, long
         if (host_seq1) LHGT_HIP(hipMemcpyAsync(host_seq1 + (size_t)o * read_len, d1, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (host_seq2) LHGT_HIP(hipMemcpyAsync(host_seq2 + (size_t)o * read_len, d2, bytes, hipMemcpyDeviceToHost, ctx->stream));
         std::vector<uint64_t> start((size_t)2 * n);
-        std::vector<uint16_t> lens((size_t)2 * n, (uint16_t)read_len);
-        for (long r = 0; r < 2 * n; r++) start[r] = (uint64_t)r * read_len;
+        std::vector<uint16_t> lens((size_t)2 * n);
+        for (long r = 0; r < 2 * n; r++) start[r] = (uint64_t)r * stride;
+        for (long r = 0; r < n; r++) lens[r] = lens[n + r] = (uint16_t)pair_read_len(s, (uint64_t)(first_pair + o + r));
         LHGT_TRY(install_pairs_dev_ascii(ctx, ctx->d_ws_ascii, start.data(), lens.data(), n, nullptr));
     }
     return LHGT_OK;

@@ -325,6 +325,10 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             nk[m] = cur.len[m] - k + 1;
             wpr[m] = ((cur.len[m] + 31) >> 5) + 1;
         }
+        if (nk[0] > FAST_NK || nk[1] > FAST_NK) {       // a read longer than this form's windows and staging words take: the generic kernel votes the pair
+            if (lane == 0) revote[1u + atomicAdd(revote, 1u)] = (uint32_t)p;
+            continue;
+        }
         // In three sweeps -- all window words, all hashes, all fold probes -- and every load unconditional (a load under a lane mask
         // is an exec region with its own wait: a dozen LDS round trips in a row instead of one); a hash the run does not have
         // (i >= e) reads mask 0 and is switched off with its `ok` bit.
@@ -428,7 +432,8 @@ template <bool Q3>   // the bitmap is three quarters of the 4 MiB its mask spans
 __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                           const uint32_t* __restrict__ prefilter, const int32_t* __restrict__ loci,
                                                           uint32_t* __restrict__ filter, int max_ev, int waves_per_block, int debug,
-                                                          uint32_t pf_mask, int pf2, unsigned long long* __restrict__ stats /* nullable: lhgt_work_stats */) {
+                                                          uint32_t pf_mask, int pf2, unsigned long long* __restrict__ stats /* nullable: lhgt_work_stats */,
+                                                          uint32_t* __restrict__ long_pairs /* nullable: [0] = how many, then the pairs with a read of more than FAST_NK offsets */) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
@@ -453,7 +458,12 @@ __global__ void __launch_bounds__(256) vote_kernel_queued(ReadBatchDev b, HashPa
     for (long p = wave;; p += n_waves, it++) {
         const bool live = p < b.n_pairs;   // one more round after the last pair drains the queue
         int T = 0;
-        if (live && !(b.flags && !(b.flags[p] & PAIR_VOTE))) {
+        bool mine = live && !(b.flags && !(b.flags[p] & PAIR_VOTE));
+        if (mine && long_pairs && (b.len[0][p] - k + 1 > FAST_NK || b.len[1][p] - k + 1 > FAST_NK)) {
+            if (lane == 0) long_pairs[1u + atomicAdd(long_pairs, 1u)] = (uint32_t)p;   // voted by the generic kernel behind this one
+            mine = false;
+        }
+        if (mine) {
             // two round trips: the four descriptors together, then both records (lane index clamped instead of a lane-masked
             // load, which the compiler would wait for on its own)
             const int len0 = b.len[0][p], len1 = b.len[1][p];
@@ -662,6 +672,11 @@ int lhgt_vote(lhgt_ctx* ctx) {
     for (const ReadBatch& b : ctx->batches) {
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
+        // a batch of short reads with a few long ones (lhgt_common.hpp: ReadBatch::n_long): the sparse forms take the pairs of short
+        // reads and list the others, which the generic kernel votes behind them (votes are sums: the order is free)
+        const bool mixed = nk > FAST_NK && b.n_long >= 0 && b.n_long * 8 <= 2 * b.d.n_pairs && ctx->e <= 3 && ctx->prefilter_on && !(ctx->debug & 32);
+        const int nk_all = nk;
+        if (mixed) nk = FAST_NK;
         int max_ev = 2 * nk;
         size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words
         int wpb = (int)(65536 / per_wave);
@@ -680,7 +695,39 @@ int lhgt_vote(lhgt_ctx* ctx) {
                            ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr);          \
     } while (0)
         const bool nt = ctx->k >= 28;
-        const bool sparse_ok = ctx->prefilter_on && nk <= 128 && ctx->e <= 3 && !(ctx->debug & 32);
+        // the pairs on a list (the fold form's deferred pairs; a mixed batch's pairs with a long read) in the generic form, sized for
+        // the batch's longest read
+        auto vote_list = [&](const uint32_t* list) -> int {
+            const int ev_all = 2 * nk_all;
+            size_t pw = ((size_t)ev_all * ctx->e * 2 + 64) * 4 + (ev_all > 256 ? 512 * 4 : 0);
+            int w = (int)(65536 / pw);
+            w = w > 4 ? 4 : w < 1 ? 1 : w;
+            long nb = (b.d.n_pairs + w - 1) / w;
+            if (nb > 256L * 16) nb = 256L * 16;
+#define LHGT_VOTE_LIST(TR_)                                                                                                          \
+    do {                                                                                                                             \
+        if (pw * w > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((vote_kernel<TR_, 1, false>), dim3((unsigned)nb), dim3(64 * w), pw * w, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, \
+                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, list);   \
+    } while (0)
+            if (ev_all <= 256) LHGT_VOTE_LIST(4);
+            else if (ev_all <= 512) LHGT_VOTE_LIST(8);
+            else LHGT_VOTE_LIST(16);
+#undef LHGT_VOTE_LIST
+            return LHGT_OK;
+        };
+        auto list_room = [&]() -> int {
+            const size_t need = (size_t)b.d.n_pairs + 1;
+            if (ctx->revote_cap < need) {
+                if (ctx->d_revote) LHGT_HIP(lhgt::dev_free(ctx->d_revote));
+                ctx->d_revote = nullptr;
+                LHGT_HIP(lhgt::dev_malloc(&ctx->d_revote, need * 4));
+                ctx->revote_cap = need;
+            }
+            LHGT_HIP(hipMemsetAsync(ctx->d_revote, 0, 4, ctx->stream));
+            return LHGT_OK;
+        };
+        const bool sparse_ok = ctx->prefilter_on && nk <= FAST_NK && ctx->e <= 3 && !(ctx->debug & 32);
         // LDS first level while the fold still screens.  The 128 KiB fold with the judge deferred (vote_kernel_fold) up to 1.15 bit
         // insertions per fold bit: 47 % of foreign probes pass on to the L2 bitmap, a pair's survivors (333 +- 13 of 714) still fit
         // the wave's queue -- beyond that the overflowing pairs would flood the deferred list.  Round 2 kept a 64 KiB fold up to a
@@ -695,14 +742,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             ctx->vote_form = 3;
             const int fold_words = (int)std::min<unsigned long long>(LF2_WORDS, (ctx->pf_mask + 1ull) / 32);
             const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
-            const size_t need = (size_t)b.d.n_pairs + 1;
-            if (ctx->revote_cap < need) {
-                if (ctx->d_revote) LHGT_HIP(lhgt::dev_free(ctx->d_revote));
-                ctx->d_revote = nullptr;
-                LHGT_HIP(lhgt::dev_malloc(&ctx->d_revote, need * 4));
-                ctx->revote_cap = need;
-            }
-            LHGT_HIP(hipMemsetAsync(ctx->d_revote, 0, 4, ctx->stream));
+            LHGT_TRY(list_room());
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
             hipLaunchKernelGGL(fold_prefilter, dim3((fold_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32),
@@ -717,9 +757,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
                                    ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
             // the deferred pairs, from scratch in the lane-per-offset form (hits in offset order for the judge); the list's length
             // is read on the device
-            hipLaunchKernelGGL((vote_kernel<4, 1, false>), dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                               ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2,
-                               (const uint32_t*)ctx->d_revote);
+            LHGT_TRY(vote_list((const uint32_t*)ctx->d_revote));
             if (d_stats) hipLaunchKernelGGL(stats_add_u32, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)ctx->d_revote, d_stats + 5);
             if (getenv("LHGT_TRACE")) {
                 uint32_t n_def = 0;
@@ -736,12 +774,15 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (wpb < 1) wpb = 1;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256L * 16) blocks = 256L * 16;
+            uint32_t* long_list = nullptr;
+            if (mixed) { LHGT_TRY(list_room()); long_list = ctx->d_revote; }
             if (ctx->pf_q3)
                 hipLaunchKernelGGL(vote_kernel_queued<true>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
+                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats, long_list);
             else
                 hipLaunchKernelGGL(vote_kernel_queued<false>, dim3((unsigned)blocks), dim3(64 * wpb), per_wave_q * wpb, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer,
-                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
+                                   ctx->d_prefilter, ctx->d_loci, ctx->d_filter, max_ev, wpb, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats, long_list);
+            if (mixed) LHGT_TRY(vote_list((const uint32_t*)ctx->d_revote));
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
             else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);

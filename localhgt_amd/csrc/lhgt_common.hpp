@@ -73,7 +73,12 @@ struct ReadBatch {
     size_t n_words = 0;
     int max_len = 0;
     uint64_t n_kmers = 0;  // valid-or-not k-mer positions of both mates (for rates)
+    // reads with more than FAST_NK k-mer offsets (> 159 bases at k = 32): the fast forms of phases A and C take reads up to that
+    // length, and a batch with only a FEW longer ones lets them pass those over and hands the long ones to the generic forms
+    // (round 5; before, one 250-base read sent its whole batch of millions of pairs down the generic paths).  -1 = not counted.
+    long n_long = -1;
 };
+constexpr int FAST_NK = 128;
 
 // ---------------------------------------------------------------- resident index
 // d_index = the index file minus its 1200-byte header: per contig [u32 len][(len-k+1)*e u32].
@@ -187,6 +192,7 @@ struct lhgt_ctx {
     uint32_t* d_part_meta = nullptr;
     int synth_snp_permille = 0, synth_n_permille = 20;   // k_synth.hip: lhgt_synth_options
     long synth_sample_contigs = 0;
+    int synth_long_permille = 0, synth_long_len = 0;     // lhgt_synth_read_mix
     // the reference's -t N, race-free (lhgt_set_thread_emulation): read partition in host_fastx.cpp, contig groups with their own
     // id ranges in k_scan.hip, one sentinel line per thread in lhgt_write_intervals
     bool count_on_load = false;              // lhgt_set_count_on_load: the FASTQ loader counts every batch as soon as it is resident
@@ -223,6 +229,7 @@ struct lhgt_ctx {
 };
 
 int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
+int lhgt_count_long_reads(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
 int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0, hipEvent_t t1);
 void lhgt_ingest_pool_free(lhgt_ctx* ctx);   // host_fastx.cpp: the SlabPool object behind ctx->ingest_pool
 
@@ -270,7 +277,7 @@ struct ChunkPairMeta { uint32_t rel1, rel2, relw, flags; };
 struct ChunkDesc { uint32_t pair0, n, b1, b2, wbase, mo; };
 constexpr uint32_t CHUNK_INTERLEAVED = 0xFFFFFFFFu;
 int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPairMeta* d_meta, const ChunkDesc* desc, long n_desc, long n,
-                          uint64_t n_words, int max_len, uint64_t n_kmers);
+                          uint64_t n_words, int max_len, uint64_t n_kmers, long n_long);
 int strip_fasta_text(lhgt_ctx* ctx, const uint8_t* d_text, uint64_t text_len, const uint64_t* kept_before, long n_blocks,
                      const uint64_t* seg, long n_seg, uint8_t* d_out);
 void ingest_free(lhgt_ctx* ctx);

@@ -259,6 +259,10 @@ class Engine:
     def synth_options(self, snp_permille: int = 0, n_permille: int = 20, sample_contigs: int = 0):
         _lib.check(self.lib.lhgt_synth_options(self.h, snp_permille, n_permille, sample_contigs))
 
+    def synth_read_mix(self, long_permille: int, long_len: int):
+        """long_permille of 1000 synthetic pairs get reads of long_len bases (0: all of synth_pairs' read_len)"""
+        _lib.check(self.lib.lhgt_synth_read_mix(self.h, long_permille, long_len))
+
     def synth_pairs(self, ref_seed: int, reads_seed: int, n_contigs: int, contig_len: int, first_pair: int,
                     n_pairs: int, read_len: int = 150, want_host: bool = False):
         h1 = np.zeros(n_pairs * read_len, dtype=np.uint8) if want_host else None

@@ -800,3 +800,74 @@ def test_fasta_longer_than_one_upload_span(Engine, tmp_path):
                 eng.vote()
                 res[from_file] = (n, eng.digest(eng.DIGEST_LOCI), eng.digest(eng.DIGEST_PEAK_KMER), eng.digest(eng.DIGEST_VOTES))
         assert res[True] == res[False] and res[True][0] > 0, (packed, res)
+
+
+def test_a_few_long_reads_do_not_demote_their_batch(Engine, oracle, tmp_path):
+    """round 5: a batch of 150-base reads with a few longer ones (at most an eighth of its reads with more than 128 k-mer offsets)
+    keeps the fast forms -- phase A's direct scatters pass the long reads over and the compare-and-swap kernel counts them, the
+    queued / fold votes list the pairs with a long read for the generic kernel.  Same count table as the compare-and-swap kernel
+    alone and as round 3's generic scatters; same votes as the generic vote without any filter; from files against the oracle."""
+    k, e = 32, 3
+    with Engine(k, e) as eng:
+        eng.rng_seed(5)
+        eng.coder_generate()
+        eng.synth_reference(3, 40, 200_000)
+        eng.synth_read_mix(20, 250)                         # 2 % of the pairs: 250-base reads
+        eng.synth_options(0, 20, 8)
+        eng.synth_pairs(3, 4, 40, 200_000, 0, 400_000)
+        tables = []
+        for mode, dbg in ((1, 0), (0, 0), (1, 65536)):      # partition (mixed form), compare-and-swap alone, round 3's generic scatters
+            eng.set_count_mode(mode)
+            eng.set_debug(dbg)
+            eng.counts_clear()
+            eng.count_kmers()
+            tables.append((eng.digest(eng.DIGEST_COUNTS), tuple(int(x) for x in eng.counts_histogram())))
+        eng.set_debug(0)
+        eng.set_count_mode(-1)
+        assert tables[0] == tables[1] == tables[2] and tables[0][1][3] > 1000
+        votes = []
+        for flags in (0, 16, 32, 4):                         # the form the engine picks (fold), queued, generic behind the bitmap, no filter at all
+            eng.set_debug(flags)
+            n = eng.ref_scan(0.1, 0.08, 10**7)
+            eng.vote()
+            loci, v = eng.peaks_export(n)
+            votes.append((n, v.copy(), eng.vote_info()["form"]))
+        eng.set_debug(0)
+        assert votes[0][0] > 20 and votes[0][1].max() >= 1
+        for other in votes[1:]:
+            assert other[0] == votes[0][0] and (other[1] == votes[0][1]).all()
+        assert {votes[0][2], votes[1][2]} <= {"fold", "queued"} and votes[0][2] != votes[2][2], [v[2] for v in votes]
+    # from files, against the oracle: k = 24 (phase C's path; phase A's applies at k = 32 and is covered above)
+    k = 24
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = [acgt[rng.integers(0, 4, 60_000)] for _ in range(6)]
+    # the sample: contig 1 with 3 kb of contig 2 pasted in, contig 2 without them -- both junction kinds
+    sample = [np.concatenate([contigs[0][:30_000], contigs[1][20_000:23_000], contigs[0][30_000:]]),
+              np.concatenate([contigs[1][:20_000], contigs[1][23_000:]])]
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, c in enumerate(contigs):
+            f.write(b">g%d\n" % (i + 1) + c.tobytes() + b"\n")
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    r1, r2 = [], []
+    for i in range(9000):
+        g = sample[i % 2]
+        L = 250 if i % 50 == 0 else 150
+        flen = int(rng.integers(300, 500))
+        st = int(rng.integers(0, len(g) - flen))
+        r1.append(g[st:st + L].tobytes())
+        r2.append(comp[g[st + flen - L:st + flen]][::-1].tobytes())
+    f1, f2 = str(tmp_path / "m.1.fq"), str(tmp_path / "m.2.fq")
+    _write_fq(f1, r1, b"1")
+    _write_fq(f2, r2, b"2")
+    from localhgt_amd import extract_ref
+    a = extract_ref.Args(f1, f2, fa, str(tmp_path / "gpu.txt"), 0.1, 0.08, 1, k, 100_000, 3, 1, 1.0)
+    rep = extract_ref.run(a, log=lambda *x: None)
+    fa2 = str(tmp_path / "cpu.fa")
+    import shutil
+    shutil.copy(fa, fa2)
+    rc, orep = oracle.run(f1, f2, fa2, str(tmp_path / "cpu.txt"), 0.1, 0.08, 1, k, 100_000, 3, 1, 1.0)
+    assert rc == 0 and (rep["n_peaks"], rep["n_filtered"]) == (orep.n_peaks, orep.n_filtered) and orep.n_filtered >= 1
+    assert open(str(tmp_path / "gpu.txt")).read() == open(str(tmp_path / "cpu.txt")).read()

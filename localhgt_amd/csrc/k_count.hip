@@ -24,8 +24,7 @@ __device__ __forceinline__ void sat_inc(uint32_t* __restrict__ T, uint32_t h) {
 // n_as_base: count_diff_kmer.cpp's `bool` coder (C:155-160) -- a non-ACGT base is not rejected: it codes 1 in every projection
 // on the forward strand (= A: both code bits 0, as pack_bases stores it) and, its complement being the NUL byte, 1 in every
 // projection on the reverse strand too (= the complement of T: both bits 1)
-// min_nk: only reads with at least that many k-mer offsets (the long reads of a batch whose short ones went through the partition)
-__global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams hp, uint32_t* __restrict__ counts, int n_as_base, int min_nk) {
+__global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams hp, uint32_t* __restrict__ counts, int n_as_base) {
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long n_waves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -36,7 +35,7 @@ __global__ void __launch_bounds__(256) count_direct(ReadBatchDev b, HashParams h
         if (b.flags && !((b.flags[p] >> m) & 1)) continue;  // quirk Q4, thread-chunk emulation
         const int len = b.len[m][p];
         const int nk = len - hp.k + 1;
-        if (nk <= 0 || nk < min_nk) continue;
+        if (nk <= 0) continue;
         const int wpr = ((len + 31) >> 5) + 1;
         const uint32_t* rec = b.words + b.off[m][p];
         for (int j = lane; j < nk; j += 64) {
@@ -116,7 +115,7 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
         long waves = 2 * b.d.n_pairs;
         long blocks = (waves + 3) / 4;
         if (blocks > 256L * 8 * 4) blocks = 256L * 8 * 4;
-        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0, 0);
+        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0);
         if (ctx->stats_on) ctx->stats_host[0] += b.n_kmers * (unsigned long long)ctx->e;   // lhgt_work_stats: upper bound (k-mers with an N are skipped)
     }
     LHGT_HIP(hipGetLastError());
@@ -130,15 +129,6 @@ int lhgt_count_kmers(lhgt_ctx* ctx) {
 
 }  // extern "C"
 
-// the reads of a batch with more than FAST_NK k-mer offsets, by the direct kernel (lhgt_count_batch_partitioned: the others went
-// through the partition's direct form, which passes these over)
-int lhgt_count_long_reads(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
-    long blocks = 256L * 8;      // the waves walk past every short read's descriptor as well
-    hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, 0, lhgt::FAST_NK + 1);
-    LHGT_HIP(hipGetLastError());
-    return LHGT_OK;
-}
-
 // phase A of ONE resident batch, asynchronously on the context's stream (the loader's count-on-load); t0 / t1 bracket it
 int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0, hipEvent_t t1) {
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: load or build the index before loading reads with count-on-load");
@@ -149,7 +139,7 @@ int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0,
         long waves = 2 * b.d.n_pairs;
         long blocks = (waves + 3) / 4;
         if (blocks > 256L * 8 * 4) blocks = 256L * 8 * 4;
-        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0, 0);
+        hipLaunchKernelGGL(count_direct, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b.d, ctx->hp, ctx->d_counts, ctx->count_compat ? 1 : 0);
         LHGT_HIP(hipGetLastError());
     }
     LHGT_HIP(hipEventRecord(t1, ctx->stream));

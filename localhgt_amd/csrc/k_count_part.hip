@@ -631,10 +631,30 @@ __host__ __device__ inline size_t final_region(const PartCap& sc, uint32_t m, ui
     return (size_t)m * seg_size(sc) + part_region(sc, t) + (size_t)half * half_region(sc, t, halves);
 }
 
-template <class G>
+// the segments of the chunk's long reads (more than FAST_NK k-mer offsets), in any order: entry = pair (inside the chunk) | mate << 24 |
+// segment << 25; list[0] counts them
+__global__ void __launch_bounds__(256) long_read_segments(ReadBatchDev b, long pair0, long npairs, int k, uint32_t* __restrict__ list, uint32_t cap) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2 * npairs) return;
+    const int m = (int)(r & 1);
+    const long p = r >> 1;
+    const int nk = (int)b.len[m][pair0 + p] - k + 1;
+    if (nk <= FAST_NK) return;
+    const uint32_t n_seg = (uint32_t)((nk + FAST_NK - 1) / FAST_NK);
+    const uint32_t at = atomicAdd(list, n_seg);
+    for (uint32_t sg = 0; sg < n_seg; sg++)
+        if (at + sg < cap) list[1 + at + sg] = (uint32_t)p | ((uint32_t)m << 24) | (sg << 25);
+}
+
+// LIST (round 5): the reads are SEGMENTS of long reads, listed by long_read_segments -- a read of more than FAST_NK k-mer offsets is
+// cut into runs of FAST_NK offsets (offset 128 s is word 4 s of each plane, so a segment's windows are cut from its own <= 6 words
+// per plane like a short read's), which go through this scatter like reads of <= 159 bases and land in the same pieces, behind the
+// keys the first launch (the short reads; it passes the long ones over) left there.  Same keys as the read would give whole.
+template <class G, bool LIST>
 __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long pair0, long npairs, HashParams hp, uint32_t piece,
                                                          uint32_t* __restrict__ cnt1 /*[bucket][workgroup]*/, uint32_t* __restrict__ out,
-                                                         uint32_t* __restrict__ counts, int ablate /* stage timing (LHGT_PART_ABLATE), results wrong: 1 no stores, 2 no placement */) {
+                                                         uint32_t* __restrict__ counts, int ablate /* stage timing (LHGT_PART_ABLATE), results wrong: 1 no stores, 2 no placement */,
+                                                         const uint32_t* __restrict__ list /* LIST: [0] = how many, then pair | mate << 24 | segment << 25 */) {
     // Rows of S1 slots, RS1 = S1 + 4 words apart: every row starts 16 bytes further round the banks than the one before (all buckets
     // fill at the same pace: with rows a multiple of the bank count apart a wave's stores would crowd into the few banks of the
     // current position), and a slot's byte address is ONE multiply-add of bucket and ticket.  (Until the instruction counters of the
@@ -656,10 +676,10 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
     const int wsel = ((lane + 31) >> 5) - 1;
     const uint32_t sh_win = (32u - (uint32_t)(lane & 31)) & 31u;
     constexpr int k = 32;
-    const long n_reads = 2 * npairs;
+    const long n_reads = LIST ? (long)list[0] : 2 * npairs;
     constexpr int RPT = NW * G::RW;           // reads per tile (even)
     const long n_tiles = (n_reads + RPT - 1) / RPT;
-    if (threadIdx.x < NBK) { cnt[threadIdx.x] = 0; cur[threadIdx.x] = 0; }
+    if (threadIdx.x < NBK) { cnt[threadIdx.x] = 0; cur[threadIdx.x] = LIST ? cnt1[threadIdx.x * G::GRID + blockIdx.x] : 0; }
     // A wave's reads of a tile are r0 + wave + 8 rr with r0 even: their mate (r & 1) is the parity of the wave's number, the same
     // for every read the wave will ever see -- the descriptor arrays of that mate are picked ONCE (indexing b.len[m] with a
     // run-time m made the compiler fetch the pointer from the kernel-argument block with a vector load and wait for it, read by
@@ -674,11 +694,39 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
     // Three tiles are in flight per wave: the one being hashed (its lengths in dA, its records in LDS), the next one (descriptors
     // arrived in dB, records on their way into recB) and the one after (descriptors on their way into dC) -- two dependent round
     // trips to memory, each given a whole tile's time.
-    struct Desc { int len[G::RW]; uint32_t off[G::RW]; };
+    struct Desc { int len[G::RW]; uint32_t off[G::RW]; uint32_t stride[LIST ? G::RW : 1]; };
     auto load_descriptors = [&](long t, Desc& d) {        // t >= n_tiles: every length 0
         const long r0 = t * RPT, r1 = r0 + RPT < n_reads ? r0 + RPT : n_reads;
         int len[G::RW];
         uint32_t fl[G::RW];
+        if constexpr (LIST) {
+            uint32_t ent[G::RW];
+#pragma unroll
+            for (int rr = 0; rr < G::RW; rr++) {
+                const long r = r0 + wib + rr * NW;
+                ent[rr] = list[1 + (r < r1 ? r : (n_reads > 0 ? n_reads - 1 : 0))];
+            }
+#pragma unroll
+            for (int rr = 0; rr < G::RW; rr++) {
+                const long p = pair0 + (long)(ent[rr] & 0xffffffu);
+                const int m = (int)((ent[rr] >> 24) & 1u);
+                len[rr] = m ? b.len[1][p] : b.len[0][p];
+                d.off[rr] = m ? b.off[1][p] : b.off[0][p];
+                fl[rr] = have_flags ? b.flags[p] : 0xffu;
+            }
+#pragma unroll
+            for (int rr = 0; rr < G::RW; rr++) {
+                const long r = r0 + wib + rr * NW;
+                const int m = (int)((ent[rr] >> 24) & 1u), seg = (int)(ent[rr] >> 25);
+                const bool counted = (fl[rr] >> m) & 1u;
+                const int nk_left = len[rr] - k + 1 - FAST_NK * seg;                    // offsets from this segment's first one on
+                const int nkv = nk_left < FAST_NK ? nk_left : FAST_NK;
+                d.stride[rr] = (uint32_t)(((len[rr] + 31) >> 5) + 1);
+                d.off[rr] += 4u * (uint32_t)seg;                                        // FAST_NK offsets = 4 words of a plane
+                d.len[rr] = r < r1 && counted && nkv > 0 ? nkv + k - 1 : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int rr = 0; rr < G::RW; rr++) {
             const long r = r0 + wib + rr * NW;
@@ -693,7 +741,7 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
             const long r = r0 + wib + rr * NW;
             const bool counted = !have_flags || ((fl[rr] >> mate) & 1u);   // quirk Q4, thread-chunk emulation
             // a read of more than 159 bases (more than FAST_NK offsets: it would overrun its staging words and the tile's rows) is
-            // passed over: the batch's few long reads are counted by count_direct behind this kernel (lhgt_count_batch_partitioned)
+            // passed over here: its segments come with the LIST launch behind this one (lhgt_count_batch_partitioned)
             d.len[rr] = r < r1 && counted && len[rr] - k + 1 <= FAST_NK ? len[rr] : 0;
         }
     };
@@ -701,7 +749,10 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
 #pragma unroll
         for (int rr = 0; rr < G::RW; rr++) {
             const int wpr = ((d.len[rr] + 31) >> 5) + 1;
-            rec[rr] = b.words[d.off[rr] + (lane < 3 * wpr ? lane : 0)];
+            if constexpr (LIST) {       // the segment's wpr words of each plane of the long read's record (planes d.stride words apart)
+                const int pl = (lane >= wpr) + (lane >= 2 * wpr), w = lane - pl * wpr;
+                rec[rr] = b.words[d.off[rr] + (lane < 3 * wpr ? (uint32_t)pl * d.stride[rr] + (uint32_t)w : 0u)];
+            } else rec[rr] = b.words[d.off[rr] + (lane < 3 * wpr ? lane : 0)];
         }
     };
     Desc dA, dB, dC;
@@ -1097,13 +1148,16 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
     const PartGeom g = part_geom(ctx->k);
     const int batch_nk = b.max_len - ctx->k + 1;
     if (batch_nk <= 0) return LHGT_OK;
-    // A batch of short reads with a FEW long ones (at most an eighth of its reads longer than 159 bases at k = 32: a 150-base sample
-    // with some 250-base reads in it) keeps the direct form for the short ones -- part_reads_direct passes the long ones over -- and
-    // the long ones go through the direct compare-and-swap kernel behind it: the table is a set of saturating counters, the order of
-    // the increments does not matter.  (Round 4: one long read sent the whole batch through the generic scatter.)
-    const bool mixed = ctx->k == 32 && ctx->e == 3 && !(ctx->debug & 65536) && batch_nk > FAST_NK && b.n_long >= 0 && b.n_long * 8 <= 2 * b.d.n_pairs;
-    const int max_nk = mixed ? FAST_NK : batch_nk;
-    const long keys_per_pair = 2L * max_nk * ctx->e;
+    // round 4's direct form of the two scatters (k = 32, e = 3); LHGT_DEBUG bit 16: round 3's sorted tiles.  It takes reads of up to
+    // FAST_NK k-mer offsets (159 bases) as they are; longer reads (round 5) go through it cut into segments of FAST_NK offsets
+    // (part_reads_direct<G, true> on the list long_read_segments makes) -- round 4 sent a batch with ONE long read through the generic
+    // scatter, and a batch of 250-base reads altogether.
+    const bool direct_form = ctx->k == 32 && ctx->e == 3 && !(ctx->debug & 65536) && b.n_long >= 0;
+    const bool have_long = direct_form && batch_nk > FAST_NK;
+    const int max_nk = have_long ? FAST_NK : batch_nk;
+    // keys a pair brings: at most 2 max_nk e; with long reads in the batch its own average (+ 1/8: the chunks of a batch differ) --
+    // a region or piece that still runs over sends its keys straight to the table, exact either way
+    const long keys_per_pair = have_long ? (long)((double)b.n_kmers * ctx->e / (double)std::max(1L, b.d.n_pairs) * 1.125) + 8 : 2L * max_nk * ctx->e;
     int reads_per_tile = (int)(TILE_KEYS / ((long)max_nk * ctx->e));
     if (reads_per_tile < 1) LHGT_FAIL(LHGT_E_ARG, "read of %d bases with e=%d exceeds the partition tile", b.max_len, ctx->e);
     // chunk of pairs whose bucket regions fit the two key buffers (u32 offsets: < 2^32 keys per buffer)
@@ -1112,10 +1166,12 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         const PartCap c = cap_of(np);
         return c.n + c.n / 16 + (unsigned long long)g.nb * 512ull + 64;
     };
-    // round 4's direct form of the two scatters (k = 32, e = 3, reads of <= 159 bases); LHGT_DEBUG bit 16: round 3's sorted tiles
-    const bool direct_form = ctx->k == 32 && ctx->e == 3 && max_nk <= 128 && !(ctx->debug & 65536);
     static const long chunk_env = getenv("LHGT_PART_CHUNK") ? atol(getenv("LHGT_PART_CHUNK")) : 0;   // pairs per chunk of the direct form (A/B)
-    const long chunk_max = direct_form ? (chunk_env > 0 ? chunk_env : (8L << 20)) : (4L << 20);   // the direct form addresses its buffers with 64 bits
+    long chunk_max = direct_form ? (chunk_env > 0 ? chunk_env : (8L << 20)) : (4L << 20);   // the direct form addresses its buffers with 64 bits
+    if (have_long) {                      // as many keys per chunk as 8 Mi pairs of 150-base reads bring, whatever the reads' lengths
+        const long same_keys = (long)((8L << 20) * 714.0 / (double)keys_per_pair);
+        chunk_max = std::max(1L << 16, std::min(chunk_max, same_keys));
+    }
     long want = b.d.n_pairs < chunk_max ? b.d.n_pairs : chunk_max;
     while (!direct_form && want > 1 && (need_of(want) >= (1ull << 32) || cap_of(want).n >= (1ull << 32))) want /= 2;
     // keys the two buffers must hold for chunks of np pairs: buffer 0 takes need x 4 bytes, buffer 1 need x 2
@@ -1161,6 +1217,14 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         need = keys_for(want);
     }
     const long chunk_pairs = want;
+    uint32_t* d_list = nullptr;
+    uint32_t list_cap = 0;
+    if (have_long) {                      // room for every segment of the batch's long reads (<= 500 bases: four segments)
+        const size_t n = (size_t)std::min<long>(b.n_long, 2 * b.d.n_pairs) * 4 + 64;
+        if (n >= ((size_t)1 << 32)) LHGT_FAIL(LHGT_E_ARG, "batch of %ld long reads", b.n_long);
+        list_cap = (uint32_t)n - 1;
+        LHGT_HIP(lhgt::dev_malloc(&d_list, n * 4));
+    }
     if (!ctx->d_part_meta) LHGT_HIP(lhgt::dev_malloc(&ctx->d_part_meta, (size_t)(2 * 65536 + NBK * 512) * 4));
     uint32_t* cur2 = ctx->d_part_meta;     // keys sent to each final bucket (direct form: to each half of its region)
     uint32_t* cur1 = cur2 + 2 * 65536;     // keys sent to each level-1 segment (direct form: to each (bucket, workgroup) piece)
@@ -1176,8 +1240,14 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
             auto run = [&](auto G_) {
                 using G = decltype(G_);
                 const uint32_t piece = piece_keys(pc.n, G::GRID);
-                hipLaunchKernelGGL(part_reads_direct<G>, dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
-                                   ctx->d_counts, ablate & 3);
+                hipLaunchKernelGGL((part_reads_direct<G, false>), dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
+                                   ctx->d_counts, ablate & 3, (const uint32_t*)nullptr);
+                if (have_long) {          // the long reads of the chunk, segment by segment, behind the short ones in the same pieces
+                    hipMemsetAsync(d_list, 0, 4, ctx->stream);
+                    hipLaunchKernelGGL(long_read_segments, dim3((unsigned)((2 * np + 255) / 256)), dim3(256), 0, ctx->stream, b.d, p0, np, ctx->k, d_list, list_cap);
+                    hipLaunchKernelGGL((part_reads_direct<G, true>), dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
+                                       ctx->d_counts, ablate & 3, (const uint32_t*)d_list);
+                }
                 hipLaunchKernelGGL(part_keys16_direct<G>, dim3(G::HALVES * NBK), dim3(G::T), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, sc, cur2,
                                    (uint16_t*)ctx->d_part_keys[1], ctx->d_counts, (ablate >> 4) & 3);
                 if (ctx->stats_on && ctx->d_stats)    // keys that reached a final bucket's region (the few sent straight to the table are not in it)
@@ -1220,6 +1290,6 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
                                ctx->d_counts);
         LHGT_HIP(hipGetLastError());
     }
-    if (mixed && b.n_long > 0) LHGT_TRY(lhgt_count_long_reads(ctx, b));   // the long reads, one wave each, straight into the table (k_count.hip)
+    if (d_list) { LHGT_HIP(hipStreamSynchronize(ctx->stream)); lhgt::dev_free(d_list); }
     return LHGT_OK;
 }

@@ -73,9 +73,10 @@ struct ReadBatch {
     size_t n_words = 0;
     int max_len = 0;
     uint64_t n_kmers = 0;  // valid-or-not k-mer positions of both mates (for rates)
-    // reads with more than FAST_NK k-mer offsets (> 159 bases at k = 32): the fast forms of phases A and C take reads up to that
-    // length, and a batch with only a FEW longer ones lets them pass those over and hands the long ones to the generic forms
-    // (round 5; before, one 250-base read sent its whole batch of millions of pairs down the generic paths).  -1 = not counted.
+    // reads with more than FAST_NK k-mer offsets (> 159 bases at k = 32).  The fast forms of phases A and C take reads up to that
+    // length as they are; phase A's direct scatters take the longer ones cut into segments (k_count_part.hip), and the sparse votes,
+    // when a batch has only a FEW of them, list their pairs for the generic kernel (k_vote.hip) -- round 4 sent the whole batch of
+    // millions of pairs down the generic paths for one 250-base read.  -1 = not counted.
     long n_long = -1;
 };
 constexpr int FAST_NK = 128;
@@ -229,7 +230,6 @@ struct lhgt_ctx {
 };
 
 int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
-int lhgt_count_long_reads(lhgt_ctx* ctx, const lhgt::ReadBatch& b);
 int lhgt_count_one_batch_async(lhgt_ctx* ctx, lhgt::ReadBatch& b, hipEvent_t t0, hipEvent_t t1);
 void lhgt_ingest_pool_free(lhgt_ctx* ctx);   // host_fastx.cpp: the SlabPool object behind ctx->ingest_pool
 

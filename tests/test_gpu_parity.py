@@ -804,8 +804,8 @@ def test_fasta_longer_than_one_upload_span(Engine, tmp_path):
 
 def test_a_few_long_reads_do_not_demote_their_batch(Engine, oracle, tmp_path):
     """round 5: a batch of 150-base reads with a few longer ones (at most an eighth of its reads with more than 128 k-mer offsets)
-    keeps the fast forms -- phase A's direct scatters pass the long reads over and the compare-and-swap kernel counts them, the
-    queued / fold votes list the pairs with a long read for the generic kernel.  Same count table as the compare-and-swap kernel
+    keeps the fast forms -- phase A's direct scatters take the long reads cut into segments of 128 k-mer offsets (also when every
+    read is long), the queued / fold votes list the pairs with a long read for the generic kernel.  Same count table as the compare-and-swap kernel
     alone and as round 3's generic scatters; same votes as the generic vote without any filter; from files against the oracle."""
     k, e = 32, 3
     with Engine(k, e) as eng:
@@ -815,6 +815,7 @@ def test_a_few_long_reads_do_not_demote_their_batch(Engine, oracle, tmp_path):
         eng.synth_read_mix(20, 250)                         # 2 % of the pairs: 250-base reads
         eng.synth_options(0, 20, 8)
         eng.synth_pairs(3, 4, 40, 200_000, 0, 400_000)
+        eng.synth_read_mix(0, 0)
         tables = []
         for mode, dbg in ((1, 0), (0, 0), (1, 65536)):      # partition (mixed form), compare-and-swap alone, round 3's generic scatters
             eng.set_count_mode(mode)
@@ -825,6 +826,29 @@ def test_a_few_long_reads_do_not_demote_their_batch(Engine, oracle, tmp_path):
         eng.set_debug(0)
         eng.set_count_mode(-1)
         assert tables[0] == tables[1] == tables[2] and tables[0][1][3] > 1000
+        # ... and batches of long reads only, of every length class up to the reference's 500 (ragged: segments of 1 .. 128 offsets)
+        rng = np.random.default_rng(12)
+        acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        reads1 = [acgt[rng.choice(5, size=int(rng.integers(150, 501)), p=[.248, .248, .248, .248, .008])].tobytes() for _ in range(30_000)]
+        reads2 = [acgt[rng.choice(5, size=int(rng.integers(0, 501)), p=[.248, .248, .248, .248, .008])].tobytes() for _ in range(30_000)]
+        eng.pairs_clear()
+        eng.pairs_append(*_pairs(reads1, reads2), count_mate2=(rng.random(len(reads1)) < 0.9).astype(np.uint8))
+        ragged = []
+        for mode, dbg in ((1, 0), (0, 0), (1, 65536)):
+            eng.set_count_mode(mode)
+            eng.set_debug(dbg)
+            eng.counts_clear()
+            eng.count_kmers()
+            ragged.append((eng.digest(eng.DIGEST_COUNTS), tuple(int(x) for x in eng.counts_histogram())))
+        eng.set_debug(0)
+        eng.set_count_mode(-1)
+        assert ragged[0] == ragged[1] == ragged[2]
+        eng.pairs_clear()
+        eng.counts_clear()
+        eng.synth_read_mix(20, 250)
+        eng.synth_pairs(3, 4, 40, 200_000, 0, 400_000)
+        eng.synth_read_mix(0, 0)
+        eng.count_kmers()
         votes = []
         for flags in (0, 16, 32, 4):                         # the form the engine picks (fold), queued, generic behind the bitmap, no filter at all
             eng.set_debug(flags)

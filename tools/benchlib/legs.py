@@ -106,7 +106,7 @@ def verify_forms(eng):
 
 
 def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_contigs=0, traffic=None, ref_bases=None, packed=False, recall=True,
-        want_stats=True):
+        want_stats=True, L=150):
     """one secondary workload on a loaded engine: a stats step, a warm-up step, `steps` timed ones"""
     w = Workload(engine, None, 0, 1, False, out_path)
     stats = w.stats_step() if want_stats else None
@@ -117,18 +117,18 @@ def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_co
          "work_stats": stats}
     if recall:
         d["planted_transfers"] = interval_recall(out_path, planted_breakpoints(n_contigs, contig_len, sample_contigs))
-    roof, dom = rooflines(k, e, 150, pairs, ref_bases or n_contigs * contig_len, n_contigs, packed, per_ms, d["scan_B_form"], n_peaks,
+    roof, dom = rooflines(k, e, L, pairs, ref_bases or n_contigs * contig_len, n_contigs, packed, per_ms, d["scan_B_form"], n_peaks,
                           traffic or {}, LIVE if traffic else None, stats, d["vote_form"])
     d["roofline"] = roof[dom]
     d["roofline_other"] = {ph: r for ph, r in roof.items() if ph != dom}
-    d["_shape"] = {"per_ms": per_ms, "k": k, "e": e, "ref_bases": ref_bases or n_contigs * contig_len, "n_contigs": n_contigs, "packed": packed}
+    d["_shape"] = {"per_ms": per_ms, "k": k, "e": e, "ref_bases": ref_bases or n_contigs * contig_len, "n_contigs": n_contigs, "packed": packed, "L": L}
     return d
 
 
 def reroof(d, traffic):
     """a leg's rooflines again once its PMC traffic is known (the children run after the engine has let go of the GPU)"""
     s = d["_shape"]
-    roof, dom = rooflines(s["k"], s["e"], 150, d["pairs"], s["ref_bases"], s["n_contigs"], s["packed"], s["per_ms"], d["scan_B_form"], d["raw_peaks"],
+    roof, dom = rooflines(s["k"], s["e"], s.get("L", 150), d["pairs"], s["ref_bases"], s["n_contigs"], s["packed"], s["per_ms"], d["scan_B_form"], d["raw_peaks"],
                           traffic or {}, LIVE if traffic else None, d.get("work_stats"), d.get("vote_form"))
     d["roofline"] = roof[dom]
     d["roofline_other"] = {ph: r for ph, r in roof.items() if ph != dom}

@@ -33,6 +33,21 @@ def run_all(detail, eng, args, wl, local, emit):
                                                    workload="13000x1000000 bp ref, 100 M pairs drawn from 300 of its contigs (100x), sample=1")
             eng.pairs_clear()
             emit("found")
+            # READ LENGTH (round 5).  The fast forms of phases A and C take reads of up to 159 bases (128 k-mer offsets);
+            # (1) the found-something sample with 1 % of its pairs as 250-base reads: those are passed over by the fast forms and
+            # handled by the generic ones -- round 4 sent the whole batch of 16 Mi pairs down the generic paths for one such read;
+            eng.synth_read_mix(10, 250)
+            eng.synth_pairs(1, 2, nc, cl, 0, args.pairs, L)
+            eng.synth_read_mix(0, 0)
+            out["uhgg_deep_focused_mixed_1pct_L250"] = dict(L_(eng, args.pairs, sample_contigs=300, steps=2),
+                                                            workload="the deep focused sample with 1 % of its pairs as 250-base reads (lhgt_synth_read_mix(10, 250))")
+            eng.pairs_clear()
+            # (2) the same sample as 250-base reads throughout: the generic scatter of phase A, the generic vote
+            eng.synth_pairs(1, 2, nc, cl, 0, args.pairs, 250)
+            out["uhgg_deep_focused_L250"] = dict(L_(eng, args.pairs, sample_contigs=300, steps=2, L=250),
+                                                 workload="the deep focused sample as 250-base reads (100 M pairs, 166x)")
+            eng.pairs_clear()
+            emit("read lengths")
             # ... with the reference's own read model: SNPs at 1 % of the sample genomes' bases (species20_snp0.01, test/run_BKP_detection.sh;
             # paper_results/simulation.py:280-299) -- sequencing differences change table fill, the form phase B picks and the vote's survivors
             eng.synth_options(10, 20, 300)

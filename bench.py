@@ -339,6 +339,8 @@ def main():
     if extras and rank == 0 and world == 1:
         from benchlib import secondary
         emit(detail, "cpu baseline", detail_path)
+        from localhgt_amd.engine import pool_trim
+        pool_trim()                  # the device blocks this process kept from its closed engines: the child gets the whole GPU
         secondary.run_e2e(detail, args, local, lambda stage: emit(detail, stage, detail_path))
     emit(detail, "final", detail_path)
     try:

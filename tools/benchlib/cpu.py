@@ -18,6 +18,29 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "extract_ref_raw")
 CPU_K, CPU_E, CPU_CONTIGS, CPU_CONTIG_LEN = 32, 3, 20, 1_000_000
 
 
+def usable_cpus():
+    """CPUs this process may use at once: the hardware threads, cut to the affinity mask and to the cgroup's quota where one is set
+    (the GPU boxes: cpu.max = 16 CPUs on a 256-thread host -- rounds 1-4 quoted "256 cores" for a leg that 16 CPUs ran)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = max(1, min(n, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def make_files(tmp, n_pairs, device=0):
     """(child process of bench.py: it uses the GPU) the FASTA / FASTQ files of the CPU legs and -- built by the product, byte-identical
     to the reference's (tests/test_gpu_parity.py) -- the index file, so that the reference's clock covers its phases, not read_ref"""
@@ -90,7 +113,7 @@ def port_and_gpu(fa, f1, f2, tmp, n_pairs, device, reference=None):
     from localhgt_amd import extract_ref
     orc = oracle_api.Oracle(build_oracle())
     orc.set_pretouch(True)     # table page faults before the phase timers, like the reference's memsets do (E:1416, 1458)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     k, e = CPU_K, CPU_E
     cpu_iv, gpu_iv, gpu_iv10 = (os.path.join(tmp, x) for x in ("interval.port.txt", "interval.gpu.txt", "interval.gpu_t10.txt"))
     rc, rep = orc.run(f1, f2, fa, cpu_iv, 0.1, 0.08, cores, k, 3000000, e, 1, 1.0)

@@ -296,7 +296,10 @@ int lhgt_synth_read_mix(lhgt_ctx* ctx, int long_permille, int long_len);
  * unchanged); bit17 / bit18: the queued sparse vote kernel reads peak_kmer / the read records with plain instead of non-temporal
  * loads (outputs unchanged); bit19: the generic vote kernel walks every pair with six hit offsets, without the bound that proves most
  * pairs with long event lists unable to vote (k <= 23; outputs unchanged); bit20: the vote bitmap takes its three-quarter (3 MiB) form whatever
- * the number of registered k-mers (k > 25; outputs unchanged).
+ * the number of registered k-mers (k > 25; outputs unchanged); bit21: phase A's direct form in its Small geometry (two 64 KiB
+ * workgroups per CU; outputs unchanged); bit22: stage ablation of phase A's direct form, the stages named by LHGT_PART_ABLATE (timing
+ * only, the table comes out WRONG); bit23: register_peaks looks every "count > 0" up in the table instead of taking what the
+ * trio-first probe kernels recorded (outputs unchanged).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts

@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(PA) part_apply(const void* __restrict__ keys_v
 //     16-byte aligned): a bucket only ever writes a multiple of 4 (8) keys, the remainder is CARRIED to the head of its row for
 //     the next tile and flushed key by key once, at the end.
 // part_apply2 is part_apply over the two half regions of a final bucket q = key >> 16.
-// Two geometries of the same kernels (LHGT_PART_GEOM picks one at run time; the table is the same):
+// Two geometries of the same kernels (debug bit 21 picks Small at run time; the table is the same):
 //   Small  512-thread workgroups with 64 KiB tiles, two per CU; two workgroups per level-1 segment in the key scatter
 //   Big    1024-thread workgroups with 128 KiB tiles, one per CU
 struct GeomSmall {
@@ -1233,8 +1233,12 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
         long np = b.d.n_pairs - p0 < chunk_pairs ? b.d.n_pairs - p0 : chunk_pairs;
         const PartCap pc = cap_of(np);
         if (direct_form) {
-            static const int ablate = getenv("LHGT_PART_ABLATE") ? atoi(getenv("LHGT_PART_ABLATE")) : 0;   // bits 0-1: the read scatter, bits 4-5: the key scatter
-            static const int geom = getenv("LHGT_PART_GEOM") ? atoi(getenv("LHGT_PART_GEOM")) : 1;          // 0 = Small (two 64 KiB workgroups per CU), 1 = Big
+            // both behind the context's debug flags (lhgt_set_debug; ADVICE r4: the geometry was an environment variable read once into
+            // a static -- untestable per context -- and the ablation switch, which makes tables WRONG, sat beside it):
+            //   bit 21: the Small geometry (two 64 KiB workgroups per CU; the table is the same: test_direct_form_...)
+            //   bit 22: stage ablation for timing, stages from LHGT_PART_ABLATE (bits 0-1: the read scatter, bits 4-5: the key scatter)
+            const int ablate = (ctx->debug & (1 << 22)) && getenv("LHGT_PART_ABLATE") ? atoi(getenv("LHGT_PART_ABLATE")) : 0;
+            const int geom = (ctx->debug & (1 << 21)) ? 0 : 1;
             const PartCap sc = seg_cap(pc.n);
             const size_t slice_bytes = (size_t)(((1 << g.slot_bits) + 15) >> 4) * 4;
             auto run = [&](auto G_) {

@@ -1331,7 +1331,7 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     if (ctx->n_tiles > 0)
         hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask,
-                       ctx->scan_form == 2 && !(ctx->debug & (1 << 20)) ? ctx->d_nzmask : nullptr /* debug bit 20: look every count up (A/B) */,
+                       ctx->scan_form == 2 && !(ctx->debug & (1 << 23)) ? ctx->d_nzmask : nullptr /* debug bit 23: look every count up (A/B) */,
                        ctx->d_tile_count, k, e, ctx->d_loci, ctx->d_peak_kmer,
                        ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (uint32_t)first_id, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());

@@ -353,7 +353,7 @@ def test_direct_form_of_the_partition_equals_direct_count(Engine):
     reads2 = rd(20001) + [b"T" * 150, b"GTGT" * 37, hot] * 700 + rd(3000)
     c2 = (rng.random(len(reads1)) < 0.9).astype(np.uint8)
     got = []
-    for mode, dbg in ((0, 0), (1, 0), (1, 65536)):
+    for mode, dbg in ((0, 0), (1, 0), (1, 65536), (1, 1 << 21)):      # bit 21: the Small geometry of the direct form
         with Engine(k, e) as eng:
             eng.rng_seed(11)
             eng.coder_generate()

@@ -5,7 +5,7 @@ o=gpurun_out/r04c
 rm -rf $o; mkdir -p $o
 for geom in ${GEOMS:-0 1}; do
 for ab in ${ABLATES:-0 1 2 3 16 32 48}; do
-  LHGT_PART_GEOM=$geom LHGT_PART_ABLATE=$ab PHASE_A_ONLY=1 timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $o/g${geom}ab$ab -- python3 tools/phase_a_time.py 25000000 > $o/g${geom}ab$ab.txt 2>&1
+  PHASE_A_DEBUG=$(( (geom == 0 ? 1 << 21 : 0) | 1 << 22 )) LHGT_PART_ABLATE=$ab PHASE_A_ONLY=1 timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $o/g${geom}ab$ab -- python3 tools/phase_a_time.py 25000000 > $o/g${geom}ab$ab.txt 2>&1
 done
 done
 python3 - <<'PY' > gpurun_out/r04c/ablation.txt
@@ -20,6 +20,6 @@ for d in sorted(glob.glob("gpurun_out/r04c/g*ab*/")):
 PY
 cat gpurun_out/r04c/ablation.txt
 if [ -n "$SQ" ]; then
-LHGT_PART_GEOM=$SQ PHASE_A_ONLY=1 tools/sq_collect_cmd.sh $o/sq_phase_a_direct.txt part_reads_direct,part_keys16_direct,part_apply tools/phase_a_time.py 8000000 > /dev/null 2>&1
+PHASE_A_DEBUG=$(( SQ == 0 ? 1 << 21 : 0 )) PHASE_A_ONLY=1 tools/sq_collect_cmd.sh $o/sq_phase_a_direct.txt part_reads_direct,part_keys16_direct,part_apply tools/phase_a_time.py 8000000 > /dev/null 2>&1
 grep -E "INSTS_VALU|INSTS_SALU|INSTS_LDS|WAVE_CYCLES|ACTIVE_INST_ANY|ACTIVE_INST_VALU|WAIT_ANY|WAIT_INST_ANY|LDS_BANK|LDS_IDX|WAIT_INST_LDS" $o/sq_phase_a_direct.txt
 fi

@@ -319,8 +319,10 @@ int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_ti
  *      three quarters of them are used (3 MiB instead of 4).  Measurement only. */
 int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarter);
 /* ---- work counters for the roofline's "bytes the implemented algorithm must move" (bench.py).  enable = 1: count from
- *      zero from now on; 0: stop; -1: leave as it is.  out (nullable, 8 values): [0] keys routed by phase A = valid k-mers x e of the
- *      counted mates (the direct kernel of k < 26 reports the upper bound k-mer positions x e); [1] count-table probes of phase B's
+ *      zero from now on; 0: stop; -1: leave as it is.  out (nullable, 8 values): [0] keys phase A's partition brought to its final
+ *      buckets = valid k-mers x e of the counted mates, minus the keys that were applied to the table on the way because a tile row, a
+ *      piece or a region was full (hot k-mers: none on uniform synthetic reads; so on hot inputs the roofline's needed bytes are
+ *      slightly understated); the direct kernel of k < 26 reports the upper bound k-mer positions x e; [1] count-table probes of phase B's
  *      probe kernel in the last lhgt_ref_scan while counting was on (e per position with a k-mer in the exact form; the hashes
  *      ref_flags_lite / ref_flags_trio marked as probed, summed before the fill of the unsettled tiles); [3] probes that
  *      went on from the LDS fold to the L2 bitmap; [4] probes that went on from the bitmap to peak_kmer; [5] pairs voted in the

@@ -151,7 +151,8 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
 
 // Work counters for bench.py's "bytes the implemented algorithm must move" (DESIGN.md 5).  enable = 1: start counting from zero;
 // 0: stop; -1: leave as it is.  out (nullable) receives
-//   [0] keys routed by phase A (valid k-mers x e of the counted mates; the direct kernel reports the upper bound k-mer positions x e)
+//   [0] keys phase A's partition brought to its final buckets (valid k-mers x e of the counted mates, minus those applied to the table on
+//       the way because a row, a piece or a region was full; the direct kernel reports the upper bound k-mer positions x e)
 //   [1] table probes of phase B's probe kernel in the LAST lhgt_ref_scan while counting was on: e per position with a k-mer in the
 //       exact form; in the single-first / trio-first forms the hashes ref_flags_lite / ref_flags_trio marked as probed in the
 //       per-position state bytes (summed right behind that kernel; the fill of the unsettled tiles comes later and is not in it)

@@ -248,7 +248,9 @@ constexpr int LF2_BITS = 20;
 constexpr int LF2_WORDS = (1 << LF2_BITS) / 32;
 constexpr int VF_Q = 368, VF_Q2 = 48, VF_WAVE_WORDS = VF_Q + VF_Q2 + 64;   // per wave: first queue (its head stages the records), second queue, scratch
 constexpr int VF_WAVES = 16;
-template <int EC>   // EC = 3: e known at compile time (no uniform branch per hash), 0: e <= 3 at run time
+// SPM (round 5): slices of 64 k-mer offsets per mate -- 2 takes reads of up to FAST_NK = 128 offsets (159 bases at k = 32), 4 reads of
+// up to 256 offsets (287 bases: 250-base reads; the staging words, 32 per mate, hold their three planes of <= 10 words)
+template <int EC, int SPM>   // EC = 3: e known at compile time (no uniform branch per hash), 0: e <= 3 at run time
 __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b, HashParams hp, const uint32_t* __restrict__ peak_kmer,
                                                                   const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                                   int fold_words, uint32_t* __restrict__ revote, int debug, uint32_t pf_mask, int pf2,
@@ -325,25 +327,26 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             nk[m] = cur.len[m] - k + 1;
             wpr[m] = ((cur.len[m] + 31) >> 5) + 1;
         }
-        if (nk[0] > FAST_NK || nk[1] > FAST_NK) {       // a read longer than this form's windows and staging words take: the generic kernel votes the pair
+        if (nk[0] > 64 * SPM || nk[1] > 64 * SPM) {     // a read longer than this instance's windows and staging words take: the generic kernel votes the pair
             if (lane == 0) revote[1u + atomicAdd(revote, 1u)] = (uint32_t)p;
             continue;
         }
         // In three sweeps -- all window words, all hashes, all fold probes -- and every load unconditional (a load under a lane mask
         // is an exec region with its own wait: a dozen LDS round trips in a row instead of one); a hash the run does not have
         // (i >= e) reads mask 0 and is switched off with its `ok` bit.
-        uint32_t hs[4][3], f1[4][3], wd[4][6];
-        bool ok[4];
+        constexpr int NS = 2 * SPM;
+        uint32_t hs[NS][3], f1[NS][3], wd[NS][6];
+        bool ok[NS];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int m = s >> 1, j = (s & 1) * 64 + lane;
+        for (int s = 0; s < NS; s++) {
+            const int m = s / SPM, j = (s % SPM) * 64 + lane;
             const uint32_t* q = stage + m * 32 + (j < nk[m] ? (j >> 5) : 0);
             const int wp = wpr[m];
             wd[s][0] = q[0]; wd[s][1] = q[1]; wd[s][2] = q[wp]; wd[s][3] = q[wp + 1]; wd[s][4] = q[2 * wp]; wd[s][5] = q[2 * wp + 1];
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int m = s >> 1, j = (s & 1) * 64 + lane, r = j & 31;
+        for (int s = 0; s < NS; s++) {
+            const int m = s / SPM, j = (s % SPM) * 64 + lane, r = j & 31;
             auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
             const uint32_t whi = win(wd[s][0], wd[s][1]), wlo = win(wd[s][2], wd[s][3]), wnb = win(wd[s][4], wd[s][5]);
             const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
@@ -352,17 +355,17 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             for (int i = 0; i < 3; i++) hs[s][i] = hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]);
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int i = 0; i < 3; i++) f1[s][i] = lds[(hs[s][i] & lf_mask) >> 5];
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int i = 0; i < 3; i++) f1[s][i] = (uint32_t)pf_pass(f1[s][i], hs[s][i], pf2) & (uint32_t)(ok[s] & (i < e));
         __builtin_amdgcn_wave_barrier();
         int c = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int i = 0; i < 3; i++) c += (int)f1[s][i];
         const int incl = wave_incl_scan(c, lane);
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(64 * VF_WAVES) vote_kernel_fold(ReadBatchDev b
             st_l2 += (unsigned long long)T;
             int slot = incl - c;
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int s = 0; s < NS; s++)
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     uint32_t* dst = f1[s][i] ? Q + slot : dump + lane;   // no branch: dead candidates land in a scratch word
@@ -676,7 +679,14 @@ int lhgt_vote(lhgt_ctx* ctx) {
         // reads and list the others, which the generic kernel votes behind them (votes are sums: the order is free)
         const bool mixed = nk > FAST_NK && b.n_long >= 0 && b.n_long * 8 <= 2 * b.d.n_pairs && ctx->e <= 3 && ctx->prefilter_on && !(ctx->debug & 32);
         const int nk_all = nk;
-        if (mixed) nk = FAST_NK;
+        // ... and a batch of reads of 160-287 bases (256 offsets) takes the fold kernel's wide instance where the fold applies (e = 3);
+        // its few still longer pairs, if any, are listed like a mixed batch's
+        static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 0.0;   // bit insertions per fold bit (0 = the defaults)
+        const double fold_ins = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1));
+        const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : 1.15) * (double)(1ull << LF2_BITS);
+        const bool wide = !mixed && nk > FAST_NK && nk <= 2 * FAST_NK && ctx->e == 3 && ctx->prefilter_on && !(ctx->debug & (32 | 16)) && ctx->k > PF_BITS &&
+                          !ctx->pf_q3 && fold_ok;
+        if (mixed || wide) nk = FAST_NK;         // (the sparse forms' own sizes below are those of short reads; vote_list sizes for nk_all)
         int max_ev = 2 * nk;
         size_t per_wave = ((size_t)max_ev * ctx->e * 2 + 64) * 4;   // events + 64 staging words
         int wpb = (int)(65536 / per_wave);
@@ -734,26 +744,27 @@ int lhgt_vote(lhgt_ctx* ctx) {
         // quarter insertion per bit; measured in round 3 on 100 M pairs from 300 genomes of the 13 Gbase reference (205 410 registered
         // k-mers): 296 ms without a fold, 146 ms with 64 KiB (0.78 insertions per bit), 128 KiB below.  2.3 M k-mers (configs[2])
         // fill any fold that fits.
-        static const double fold_max = getenv("LHGT_FOLD_MAX") ? atof(getenv("LHGT_FOLD_MAX")) : 0.0;   // bit insertions per fold bit (0 = the defaults)
-        const double fold_ins = (double)(ctx->n_selected * (unsigned long long)ctx->e * (ctx->pf2 ? 2 : 1));
-        const bool fold_ok = fold_ins <= (fold_max > 0 ? fold_max : 1.15) * (double)(1ull << LF2_BITS);
         ctx->vote_form = ctx->prefilter_on ? 1 : 0;
         if (sparse_ok && ctx->k > PF_BITS && fold_ok && !ctx->pf_q3 && !(ctx->debug & 16)) {
             ctx->vote_form = 3;
             const int fold_words = (int)std::min<unsigned long long>(LF2_WORDS, (ctx->pf_mask + 1ull) / 32);
             const size_t lds3 = (size_t)(LF2_WORDS + VF_WAVES * VF_WAVE_WORDS) * 4;
             LHGT_TRY(list_room());
-            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel_fold<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
             hipLaunchKernelGGL(fold_prefilter, dim3((fold_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_prefilter, (int)((ctx->pf_mask + 1ull) / 32),
                                ctx->d_prefilter_fold, fold_words);
             long fb = (b.d.n_pairs + VF_WAVES - 1) / VF_WAVES;
             if (fb > 256) fb = 256;             // one resident workgroup per CU
-            if (ctx->e == 3)
-                hipLaunchKernelGGL(vote_kernel_fold<3>, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
+            if (wide)               // reads of 160-287 bases throughout: four slices of 64 offsets per mate
+                hipLaunchKernelGGL((vote_kernel_fold<3, 4>), dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
+                                   ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
+            else if (ctx->e == 3)
+                hipLaunchKernelGGL((vote_kernel_fold<3, 2>), dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
                                    ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
             else
-                hipLaunchKernelGGL(vote_kernel_fold<0>, dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
+                hipLaunchKernelGGL((vote_kernel_fold<0, 2>), dim3((unsigned)fb), dim3(64 * VF_WAVES), lds3, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter,
                                    ctx->d_prefilter_fold, fold_words, ctx->d_revote, ctx->debug, ctx->pf_mask, ctx->pf2, d_stats);
             // the deferred pairs, from scratch in the lane-per-offset form (hits in offset order for the judge); the list's length
             // is read on the device

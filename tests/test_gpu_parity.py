@@ -861,6 +861,21 @@ def test_a_few_long_reads_do_not_demote_their_batch(Engine, oracle, tmp_path):
         for other in votes[1:]:
             assert other[0] == votes[0][0] and (other[1] == votes[0][1]).all()
         assert {votes[0][2], votes[1][2]} <= {"fold", "queued"} and votes[0][2] != votes[2][2], [v[2] for v in votes]
+        # 250-base reads throughout: the fold kernel's wide instance (four slices of 64 offsets per mate) against the generic kernels
+        eng.pairs_clear()
+        eng.counts_clear()
+        eng.synth_pairs(3, 4, 40, 200_000, 0, 300_000, 250)
+        eng.count_kmers()
+        wide = []
+        for flags in (0, 32, 4):
+            eng.set_debug(flags)
+            n = eng.ref_scan(0.1, 0.08, 10**7)
+            eng.vote()
+            wide.append((n, eng.peaks_export(n)[1].copy(), eng.vote_info()["form"]))
+        eng.set_debug(0)
+        assert wide[0][2] == "fold" and wide[1][2] == "bitmap" and wide[0][0] > 20 and wide[0][1].max() >= 1, [w[2] for w in wide]
+        for other in wide[1:]:
+            assert other[0] == wide[0][0] and (other[1] == wide[0][1]).all()
     # from files, against the oracle: k = 24 (phase C's path; phase A's applies at k = 32 and is covered above)
     k = 24
     rng = np.random.default_rng(3)

@@ -876,6 +876,8 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     const long BATCH_PAIRS_MAX = 4L << 20, META_CAP = BATCH_PAIRS_MAX + (1L << 18);
     const size_t BATCH_BYTES_MAX = (size_t)1280 << 20, CHUNK = (size_t)lhgt_fastq_plan_chunk_bytes();
     long BATCH_PAIRS = ctx->count_on_load ? 1L << 20 : BATCH_PAIRS_MAX;
+    const long batch_hook = getenv("LHGT_INGEST_BATCH_PAIRS") ? atol(getenv("LHGT_INGEST_BATCH_PAIRS")) : 0;   // test hook: small files close batches too
+    if (batch_hook >= 64 && batch_hook < BATCH_PAIRS) BATCH_PAIRS = batch_hook;
     if (ctx->count_on_load) ctx->part_reserve_pairs = BATCH_PAIRS_MAX;     // phase A's key buffers: made once, for the largest batch
     size_t BATCH_BYTES = ctx->count_on_load ? (size_t)320 << 20 : BATCH_BYTES_MAX;
     const size_t HALF = CHUNK + 1024, SLAB = 2 * HALF + sizeof(ChunkPairMeta) * (CHUNK_META_CAP + 1);
@@ -1019,7 +1021,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
         count_ev.clear();
         fill = 0; n_open = 0; kept = 0; n_desc = 0; n_batches = 0; words = 0; nkm = 0; max_len = 0; n_long = 0;
         used[0] = used[1] = false;
-        if (ctx->count_on_load) { BATCH_PAIRS = 1L << 20; BATCH_BYTES = (size_t)320 << 20; }
+        if (ctx->count_on_load) { BATCH_PAIRS = batch_hook >= 64 && batch_hook < (1L << 20) ? batch_hook : 1L << 20; BATCH_BYTES = (size_t)320 << 20; }
         return LHGT_OK;
     };
     int rc = parse_pairs(fq1, fq2, ratio_percent, ctx->random_array.data(), shard_rank, shard_world, shard_block, threads, CHUNK,

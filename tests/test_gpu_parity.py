@@ -910,3 +910,41 @@ def test_a_few_long_reads_do_not_demote_their_batch(Engine, oracle, tmp_path):
     rc, orep = oracle.run(f1, f2, fa2, str(tmp_path / "cpu.txt"), 0.1, 0.08, 1, k, 100_000, 3, 1, 1.0)
     assert rc == 0 and (rep["n_peaks"], rep["n_filtered"]) == (orep.n_peaks, orep.n_filtered) and orep.n_filtered >= 1
     assert open(str(tmp_path / "gpu.txt")).read() == open(str(tmp_path / "cpu.txt")).read()
+
+
+def test_single_pass_gives_up_midway_and_the_planned_loader_takes_over(Engine, oracle, case_inputs, tmp_path, monkeypatch):
+    """the single-pass loader meets a line longer than a chunk's margin two thirds into the files, after batches have been installed
+    AND counted (count-on-load; LHGT_INGEST_BATCH_PAIRS makes a small file close batches): what it delivered is taken back -- batches
+    dropped, the count table cleared -- and the planned loader's result stands: same interval file as with the single pass switched
+    off, and as the oracle's"""
+    from localhgt_amd import extract_ref, _lib
+    import ctypes as C
+    fa, f1, f2, meta = case_inputs("k24_seed7")
+    l1, l2 = open(f1, "rb").read().split(b"\n"), open(f2, "rb").read().split(b"\n")
+    cut = (len(l1) * 2 // 3) // 4 * 4
+    g1, g2 = str(tmp_path / "g.1.fq"), str(tmp_path / "g.2.fq")
+    open(g1, "wb").write(b"\n".join(l1[:cut] + [b"@long/1", b"ACGT" * 30, b"+", b"I" * 70000] + l1[cut:]))
+    open(g2, "wb").write(b"\n".join(l2[:cut] + [b"@long/2", b"ACGT" * 30, b"+", b"I" * 70000] + l2[cut:]))
+    case = cases.CASES["k24_seed7"]
+    monkeypatch.setenv("LHGT_INGEST_CHUNK_BYTES", "30000")
+    monkeypatch.setenv("LHGT_INGEST_BATCH_PAIRS", "512")
+    outs = {}
+    for tag, stream in (("single pass first", "1"), ("planned only", "0")):
+        monkeypatch.setenv("LHGT_INGEST_STREAM", stream)
+        d = tmp_path / tag.replace(" ", "_")
+        d.mkdir()
+        fa2 = str(d / "ref.fa")
+        shutil.copy(fa, fa2)
+        a = extract_ref.Args(g1, g2, fa2, str(d / "i.txt"), case.hit_ratio, case.match_ratio, 1, case.k, case.max_peak, case.e, case.seed, 1.0)
+        rep = extract_ref.run(a, log=lambda *x: None)
+        why = C.create_string_buffer(200)
+        path = _lib.load().lhgt_ingest_last_path(why, 200)
+        outs[tag] = (open(str(d / "i.txt")).read(), rep["pairs_kept"], rep["n_peaks"], rep["n_filtered"], path, why.value.decode())
+    assert outs["single pass first"][:4] == outs["planned only"][:4]
+    assert outs["single pass first"][4] == 0 and "longer than a chunk's margin" in outs["single pass first"][5], outs["single pass first"][4:]
+    d = tmp_path / "cpu"
+    d.mkdir()
+    fa2 = str(d / "ref.fa")
+    shutil.copy(fa, fa2)
+    rc, orep = oracle.run(g1, g2, fa2, str(d / "i.txt"), case.hit_ratio, case.match_ratio, 1, case.k, case.max_peak, case.e, case.seed, 1.0)
+    assert rc == 0 and open(str(d / "i.txt")).read() == outs["planned only"][0] and orep.n_peaks == outs["planned only"][2] > 10

@@ -120,6 +120,17 @@ struct ByteParts {
     std::vector<long> pos, stop;
     std::unique_ptr<std::atomic<long>[]> first;
     std::atomic<bool>* odd = nullptr;      // set when a thread turns out to enter off a record boundary (the planned loader refuses that)
+    // Do all lines that start in [a, b) belong to ONE thread's chunk, whose first line number is known?  Then the keep test of a
+    // sequence line g there is sampled((g - first) / 4) -- no search, no atomic: -> first line number, or -1
+    long whole(size_t a, size_t b) const {
+        if (a >= b) return -1;
+        const size_t i1 = (size_t)(std::upper_bound(pos.begin(), pos.end(), (long)a) - pos.begin());
+        if (i1 == 0) return -1;
+        const size_t i = i1 - 1;
+        if ((long)b > stop[i] || (i + 1 < pos.size() && pos[i + 1] < (long)b)) return -1;
+        const long f = first[i].load(std::memory_order_acquire);
+        return f >= 0 && f % 4 == 0 ? f : -1;
+    }
     // the reference's keep test for the sequence line g that starts at byte sa (host_fastx.cpp: ThreadPart::keep).  *hint: the
     // part the caller's previous line fell into -- a column's lines come in file order, so the search is a step or two
     int keep(long g, size_t sa, double ratio, const float* random_array, size_t* hint) const {
@@ -430,6 +441,9 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                     }
                 }
                 size_t hint1 = 0, hint2 = 0;
+                // a chunk that lies inside one thread's chunk (485 of 4853 columns at -t 10 hold a boundary): its lines' keep test is
+                // arithmetic on the line number
+                const long whole1 = emu && !emu_lines ? bp1.whole(v1.S, v1.E) : -1, whole2 = emu && !emu_lines ? bp2.whole(v2.S, v2.E) : -1;
                 LineCursor fwd(m2);                      // partner lines behind fq2's chunk
                 fwd.cur = v2.E;
                 long fwd_idx = h1, walked = 0;
@@ -460,9 +474,13 @@ int parse_pairs_stream(const Mapped& m1, const Mapped& m2, const char* fq1, cons
                     if (emu_lines)
                         fl = (uint8_t)((emu_lines->f1.keep(g, ratio, random_array) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
                                        (have2 && emu_lines->f2.keep(h, ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
-                    else if (emu)
-                        fl = (uint8_t)((bp1.keep(g, sa, ratio, random_array, &hint1) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
-                                       (have2 && bp2.keep(h, sb, ratio, random_array, &hint2) == 1 ? PAIR_COUNT2 : 0));
+                    else if (emu) {
+                        const bool in2 = h >= h0 && h < h1;      // the partner line lies in fq2's chunk (not walked to)
+                        const int k1 = whole1 >= 0 ? (int)sampled((g - whole1) / 4) : bp1.keep(g, sa, ratio, random_array, &hint1);
+                        const int k2 = !have2 ? 0 : whole2 >= 0 && in2 ? ((h - whole2) % 4 == 1 ? (int)sampled((h - whole2) / 4) : -1)
+                                                                       : bp2.keep(h, sb, ratio, random_array, &hint2);
+                        fl = (uint8_t)((k1 == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) | (k2 == 1 ? PAIR_COUNT2 : 0));
+                    }
                     else
                         fl = (uint8_t)((sampled(n) ? PAIR_COUNT1 | PAIR_VOTE : 0) | (have2 && sb <= n1 && sampled(h / 4) ? PAIR_COUNT2 : 0));   // quirk Q4
                     if (!fl || (shard_world > 1 && (n / shard_block) % shard_world != shard_rank)) continue;

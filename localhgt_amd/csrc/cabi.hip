@@ -167,6 +167,7 @@ int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]) {
         LHGT_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
         memset(ctx->stats_host, 0, sizeof ctx->stats_host);
         ctx->stats_on = true;
+        ctx->stats_scan = false;
     } else if (enable == 0) ctx->stats_on = false;
     if (!out) return LHGT_OK;
     for (int i = 0; i < 8; i++) out[i] = 0;
@@ -174,7 +175,7 @@ int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]) {
     // phase B, exact form: e probes per position with a k-mer (the single-first / trio-first forms count theirs on the device, right
     // behind the probe kernel and before the fill of the unsettled tiles: k_scan.hip)
     unsigned long long probes_exact = 0;
-    if (ctx->n_peaks >= 0 && ctx->index_resident && ctx->scan_form == 0)
+    if (ctx->n_peaks >= 0 && ctx->index_resident && ctx->scan_form == 0 && ctx->stats_scan)
         for (const ContigDev& c : ctx->contigs) probes_exact += (unsigned long long)(c.len >= (uint32_t)ctx->k ? c.len - ctx->k + 1 : 0) * ctx->e;
     unsigned long long h[8];
     LHGT_HIP(hipMemcpyAsync(h, ctx->d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));

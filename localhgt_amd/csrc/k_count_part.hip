@@ -1129,8 +1129,8 @@ __global__ void __launch_bounds__(PA) part_apply2(const uint16_t* __restrict__ k
     for (int i = threadIdx.x; i < words; i += PA) T[i] = slice[i];
 }
 
-// lhgt_work_stats: keys the read scatter sent to the level-1 segments of this chunk (every key, also those that found their
-// region full and went straight to the table)
+// lhgt_work_stats [0]: the sum of a chunk's cursors -- the sorted tiles' level-1 cursors (every key the read scatter routed), the
+// direct form's final-bucket cursors (keys that reached a region; the few applied to the table on the way are not in them)
 __global__ void __launch_bounds__(256) part_sum_cursors(const uint32_t* __restrict__ cur1, int n, unsigned long long* __restrict__ out) {
     unsigned long long v = 0;
     for (int i = threadIdx.x; i < n; i += 256) v += cur1[i];

@@ -1070,6 +1070,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // 74.2 % / 92.7 % (50 M) 878 -> 494; 67.4 % / 32.3 % (35 M) 946 -> 890; 58.6 % / 0.5 % (25 M) 1067 -> 1169; 24.5 % / 25.1 % (configs[1]) 97 -> 105
     ctx->scan_lite = sparse_form || (e <= 3 && !(ctx->debug & (8192 | 16384)) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.4 : frac3 >= 0.65)));
     ctx->scan_form = sparse_form ? 2 : ctx->scan_lite ? 1 : 0;
+    ctx->stats_scan = ctx->stats_on;
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (sparse_form) {

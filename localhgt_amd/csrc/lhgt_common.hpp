@@ -211,6 +211,7 @@ struct lhgt_ctx {
     // filter level (8 x u64 on the device; null = off, the kernels then issue no extra instruction but a scalar add per pair)
     unsigned long long* d_stats = nullptr;
     bool stats_on = false;
+    bool stats_scan = false;   // the last lhgt_ref_scan ran while counting was on (lhgt_work_stats [1] of the exact form is computed on the host)
     unsigned long long stats_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // contributions known on the host (direct count kernel: upper bound of its keys)
     int debug = 0;             // ablation switches for profiling (bit0: vote skips judge_base); results are wrong when set
     // FASTQ loader (host_fastx.cpp): pinned slabs the parse threads write into (bases + per-pair records), pinned chunk descriptors of the open batch,

@@ -104,6 +104,7 @@ SIGNATURES = {
     "lhgt_set_cu_mask": [_vp, _u32p, _i],
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_scan_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), _lp, _lp],
+    "lhgt_slot_list": [_vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "lhgt_work_stats": [_vp, _i, _u64p],
     "lhgt_vote_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lhgt_stream": [_vp, C.POINTER(_vp)],

@@ -217,6 +217,7 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     c->k = k;
     c->e = e;
     memset(c->cc, 0, sizeof c->cc);
+    if (const char* sl = getenv("LHGT_SLOT_LIST")) c->sl_mode = atoi(sl) < 0 || atoi(sl) > 2 ? 1 : atoi(sl);
     if (const char* dbg = getenv("LHGT_DEBUG")) c->debug = atoi(dbg);   // lhgt_set_debug's switches for whole-program runs (tests)
     memset(c->rng_state, 0, sizeof c->rng_state);
     c->counts_words = ((size_t)1 << k) / 16;
@@ -248,6 +249,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt_pairs_clear(c);
     lhgt::ingest_free(c);
     lhgt_ingest_pool_free(c);
+    lhgt::slot_list_drop(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words,
@@ -326,10 +328,26 @@ int lhgt_phase_ms(lhgt_ctx* ctx, int phase, float* ms) {
 
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
-    if (lite) *lite = ctx->scan_form;   // 0 exact, 1 single-first (lite), 2 trio-first
+    if (lite) *lite = ctx->scan_form == 2 && ctx->scan_slots ? 3 : ctx->scan_form;   // 0 exact, 1 single-first (lite), 2 trio-first, 3 slot-first (trio-first answered from the slot list)
     if (frac_slots_at_3) *frac_slots_at_3 = ctx->scan_frac3;
     if (n_tiles) *n_tiles = ctx->n_tiles;
     if (n_tiles_exact) *n_tiles_exact = ctx->scan_lite ? ctx->scan_n_need : ctx->n_tiles;
+    return LHGT_OK;
+}
+
+// The slot list of the resident reference (k_scan.hip: ref_flags_slots).  mode 0: never build one, and drop the one that exists;
+// 1 (default; LHGT_SLOT_LIST): build it before the second sparse-form scan of the same resident reference; 2: before the first;
+// -1: leave the mode as it is.  entries / bytes (nullable): the list as it stands (0 = none).
+int lhgt_slot_list(lhgt_ctx* ctx, int mode, unsigned long long* entries, unsigned long long* bytes) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || mode < -1 || mode > 2) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    if (mode >= 0) ctx->sl_mode = mode;
+    if (mode == 0 && ctx->sl_state != 0) {
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        lhgt::slot_list_drop(ctx);
+    }
+    if (entries) *entries = ctx->sl_state == 1 ? ctx->sl_entries : 0ull;
+    if (bytes) *bytes = ctx->sl_state == 1 ? 6ull * ctx->sl_entries + 8ull * (unsigned long long)(ctx->sl_buckets + 1) : 0ull;
     return LHGT_OK;
 }
 

@@ -146,9 +146,12 @@ __global__ void __launch_bounds__(256) pack_span_flat(const uint8_t* __restrict_
             if (code & 1) wlo |= bit;
         }
     }
-    if (whi) atomicOr(planes + w, whi);
-    if (wlo) atomicOr(planes + plane_words + w, wlo);
-    if (wnb) atomicOr(planes + 2 * plane_words + w, wnb);
+    // the three planes interleaved word by word (round 5): a k-mer's 2 x 3 words are 24 consecutive bytes, one memory line for a
+    // position looked up on its own (k_scan.hip: ref_flags_slots) where three separate planes were three
+    (void)plane_words;
+    if (whi) atomicOr(planes + 3 * w, whi);
+    if (wlo) atomicOr(planes + 3 * w + 1, wlo);
+    if (wnb) atomicOr(planes + 3 * w + 2, wnb);
 }
 
 // ---------------------------------------------------------------- FASTA text -> its sequences back to back
@@ -587,6 +590,7 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
 // ---------------------------------------------------------------- index layout / install
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index) {
     const int k = ctx->k, e = ctx->e;
+    slot_list_drop(ctx);
     for (void* p : {(void*)ctx->d_index, (void*)ctx->d_ref_planes, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count})
         if (p) lhgt::dev_free(p);
     ctx->d_ref_planes = nullptr; ctx->ref_plane_words = 0;

@@ -987,6 +987,156 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
     }
 }
 
+// ---- B1 for a sparse table with the reference resident across samples ("slot-first", round 5).  The trio-first kernel above asks
+// the table ONE question per reference position before anything else -- does the slot of hash 0 read 3? -- and on a sparse table
+// that first probe is all most positions ever cost: 13 G random 128-byte line fills for 13 Gbase, 232 ms at the fabric's line
+// rate whatever the sample.  The question does not depend on the sample, only its answer does.  So a context that scans a second
+// sample against the same resident reference turns the question round, once: the SLOT LIST holds every position with a k-mer,
+// grouped by the top bits of its hash 0 -- bucket b = the 2^14 slots [b << 14, (b + 1) << 14), an entry = (low 14 bits of the
+// slot, flat position): 6 bytes, two arrays (u32 low position bits; u16 slot bits | position bits 32-33 << 14).  A scan then
+// streams the list (78 GB for 13 Gbase) next to each bucket's 4 KiB of counters in LDS, and only the positions whose slot reads 3
+// (the table's fill: 15-20 %) go on to hash 1 and 2 exactly as ref_flags_trio's loop does -- one line for the k-mer's hashes or
+// bases, 1 + f probes.  Only positions whose e hashes ALL read 3 are written (flags 0x83, pstate = all probed, all 3): flags and
+// pstate are cleared beforehand, and "nothing known" is what ref_flags_fill and register_peaks take a zero byte for, so the tiles
+// near a candidate window get every probe from the fill -- the trio bit is exact everywhere, which is all window_trio reads.
+// Same peaks, ids and votes as every other form (the form tests run it next to them).
+constexpr int SL_BITS = 14;
+constexpr uint32_t SL_SLOTS = 1u << SL_BITS;
+
+__global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
+                                                     int k, int e, uint32_t* __restrict__ hist, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        const long j = (long)t.j0 + jj;
+        if (j >= nk) break;
+        const RefKmer km = ref_kmer(rs, c, j, k, e);
+        const uint32_t h = ref_hash(rs, km, 0);
+        if (h != 0) atomicAdd(&hist[h >> SL_BITS], 1u);     // hash 0 = invalid (E:936-941): never at 3, not listed
+    }
+}
+// one workgroup: hist -> exclusive offsets (u64), hist cleared to serve as the fill's cursors
+__global__ void __launch_bounds__(1024) slot_list_offsets(uint32_t* __restrict__ hist, long nb, unsigned long long* __restrict__ off) {
+    __shared__ unsigned long long part[1024];
+    const long per = (nb + 1023) / 1024, b0 = (long)threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+    unsigned long long s = 0;
+    for (long b = b0; b < b1; b++) s += hist[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        off[nb] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (long b = b0; b < b1; b++) { off[b] = run; run += hist[b]; hist[b] = 0u; }
+}
+__global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
+                                                     int k, int e, const unsigned long long* __restrict__ off, uint32_t* __restrict__ cur,
+                                                     uint32_t* __restrict__ lo, uint16_t* __restrict__ hi, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    for (int jj = threadIdx.x; jj < TILE; jj += BT) {
+        const long j = (long)t.j0 + jj;
+        if (j >= nk) break;
+        const RefKmer km = ref_kmer(rs, c, j, k, e);
+        const uint32_t h = ref_hash(rs, km, 0);
+        if (h == 0) continue;
+        const uint32_t b = h >> SL_BITS;
+        const unsigned long long at = off[b] + atomicAdd(&cur[b], 1u);
+        const uint64_t x = c.flat_base + (uint64_t)j;
+        lo[at] = (uint32_t)x;
+        hi[at] = (uint16_t)((h & (SL_SLOTS - 1u)) | ((uint32_t)(x >> 32) << SL_BITS));
+    }
+}
+
+// one workgroup per bucket; a wave gathers the entries whose slot reads 3 in a queue of its own and works them off 64 at a time, so
+// the dependent chain of a survivor (the line with its hashes, then one or two probes) runs with every lane busy
+template <bool PACKED>
+__global__ void __launch_bounds__(BT) ref_flags_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
+                                                      const uint16_t* __restrict__ hi, const RefSource rs, const ContigDev* __restrict__ contigs,
+                                                      int n_contigs, const uint32_t* __restrict__ counts, int slice_words, int k, int e,
+                                                      uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
+                                                      unsigned long long* __restrict__ stats /* nullable: [0] probes of the table */, long n_buckets) {
+    __shared__ uint32_t slice[SL_SLOTS / 16];
+    __shared__ uint64_t queue[BT / 64][128];
+    const long b = block2d();
+    if (b >= n_buckets) return;
+    const unsigned long long begin = off[b], end = off[b + 1];
+    if (begin == end) return;                                   // uniform
+    uint32_t any3 = 0;
+    for (int i = threadIdx.x; i < slice_words; i += BT) {
+        const uint32_t w = counts[(size_t)b * (SL_SLOTS / 16) + i];
+        slice[i] = w;
+        any3 |= w & (w >> 1) & 0x55555555u;
+    }
+    if (!__syncthreads_or(any3 != 0u)) return;                  // no slot of the bucket reads 3: none of its positions goes on
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t full = (1u << e) - 1u;
+    uint64_t* q = queue[wv];
+    int qn = 0;
+    unsigned long long probes = 0;
+    auto work = [&](uint64_t x) {
+        RefKmer km;
+        if (PACKED) {
+            ContigDev flat{};                                   // the planes run over the flat positions: no contig needed
+            km = ref_kmer(rs, flat, (long)x, k, e);
+        } else {
+            int a = 0, z = n_contigs;                           // last contig with flat_base <= x
+            while (z - a > 1) { const int mid = (a + z) >> 1; if (contigs[mid].flat_base <= x) a = mid; else z = mid; }
+            const ContigDev c = contigs[a];
+            km = ref_kmer(rs, c, (long)(x - c.flat_base), k, e);
+        }
+        uint32_t known = 1u, is3 = 1u;
+        bool all3 = true;
+#pragma unroll
+        for (int i = 1; i < 3; i++)
+            if (i < e && all3) {
+                const uint32_t h = ref_hash(rs, km, i);
+                const uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;
+                known |= 1u << i;
+                probes++;
+                if (cnt == 3u) is3 |= 1u << i;
+                else all3 = false;
+            }
+        if (is3 == full) {
+            flags[x] = 0x83;                                    // single, trio, exact
+            pstate[x] = (uint8_t)(is3 | (known << 4));
+        }
+    };
+    for (unsigned long long i0 = begin + (unsigned long long)wv * 64u; i0 < end; i0 += BT) {    // wave-uniform bounds
+        const unsigned long long i = i0 + lane;
+        bool pass = false;
+        uint64_t x = 0;
+        if (i < end) {
+            const uint32_t hv = hi[i];
+            const uint32_t s = hv & (SL_SLOTS - 1u);
+            pass = ((slice[s >> 4] >> ((s & 15u) * 2u)) & 3u) == 3u;
+            x = (uint64_t)lo[i] | ((uint64_t)(hv >> SL_BITS) << 32);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) q[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x;
+        qn += __popcll(m);
+        if (qn >= 64) {
+            qn -= 64;
+            work(q[qn + lane]);
+        }
+    }
+    if (lane < qn) work(q[lane]);
+    if (stats) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) probes += __shfl_xor(probes, d, 64);
+        if (lane == 0 && probes) atomicAdd(stats, probes);
+    }
+}
+
 }  // namespace lhgt
 
 using namespace lhgt;
@@ -998,6 +1148,65 @@ static RefSource ref_source(const lhgt_ctx* ctx) {
     rs.plane_words = ctx->ref_plane_words;
     rs.hp = ctx->hp;
     return rs;
+}
+
+// The slot list of the resident reference (see ref_flags_slots).  Built once per reference: a histogram pass over the positions'
+// hash 0, the bucket offsets, a placing pass -- 2 x 13 G atomics on 2^18 counters for 13 Gbase, a second or two; kept until the
+// reference is replaced.  Not built (the trio-first kernel scans) when a position needs more than 34 bits, when e > 3, or when
+// it would leave less than LHGT_SLOT_LIST_HEADROOM_GB (default 40) of the device's memory free.
+namespace lhgt {
+void slot_list_drop(lhgt_ctx* ctx) {
+    for (void* p : {(void*)ctx->d_sl_lo, (void*)ctx->d_sl_hi, (void*)ctx->d_sl_off}) if (p) lhgt::dev_free(p);
+    ctx->d_sl_lo = nullptr; ctx->d_sl_hi = nullptr; ctx->d_sl_off = nullptr;
+    ctx->sl_entries = 0; ctx->sl_buckets = 0; ctx->sl_state = 0; ctx->sl_sparse_scans = 0;
+}
+}  // namespace lhgt
+static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int slot_list_build(lhgt_ctx* ctx) {
+    const bool trace = getenv("LHGT_TRACE") != nullptr;
+    ctx->sl_state = -1;                                          // whatever happens below: one attempt per reference
+    if (ctx->e > 3 || ctx->n_tiles == 0 || ctx->n_pos >= (1ull << 34)) return LHGT_OK;
+    const long nb = ctx->k > SL_BITS ? 1L << (ctx->k - SL_BITS) : 1;
+    static const double headroom_gb = getenv("LHGT_SLOT_LIST_HEADROOM_GB") ? atof(getenv("LHGT_SLOT_LIST_HEADROOM_GB")) : 40.0;
+    size_t free_b = 0, total_b = 0;
+    LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double need = 6.0 * (double)ctx->n_pos + 12.0 * (double)nb;
+    if ((double)free_b - need < headroom_gb * 1e9 && (double)free_b - need < 0.25 * (double)free_b) {
+        if (trace) fprintf(stderr, "[lhgt] slot list: %.1f GB wanted, %.1f GB free -- not built\n", need / 1e9, (double)free_b / 1e9);
+        return LHGT_OK;
+    }
+    const double t0 = wall_s();
+    uint32_t* d_hist = nullptr;
+    if (lhgt::dev_malloc(&d_hist, (size_t)nb * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_off, (size_t)(nb + 1) * 8) != hipSuccess) {
+        if (d_hist) lhgt::dev_free(d_hist);
+        slot_list_drop(ctx); ctx->sl_state = -1;
+        (void)hipGetLastError();
+        return LHGT_OK;
+    }
+    const dim3 grid = blocks2d(ctx->n_tiles), blk(BT);
+    LHGT_HIP(hipMemsetAsync(d_hist, 0, (size_t)nb * 4, ctx->stream));
+    hipLaunchKernelGGL(slot_list_hist, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, d_hist, ctx->n_tiles);
+    hipLaunchKernelGGL(slot_list_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_hist, nb, ctx->d_sl_off);
+    unsigned long long n_entries = 0;
+    LHGT_HIP(hipMemcpyAsync(&n_entries, ctx->d_sl_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    if (lhgt::dev_malloc(&ctx->d_sl_lo, (size_t)(n_entries + 64) * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_hi, (size_t)(n_entries + 64) * 2) != hipSuccess) {
+        lhgt::dev_free(d_hist);
+        slot_list_drop(ctx); ctx->sl_state = -1;
+        (void)hipGetLastError();
+        if (trace) fprintf(stderr, "[lhgt] slot list: no memory for %llu entries -- not built\n", n_entries);
+        return LHGT_OK;
+    }
+    hipLaunchKernelGGL(slot_list_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, ctx->d_sl_off, d_hist,
+                       ctx->d_sl_lo, ctx->d_sl_hi, ctx->n_tiles);
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    lhgt::dev_free(d_hist);
+    ctx->sl_entries = n_entries;
+    ctx->sl_buckets = nb;
+    ctx->sl_state = 1;
+    if (trace) fprintf(stderr, "[lhgt] slot list: %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", n_entries, nb, 6.0 * (double)n_entries / 1e9, wall_s() - t0);
+    return LHGT_OK;
 }
 
 // B1-B4 on the resident contigs: flags, and tile_count turned into exclusive local ids.
@@ -1040,8 +1249,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // form asks 1 + f + f^2 <= 1.65 probes per position instead of 3 and random positions almost never make a candidate window;
     // above, the old rule: lite from 90 %, exact in between unless a trial of the lite kernels settles 40 % of its tiles.
     // bit 12 / 13 / 14 force single-first / exact / trio-first.
-    const bool force_any = (ctx->debug & (4096 | 8192 | 16384)) != 0;
-    const bool sparse_form = e <= 3 && ((ctx->debug & 16384) || (!force_any && frac3 < 0.45 && n_lines >= 64 && !(ctx->debug & 64)));
+    const bool force_any = (ctx->debug & (4096 | 8192 | 16384 | (1 << 24))) != 0;
+    const bool sparse_form = e <= 3 && ((ctx->debug & (16384 | (1 << 24))) || (!force_any && frac3 < 0.45 && n_lines >= 64 && !(ctx->debug & 64)));
     double pilot_settled = -1.0;
     if (e <= 3 && !force_any && !sparse_form && frac3 >= 0.2 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
         std::vector<uint32_t> pl, pw;
@@ -1071,9 +1280,32 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     ctx->scan_lite = sparse_form || (e <= 3 && !(ctx->debug & (8192 | 16384)) && ((ctx->debug & 4096) || (pilot_settled >= 0.0 ? pilot_settled >= 0.4 : frac3 >= 0.65)));
     ctx->scan_form = sparse_form ? 2 : ctx->scan_lite ? 1 : 0;
     ctx->stats_scan = ctx->stats_on;
+    // slot-first instead of the trio-first kernel: the list is there, or this is the moment to build it -- a second sparse scan of the
+    // same resident reference (LHGT_SLOT_LIST: 0 never, 1 that rule, 2 at the first sparse scan; lhgt_slot_list), debug bit 24 now;
+    // bit 14 means the trio-first KERNEL, bit 25 leaves a list that exists unused (A/B)
+    ctx->scan_slots = false;
+    if (sparse_form && !(ctx->debug & (1 << 25)) && (!(ctx->debug & 16384) || (ctx->debug & (1 << 24)))) {
+        if (ctx->sl_state == 0 && ((ctx->debug & (1 << 24)) || ctx->sl_mode == 2 || (ctx->sl_mode == 1 && ctx->sl_sparse_scans >= 1))) LHGT_TRY(slot_list_build(ctx));
+        ctx->scan_slots = ctx->sl_state == 1;
+    }
+    if (sparse_form) ctx->sl_sparse_scans++;
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
-    if (sparse_form) {
+    if (sparse_form && ctx->scan_slots) {
+        // slot-first: the list answers "does hash 0 read 3" for every position; flags / pstate start from "nothing known"
+        LHGT_HIP(hipMemsetAsync(ctx->d_flags, 0, ctx->n_pos, ctx->stream));
+        LHGT_HIP(hipMemsetAsync(ctx->d_nzmask, 0, ctx->n_pos, ctx->stream));
+        unsigned long long* st = ctx->stats_on && ctx->d_stats ? ctx->d_stats + 1 : nullptr;
+        if (st) LHGT_HIP(hipMemsetAsync(st, 0, 8, ctx->stream));
+        const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
+        if (ctx->ref_packed)
+            hipLaunchKernelGGL(ref_flags_slots<true>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, ctx->d_nzmask, st, ctx->sl_buckets);
+        else
+            hipLaunchKernelGGL(ref_flags_slots<false>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, ctx->d_nzmask, st, ctx->sl_buckets);
+        LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
+    } else if (sparse_form) {
         hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                            ctx->d_nzmask, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
@@ -1081,6 +1313,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
             LHGT_HIP(hipMemsetAsync(ctx->d_stats + 1, 0, 8, ctx->stream));
             hipLaunchKernelGGL(pstate_probe_sum, dim3(8192), dim3(256), 0, ctx->stream, ctx->d_nzmask, ctx->n_pos, ctx->d_stats + 1);
         }
+    }
+    if (sparse_form) {
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(window_trio, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, three_min, ctx->d_flags, ctx->d_tile_count, nt);   // tile_count: free until the id scan

@@ -156,6 +156,16 @@ struct lhgt_ctx {
     double scan_frac3 = 0.0;      // fraction of the table's slots holding 3 at the last scan
     long scan_n_need = 0;         // tiles the lite form had to treat exactly
     int scan_form = 0;            // 0 exact, 1 single-first (lite), 2 trio-first
+    bool scan_slots = false;      // ... the trio-first form answered from the slot list (k_scan.hip: ref_flags_slots)
+    // the slot list of the resident reference: every position with a k-mer, grouped by the top bits of its hash 0
+    uint32_t* d_sl_lo = nullptr;             // low 32 bits of the flat position
+    uint16_t* d_sl_hi = nullptr;             // low 14 bits of the slot | position bits 32-33 << 14
+    unsigned long long* d_sl_off = nullptr;  // [sl_buckets + 1]
+    unsigned long long sl_entries = 0;
+    long sl_buckets = 0;
+    int sl_state = 0;                        // 0 not tried for this reference, 1 built, -1 tried and left (no memory, e > 3, positions beyond 2^34)
+    int sl_mode = 1;                         // lhgt_slot_list / LHGT_SLOT_LIST: 0 never, 1 before the second sparse scan of a reference, 2 before the first
+    int sl_sparse_scans = 0;                 // sparse-form scans of the resident reference so far
     bool scan_lite = false;       // the last scan took the lite form of B1/B2: d_nzmask then holds the per-hash probe state, not nz bits
     // reads
     std::vector<lhgt::ReadBatch> batches;
@@ -259,6 +269,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
 int index_install(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, bool words_on_device);
 int index_install_shard(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, int rank, int world);
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words);
+void slot_list_drop(lhgt_ctx* ctx);   // k_scan.hip: the resident reference changes
 int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const uint64_t* out_word,

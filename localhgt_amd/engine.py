@@ -365,8 +365,15 @@ class Engine:
         """form of the last ref_scan: {'lite': bool, 'frac_slots_at_3': float, 'tiles': int, 'tiles_exact': int}"""
         lite, frac, nt, ne = C.c_int(0), C.c_double(0), C.c_long(0), C.c_long(0)
         _lib.check(self.lib.lhgt_scan_info(self.h, C.byref(lite), C.byref(frac), C.byref(nt), C.byref(ne)))
-        return {"lite": lite.value == 1, "form": ("exact", "single-first", "trio-first")[lite.value], "frac_slots_at_3": round(frac.value, 4),
+        return {"lite": lite.value == 1, "form": ("exact", "single-first", "trio-first", "slot-first")[lite.value], "frac_slots_at_3": round(frac.value, 4),
                 "tiles": nt.value, "tiles_exact": ne.value}
+
+    def slot_list(self, mode: int = -1) -> dict:
+        """the slot list of the resident reference (include/localhgt_hip.h: lhgt_slot_list): mode 0 never / drop, 1 before the second
+        sparse-form scan of a reference (default), 2 before the first, -1 query"""
+        n, b = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.lhgt_slot_list(self.h, int(mode), C.byref(n), C.byref(b)))
+        return {"entries": n.value, "bytes": b.value}
 
     WORK_STATS = ("count_keys", "scan_probes", None, "vote_l2_probes", "vote_hbm_probes", "vote_revoted_pairs", None, None)
 

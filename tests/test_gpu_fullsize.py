@@ -100,7 +100,7 @@ def test_settled_tiles_change_nothing_on_a_saturated_table(eng):
     hist = eng.counts_histogram()
     assert hist[3] > 0.2 * (1 << 32) and hist[1] == hist[2] == 0, hist
     res = []
-    for flags in (8192, 8192 | 256, 4096, 16384, 0):    # exact scan with / without settled tiles, single-first, trio-first, the form the engine picks
+    for flags in (8192, 8192 | 256, 4096, 16384, 1 << 24, 0):    # exact scan with / without settled tiles, single-first, trio-first, the same from the slot list, the form the engine picks
         eng.set_debug(flags)
         n = eng.ref_scan(0.1, 0.08, 300_000_000)
         res.append((n, eng.peaks_export(n)[0].copy(), eng.flags_export(0, NC * CL) & 0b1111100))   # single / trio are bounds outside the tiles a lite form treats exactly

@@ -219,6 +219,17 @@ def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
             assert got == expect, (dbg, sinfo, got, expect)
         assert _vote(eng, 0) == want_votes
         assert _vote(eng, 4) == want_votes
+        # round 5: the trio-first form answered from the slot list (13 G positions by the bucket of their hash 0, 78 GB next to the
+        # 4.9 GB of planes): built by the first scan that asks for it, taken by itself from then on; positions beyond 2^32 in its entries
+        assert eng.slot_list()["entries"] == 0
+        got, sinfo = _scan(eng, 1 << 24)
+        assert sinfo["form"] == "slot-first" and got == want[16384], (sinfo, got, want[16384])
+        sl = eng.slot_list()
+        assert sl["entries"] == NC * (CL - K + 1) and 77e9 < sl["bytes"] < 79e9, sl
+        got, sinfo = _scan(eng, 0)
+        assert got == want[0] and sinfo["form"] == ("slot-first" if _scan(eng, 1 << 25)[1]["form"] == "trio-first" else sinfo["form"]), sinfo
+        assert _vote(eng, 1 << 24) == want_votes
+        assert eng.slot_list(0)["entries"] == 0                      # dropped again: the oracle check below scans shards of its own
         # ... and against the CPU restatement at the plane-word addresses of 13 Gbase (tests/bigaddr.py)
         import bigaddr
         checked, n_peaks, _ = bigaddr.check_against_oracle(eng, oracle, str(tmp_path), NC, CL, K, E, bigaddr.boundary_contigs(NC, CL, K, E, True))

@@ -101,9 +101,9 @@ _FIRST = int(os.environ.get("LHGT_FUZZ_FIRST", "0"))          # LHGT_FUZZ_FIRST=
 def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     from localhgt_amd import _lib, extract_ref
     import shutil
-    # a third of the cases each: the form the engine picks, single-first, trio-first (when e <= 3); every fourth case with the vote
-    # bitmap in its three-quarter form (bit 20; k > 25)
-    dbg = (0, 4096, 16384)[idx % 3] | ((1 << 20) if idx % 4 == 3 else 0)
+    # a third of the cases each: the form the engine picks, single-first, trio-first (when e <= 3) -- every other of those answered
+    # from the slot list (bit 24, round 5); every fourth case with the vote bitmap in its three-quarter form (bit 20; k > 25)
+    dbg = (0, 4096, 16384, 0, 4096, 1 << 24)[idx % 6] | ((1 << 20) if idx % 4 == 3 else 0)
     if dbg:
         monkeypatch.setenv("LHGT_DEBUG", str(dbg))
     g, c = tmp_path / "gpu", tmp_path / "cpu"

@@ -115,7 +115,7 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         assert (pf_g == pf_o[:n_g]).all()
         # every vote kernel (queued with its direct branch forced, generic with / without the bitmap, no LDS fold); the form of the scan the
         # engine picks by itself (0), the single-first ("lite") form, also with no tile settled early, and the trio-first form
-        for flags in (0, 2048, 32, 4, 16, 4096, 4096 | 256, 16384, 16384 | 256):
+        for flags in (0, 2048, 32, 4, 16, 4096, 4096 | 256, 16384, 16384 | 256, 1 << 24, (1 << 24) | 256, 16384 | (1 << 25)):
             eng.set_debug(flags)
             assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
             eng.vote()
@@ -130,7 +130,11 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
                 assert (((fl ^ flags_g) & 1) == 0).all(), "single-first: the single flag is exact everywhere"
                 assert (((fl ^ flags_g) & 0b10)[exact] == 0).all(), "single-first: trio flag differs where it claims to be exact"
                 assert (((fl & ~flags_g) & 0b10) == 0).all(), "single-first: trio flag is not a lower bound"
-            elif form == "trio-first":
+            if flags & (1 << 24):
+                assert form == "slot-first" and eng.slot_list()["entries"] > 0, (form, eng.slot_list())
+            if form in ("trio-first", "slot-first"):
+                if flags & 16384:
+                    assert form == "trio-first", (form, flags)      # bit 14 alone: the trio-first KERNEL, list or no list
                 assert (((fl ^ flags_g) & 0b10) == 0).all(), "trio-first: the trio flag is exact everywhere"
                 assert (((fl ^ flags_g) & 1)[exact] == 0).all(), "trio-first: single flag differs where it claims to be exact"
                 assert (((fl & ~flags_g) & 1) == 0).all(), "trio-first: single flag is not a lower bound"
@@ -156,9 +160,12 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
             info = eng.reference_info()
             assert info["form"] == ("packed" if packed else "index")
             assert info["resident_bytes"] == (12 * ((n_bases + 31) // 32 + 2) if packed else index_bytes)
-            for flags in (8192, 0, 4096, 4096 | 256, 16384, 16384 | 256):
+            assert eng.slot_list()["entries"] == 0, "a new reference drops the list of the one before"
+            for flags in (8192, 0, 4096, 4096 | 256, 16384, 16384 | 256, 1 << 24, (1 << 24) | 256, 0):
                 eng.set_debug(flags)
                 assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o
+                if flags & (1 << 24):
+                    assert eng.scan_info()["form"] == "slot-first" and eng.slot_list()["entries"] > 0
                 eng.vote()
                 loci_p, pf_p = eng.peaks_export(n_g)
                 assert (loci_p == loci_o[:2 * n_o]).all() and (pf_p == pf_o[:n_g]).all() and (eng.peak_kmer_export() == pk_o).all(), (packed, flags)

@@ -300,7 +300,9 @@ int lhgt_synth_read_mix(lhgt_ctx* ctx, int long_permille, int long_len);
  * workgroups per CU; outputs unchanged); bit22: stage ablation of phase A's direct form, the stages named by LHGT_PART_ABLATE (timing
  * only, the table comes out WRONG); bit23: register_peaks looks every "count > 0" up in the table instead of taking what the
  * trio-first probe kernels recorded (outputs unchanged); bit24: lhgt_ref_scan takes the trio-first form answered from the slot
- * list, which it builds at once if there is none (lhgt_slot_list; outputs unchanged); bit25: a slot list that exists is not used.
+ * list, which it builds at once if there is none (lhgt_slot_list; outputs unchanged); bit25: a slot list that exists is not used;
+ * bit26: stage ablation of the slot-first kernel, the stage named by LHGT_SLOTS_ABLATE (1: no listed position is followed, 2: none
+ * probes the table; timing only, the flags come out WRONG).
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts
@@ -334,7 +336,8 @@ int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarte
  *      piece or a region was full (hot k-mers: none on uniform synthetic reads; so on hot inputs the roofline's needed bytes are
  *      slightly understated); the direct kernel of k < 26 reports the upper bound k-mer positions x e; [1] count-table probes of phase B's
  *      probe kernel in the last lhgt_ref_scan while counting was on (e per position with a k-mer in the exact form; the hashes
- *      ref_flags_lite / ref_flags_trio marked as probed, summed before the fill of the unsettled tiles); [3] probes that
+ *      ref_flags_lite / ref_flags_trio marked as probed, summed before the fill of the unsettled tiles; the slot-first form: the
+ *      probes of the positions it followed beyond the slot list, their number in [2]); [3] probes that
  *      went on from the LDS fold to the L2 bitmap; [4] probes that went on from the bitmap to peak_kmer; [5] pairs voted in the
  *      lane-per-offset form behind the filters; the others 0.  No reference counterpart: measurement only. */
 int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]);

@@ -158,7 +158,8 @@ int lhgt_digest(lhgt_ctx* ctx, int what, uint64_t mask, uint64_t out[2]) {
 //       per-position state bytes (summed right behind that kernel; the fill of the unsettled tiles comes later and is not in it)
 //   [3] probes that went on from the LDS fold to the L2 bitmap (vote_kernel_fold), [4] probes that went on from the bitmap to peak_kmer
 //       (vote_kernel_queued / vote_kernel_fold), [5] pairs voted in the lane-per-offset form after the filters (deferred / re-voted)
-//   [2], [6], [7] reserved (0).
+//   [2] positions phase B's slot-first form followed beyond the list (their slot reads 3: one line of hashes / bases each; [1] then holds
+//       their probes), [6], [7] reserved (0).
 int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx || enable < -1 || enable > 1) LHGT_FAIL(LHGT_E_ARG, "bad argument");

@@ -146,12 +146,12 @@ __global__ void __launch_bounds__(256) pack_span_flat(const uint8_t* __restrict_
             if (code & 1) wlo |= bit;
         }
     }
-    // the three planes interleaved word by word (round 5): a k-mer's 2 x 3 words are 24 consecutive bytes, one memory line for a
-    // position looked up on its own (k_scan.hip: ref_flags_slots) where three separate planes were three
-    (void)plane_words;
-    if (whi) atomicOr(planes + 3 * w, whi);
-    if (wlo) atomicOr(planes + 3 * w + 1, wlo);
-    if (wnb) atomicOr(planes + 3 * w + 2, wnb);
+    // the hi and lo planes interleaved word by word, the not-a-base plane behind them (round 5): a k-mer's 2 x 2 words of bases are 16
+    // consecutive bytes -- ONE load and mostly one memory line for a position looked up on its own (k_scan.hip: ref_flags_slots; its
+    // positions are known to hold a k-mer) where three separate planes were six loads in three lines
+    if (whi) atomicOr(planes + 2 * w, whi);
+    if (wlo) atomicOr(planes + 2 * w + 1, wlo);
+    if (wnb) atomicOr(planes + 2 * plane_words + w, wnb);
 }
 
 // ---------------------------------------------------------------- FASTA text -> its sequences back to back

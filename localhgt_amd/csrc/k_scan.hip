@@ -219,6 +219,20 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
     }
 }
 
+// slot-first form: the probe-state bytes of the listed tiles (and of their look-back) back to "nothing known" -- the sweep writes none,
+// what is there is the last scan's
+__global__ void __launch_bounds__(BT) clear_pstate_tiles(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
+                                                         const uint32_t* __restrict__ list, uint8_t* __restrict__ pstate, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[list[blk]];
+    const ContigDev c = contigs[t.contig];
+    for (int i0 = threadIdx.x; i0 < TILE + HL2; i0 += BT) {
+        const long j = (long)t.j0 - HL2 + i0;
+        if (j >= 0 && j < c.len) pstate[c.flat_base + j] = 0;
+    }
+}
+
 // the remaining probes of the listed tiles and of the HL2 positions their window sums look back on
 __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ list, const RefSource rs,
@@ -896,7 +910,8 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
             uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u, have = nzmask ? 0xffu : 0u;
             if (pstate) {                 // trio-first form (e <= 3): what the probe kernels already know about "count > 0" per hash
                 const uint32_t ps = pstate[c.flat_base + j];
-                if (ps & 0x80u) { nz = (ps >> 4) & 7u; have = 7u; }                         // filled: every hash
+                if ((f & 0x82u) == 0x82u) { nz = 7u; have = 7u; }                          // an exact trio bit: every hash reads 3 (the slot-first form leaves no other record of it)
+                else if (ps & 0x80u) { nz = (ps >> 4) & 7u; have = 7u; }                    // filled: every hash
                 else {
                     const uint32_t known = (ps >> 4) & 7u, is3 = ps & 7u;
                     nz = is3 | (((ps >> 3) & 1u) ? (known & ~is3) : 0u);
@@ -988,20 +1003,31 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
 }
 
 // ---- B1 for a sparse table with the reference resident across samples ("slot-first", round 5).  The trio-first kernel above asks
-// the table ONE question per reference position before anything else -- does the slot of hash 0 read 3? -- and on a sparse table
-// that first probe is all most positions ever cost: 13 G random 128-byte line fills for 13 Gbase, 232 ms at the fabric's line
+// the table ONE question per reference position before anything else -- does the slot of its first hash read 3? -- and on a sparse
+// table that first probe is all most positions ever cost: 13 G random 128-byte line fills for 13 Gbase, 232 ms at the fabric's line
 // rate whatever the sample.  The question does not depend on the sample, only its answer does.  So a context that scans a second
 // sample against the same resident reference turns the question round, once: the SLOT LIST holds every position with a k-mer,
-// grouped by the top bits of its hash 0 -- bucket b = the 2^14 slots [b << 14, (b + 1) << 14), an entry = (low 14 bits of the
-// slot, flat position): 6 bytes, two arrays (u32 low position bits; u16 slot bits | position bits 32-33 << 14).  A scan then
-// streams the list (78 GB for 13 Gbase) next to each bucket's 4 KiB of counters in LDS, and only the positions whose slot reads 3
-// (the table's fill: 15-20 %) go on to hash 1 and 2 exactly as ref_flags_trio's loop does -- one line for the k-mer's hashes or
-// bases, 1 + f probes.  Only positions whose e hashes ALL read 3 are written (flags 0x83, pstate = all probed, all 3): flags and
-// pstate are cleared beforehand, and "nothing known" is what ref_flags_fill and register_peaks take a zero byte for, so the tiles
-// near a candidate window get every probe from the fill -- the trio bit is exact everywhere, which is all window_trio reads.
-// Same peaks, ids and votes as every other form (the form tests run it next to them).
+// grouped by the top bits of ONE of its hashes (slot_list_key below) -- bucket b = the 2^14 slots [b << 14, (b + 1) << 14), an
+// entry = (low 14 bits of the slot, flat position): 6 bytes, two arrays (u32 low position bits; u16 slot bits | position bits
+// 32-33 << 14).  A scan then streams the list (78 GB for 13 Gbase, 14 ms) next to each bucket's 4 KiB of counters in LDS, and only
+// the positions whose slot reads 3 -- a fifth -- go on to their other hashes: one line for the k-mer's hashes or bases, then 1 + f
+// probes.  Only positions whose e hashes ALL read 3 are written (flags 0x83 = single, trio, exact): the flags are cleared
+// beforehand, the probe-state bytes of the tiles that go on to the fill too (clear_pstate_tiles), and "nothing known" is what
+// ref_flags_fill and register_peaks take a zero byte for -- the tiles near a candidate window get every probe from the fill, an
+// exact trio bit tells register_peaks that all counts are > 0.  The trio bit is exact everywhere, which is all window_trio reads.
+// Same peaks, ids and votes as every other form (the form tests run it next to them).  Deep focused sample on 13 Gbase (packed):
+// the probe kernel 325 -> 150 ms, phase B 340 -> 181 ms (tools/slot_list_leg.py); 7.0 G line fills where trio-first makes 17.4 G.
 constexpr int SL_BITS = 14;
 constexpr uint32_t SL_SLOTS = 1u << SL_BITS;
+// A position is listed under the LARGEST of its e hashes.  A hash is min(fwd, rc) of two uniform words, so slots thin out towards the
+// top of the table (density 2(1 - x)) and so do the reads' k-mers: the largest of three hashes addresses the slot least likely to
+// read 3 -- 19 % of the positions go on where 27 % would under hash 0 (deep focused sample, 18 % of all slots at 3).  Any hash of an
+// invalid k-mer is 0 (quirk Q6), then all are.
+__device__ __forceinline__ uint32_t slot_list_key(const RefSource& rs, const RefKmer& km, int e) {
+    uint32_t h = ref_hash(rs, km, 0);
+    for (int i = 1; i < e && i < 3; i++) { const uint32_t g = ref_hash(rs, km, i); h = g > h ? g : h; }
+    return h;
+}
 
 __global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
                                                      int k, int e, uint32_t* __restrict__ hist, long n_blk) {
@@ -1014,7 +1040,7 @@ __global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__
         const long j = (long)t.j0 + jj;
         if (j >= nk) break;
         const RefKmer km = ref_kmer(rs, c, j, k, e);
-        const uint32_t h = ref_hash(rs, km, 0);
+        const uint32_t h = slot_list_key(rs, km, e);
         if (h != 0) atomicAdd(&hist[h >> SL_BITS], 1u);     // hash 0 = invalid (E:936-941): never at 3, not listed
     }
 }
@@ -1047,7 +1073,7 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
         const long j = (long)t.j0 + jj;
         if (j >= nk) break;
         const RefKmer km = ref_kmer(rs, c, j, k, e);
-        const uint32_t h = ref_hash(rs, km, 0);
+        const uint32_t h = slot_list_key(rs, km, e);
         if (h == 0) continue;
         const uint32_t b = h >> SL_BITS;
         const unsigned long long at = off[b] + atomicAdd(&cur[b], 1u);
@@ -1057,83 +1083,166 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
     }
 }
 
-// one workgroup per bucket; a wave gathers the entries whose slot reads 3 in a queue of its own and works them off 64 at a time, so
-// the dependent chain of a survivor (the line with its hashes, then one or two probes) runs with every lane busy
-template <bool PACKED>
-__global__ void __launch_bounds__(BT) ref_flags_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
+// One workgroup of ST threads per bucket.  It streams the bucket's entries 4 ST at a time (four loads per thread in flight), tests
+// them against the counters in LDS and appends those whose slot reads 3 to a ring in LDS; whenever the ring holds 4 ST of them every
+// thread follows FOUR at once -- their four lines of hashes / bases are requested together, then their four probes -- so the
+// dependent chain of a survivor runs with all lanes busy and four requests per lane in flight (a wave that followed 64 survivors one
+// per lane, between two loads of its stream, reached 33 G lines/s of the fabric's 56; waves with rings of their own, no barrier: 38).
+template <bool PACKED, int ST>
+__global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
                                                       const uint16_t* __restrict__ hi, const RefSource rs, const ContigDev* __restrict__ contigs,
                                                       int n_contigs, const uint32_t* __restrict__ counts, int slice_words, int k, int e,
-                                                      uint8_t* __restrict__ flags, uint8_t* __restrict__ pstate,
-                                                      unsigned long long* __restrict__ stats /* nullable: [0] probes of the table */, long n_buckets) {
+                                                      uint8_t* __restrict__ flags,
+                                                      unsigned long long* __restrict__ stats /* nullable: [0] probes of the table, [1] positions followed */, long n_buckets,
+                                                      int ablate /* timing only (debug bit 26, LHGT_SLOTS_ABLATE): 1 no survivor is followed, 2 none probes the table */) {
     __shared__ uint32_t slice[SL_SLOTS / 16];
-    __shared__ uint64_t queue[BT / 64][128];
+    constexpr int SL_CHUNK = 4 * ST, SL_RING = 2 * SL_CHUNK;
+    __shared__ uint32_t ring_lo[SL_RING];
+    __shared__ uint8_t ring_hi[SL_RING];
+    __shared__ uint32_t s_tail;
     const long b = block2d();
     if (b >= n_buckets) return;
     const unsigned long long begin = off[b], end = off[b + 1];
     if (begin == end) return;                                   // uniform
     uint32_t any3 = 0;
-    for (int i = threadIdx.x; i < slice_words; i += BT) {
+    for (int i = threadIdx.x; i < slice_words; i += ST) {
         const uint32_t w = counts[(size_t)b * (SL_SLOTS / 16) + i];
         slice[i] = w;
         any3 |= w & (w >> 1) & 0x55555555u;
     }
+    if (threadIdx.x == 0) s_tail = 0u;
     if (!__syncthreads_or(any3 != 0u)) return;                  // no slot of the bucket reads 3: none of its positions goes on
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t full = (1u << e) - 1u;
-    uint64_t* q = queue[wv];
-    int qn = 0;
-    unsigned long long probes = 0;
-    auto work = [&](uint64_t x) {
-        RefKmer km;
-        if (PACKED) {
-            ContigDev flat{};                                   // the planes run over the flat positions: no contig needed
-            km = ref_kmer(rs, flat, (long)x, k, e);
-        } else {
-            int a = 0, z = n_contigs;                           // last contig with flat_base <= x
-            while (z - a > 1) { const int mid = (a + z) >> 1; if (contigs[mid].flat_base <= x) a = mid; else z = mid; }
-            const ContigDev c = contigs[a];
-            km = ref_kmer(rs, c, (long)(x - c.flat_base), k, e);
-        }
-        uint32_t known = 1u, is3 = 1u;
-        bool all3 = true;
+    const int lane = threadIdx.x & 63;
+    unsigned long long probes = 0, followed = 0;
+    // follow n <= SL_CHUNK survivors from ring position `from`: thread t takes t, t + ST, ...
+    auto follow = [&](uint32_t from, uint32_t n) {
+        if (ablate == 1) return;
+        const uint32_t first = from & (SL_RING - 1);
+        const uint64_t x_first = (uint64_t)ring_lo[first] | ((uint64_t)ring_hi[first] << 32);   // n >= 1: a listed position, safe to read for idle lanes
+        uint64_t x[4];
+        bool on[4];
 #pragma unroll
-        for (int i = 1; i < 3; i++)
-            if (i < e && all3) {
-                const uint32_t h = ref_hash(rs, km, i);
-                const uint32_t cnt = h != 0 ? count_of(counts, h) : 0u;
-                known |= 1u << i;
-                probes++;
-                if (cnt == 3u) is3 |= 1u << i;
-                else all3 = false;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = threadIdx.x + (uint32_t)u * ST, at = (from + idx) & (SL_RING - 1);
+            on[u] = idx < n;
+            x[u] = on[u] ? (uint64_t)ring_lo[at] | ((uint64_t)ring_hi[at] << 32) : x_first;
+        }
+        // the four lines first, all requested before any is looked at: a k-mer's 2 x 2 interleaved words of bases (packed form)
+        // or its e stored hashes (index form); then the hashes, the listed one (the largest) aside -- it reads 3 --
+        // and the others sorted, the larger one first
+        uint32_t w[4][4];
+        if (PACKED) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t* p = rs.planes + 2 * (x[u] >> 5);   // [hi, lo] of word x >> 5, [hi, lo] of the next: 16 bytes, one load (a listed position holds a k-mer: no look at the not-a-base plane)
+#pragma unroll
+                for (int q = 0; q < 4; q++) w[u][q] = p[q];
             }
-        if (is3 == full) {
-            flags[x] = 0x83;                                    // single, trio, exact
-            pstate[x] = (uint8_t)(is3 | (known << 4));
+        } else {
+            const uint32_t* p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int a = 0, z = n_contigs;                       // last contig with flat_base <= x
+                while (z - a > 1) { const int mid = (a + z) >> 1; if (contigs[mid].flat_base <= x[u]) a = mid; else z = mid; }
+                const ContigDev c = contigs[a];
+                p[u] = rs.index + c.hash_word + (x[u] - c.flat_base) * (uint64_t)e;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) w[u][q] = p[u][q < e ? q : e - 1];
+        }
+        uint32_t h1[4], h2[4], c1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t a0, a1, a2;
+            if (PACKED) {
+                const int r = (int)(x[u] & 31);
+                const uint32_t whi = window32(w[u][0], w[u][2], r) >> (32 - k), wlo = window32(w[u][1], w[u][3], r) >> (32 - k);
+                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+                a0 = hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[0]);
+                a1 = e > 1 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[1]) : 0u;
+                a2 = e > 2 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[2]) : 0u;
+            } else {
+                a0 = w[u][0];
+                a1 = e > 1 ? w[u][1] : 0u;
+                a2 = e > 2 ? w[u][2] : 0u;
+            }
+            if (a1 > a0) { const uint32_t t = a0; a0 = a1; a1 = t; }
+            if (a2 > a0) { const uint32_t t = a0; a0 = a2; a2 = t; }
+            if (a2 > a1) { const uint32_t t = a1; a1 = a2; a2 = t; }
+            h1[u] = a1; h2[u] = a2;
+        }
+        // the four first probes together, then the four second ones: a lane with nothing to ask reads word 0 (a line every
+        // wave shares -- a cache hit, not a line fill; the branches the compiler made of "only if" probes waited one by one)
+#pragma unroll
+        for (int u = 0; u < 4; u++) c1[u] = counts[e > 1 && on[u] && ablate != 2 ? h1[u] >> 4 : 0u];
+        bool all3[4];
+        uint32_t c2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            all3[u] = on[u] && (e < 2 || (h1[u] != 0u && ((c1[u] >> ((h1[u] & 15u) * 2u)) & 3u) == 3u));
+            if (on[u]) followed++;
+            if (on[u] && e > 1) probes++;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) c2[u] = counts[e > 2 && all3[u] && ablate != 2 ? h2[u] >> 4 : 0u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (e > 2 && all3[u]) {
+                probes++;
+                all3[u] = h2[u] != 0u && ((c2[u] >> ((h2[u] & 15u) * 2u)) & 3u) == 3u;
+            }
+            if (all3[u]) flags[x[u]] = 0x83;                    // single, trio, exact -- the one random store of a listed trio position
         }
     };
-    for (unsigned long long i0 = begin + (unsigned long long)wv * 64u; i0 < end; i0 += BT) {    // wave-uniform bounds
-        const unsigned long long i = i0 + lane;
-        bool pass = false;
-        uint64_t x = 0;
-        if (i < end) {
-            const uint32_t hv = hi[i];
-            const uint32_t s = hv & (SL_SLOTS - 1u);
-            pass = ((slice[s >> 4] >> ((s & 15u) * 2u)) & 3u) == 3u;
-            x = (uint64_t)lo[i] | ((uint64_t)(hv >> SL_BITS) << 32);
+    uint32_t head = 0;
+    for (unsigned long long c0 = begin; c0 < end; c0 += SL_CHUNK) {
+        uint32_t lo4[4], hi4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long i = c0 + threadIdx.x + (unsigned long long)u * ST;
+            const bool ok = i < end;
+            lo4[u] = ok ? lo[i] : 0u;
+            hi4[u] = ok ? (uint32_t)hi[i] : 0x10000u;           // bit 16: no entry
         }
-        const unsigned long long m = __ballot(pass);
-        if (pass) q[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x;
-        qn += __popcll(m);
-        if (qn >= 64) {
-            qn -= 64;
-            work(q[qn + lane]);
+        unsigned long long m[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t sl = hi4[u] & (SL_SLOTS - 1u);
+            const bool pass = !(hi4[u] & 0x10000u) && ((slice[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) == 3u;
+            m[u] = __ballot(pass);
+            mine |= pass ? 1u << u : 0u;
         }
+        const uint32_t total = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(&s_tail, total);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if ((mine >> u) & 1u) {
+                const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u))) & (SL_RING - 1);
+                ring_lo[at] = lo4[u];
+                ring_hi[at] = (uint8_t)(hi4[u] >> SL_BITS);
+            }
+            base += (uint32_t)__popcll(m[u]);
+        }
+        __syncthreads();
+        const uint32_t tail = s_tail;
+        while (tail - head >= (uint32_t)SL_CHUNK) {              // uniform
+            follow(head, SL_CHUNK);
+            head += SL_CHUNK;
+        }
+        __syncthreads();                                         // the next appends reuse the ring slots just read
     }
-    if (lane < qn) work(q[lane]);
+    const uint32_t tail = s_tail;
+    if (tail != head) follow(head, tail - head);
     if (stats) {
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) probes += __shfl_xor(probes, d, 64);
+        for (int d = 32; d > 0; d >>= 1) { probes += __shfl_xor(probes, d, 64); followed += __shfl_xor(followed, d, 64); }
         if (lane == 0 && probes) atomicAdd(stats, probes);
+        if (lane == 0 && followed) atomicAdd(stats + 1, followed);
     }
 }
 
@@ -1294,16 +1403,16 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     if (sparse_form && ctx->scan_slots) {
         // slot-first: the list answers "does hash 0 read 3" for every position; flags / pstate start from "nothing known"
         LHGT_HIP(hipMemsetAsync(ctx->d_flags, 0, ctx->n_pos, ctx->stream));
-        LHGT_HIP(hipMemsetAsync(ctx->d_nzmask, 0, ctx->n_pos, ctx->stream));
         unsigned long long* st = ctx->stats_on && ctx->d_stats ? ctx->d_stats + 1 : nullptr;
-        if (st) LHGT_HIP(hipMemsetAsync(st, 0, 8, ctx->stream));
+        if (st) LHGT_HIP(hipMemsetAsync(st, 0, 16, ctx->stream));
         const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
+        const int ablate = (ctx->debug & (1 << 26)) && getenv("LHGT_SLOTS_ABLATE") ? atoi(getenv("LHGT_SLOTS_ABLATE")) : 0;
         if (ctx->ref_packed)
-            hipLaunchKernelGGL(ref_flags_slots<true>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
-                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, ctx->d_nzmask, st, ctx->sl_buckets);
+            hipLaunchKernelGGL((ref_flags_slots<true, BT>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
         else
-            hipLaunchKernelGGL(ref_flags_slots<false>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
-                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, ctx->d_nzmask, st, ctx->sl_buckets);
+            hipLaunchKernelGGL((ref_flags_slots<false, BT>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
     } else if (sparse_form) {
         hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
@@ -1326,6 +1435,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, near a window that reaches the trio threshold %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
+            if (ctx->scan_slots)   // (two launches: a tile's look-back is another tile's body, and the fill tells "written in this launch" by the byte)
+                hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
                                ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 1);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,

@@ -44,13 +44,13 @@ __device__ __forceinline__ uint32_t hash_from_windows(uint32_t whi, uint32_t wlo
 
 // Where phase B takes the e hashes of reference position (contig c, offset j) from.  Two resident forms of the reference:
 //   index  : the index file's own layout, [u32 len][(len-k+1)*e u32] per contig (E:785-813) -- 4e bytes per base, read as stored;
-//   packed : three bit-planes (hi bit, lo bit, not-a-base) over the flat positions of the indexed contigs, interleaved word by
-//            word -- 3/8 byte per base,
+//   packed : three bit-planes (hi bit, lo bit, not-a-base) over the flat positions of the indexed contigs, the first two
+//            interleaved word by word -- 3/8 byte per base,
 //            the hashes recomputed where they are needed (156 GB -> 4.9 GB for a 13 Gbase catalogue).
 //            An invalid k-mer hashes to 0 exactly as the index stores it (E:808-810, quirk Q6).
 struct RefSource {
     const uint32_t* index;    // non-null: index form
-    const uint32_t* planes;   // packed form: word x >> 5 of plane m (hi bit, lo bit, not-a-base) is planes[3 * (x >> 5) + m], position x at its bit 31 - (x & 31)
+    const uint32_t* planes;   // packed form: word x >> 5 of the hi / lo plane is planes[2 * (x >> 5) + 0 / 1], of the not-a-base plane planes[2 * plane_words + (x >> 5)]; position x at bit 31 - (x & 31)
     uint64_t plane_words;
     HashParams hp;
 };
@@ -65,11 +65,12 @@ __device__ __forceinline__ RefKmer ref_kmer(const RefSource& rs, const ContigDev
         km.stored = rs.index + c.hash_word + j * e;
     } else {
         const uint64_t x = c.flat_base + (uint64_t)j;
-        const uint32_t* w = rs.planes + 3 * (x >> 5);
+        const uint32_t* w = rs.planes + 2 * (x >> 5);
+        const uint32_t* nb = rs.planes + 2 * rs.plane_words + (x >> 5);
         const int r = (int)(x & 31);
-        km.whi = window32(w[0], w[3], r) >> (32 - k);
-        km.wlo = window32(w[1], w[4], r) >> (32 - k);
-        km.valid = (window32(w[2], w[5], r) >> (32 - k)) == 0u;
+        km.whi = window32(w[0], w[2], r) >> (32 - k);
+        km.wlo = window32(w[1], w[3], r) >> (32 - k);
+        km.valid = (window32(nb[0], nb[1], r) >> (32 - k)) == 0u;
         km.rhi = brev_k(km.whi, k);
         km.rlo = brev_k(km.wlo, k);
     }

@@ -375,7 +375,7 @@ class Engine:
         _lib.check(self.lib.lhgt_slot_list(self.h, int(mode), C.byref(n), C.byref(b)))
         return {"entries": n.value, "bytes": b.value}
 
-    WORK_STATS = ("count_keys", "scan_probes", None, "vote_l2_probes", "vote_hbm_probes", "vote_revoted_pairs", None, None)
+    WORK_STATS = ("count_keys", "scan_probes", "scan_followed", "vote_l2_probes", "vote_hbm_probes", "vote_revoted_pairs", None, None)
 
     def work_stats(self, enable: int = -1) -> dict:
         """work counters of the phases run since work_stats(1) (include/localhgt_hip.h: lhgt_work_stats); measurement only"""

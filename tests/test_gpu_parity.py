@@ -125,14 +125,14 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
             fl = eng.flags_export(0, n_bases)
             assert (((fl ^ flags_g) & 0b1111100) == 0).all(), f"{form}: good / peak / inside / selected / new flags differ"
             exact = (fl & 0x80) != 0
+            if flags & (1 << 24):
+                assert form == "slot-first" and eng.slot_list()["entries"] > 0, (form, eng.slot_list())
             if form == "single-first":
                 assert flags & 4096
                 assert (((fl ^ flags_g) & 1) == 0).all(), "single-first: the single flag is exact everywhere"
                 assert (((fl ^ flags_g) & 0b10)[exact] == 0).all(), "single-first: trio flag differs where it claims to be exact"
                 assert (((fl & ~flags_g) & 0b10) == 0).all(), "single-first: trio flag is not a lower bound"
-            if flags & (1 << 24):
-                assert form == "slot-first" and eng.slot_list()["entries"] > 0, (form, eng.slot_list())
-            if form in ("trio-first", "slot-first"):
+            elif form in ("trio-first", "slot-first"):
                 if flags & 16384:
                     assert form == "trio-first", (form, flags)      # bit 14 alone: the trio-first KERNEL, list or no list
                 assert (((fl ^ flags_g) & 0b10) == 0).all(), "trio-first: the trio flag is exact everywhere"

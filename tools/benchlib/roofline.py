@@ -79,9 +79,17 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
     n_pos = max(0, ref_bases - n_contigs * (k - 1))          # positions with a k-mer
     probes = stats.get("scan_probes") or n_pos * e
     stream = ref_bases * 3 // 8 if packed else n_pos * 4 * e
-    out["ref_flags"] = (probes * LINE + stream + 2 * ref_bases,
-                        f"{probes} table probes x {LINE} B ({scan_form}: {probes / max(1, n_pos):.3f} per position) + "
-                        f"{'packed planes' if packed else 'index words'} {stream} + flag and state bytes written 2 x {ref_bases}")
+    if scan_form == "slot-first":
+        # the slot list streamed (6 B per position with a k-mer), one line of hashes / bases per position followed, their probes, the
+        # flags cleared and the trio positions written (counted with the clearing)
+        followed = stats.get("scan_followed", 0)
+        out["ref_flags"] = (6 * n_pos + (followed + probes) * LINE + ref_bases,
+                            f"slot list 6 B x {n_pos} positions + {followed} positions followed ({followed / max(1, n_pos):.3f} of them) x {LINE} B of "
+                            f"{'bases' if packed else 'stored hashes'} + {probes} table probes x {LINE} B + flag bytes cleared {ref_bases}")
+    else:
+        out["ref_flags"] = (probes * LINE + stream + 2 * ref_bases,
+                            f"{probes} table probes x {LINE} B ({scan_form}: {probes / max(1, n_pos):.3f} per position) + "
+                            f"{'packed planes' if packed else 'index words'} {stream} + flag and state bytes written 2 x {ref_bases}")
     if vote_form in ("queued", "fold"):
         hb = stats.get("vote_hbm_probes", 0)
         out["vote_kernel"] = (reads + hb * LINE,
@@ -160,14 +168,15 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     vform = vote_form_of(vote, stats or {})
     need = needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats or {}, partitioned, scan["form"], vform) if stats is not None else {}
     kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
-    scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio"}.get(scan["form"], "ref_flags")
+    scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio", "slot-first": "ref_flags_slots"}.get(scan["form"], "ref_flags")
     vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
     info = {
         "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
                     f"phase A kernel family, {n_chunks} chunks of <= {8 if direct else 4} Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
                     model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING, "lds_random" if partitioned else "hbm_lines"),
         "ref_flags": (scan_kernel, {"single-first": "phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base",
-                                    "trio-first": "phase B on a sparse table: probes per base until a hash does not read 3"}.get(
+                                    "trio-first": "phase B on a sparse table: probes per base until a hash does not read 3",
+                                    "slot-first": "phase B on a sparse table, the first probe of every position answered from the slot list of the resident reference"}.get(
                                         scan["form"], "phase B: e random 2-bit table probes per reference base") + "; 1 launch per step",
                       model_ref, 1, HBM_CEILING, "hbm_lines"),
         "vote_kernel": (vote_kernel, f"phase C read re-scan, {2 * (L - k + 1) * e} probes per pair "

@@ -104,6 +104,26 @@ def run_all(detail, eng, args, wl, local, emit):
                          same_peaks_as_headline=(d["raw_peaks"], d["filtered_peaks"]) == (detail["raw_peaks"], detail["filtered_peaks"]))
                 out["uhgg_packed_reference"] = d
                 eng.pairs_clear()
+                # SLOT LIST (round 5): the packed reference leaves room for the list of its 13 G positions by hash bucket (78 GB), which a
+                # context builds before its second sparse-form scan of a resident reference; phase B of the sparse regimes then streams
+                # that list instead of probing the table once per position.  The deep focused sample and the CLI's default down-sampled
+                # regime on a realistic sample (6.67 M pairs from the 300 genomes), each with the trio-first kernel (debug bit 25) beside it
+                for name, n_pairs, what in (("uhgg_deep_focused", args.pairs, "100 M pairs drawn from 300 of its contigs (100x)"),
+                                            ("uhgg_default_sample_focused", int(2e9 / (2 * 150)), "6.67 M pairs drawn from 300 of its contigs: a 100 M-pair sample of them under the CLI's default --sample 2000000000")):
+                    eng.synth_options(0, 20, 300)
+                    eng.synth_pairs(1, 2, nc, cl, 0, n_pairs, L)
+                    eng.synth_options(0, 20, 0)
+                    eng.set_debug(1 << 25)
+                    d0 = L_(eng, n_pairs, packed=True, sample_contigs=300, steps=2)
+                    eng.set_debug(0)
+                    d = L_(eng, n_pairs, packed=True, sample_contigs=300, steps=3)
+                    d.update(workload=f"13000x1000000 bp ref resident as packed bases + its slot list, {what}, sample=1",
+                             slot_list=eng.slot_list(), trio_first_kernel={"value": d0["value"], "ms_per_step": d0["ms_per_step"], "phase_ms": d0["phase_ms"],
+                                                                            "scan_B_form": d0.get("scan_B_form")},
+                             same_peaks_as_trio_first=(d["raw_peaks"], d["filtered_peaks"]) == (d0["raw_peaks"], d0["filtered_peaks"]))
+                    out[name + "_slot_list"] = d
+                    eng.pairs_clear()
+                emit("slot list")
     except Exception as ex:
         out["uhgg_error"] = str(ex)[:200]
     eng.close()

@@ -316,14 +316,15 @@ int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the pha
  *      be settled from that); 2 trio-first, for a sparse table (probes until a hash does not read 3; complete probes only near
  *      windows that reach the trio threshold).  n_tiles_exact = tiles that got the exact treatment. */
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact);
-/* The slot list of the resident reference: every position with a k-mer, grouped by the top bits of the slot its hash 0 addresses
- * (6 bytes per position).  A context that scans sample after sample against one resident reference answers the first question
- * of the sparse-table scan ("does hash 0 of this position read 3?", E:580) for all positions from a stream over that list and
- * each bucket's counters in LDS instead of one random probe per position; same flags where they are read, same peaks and
- * votes.  mode 0: never build one and drop the one there is; 1 (default; environment LHGT_SLOT_LIST): build it before the
- * SECOND sparse-form scan of the same resident reference; 2: before the first; -1: leave the mode.  entries / bytes (nullable):
- * the list as it stands (0 = none: not built yet, no memory for it, e > 3, or positions beyond 2^34).  No reference
- * counterpart (the reference walks its index file once per run, E:888-979). */
+/* The slot list of the resident reference: every position with a k-mer, grouped by the top bits of the slot its largest hash
+ * addresses (6 bytes per position).  A context that scans sample after sample against one resident reference answers the first
+ * question of the sparse-table scan ("does this hash of the position read 3?", E:580) for all positions from a stream over that
+ * list and each bucket's counters in LDS instead of one random probe per position; same flags where they are read, same peaks
+ * and votes.  mode 0: never build one and drop the one there is; 1 (default; environment LHGT_SLOT_LIST): build it before the
+ * SECOND sparse-form scan of the same resident reference when that pays -- 2^32 positions or more, and the last sparse scan sent
+ * at most half of the tiles to the exact fill --, and use it under the same condition; 2: build it before the first such scan and
+ * use it always; -1: leave the mode.  entries / bytes (nullable): the list as it stands (0 = none: not built yet, no memory for
+ * it, e > 3, or positions beyond 2^34).  No reference counterpart (the reference walks its index file once per run, E:888-979). */
 int lhgt_slot_list(lhgt_ctx* ctx, int mode, unsigned long long* entries, unsigned long long* bytes);
 /* ---- which kernel the last lhgt_vote took (k_vote.hip): *form = 0 the generic kernel probing peak_kmer itself (dense peak sets), 1 the
  *      generic kernel behind the L2-resident bitmap, 2 the queued sparse kernel behind the bitmap, 3 the 128 KiB LDS fold in front of

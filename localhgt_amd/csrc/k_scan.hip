@@ -1267,7 +1267,7 @@ namespace lhgt {
 void slot_list_drop(lhgt_ctx* ctx) {
     for (void* p : {(void*)ctx->d_sl_lo, (void*)ctx->d_sl_hi, (void*)ctx->d_sl_off}) if (p) lhgt::dev_free(p);
     ctx->d_sl_lo = nullptr; ctx->d_sl_hi = nullptr; ctx->d_sl_off = nullptr;
-    ctx->sl_entries = 0; ctx->sl_buckets = 0; ctx->sl_state = 0; ctx->sl_sparse_scans = 0;
+    ctx->sl_entries = 0; ctx->sl_buckets = 0; ctx->sl_state = 0; ctx->sl_sparse_scans = 0; ctx->sl_need_share = 0.0;
 }
 }  // namespace lhgt
 static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1280,6 +1280,8 @@ static int slot_list_build(lhgt_ctx* ctx) {
     size_t free_b = 0, total_b = 0;
     LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
     const double need = 6.0 * (double)ctx->n_pos + 12.0 * (double)nb;
+    if ((double)free_b - need < headroom_gb * 1e9 && lhgt::big_release_all())     // blocks parked by earlier contexts of the process count as free
+        LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
     if ((double)free_b - need < headroom_gb * 1e9 && (double)free_b - need < 0.25 * (double)free_b) {
         if (trace) fprintf(stderr, "[lhgt] slot list: %.1f GB wanted, %.1f GB free -- not built\n", need / 1e9, (double)free_b / 1e9);
         return LHGT_OK;
@@ -1392,10 +1394,17 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // slot-first instead of the trio-first kernel: the list is there, or this is the moment to build it -- a second sparse scan of the
     // same resident reference (LHGT_SLOT_LIST: 0 never, 1 that rule, 2 at the first sparse scan; lhgt_slot_list), debug bit 24 now;
     // bit 14 means the trio-first KERNEL, bit 25 leaves a list that exists unused (A/B)
+    // Where it does not pay, left alone unless asked for (bit 24, mode 2): a small reference -- a bucket of 2^14 slots wants some 10^4
+    // positions for a workgroup's set-up, i.e. a few Gbase (1 Gbase, index form: the kernel 52 ms where trio-first's takes 45) --; and a
+    // sample that makes most tiles candidates (configs[1]: every genome sampled), whose fill then asks all e probes of every position
+    // where trio-first's asks the missing ones: when the last sparse scan sent more than half of the tiles to the fill, this one takes
+    // the trio-first kernel (and reports its own share for the next).
     ctx->scan_slots = false;
     if (sparse_form && !(ctx->debug & (1 << 25)) && (!(ctx->debug & 16384) || (ctx->debug & (1 << 24)))) {
-        if (ctx->sl_state == 0 && ((ctx->debug & (1 << 24)) || ctx->sl_mode == 2 || (ctx->sl_mode == 1 && ctx->sl_sparse_scans >= 1))) LHGT_TRY(slot_list_build(ctx));
-        ctx->scan_slots = ctx->sl_state == 1;
+        const bool asked = (ctx->debug & (1 << 24)) || ctx->sl_mode == 2;
+        const bool pays = ctx->n_pos >= (1ull << 32) && ctx->sl_need_share <= 0.5;
+        if (ctx->sl_state == 0 && (asked || (ctx->sl_mode == 1 && ctx->sl_sparse_scans >= 1 && pays))) LHGT_TRY(slot_list_build(ctx));
+        ctx->scan_slots = ctx->sl_state == 1 && (asked || pays);
     }
     if (sparse_form) ctx->sl_sparse_scans++;
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
@@ -1434,6 +1443,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, near a window that reaches the trio threshold %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
+        ctx->sl_need_share = (double)n_need / (double)ctx->n_tiles;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             if (ctx->scan_slots)   // (two launches: a tile's look-back is another tile's body, and the fill tells "written in this launch" by the byte)
                 hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);

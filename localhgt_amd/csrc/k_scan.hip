@@ -80,6 +80,27 @@ __global__ void __launch_bounds__(256) pstate_probe_sum(const uint8_t* __restric
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+// Which hash of a position to ask first (round 5).  A hash is min(fwd, rc) of two uniform words: slots thin out towards the top
+// of the table (density 2(1 - x)), and the reads' k-mers with them, so the SMALLER a hash the likelier its slot reads 3.  The
+// single-first form wants a 3 soonest -- smallest hash first --, a position it probes completely then wants a "not 3" -- the largest
+// next --; the trio-first form wants a "not 3" soonest: largest first.  The record bits (flags, pstate) stay by hash number.
+// t-th hash to probe of e <= 3: lo = number of the smallest hash, hi = of the largest (of the first e), mid the third.
+struct ProbeOrder { int lo, mid, hi; };
+__device__ __forceinline__ ProbeOrder probe_order(const uint32_t (&h)[3], int e) {
+    ProbeOrder o{0, 1, 2};
+    if (e == 2) { o.lo = h[1] < h[0] ? 1 : 0; o.hi = 1 - o.lo; o.mid = o.hi; }
+    else if (e >= 3) {
+        o.lo = h[1] < h[0] ? 1 : 0;
+        o.lo = h[2] < (o.lo ? h[1] : h[0]) ? 2 : o.lo;
+        o.hi = h[1] >= h[0] ? 1 : 0;
+        o.hi = h[2] >= (o.hi ? h[1] : h[0]) ? 2 : o.hi;
+        if (o.hi == o.lo) o.hi = (o.lo + 1) % 3;        // three equal hashes
+        o.mid = 3 - o.lo - o.hi;
+    } else o.mid = o.hi = 0;
+    return o;
+}
+__device__ __forceinline__ uint32_t pick3(const uint32_t (&h)[3], int i) { return i == 0 ? h[0] : i == 1 ? h[1] : h[2]; }
+
 // ---- B1
 template <bool SAT>
 __global__ void __launch_bounds__(BT) ref_flags(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
@@ -149,15 +170,20 @@ __global__ void __launch_bounds__(BT) ref_flags_lite(const TileDev* __restrict__
             for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
             const bool sample = (j % stride) == 0;
             uint32_t known = 0, is3 = 0;
+            // smallest hash first (probe_order); a sampled position then asks its largest
+            const ProbeOrder po = probe_order(h, e);
+            const int second = sample ? po.hi : po.mid, third = sample ? po.mid : po.hi;
 #pragma unroll
-            for (int i = 0; i < 3; i++)
+            for (int t = 0; t < 3; t++)
                 // a sampled position goes on until `single` AND `trio` are decided: a hash that reads 3 and one that does not settle
                 // both (round 4: before, all e hashes -- 3 probes where 2.5 do); any other position stops at the first 3
-                if (i < e && (is3 == 0u || (sample && known == is3))) {
+                if (t < e && (is3 == 0u || (sample && known == is3))) {
+                    const int i = t == 0 ? po.lo : t == 1 ? second : third;
+                    const uint32_t hv = pick3(h, i);
                     uint32_t cnt = 0u;                                 // hash 0 = invalid (E:936-941)
-                    if (h[i] != 0) {
-                        if (SAT && ((satline[h[i] >> 13] >> ((h[i] >> 8) & 31u)) & 1u)) cnt = 3u;
-                        else cnt = count_of(counts, h[i]);
+                    if (hv != 0) {
+                        if (SAT && ((satline[hv >> 13] >> ((hv >> 8) & 31u)) & 1u)) cnt = 3u;
+                        else cnt = count_of(counts, hv);
                     }
                     known |= 1u << i;
                     if (cnt == 3u) is3 |= 1u << i;                     // least_depth 3 (E:580)
@@ -200,10 +226,13 @@ __global__ void __launch_bounds__(BT) ref_flags_trio(const TileDev* __restrict__
             for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
             uint32_t known = 0, is3 = 0, stop_nz = 0;
             bool all3 = true;
+            const ProbeOrder po = probe_order(h, e);                              // largest hash first: the likeliest "not 3"
 #pragma unroll
-            for (int i = 0; i < 3; i++)
-                if (i < e && all3) {
-                    const uint32_t cnt = h[i] != 0 ? count_of(counts, h[i]) : 0u;   // hash 0 = invalid (E:936-941)
+            for (int t = 0; t < 3; t++)
+                if (t < e && all3) {
+                    const int i = t == 0 ? po.hi : t == 1 ? (e == 2 ? po.lo : po.mid) : po.lo;
+                    const uint32_t hv = pick3(h, i);
+                    const uint32_t cnt = hv != 0 ? count_of(counts, hv) : 0u;       // hash 0 = invalid (E:936-941)
                     known |= 1u << i;
                     if (cnt == 3u) is3 |= 1u << i;                                    // least_depth 3 (E:580)
                     else { all3 = false; stop_nz = cnt > 0u; }

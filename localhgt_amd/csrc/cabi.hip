@@ -329,7 +329,7 @@ int lhgt_phase_ms(lhgt_ctx* ctx, int phase, float* ms) {
 
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact) {
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
-    if (lite) *lite = ctx->scan_form == 2 && ctx->scan_slots ? 3 : ctx->scan_form;   // 0 exact, 1 single-first (lite), 2 trio-first, 3 slot-first (trio-first answered from the slot list)
+    if (lite) *lite = ctx->scan_slots ? (ctx->scan_form == 2 ? 3 : 4) : ctx->scan_form;   // 0 exact, 1 single-first (lite), 2 trio-first; with the slot list: 3 slot-first (trio-first's), 4 slot-single (single-first's)
     if (frac_slots_at_3) *frac_slots_at_3 = ctx->scan_frac3;
     if (n_tiles) *n_tiles = ctx->n_tiles;
     if (n_tiles_exact) *n_tiles_exact = ctx->scan_lite ? ctx->scan_n_need : ctx->n_tiles;

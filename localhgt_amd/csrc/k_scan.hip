@@ -1052,14 +1052,22 @@ constexpr uint32_t SL_SLOTS = 1u << SL_BITS;
 // top of the table (density 2(1 - x)) and so do the reads' k-mers: the largest of three hashes addresses the slot least likely to
 // read 3 -- 19 % of the positions go on where 27 % would under hash 0 (deep focused sample, 18 % of all slots at 3).  Any hash of an
 // invalid k-mer is 0 (quirk Q6), then all are.
-__device__ __forceinline__ uint32_t slot_list_key(const RefSource& rs, const RefKmer& km, int e) {
+__device__ __forceinline__ uint32_t slot_list_key(const RefSource& rs, const RefKmer& km, int e, bool smallest) {
     uint32_t h = ref_hash(rs, km, 0);
-    for (int i = 1; i < e && i < 3; i++) { const uint32_t g = ref_hash(rs, km, i); h = g > h ? g : h; }
+    for (int i = 1; i < e && i < 3; i++) {
+        const uint32_t g = ref_hash(rs, km, i);
+        if (smallest) h = g != 0u && (h == 0u || g < h) ? g : h;     // the smallest hash that is one (0 = no hash, E:936-941)
+        else h = g > h ? g : h;
+    }
     return h;
 }
+// The list for a SATURATED table (round 5, "slot-single") turns the same idea round: there the single-first form wants to know of
+// every position whether ANY of its hashes reads 3, almost all do, and the hash likeliest to is the smallest.  Listed under their
+// smallest hash, the positions whose slot reads 3 are settled -- `single`, which is what the flags are preset to -- without being
+// touched, and only the few per cent whose slot does not are followed to their other hashes (ref_single_slots).
 
 __global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
-                                                     int k, int e, uint32_t* __restrict__ hist, long n_blk) {
+                                                     int k, int e, int smallest, uint32_t* __restrict__ hist /* [nb], then [nb]: k-mers whose hashes are all 0 */, long nb, long n_blk) {
     const long blk = block2d();
     if (blk >= n_blk) return;
     const TileDev t = tiles[blk];
@@ -1069,8 +1077,9 @@ __global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__
         const long j = (long)t.j0 + jj;
         if (j >= nk) break;
         const RefKmer km = ref_kmer(rs, c, j, k, e);
-        const uint32_t h = slot_list_key(rs, km, e);
+        const uint32_t h = slot_list_key(rs, km, e, smallest != 0);
         if (h != 0) atomicAdd(&hist[h >> SL_BITS], 1u);     // hash 0 = invalid (E:936-941): never at 3, not listed
+        else if (!rs.index && km.valid) atomicAdd(&hist[nb], 1u);   // a k-mer all of whose hashes are 0 (2^-93 each): no entry speaks for it
     }
 }
 // one workgroup: hist -> exclusive offsets (u64), hist cleared to serve as the fill's cursors
@@ -1091,7 +1100,7 @@ __global__ void __launch_bounds__(1024) slot_list_offsets(uint32_t* __restrict__
     for (long b = b0; b < b1; b++) { off[b] = run; run += hist[b]; hist[b] = 0u; }
 }
 __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
-                                                     int k, int e, const unsigned long long* __restrict__ off, uint32_t* __restrict__ cur,
+                                                     int k, int e, int smallest, const unsigned long long* __restrict__ off, uint32_t* __restrict__ cur,
                                                      uint32_t* __restrict__ lo, uint16_t* __restrict__ hi, long n_blk) {
     const long blk = block2d();
     if (blk >= n_blk) return;
@@ -1102,7 +1111,7 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
         const long j = (long)t.j0 + jj;
         if (j >= nk) break;
         const RefKmer km = ref_kmer(rs, c, j, k, e);
-        const uint32_t h = slot_list_key(rs, km, e);
+        const uint32_t h = slot_list_key(rs, km, e, smallest != 0);
         if (h == 0) continue;
         const uint32_t b = h >> SL_BITS;
         const unsigned long long at = off[b] + atomicAdd(&cur[b], 1u);
@@ -1275,6 +1284,200 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
     }
 }
 
+// ---- B1 for a nearly saturated table with the packed reference and its slot list resident ("slot-single", round 5).  What the later
+// steps need from the single-first form (ref_flags_lite) is the exact `single` bit of every position and a lower bound of the trio
+// sums.  Here the flags are preset to "single" (0x01), and three small kernels take back what is not:
+//   no_kmer_flags      positions without a k-mer -- a not-a-base inside the window, the last k - 1 of a contig -- get 0x80 (exact zeros);
+//   ref_single_slots   the list, kept under every position's SMALLEST hash: an entry whose slot reads 3 is done without being touched;
+//                      the others (a few per cent) are followed to their other hashes, and only a position none of whose hashes
+//                      reads 3 is written (0x80);
+//   ref_trio_runs      the lower bound: 32 consecutive positions of every 250 (64 of any 500-position window, as many as every 8th
+//                      position gave; consecutive ones share their lines of bases) are probed largest hash first until one does not
+//                      read 3, and those whose e hashes all do are written 0x83.
+// window_lite, the fill of the tiles it cannot settle and window_good follow as in the single-first form (the probe-state bytes of
+// those tiles cleared first: nothing is known of them).  Same peaks, ids and votes; e <= 3, packed form only (which positions hold
+// no k-mer is read off the not-a-base plane; the index form would have to stream its 12 bytes per base for it).
+__global__ void __launch_bounds__(256) no_kmer_flags(const uint32_t* __restrict__ nb, uint64_t n_words, int k, uint8_t* __restrict__ flags, uint64_t n_pos) {
+    const uint64_t w = (uint64_t)block2d() * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t a = nb[w], b = nb[w + 1];
+    if ((a | b) == 0u) return;                               // all 32 windows that start in this word are clean
+    for (int r = 0; r < 32; r++) {
+        const uint64_t x = w * 32 + (uint64_t)r;
+        if (x < n_pos && (window32(a, b, r) >> (32 - k)) != 0u) flags[x] = 0x80;
+    }
+}
+__global__ void __launch_bounds__(256) contig_tail_flags(const ContigDev* __restrict__ contigs, long n_contigs, int k, uint8_t* __restrict__ flags) {
+    const long c = (long)blockIdx.x * (256 / 32) + (threadIdx.x >> 5);
+    if (c >= n_contigs) return;
+    const ContigDev cd = contigs[c];
+    const long nk = (long)cd.len - k + 1, from = nk > 0 ? nk : 0;
+    for (long j = from + (threadIdx.x & 31); j < (long)cd.len; j += 32) flags[cd.flat_base + j] = 0x80;
+}
+template <int ST>
+__global__ void __launch_bounds__(ST) ref_single_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
+                                                       const uint16_t* __restrict__ hi, const RefSource rs, const uint32_t* __restrict__ counts,
+                                                       int slice_words, int k, int e, uint8_t* __restrict__ flags,
+                                                       unsigned long long* __restrict__ stats /* nullable: [0] probes, [1] positions followed */, long n_buckets) {
+    constexpr int SL_CHUNK = 4 * ST, SL_RING = 2 * SL_CHUNK;
+    __shared__ uint32_t slice[SL_SLOTS / 16];
+    __shared__ uint32_t ring_lo[SL_RING];
+    __shared__ uint8_t ring_hi[SL_RING];
+    __shared__ uint32_t s_tail;
+    const long b = block2d();
+    if (b >= n_buckets) return;
+    const unsigned long long begin = off[b], end = off[b + 1];
+    if (begin == end) return;                                   // uniform
+    uint32_t not3 = 0;
+    for (int i = threadIdx.x; i < slice_words; i += ST) {
+        const uint32_t w = counts[(size_t)b * (SL_SLOTS / 16) + i];
+        slice[i] = w;
+        not3 |= ~(w & (w >> 1)) & 0x55555555u;
+    }
+    if (threadIdx.x == 0) s_tail = 0u;
+    if (!__syncthreads_or(not3 != 0u)) return;                  // every slot of the bucket reads 3: all its positions are `single`
+    const int lane = threadIdx.x & 63;
+    unsigned long long probes = 0, followed = 0;
+    auto follow = [&](uint32_t from, uint32_t n) {
+        const uint32_t first = from & (SL_RING - 1);
+        const uint64_t x_first = (uint64_t)ring_lo[first] | ((uint64_t)ring_hi[first] << 32);
+        uint64_t x[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = threadIdx.x + (uint32_t)u * ST, at = (from + idx) & (SL_RING - 1);
+            on[u] = idx < n;
+            x[u] = on[u] ? (uint64_t)ring_lo[at] | ((uint64_t)ring_hi[at] << 32) : x_first;
+        }
+        uint32_t w[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t* p = rs.planes + 2 * (x[u] >> 5);
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[u][q] = p[q];
+        }
+        // the listed hash (the smallest that is one) does not read 3; the others, the smaller one first (the likelier 3)
+        uint32_t h1[4], h2[4], c1[4], c2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = (int)(x[u] & 31);
+            const uint32_t whi = window32(w[u][0], w[u][2], r) >> (32 - k), wlo = window32(w[u][1], w[u][3], r) >> (32 - k);
+            const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+            uint32_t a0 = hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[0]);
+            uint32_t a1 = e > 1 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[1]) : 0u;
+            uint32_t a2 = e > 2 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[2]) : 0u;
+            // ascending with the zeros (no hash: never a 3) last; a0 then is the listed one
+            a0 = a0 ? a0 : 0xffffffffu; a1 = a1 ? a1 : 0xffffffffu; a2 = a2 ? a2 : 0xffffffffu;
+            if (a1 < a0) { const uint32_t t = a0; a0 = a1; a1 = t; }
+            if (a2 < a0) { const uint32_t t = a0; a0 = a2; a2 = t; }
+            if (a2 < a1) { const uint32_t t = a1; a1 = a2; a2 = t; }
+            h1[u] = a1 == 0xffffffffu ? 0u : a1;
+            h2[u] = a2 == 0xffffffffu ? 0u : a2;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) c1[u] = counts[on[u] && h1[u] != 0u ? h1[u] >> 4 : 0u];
+        bool none[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            none[u] = on[u] && !(h1[u] != 0u && ((c1[u] >> ((h1[u] & 15u) * 2u)) & 3u) == 3u);
+            if (on[u]) followed++;
+            if (on[u] && h1[u] != 0u) probes++;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) c2[u] = counts[none[u] && h2[u] != 0u ? h2[u] >> 4 : 0u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (none[u] && h2[u] != 0u) {
+                probes++;
+                none[u] = ((c2[u] >> ((h2[u] & 15u) * 2u)) & 3u) != 3u;
+            }
+            if (none[u]) flags[x[u]] = 0x80;                    // no hash of the position reads 3: exact zeros
+        }
+    };
+    uint32_t head = 0;
+    for (unsigned long long c0 = begin; c0 < end; c0 += SL_CHUNK) {
+        uint32_t lo4[4], hi4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long i = c0 + threadIdx.x + (unsigned long long)u * ST;
+            const bool ok = i < end;
+            lo4[u] = ok ? lo[i] : 0u;
+            hi4[u] = ok ? (uint32_t)hi[i] : 0x10000u;           // bit 16: no entry
+        }
+        unsigned long long m[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t sl = hi4[u] & (SL_SLOTS - 1u);
+            const bool pass = !(hi4[u] & 0x10000u) && ((slice[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) != 3u;
+            m[u] = __ballot(pass);
+            mine |= pass ? 1u << u : 0u;
+        }
+        const uint32_t total = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(&s_tail, total);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if ((mine >> u) & 1u) {
+                const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u))) & (SL_RING - 1);
+                ring_lo[at] = lo4[u];
+                ring_hi[at] = (uint8_t)(hi4[u] >> SL_BITS);
+            }
+            base += (uint32_t)__popcll(m[u]);
+        }
+        __syncthreads();
+        const uint32_t tail = s_tail;
+        while (tail - head >= (uint32_t)SL_CHUNK) {              // uniform
+            follow(head, SL_CHUNK);
+            head += SL_CHUNK;
+        }
+        __syncthreads();
+    }
+    const uint32_t tail = s_tail;
+    if (tail != head) follow(head, tail - head);
+    if (stats) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { probes += __shfl_xor(probes, d, 64); followed += __shfl_xor(followed, d, 64); }
+        if (lane == 0 && probes) atomicAdd(stats, probes);
+        if (lane == 0 && followed) atomicAdd(stats + 1, followed);
+    }
+}
+constexpr int RUN_PERIOD = 250, RUN_LEN = 32;      // TILE = 8 periods; BT = 8 runs x 32 positions: one position per thread
+static_assert(TILE % RUN_PERIOD == 0 && (TILE / RUN_PERIOD) * RUN_LEN == BT && 2 * RUN_PERIOD <= WINDOW, "runs tile the tile; every window holds two of them");
+__global__ void __launch_bounds__(BT) ref_trio_runs(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
+                                                    const uint32_t* __restrict__ counts, int k, int e, uint8_t* __restrict__ flags,
+                                                    unsigned long long* __restrict__ stats /* nullable: [0] probes */, long n_blk) {
+    const long blk = block2d();
+    if (blk >= n_blk) return;
+    const TileDev t = tiles[blk];
+    const ContigDev c = contigs[t.contig];
+    const long nk = (long)c.len - k + 1;
+    const long j = (long)t.j0 + (threadIdx.x >> 5) * RUN_PERIOD + (threadIdx.x & 31);
+    unsigned long long probes = 0;
+    if (j < nk) {
+        const RefKmer km = ref_kmer(rs, c, j, k, e);
+        uint32_t h[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
+        const ProbeOrder po = probe_order(h, e);                  // largest hash first: the likeliest "not 3"
+        bool all3 = true;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (q < e && all3) {
+                const uint32_t hv = pick3(h, q == 0 ? po.hi : q == 1 ? (e == 2 ? po.lo : po.mid) : po.lo);
+                if (hv != 0) probes++;
+                all3 = hv != 0 && count_of(counts, hv) == 3u;
+            }
+        if (all3) flags[c.flat_base + j] = 0x83;                  // single, trio, exact
+    }
+    if (stats) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) probes += __shfl_xor(probes, d, 64);
+        if ((threadIdx.x & 63) == 0 && probes) atomicAdd(stats, probes);
+    }
+}
+
 }  // namespace lhgt
 
 using namespace lhgt;
@@ -1300,7 +1503,7 @@ void slot_list_drop(lhgt_ctx* ctx) {
 }
 }  // namespace lhgt
 static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static int slot_list_build(lhgt_ctx* ctx) {
+static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
     const bool trace = getenv("LHGT_TRACE") != nullptr;
     ctx->sl_state = -1;                                          // whatever happens below: one attempt per reference
     if (ctx->e > 3 || ctx->n_tiles == 0 || ctx->n_pos >= (1ull << 34)) return LHGT_OK;
@@ -1317,15 +1520,17 @@ static int slot_list_build(lhgt_ctx* ctx) {
     }
     const double t0 = wall_s();
     uint32_t* d_hist = nullptr;
-    if (lhgt::dev_malloc(&d_hist, (size_t)nb * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_off, (size_t)(nb + 1) * 8) != hipSuccess) {
+    if (lhgt::dev_malloc(&d_hist, (size_t)(nb + 1) * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_off, (size_t)(nb + 1) * 8) != hipSuccess) {
         if (d_hist) lhgt::dev_free(d_hist);
         slot_list_drop(ctx); ctx->sl_state = -1;
         (void)hipGetLastError();
         return LHGT_OK;
     }
     const dim3 grid = blocks2d(ctx->n_tiles), blk(BT);
-    LHGT_HIP(hipMemsetAsync(d_hist, 0, (size_t)nb * 4, ctx->stream));
-    hipLaunchKernelGGL(slot_list_hist, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, d_hist, ctx->n_tiles);
+    LHGT_HIP(hipMemsetAsync(d_hist, 0, (size_t)(nb + 1) * 4, ctx->stream));
+    hipLaunchKernelGGL(slot_list_hist, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, smallest ? 1 : 0, d_hist, nb, ctx->n_tiles);
+    uint32_t unlisted = 0;
+    LHGT_HIP(hipMemcpyAsync(&unlisted, d_hist + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(slot_list_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_hist, nb, ctx->d_sl_off);
     unsigned long long n_entries = 0;
     LHGT_HIP(hipMemcpyAsync(&n_entries, ctx->d_sl_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1337,7 +1542,7 @@ static int slot_list_build(lhgt_ctx* ctx) {
         if (trace) fprintf(stderr, "[lhgt] slot list: no memory for %llu entries -- not built\n", n_entries);
         return LHGT_OK;
     }
-    hipLaunchKernelGGL(slot_list_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, ctx->d_sl_off, d_hist,
+    hipLaunchKernelGGL(slot_list_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, smallest ? 1 : 0, ctx->d_sl_off, d_hist,
                        ctx->d_sl_lo, ctx->d_sl_hi, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
@@ -1345,7 +1550,9 @@ static int slot_list_build(lhgt_ctx* ctx) {
     ctx->sl_entries = n_entries;
     ctx->sl_buckets = nb;
     ctx->sl_state = 1;
-    if (trace) fprintf(stderr, "[lhgt] slot list: %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", n_entries, nb, 6.0 * (double)n_entries / 1e9, wall_s() - t0);
+    ctx->sl_smallest = smallest;
+    ctx->sl_unlisted = unlisted;
+    if (trace) fprintf(stderr, "[lhgt] slot list (by the %s hash): %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", smallest ? "smallest" : "largest", n_entries, nb, 6.0 * (double)n_entries / 1e9, wall_s() - t0);
     return LHGT_OK;
 }
 
@@ -1390,7 +1597,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // above, the old rule: lite from 90 %, exact in between unless a trial of the lite kernels settles 40 % of its tiles.
     // bit 12 / 13 / 14 force single-first / exact / trio-first.
     const bool force_any = (ctx->debug & (4096 | 8192 | 16384 | (1 << 24))) != 0;
-    const bool sparse_form = e <= 3 && ((ctx->debug & (16384 | (1 << 24))) || (!force_any && frac3 < 0.45 && n_lines >= 64 && !(ctx->debug & 64)));
+    const bool sparse_form = e <= 3 && ((ctx->debug & 16384) || ((ctx->debug & (1 << 24)) && !(ctx->debug & (4096 | 8192))) || (!force_any && frac3 < 0.45 && n_lines >= 64 && !(ctx->debug & 64)));
     double pilot_settled = -1.0;
     if (e <= 3 && !force_any && !sparse_form && frac3 >= 0.2 && frac3 < 0.9 && ctx->n_tiles >= 65 * 64 * 4) {
         std::vector<uint32_t> pl, pw;
@@ -1426,16 +1633,26 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     // Where it does not pay, left alone unless asked for (bit 24, mode 2): a small reference -- a bucket of 2^14 slots wants some 10^4
     // positions for a workgroup's set-up, i.e. a few Gbase (1 Gbase, index form: the kernel 52 ms where trio-first's takes 45) --; and a
     // sample that makes most tiles candidates (configs[1]: every genome sampled), whose fill then asks all e probes of every position
-    // where trio-first's asks the missing ones: when the last sparse scan sent more than half of the tiles to the fill, this one takes
-    // the trio-first kernel (and reports its own share for the next).
+    // where trio-first's asks the missing ones: when the last scan of a list form sent more than half of the tiles to the fill, this
+    // one takes the position-ordered kernel (and reports its own share for the next).
+    // The single-first form has a list kernel too (slot-single: packed form, the list under the SMALLEST hash); a context keeps the
+    // list of the form that built it -- one of 78 GB is what fits -- and only a scan that asks (bit 24) swaps it.
     ctx->scan_slots = false;
-    if (sparse_form && !(ctx->debug & (1 << 25)) && (!(ctx->debug & 16384) || (ctx->debug & (1 << 24)))) {
+    const bool list_form = sparse_form || (ctx->scan_form == 1 && ctx->ref_packed && e <= 3);
+    const bool want_smallest = !sparse_form;
+    if (list_form && !(ctx->debug & (1 << 25)) && (!(ctx->debug & (16384 | 4096)) || (ctx->debug & (1 << 24)))) {
         const bool asked = (ctx->debug & (1 << 24)) || ctx->sl_mode == 2;
         const bool pays = ctx->n_pos >= (1ull << 32) && ctx->sl_need_share <= 0.5;
-        if (ctx->sl_state == 0 && (asked || (ctx->sl_mode == 1 && ctx->sl_sparse_scans >= 1 && pays))) LHGT_TRY(slot_list_build(ctx));
-        ctx->scan_slots = ctx->sl_state == 1 && (asked || pays);
+        if ((ctx->debug & (1 << 24)) && ctx->sl_state == 1 && ctx->sl_smallest != want_smallest) {
+            const int scans = ctx->sl_sparse_scans;
+            LHGT_HIP(hipStreamSynchronize(ctx->stream));
+            slot_list_drop(ctx);
+            ctx->sl_sparse_scans = scans;
+        }
+        if (ctx->sl_state == 0 && (asked || (ctx->sl_mode == 1 && ctx->sl_sparse_scans >= 1 && pays))) LHGT_TRY(slot_list_build(ctx, want_smallest));
+        ctx->scan_slots = ctx->sl_state == 1 && ctx->sl_smallest == want_smallest && (asked || pays) && (sparse_form || ctx->sl_unlisted == 0);
     }
-    if (sparse_form) ctx->sl_sparse_scans++;
+    if (list_form) ctx->sl_sparse_scans++;
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
     if (sparse_form && ctx->scan_slots) {
@@ -1481,6 +1698,21 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
+    } else if (ctx->scan_lite && ctx->scan_slots) {
+        // slot-single: flags preset to `single`, taken back where there is no k-mer and where the list's followed positions find no 3;
+        // the trio lower bound from runs of 32 positions
+        LHGT_HIP(hipMemsetAsync(ctx->d_flags, 0x01, ctx->n_pos, ctx->stream));
+        const uint64_t n_words = (ctx->n_pos + 31) / 32;
+        hipLaunchKernelGGL(no_kmer_flags, blocks2d((long)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref_planes + 2 * ctx->ref_plane_words, n_words, k,
+                           ctx->d_flags, ctx->n_pos);
+        hipLaunchKernelGGL(contig_tail_flags, dim3((unsigned)((ctx->contigs.size() + 7) / 8)), dim3(256), 0, ctx->stream, ctx->d_contigs, (long)ctx->contigs.size(), k, ctx->d_flags);
+        unsigned long long* st = ctx->stats_on && ctx->d_stats ? ctx->d_stats + 1 : nullptr;
+        if (st) LHGT_HIP(hipMemsetAsync(st, 0, 16, ctx->stream));
+        const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
+        hipLaunchKernelGGL(ref_single_slots<BT>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx), ctx->d_counts,
+                           slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets);
+        hipLaunchKernelGGL(ref_trio_runs, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags, st, nt);
+        LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
     } else if (ctx->scan_lite) {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags_lite<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
@@ -1493,6 +1725,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
             LHGT_HIP(hipMemsetAsync(ctx->d_stats + 1, 0, 8, ctx->stream));
             hipLaunchKernelGGL(pstate_probe_sum, dim3(8192), dim3(256), 0, ctx->stream, ctx->d_nzmask, ctx->n_pos, ctx->d_stats + 1);
         }
+    }
+    if (ctx->scan_lite && !sparse_form) {
         unsigned int* d_nneed = (unsigned int*)(d_nsat + 2);
         LHGT_HIP(hipMemsetAsync(d_nneed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(window_lite, blocks2d((nt + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, one_min, three_min, ctx->d_flags, ctx->d_tile_good,
@@ -1502,13 +1736,16 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         LHGT_HIP(hipStreamSynchronize(ctx->stream));
         if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, not settled by the lower bound %u\n", ctx->n_tiles, n_need);
         ctx->scan_n_need = n_need;
+        ctx->sl_need_share = (double)n_need / (double)ctx->n_tiles;
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
+            if (ctx->scan_slots)
+                hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
                                ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 0);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
-    } else {
+    } else if (!ctx->scan_lite) {
         if (use_sat)
             hipLaunchKernelGGL(ref_flags<true>, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,
                                ctx->d_nzmask, ctx->d_satline, nt);

@@ -166,6 +166,8 @@ struct lhgt_ctx {
     int sl_state = 0;                        // 0 not tried for this reference, 1 built, -1 tried and left (no memory, e > 3, positions beyond 2^34)
     int sl_mode = 1;                         // lhgt_slot_list / LHGT_SLOT_LIST: 0 never, 1 before the second sparse scan of a reference, 2 before the first
     int sl_sparse_scans = 0;                 // sparse-form scans of the resident reference so far
+    bool sl_smallest = false;                // the list is kept under every position's smallest hash (for a saturated table), not its largest (a sparse one)
+    uint32_t sl_unlisted = 0;                // k-mers all of whose hashes are 0 (packed form): no entry speaks for them
     double sl_need_share = 0.0;              // share of the tiles the last sparse-form scan sent to the fill
     bool scan_lite = false;       // the last scan took the lite form of B1/B2: d_nzmask then holds the per-hash probe state, not nz bits
     // reads

@@ -365,7 +365,7 @@ class Engine:
         """form of the last ref_scan: {'lite': bool, 'frac_slots_at_3': float, 'tiles': int, 'tiles_exact': int}"""
         lite, frac, nt, ne = C.c_int(0), C.c_double(0), C.c_long(0), C.c_long(0)
         _lib.check(self.lib.lhgt_scan_info(self.h, C.byref(lite), C.byref(frac), C.byref(nt), C.byref(ne)))
-        return {"lite": lite.value == 1, "form": ("exact", "single-first", "trio-first", "slot-first")[lite.value], "frac_slots_at_3": round(frac.value, 4),
+        return {"lite": lite.value in (1, 4), "form": ("exact", "single-first", "trio-first", "slot-first", "slot-single")[lite.value], "frac_slots_at_3": round(frac.value, 4),
                 "tiles": nt.value, "tiles_exact": ne.value}
 
     def slot_list(self, mode: int = -1) -> dict:

@@ -234,6 +234,9 @@ def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
         got, sinfo = _scan(eng, 16384)                               # bit 14 alone: the trio-first kernel, list or no list
         assert got == want[16384] and sinfo["form"] == "trio-first", sinfo
         assert _vote(eng, 1 << 24) == want_votes
+        got, sinfo = _scan(eng, 4096 | (1 << 24))                    # single-first's list form: the list rebuilt under the smallest hash
+        assert sinfo["form"] == "slot-single" and got == want[4096], (sinfo, got, want[4096])
+        assert eng.slot_list()["entries"] == NC * (CL - K + 1)
         assert eng.slot_list(0)["entries"] == 0                      # dropped again: the oracle check below scans shards of its own
         # ... and against the CPU restatement at the plane-word addresses of 13 Gbase (tests/bigaddr.py)
         import bigaddr

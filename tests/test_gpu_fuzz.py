@@ -103,7 +103,7 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     import shutil
     # a third of the cases each: the form the engine picks, single-first, trio-first (when e <= 3) -- every other of those answered
     # from the slot list (bit 24, round 5); every fourth case with the vote bitmap in its three-quarter form (bit 20; k > 25)
-    dbg = (0, 4096, 16384, 0, 4096, 1 << 24)[idx % 6] | ((1 << 20) if idx % 4 == 3 else 0)
+    dbg = (0, 4096, 16384, 0, 4096 | (1 << 24), 1 << 24)[idx % 6] | ((1 << 20) if idx % 4 == 3 else 0)   # 4096 | bit 24: slot-single where the reference is packed
     if dbg:
         monkeypatch.setenv("LHGT_DEBUG", str(dbg))
     g, c = tmp_path / "gpu", tmp_path / "cpu"

@@ -161,16 +161,22 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
             assert info["form"] == ("packed" if packed else "index")
             assert info["resident_bytes"] == (12 * ((n_bases + 31) // 32 + 2) if packed else index_bytes)
             assert eng.slot_list()["entries"] == 0, "a new reference drops the list of the one before"
-            for flags in (8192, 0, 4096, 4096 | 256, 16384, 16384 | 256, 1 << 24, (1 << 24) | 256, 0):
+            # bit 24: the forms that read the slot list -- trio-first's (slot-first: either resident form) and, with bit 12, single-first's
+            # (slot-single: packed form only; the list is rebuilt under the positions' smallest hash)
+            for flags in (8192, 0, 4096, 4096 | 256, 16384, 16384 | 256, 1 << 24, (1 << 24) | 256, 0, 4096 | (1 << 24), 4096 | (1 << 24) | 256, 1 << 24):
                 eng.set_debug(flags)
                 assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o
                 if flags & (1 << 24):
-                    assert eng.scan_info()["form"] == "slot-first" and eng.slot_list()["entries"] > 0
+                    want_form = "slot-first" if not flags & 4096 else "slot-single" if packed else "single-first"
+                    assert eng.scan_info()["form"] == want_form and (eng.slot_list()["entries"] > 0 or want_form == "single-first"), (flags, eng.scan_info())
                 eng.vote()
                 loci_p, pf_p = eng.peaks_export(n_g)
                 assert (loci_p == loci_o[:2 * n_o]).all() and (pf_p == pf_o[:n_g]).all() and (eng.peak_kmer_export() == pk_o).all(), (packed, flags)
                 fl = eng.flags_export(0, n_bases)
                 assert (((fl ^ flags_g) & (0b1111111 if flags == 8192 else 0b1111100)) == 0).all(), (packed, flags)
+                if eng.scan_info()["form"] == "slot-single":
+                    assert (((fl ^ flags_g) & 1) == 0).all(), "slot-single: the single flag is exact everywhere"
+                    assert (((fl ^ flags_g) & 0b10)[(fl & 0x80) != 0] == 0).all() and (((fl & ~flags_g) & 0b10) == 0).all(), "slot-single: trio flag exact where claimed, a lower bound elsewhere"
             eng.set_debug(0)
             eng.write_intervals(out)
             assert open(out).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read()

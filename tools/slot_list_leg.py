@@ -56,4 +56,25 @@ for pairs, contigs, tag in ((100_000_000, 300, "deep focused"), (10_000_000, 300
           f"phase B trio-first {b_t:.1f} ms (probe kernel {k_t:.1f}, wall {w_t:.0f}), tiles treated exactly {info_t['tiles_exact']}; "
           f"slot-first {b_s:.1f} ms (sweep kernel {k_s:.1f}, wall {w_s:.0f}), tiles {info_s['tiles_exact']}; three scans incl. any build {first:.2f} s; "
           f"step {a + b_t + c:.0f} -> {a + b_s + c:.0f} ms, {pairs / (a + b_t + c) / 1e3:.1f} -> {pairs / (a + b_s + c) / 1e3:.1f} M pairs/s; list {g.slot_list()}", flush=True)
+
+# the headline's sample (half of the catalogue, a saturated table): the single-first kernel against its list form (slot-single:
+# the list rebuilt under the smallest hash; packed form only)
+if form == "packed":
+    g.pairs_clear()
+    g.synth_pairs(1, 2, NC, CL, 0, 100_000_000)
+    g.counts_clear()
+    g.count_kmers()
+    a = g.phase_ms(0)
+    (b_t, k_t, w_t), info_t, dig_t = scan(4096)
+    t = time.time()
+    (b_s, k_s, w_s), info_s, dig_s = scan(4096 | (1 << 24))
+    first = time.time() - t
+    assert info_s["form"] == "slot-single", info_s
+    assert dig_t == dig_s, (dig_t, dig_s)
+    g.vote()
+    c = g.phase_ms(2)
+    print(f"configs[2]'s sample: table {100 * info_t['frac_slots_at_3']:.1f} % at 3, {dig_t[0]} raw peaks; phase A {a:.1f} ms, C {c:.1f} ms; "
+          f"phase B single-first {b_t:.1f} ms (probe kernel {k_t:.1f}), tiles treated exactly {info_t['tiles_exact']}; "
+          f"slot-single {b_s:.1f} ms (its kernels {k_s:.1f}), tiles {info_s['tiles_exact']}; three scans incl. the rebuild {first:.2f} s; "
+          f"step {a + b_t + c:.0f} -> {a + b_s + c:.0f} ms, {1e5 / (a + b_t + c):.1f} -> {1e5 / (a + b_s + c):.1f} M pairs/s; list {g.slot_list()}", flush=True)
 g.close()

@@ -73,9 +73,11 @@ def parse_args(argv=None):
     ap.add_argument("-e", type=int, default=3)
     ap.add_argument("--shard-index", action="store_true", help="N > 1: time ONLY the reference-sharded phase B (each rank holds 1/N of the index)")
     ap.add_argument("--replicate-index", action="store_true", help="N > 1: time ONLY the replicated form (the whole index on every GPU, no exchange in phase B)")
-    ap.add_argument("--ref-form", choices=["index", "packed"], default="index",
-                    help="resident form of the reference: the index file's hashes (12 B/base at e=3; what configs[2] names) or the packed bases "
-                         "(3/8 B/base), phase B recomputing the hashes")
+    ap.add_argument("--ref-form", choices=["index", "packed"], default="packed",
+                    help="resident form of the reference: the packed bases (3/8 B/base), phase B recomputing the hashes, with the slot list -- the "
+                         "reference's k-mer positions by hash bucket, 6 B/base -- next to them (default since round 5); or the index file's hashes "
+                         "(12 B/base at e=3: rounds 1-4's headline, now the `index_form` leg of the same line)")
+    ap.add_argument("--no-slot-list", action="store_true", help="packed form without the slot list: phase B's position-ordered kernels (A/B)")
     ap.add_argument("--count-mode", type=int, default=-1, help="-1 = engine default (adaptive), 0 = direct CAS kernel, 1 = radix partition")
     ap.add_argument("--debug", type=int, default=0, help="engine debug/A-B switches (include/localhgt_hip.h: lhgt_set_debug)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange code even at world size 1 (self-test of the N>1 path)")
@@ -136,7 +138,8 @@ def main():
 
     # ---- does it fit?  (before anything is allocated; DESIGN.md 6 holds the configs[3] plan)
     shard_only = args.shard_index and world > 1
-    plan = check_fits(memory_plan(args.pairs, args.contigs * args.contig_len, args.contigs, k, e, L, args.ref_form == "packed", world, shard_only),
+    use_list = args.ref_form == "packed" and not args.no_slot_list and not shard_only
+    plan = check_fits(memory_plan(args.pairs, args.contigs * args.contig_len, args.contigs, k, e, L, args.ref_form == "packed", world, shard_only, slot_list=use_list),
                       HBM_BYTES, f"--gpus {world}: {args.pairs} pairs per GPU vs {args.contigs * args.contig_len / 1e9:.1f} Gbase "
                                  f"({'packed' if args.ref_form == 'packed' else 'index'} form{', sharded' if shard_only else ''})")
 
@@ -221,6 +224,10 @@ def main():
         forms = [True]
     t0 = time.time()
     load_reference(forms[0])
+    if args.ref_form == "packed":
+        # the slot list of the resident reference (include/localhgt_hip.h: lhgt_slot_list): built before the first scan that has a
+        # use for it -- untimed, like the reference load it belongs to -- instead of before the second (the engine's own rule)
+        eng.slot_list(2 if use_list and not forms[0] else 0)
     eng.synth_options(args.snp, 20, args.sample_contigs)
     eng.synth_pairs(1, 2, args.contigs, args.contig_len, rank * args.pairs, args.pairs, L)   # this rank's shard, packed, resident
     eng.synchronize()
@@ -281,6 +288,9 @@ def main():
         print("bench: exchanges of rank 0 per step (" + dist.backend + "): " + "; ".join(
             f"{kk} {v['bytes_per_step'] / 1e6:.1f} MB in {xch_ms[kk]:.2f} ms" + (f" = {v['GB_per_s']} GB/s" if v["GB_per_s"] else "") for kk, v in xch_bytes.items()),
             file=sys.stderr, flush=True)
+    sl_info = eng.slot_list() if args.ref_form == "packed" else {"entries": 0, "bytes": 0}
+    resident_txt = ("index resident" if args.ref_form != "packed" else
+                    f"resident as packed bases + slot list = its k-mer positions by hash bucket, {(sl_info['bytes'] + ref_bases * 3 // 8) / 1e9:.0f} GB" if sl_info["entries"] else "packed bases resident")
     cfg_no = 2 if headline else 1 if workload_key(args) == (1000, 10_000_000, 0, False, 0) else "-"
     sample_txt = (f"drawn from {args.sample_contigs} of its contigs" if args.sample_contigs else "drawn from half of its contigs") + (f", SNP {args.snp / 10:g} %" if args.snp else "")
     detail = {
@@ -288,7 +298,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{cfg_no}]: {args.contigs}x{args.contig_len} bp synthetic ref ({args.contigs * args.contig_len / 1e9:.2f} Gbase"
-                               f"{', cut into a ragged catalogue' if args.ragged else ''}, {'packed bases resident' if args.ref_form == 'packed' else 'index resident'}), "
+                               f"{', cut into a ragged catalogue' if args.ragged else ''}, {resident_txt}), "
                                f"{args.pairs} 150bp pairs per GPU {sample_txt}, k={k} e={e}, sample=1, phases A-D",
                    "pairs_per_gpu": args.pairs, "ref_bases": args.contigs * args.contig_len, "k": k, "e": e,
                    "parallelism": f"reads sharded x{world}" + (", index sharded" if forms[0] else ", phase B replicated on every GPU (per-GPU work fixed)" if world > 1 else "")},
@@ -297,7 +307,7 @@ def main():
         "exchange_ms": xch_ms, "exchange_bytes": xch_bytes,
         "n1_equivalent_ms": round(step_s * 1e3 - sum(xch_ms.values()), 3) if xch_ms else round(step_s * 1e3, 3),
         "sharded_index" if (other_form and forms[1]) else "replicated_index": other_form,
-        "scan_B_form": scan, "vote_form": vote_form, "work_stats": stats, "memory_plan_bytes": plan,
+        "scan_B_form": scan, "vote_form": vote_form, "work_stats": stats, "memory_plan_bytes": plan, "slot_list": sl_info,
         "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
         "planted_transfers": interval_recall(out_path, planted_breakpoints(args.contigs, args.contig_len, args.sample_contigs)) if world == 1 and not args.ragged else None,
         "verify": verify,

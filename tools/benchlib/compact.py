@@ -61,9 +61,12 @@ def compact_line(detail):
                          "ms_per_step": found.get("ms_per_step"), "phase_ms": {k: _num(v, 1) for k, v in found.get("phase_ms", {}).items()},
                          "recall": (found.get("planted_transfers") or {}).get("recall"), "filtered_peaks": found.get("filtered_peaks"),
                          "roofline": _roof(found.get("roofline"))}
-    sl = (detail.get("secondary") or {}).get("uhgg_deep_focused_slot_list")
-    if isinstance(sl, dict) and "value" in sl:            # ... and with the reference resident as packed bases + its slot list (round 5)
-        line["value_found_slot_list"] = _num(sl["value"])
+    ix = (detail.get("secondary") or {}).get("uhgg_index_form")
+    if isinstance(ix, dict) and "value" in ix:            # the same workload with the index file's hashes resident: what rounds 1-4 led with
+        line["value_index_form"] = _num(ix["value"])
+    fx = (detail.get("secondary") or {}).get("uhgg_deep_focused_index_form")
+    if isinstance(fx, dict) and "value" in fx:
+        line["value_found_index_form"] = _num(fx["value"])
     sh = detail.get("sharded_index")
     if isinstance(sh, dict):
         line["sharded_index"] = {"value": sh.get("value"), "ms_per_step": sh.get("ms_per_step"), "same_peaks": sh.get("same_peaks")}

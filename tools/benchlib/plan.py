@@ -4,7 +4,7 @@ GB = 1e9
 HBM_BYTES = 288 * GB           # MI355X
 
 
-def memory_plan(pairs, ref_bases, n_contigs, k=32, e=3, L=150, packed=False, world=1, shard_index=False):
+def memory_plan(pairs, ref_bases, n_contigs, k=32, e=3, L=150, packed=False, world=1, shard_index=False, slot_list=False):
     """bytes resident on ONE GPU during a step.  pairs = read pairs of this GPU's shard; the reference is whole on every GPU
     unless shard_index (then 1/world of it)."""
     share = 1.0 / world if shard_index else 1.0
@@ -16,6 +16,7 @@ def memory_plan(pairs, ref_bases, n_contigs, k=32, e=3, L=150, packed=False, wor
     nb = 1 << max(0, k - 16)
     plan = {
         "reference": n_pos * 3 / 8 + 64 if packed else (n_pos - n_contigs * share * (k - 1)) * 4 * e + 4 * n_contigs * share,
+        "slot_list": 6 * n_pos + 8 * ((1 << max(0, k - 14)) + 1) if slot_list and packed and n_pos < (1 << 34) else 0,
         "per_position_flags_and_state": 2 * n_pos,
         "tile_tables": (n_pos / 2000 + n_contigs * share) * (8 + 1 + 4 + 4) + n_contigs * share * 24,
         "read_store": pairs * 2 * (3 * wpr * 4 + 4 + 2) + pairs,

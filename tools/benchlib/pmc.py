@@ -26,7 +26,8 @@ KERNEL_SOURCES = {   # which sources a kernel's measured traffic depends on (sta
 COMMON_SOURCES = ("lhgt_hash.hpp", "lhgt_common.hpp", "k_ingest.hip", "k_synth.hip")
 PHASE_KERNELS = {
     "count_A": ("part_scatter_reads", "part_scatter_keys", "part_reads_direct", "part_keys16_direct", "part_apply", "count_direct"),
-    "ref_flags": ("ref_flags=", "ref_flags_lite=", "ref_flags_trio="),      # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
+    "ref_flags": ("ref_flags=", "ref_flags_lite=", "ref_flags_trio=",       # "=": the whole name (ref_flags_fill belongs to the few unsettled tiles)
+                  "ref_flags_slots=", "no_kmer_flags=", "contig_tail_flags=", "ref_single_slots=", "ref_trio_runs="),   # round 5: the list forms' kernels
     "vote_kernel": ("vote_kernel",),
 }
 WORKLOAD_FLAGS = ("workload", "pairs", "contigs", "contig_len", "k", "e", "count_mode", "debug", "sample_contigs", "ref_form", "snp")
@@ -51,7 +52,7 @@ def child_command(args):
             "--quiet", "--workload", args.workload, "--pairs", str(args.pairs), "--contigs", str(args.contigs),
             "--contig-len", str(args.contig_len), "-k", str(args.k), "-e", str(args.e), "--count-mode", str(args.count_mode),
             "--debug", str(args.debug), "--sample-contigs", str(args.sample_contigs), "--snp", str(args.snp),
-            "--ref-form", args.ref_form] + (["--ragged"] if args.ragged else [])
+            "--ref-form", args.ref_form] + (["--ragged"] if args.ragged else []) + (["--no-slot-list"] if getattr(args, "no_slot_list", False) else [])
 
 
 def collect_pmc(args, passes, timeout_s=420):

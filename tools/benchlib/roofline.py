@@ -79,7 +79,16 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
     n_pos = max(0, ref_bases - n_contigs * (k - 1))          # positions with a k-mer
     probes = stats.get("scan_probes") or n_pos * e
     stream = ref_bases * 3 // 8 if packed else n_pos * 4 * e
-    if scan_form == "slot-first":
+    if scan_form == "slot-single":
+        # flags preset and the not-a-base plane read (no_kmer_flags), the slot list streamed, one line of bases per position followed, the
+        # probes of the followed positions and of the runs (32 positions of every 250: one line of bases per run)
+        followed = stats.get("scan_followed", 0)
+        runs = n_pos // 250
+        out["ref_flags"] = (ref_bases + ref_bases // 8 + 6 * n_pos + (followed + probes + runs) * LINE,
+                            f"flag bytes preset {ref_bases} + not-a-base plane {ref_bases // 8} + slot list 6 B x {n_pos} positions + {followed} positions followed "
+                            f"({followed / max(1, n_pos):.3f} of them) x {LINE} B of bases + {probes} table probes x {LINE} B ({probes / max(1, n_pos):.3f} per position) "
+                            f"+ {runs} runs x {LINE} B of bases")
+    elif scan_form == "slot-first":
         # the slot list streamed (6 B per position with a k-mer), one line of hashes / bases per position followed, their probes, the
         # flags cleared and the trio positions written (counted with the clearing)
         followed = stats.get("scan_followed", 0)
@@ -168,7 +177,8 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     vform = vote_form_of(vote, stats or {})
     need = needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats or {}, partitioned, scan["form"], vform) if stats is not None else {}
     kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
-    scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio", "slot-first": "ref_flags_slots"}.get(scan["form"], "ref_flags")
+    scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio", "slot-first": "ref_flags_slots",
+                   "slot-single": "no_kmer_flags+ref_single_slots+ref_trio_runs"}.get(scan["form"], "ref_flags")
     vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
     info = {
         "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
@@ -176,7 +186,9 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
                     model_pairs, 3 * n_chunks if partitioned else n_batches, HBM_CEILING, "lds_random" if partitioned else "hbm_lines"),
         "ref_flags": (scan_kernel, {"single-first": "phase B on a nearly saturated table: one probe per base until a hash reads 3, all e at every 8th base",
                                     "trio-first": "phase B on a sparse table: probes per base until a hash does not read 3",
-                                    "slot-first": "phase B on a sparse table, the first probe of every position answered from the slot list of the resident reference"}.get(
+                                    "slot-first": "phase B on a sparse table, the first probe of every position answered from the slot list of the resident reference",
+                                    "slot-single": "phase B on a nearly saturated table: `single` of every position from the slot list of the resident reference (positions whose "
+                                                   "smallest hash's slot reads 3 are not touched), the trio lower bound from runs of 32 positions"}.get(
                                         scan["form"], "phase B: e random 2-bit table probes per reference base") + "; 1 launch per step",
                       model_ref, 1, HBM_CEILING, "hbm_lines"),
         "vote_kernel": (vote_kernel, f"phase C read re-scan, {2 * (L - k + 1) * e} probes per pair "

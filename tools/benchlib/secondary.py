@@ -21,6 +21,11 @@ def run_all(detail, eng, args, wl, local, emit):
     packed = args.ref_form == "packed"
 
     def L_(engine, pairs, **kw):
+        # packed form: every leg is "a context that scans sample after sample of this kind" -- whatever slot list the leg before built is
+        # dropped, and the engine's own rule builds the one this leg's table wants before its second scan (the warm-up step of leg())
+        if kw.get("packed", packed) and not args.no_slot_list:
+            engine.slot_list(0)
+            engine.slot_list(1)
         return leg(engine, wl.out_path, k, e, pairs, kw.pop("n_contigs", nc), cl, packed=kw.pop("packed", packed), **kw)
 
     try:
@@ -31,6 +36,13 @@ def run_all(detail, eng, args, wl, local, emit):
             eng.synth_pairs(1, 2, nc, cl, 0, args.pairs, L)
             out["uhgg_deep_focused_sample"] = dict(L_(eng, args.pairs, sample_contigs=300),
                                                    workload="13000x1000000 bp ref, 100 M pairs drawn from 300 of its contigs (100x), sample=1")
+            if packed and not args.no_slot_list:       # the same sample with phase B's position-ordered kernel (debug bit 25: the slot list is left unused)
+                eng.set_debug(1 << 25)
+                d0 = leg(eng, wl.out_path, k, e, args.pairs, nc, cl, packed=True, sample_contigs=300, steps=2, want_stats=False)
+                eng.set_debug(0)
+                out["uhgg_deep_focused_sample"]["position_ordered_kernel"] = {"value": d0["value"], "ms_per_step": d0["ms_per_step"], "phase_ms": d0["phase_ms"],
+                                                                              "scan_B_form": d0["scan_B_form"]["form"],
+                                                                              "same_peaks": (d0["raw_peaks"], d0["filtered_peaks"]) == (out["uhgg_deep_focused_sample"]["raw_peaks"], out["uhgg_deep_focused_sample"]["filtered_peaks"])}
             eng.pairs_clear()
             emit("found")
             # READ LENGTH (round 5).  The fast forms of phases A and C take reads of up to 159 bases (128 k-mer offsets);
@@ -71,6 +83,15 @@ def run_all(detail, eng, args, wl, local, emit):
                      input_pairs=args.pairs, input_pairs_per_s_M=round(args.pairs / (d["ms_per_step"] * 1e-3) / 1e6, 1))
             out["uhgg_default_sample"] = d
             eng.pairs_clear()
+            # ... and on a realistic sample: the same 6.67 M pairs drawn from the 300 genomes (a 100 M-pair sample of them under --sample 2000000000)
+            eng.synth_options(0, 20, 300)
+            eng.synth_pairs(1, 2, nc, cl, 0, kept, L)
+            eng.synth_options(0, 20, 0)
+            d = L_(eng, kept, sample_contigs=300)
+            d.update(workload=f"the deep focused sample under the pipeline's default --sample 2000000000: {kept} of 100 M pairs kept", input_pairs=args.pairs,
+                     input_pairs_per_s_M=round(args.pairs / (d["ms_per_step"] * 1e-3) / 1e6, 1))
+            out["uhgg_default_sample_focused"] = d
+            eng.pairs_clear()
             emit("focused")
             # a RAGGED catalogue: the same 13 Gbase cut into ~118 k contigs (median 4.8 kb, a third shorter than one scan tile) -- what
             # UHGG looks like.  The k - 1 positions without a k-mer at every contig end are contrast peaks (E:931-932, 644-671), so
@@ -91,7 +112,29 @@ def run_all(detail, eng, args, wl, local, emit):
             out["uhgg_ragged_deep_focused"] = d
             eng.synth_options(0, 20, 0)
             eng.pairs_clear()
-            if not packed:
+            if packed:
+                # INDEX FORM: the headline of rounds 1-4 -- the index file's hashes resident (12 B per base: 156 GB, no room for a slot
+                # list), phase B's position-ordered kernels -- and the deep focused sample on it, for the comparison across rounds
+                eng.slot_list(0)
+                eng.set_reference_form(False)
+                eng.synth_reference(1, nc, cl)
+                index_bytes = eng.reference_info()["resident_bytes"]
+                eng.synth_pairs(1, 2, nc, cl, 0, args.pairs, L)
+                d = L_(eng, args.pairs, packed=False, steps=3)
+                d.update(workload="configs[2] with the index file's hashes resident (lhgt_set_reference_form(0), --ref-form index): rounds 1-4's headline",
+                         resident_index_bytes=index_bytes,
+                         same_peaks_as_headline=(d["raw_peaks"], d["filtered_peaks"]) == (detail["raw_peaks"], detail["filtered_peaks"]))
+                out["uhgg_index_form"] = d
+                eng.pairs_clear()
+                eng.synth_options(0, 20, 300)
+                eng.synth_pairs(1, 2, nc, cl, 0, args.pairs, L)
+                eng.synth_options(0, 20, 0)
+                d = L_(eng, args.pairs, packed=False, sample_contigs=300, steps=2)
+                d.update(workload="the deep focused sample with the index file's hashes resident: rounds 3-4's value_found")
+                out["uhgg_deep_focused_index_form"] = d
+                eng.pairs_clear()
+                emit("index form")
+            else:
                 # the headline workload with the reference resident as packed bases (3/8 byte per base instead of 12)
                 eng.synth_reference(1, nc, cl)
                 index_bytes = eng.reference_info()["resident_bytes"]
@@ -100,30 +143,10 @@ def run_all(detail, eng, args, wl, local, emit):
                 eng.synth_pairs(1, 2, nc, cl, 0, args.pairs, L)
                 d = L_(eng, args.pairs, packed=True, steps=2)
                 d.update(workload="configs[2] with the reference resident as packed bases (lhgt_set_reference_form(1), LHGT_REF_FORM=packed), hashes recomputed in phase B",
-                         resident_reference_bytes=eng.reference_info()["resident_bytes"], resident_index_bytes=index_bytes,
+                         resident_reference_bytes=eng.reference_info()["resident_bytes"], resident_index_bytes=index_bytes, slot_list=eng.slot_list(),
                          same_peaks_as_headline=(d["raw_peaks"], d["filtered_peaks"]) == (detail["raw_peaks"], detail["filtered_peaks"]))
                 out["uhgg_packed_reference"] = d
                 eng.pairs_clear()
-                # SLOT LIST (round 5): the packed reference leaves room for the list of its 13 G positions by hash bucket (78 GB), which a
-                # context builds before its second sparse-form scan of a resident reference; phase B of the sparse regimes then streams
-                # that list instead of probing the table once per position.  The deep focused sample and the CLI's default down-sampled
-                # regime on a realistic sample (6.67 M pairs from the 300 genomes), each with the trio-first kernel (debug bit 25) beside it
-                for name, n_pairs, what in (("uhgg_deep_focused", args.pairs, "100 M pairs drawn from 300 of its contigs (100x)"),
-                                            ("uhgg_default_sample_focused", int(2e9 / (2 * 150)), "6.67 M pairs drawn from 300 of its contigs: a 100 M-pair sample of them under the CLI's default --sample 2000000000")):
-                    eng.synth_options(0, 20, 300)
-                    eng.synth_pairs(1, 2, nc, cl, 0, n_pairs, L)
-                    eng.synth_options(0, 20, 0)
-                    eng.set_debug(1 << 25)
-                    d0 = L_(eng, n_pairs, packed=True, sample_contigs=300, steps=2)
-                    eng.set_debug(0)
-                    d = L_(eng, n_pairs, packed=True, sample_contigs=300, steps=3)
-                    d.update(workload=f"13000x1000000 bp ref resident as packed bases + its slot list, {what}, sample=1",
-                             slot_list=eng.slot_list(), trio_first_kernel={"value": d0["value"], "ms_per_step": d0["ms_per_step"], "phase_ms": d0["phase_ms"],
-                                                                            "scan_B_form": d0.get("scan_B_form")},
-                             same_peaks_as_trio_first=(d["raw_peaks"], d["filtered_peaks"]) == (d0["raw_peaks"], d0["filtered_peaks"]))
-                    out[name + "_slot_list"] = d
-                    eng.pairs_clear()
-                emit("slot list")
     except Exception as ex:
         out["uhgg_error"] = str(ex)[:200]
     eng.close()

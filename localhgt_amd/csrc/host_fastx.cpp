@@ -1,5 +1,8 @@
 // host_fastx.cpp -- FASTA / FASTQ ingest on the host (mmap + memchr), reference line semantics.
 #include "host_fastx.hpp"
+#include <sched.h>
+#include <cctype>
+#include <cstring>
 
 namespace lhgt {
 
@@ -859,6 +862,49 @@ extern "C" {
 
 using ShareFn = std::function<int(const lhgt::Mapped&, const lhgt::Mapped&, lhgt::ParseShare*, lhgt::ChunkPlan*, lhgt::ChunkPlan*)>;
 
+// The GPU boxes are two-socket hosts that give a container a CPU QUOTA, not a CPU set (profiles/r05/host_cpu_quota.txt: 16 CPUs' worth
+// of 256, affinity 0-255): the loader's threads float over both sockets, and with them the pinned slabs they first touch and the
+// side of the link their copies start from.  While a load runs, the calling thread -- and the workers it creates, which inherit its
+// mask -- keep to the CPUs of the NUMA node the GPU hangs on (sysfs: .../numa_node, local_cpulist of its PCI function).
+// LHGT_INGEST_NUMA=off: leave the mask alone; =other: the other node(s) (A/B).
+struct NodeAffinity {
+    cpu_set_t old;
+    bool on = false;
+    explicit NodeAffinity(int device) {
+        const std::string mode = getenv("LHGT_INGEST_NUMA") ? getenv("LHGT_INGEST_NUMA") : "gpu";
+        if (mode == "off" || mode == "0") return;
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return; }
+        for (char* c = bdf; *c; c++) *c = (char)tolower(*c);
+        char path[256];
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+        FILE* f = fopen(path, "r");
+        if (!f) return;
+        char list[4096] = {0};
+        const bool got = fgets(list, sizeof list, f) != nullptr;
+        fclose(f);
+        if (!got) return;
+        cpu_set_t want, cur;
+        CPU_ZERO(&want);
+        for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            const int n = sscanf(tok, "%d-%d", &a, &b);
+            if (n == 1) b = a;
+            if (n >= 1) for (int c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &want);
+        }
+        if (sched_getaffinity(0, sizeof cur, &cur) != 0) return;
+        cpu_set_t pick;
+        CPU_ZERO(&pick);
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &cur) && (CPU_ISSET(c, &want) != 0) == (mode != "other")) CPU_SET(c, &pick);
+        if (CPU_COUNT(&pick) < 4 || CPU_COUNT(&pick) == CPU_COUNT(&cur)) return;       // nothing to choose from, or nothing to choose
+        old = cur;
+        on = sched_setaffinity(0, sizeof pick, &pick) == 0;
+        if (on && ingest_trace()) fprintf(stderr, "[lhgt ingest] threads kept to %d CPUs %s the GPU's NUMA node (%s)\n", CPU_COUNT(&pick), mode == "other" ? "away from" : "of", bdf);
+    }
+    ~NodeAffinity() { if (on) sched_setaffinity(0, sizeof old, &old); }
+};
+
 static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, double ratio_percent, int shard_rank,
                            int shard_world, long shard_block, long* n_pairs_seen, long* n_pairs_kept, const ShareFn& share_fn) {
     LHGT_DEVICE_ENTRY(ctx);
@@ -868,6 +914,7 @@ static int load_fastq_impl(lhgt_ctx* ctx, const char* fq1, const char* fq2, doub
     lhgt::sampling_join(ctx);
     if (ratio_percent < 100.0 && (long)ctx->random_array.size() != LHGT_MAX_RANDOM)
         LHGT_FAIL(LHGT_E_STATE, "lhgt_sampling_init(ratio) must precede lhgt_pairs_load_fastq when ratio < 100");
+    NodeAffinity near_gpu(ctx->device);
     // a batch is closed at 4 Mi pairs (1 Mi with count-on-load, so that phase A of one batch hides behind the parsing of the next;
     // every batch costs phase A one sweep of the count table, which is why they are not smaller)
     // (round 5: with count-on-load the limits GROW -- 1, 2, 4 Mi pairs -- so that a small input still overlaps its count with its
@@ -1393,6 +1440,7 @@ int lhgt_fastq_thread_chunks(const char* fq, long size_for_chunks, int threads, 
 int lhgt_index_build(lhgt_ctx* ctx, const char* fasta_path, const char* index_path, const char* genome_len_path,
                      long* n_contigs, long* n_bases) {
     LHGT_DEVICE_ENTRY(ctx);
+    NodeAffinity near_gpu(ctx ? ctx->device : 0);   // the upload's host threads and staging next to the GPU (see NodeAffinity)
     if (!ctx || !fasta_path || !index_path || !genome_len_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: call lhgt_coder_generate or lhgt_coder_set first");
     FILE* idx = fopen(index_path, "wb");
@@ -1487,6 +1535,7 @@ int lhgt_index_read_coder(lhgt_ctx* ctx, const char* index_path) {
 // (3/8 byte per base instead of 4e) and phase B recomputes the hashes.  genome_len_path (nullable): also write genome.len.txt.
 int lhgt_reference_load_fasta(lhgt_ctx* ctx, const char* fasta_path, const char* genome_len_path, long* n_contigs, long* n_bases) {
     LHGT_DEVICE_ENTRY(ctx);
+    NodeAffinity near_gpu(ctx ? ctx->device : 0);   // the upload's host threads and staging next to the GPU (see NodeAffinity)
     if (!ctx || !fasta_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     if (!ctx->have_coder) LHGT_FAIL(LHGT_E_STATE, "no coder: call lhgt_coder_generate, lhgt_coder_set or lhgt_index_read_coder first");
     const int k = ctx->k;
@@ -1553,6 +1602,7 @@ int lhgt_fasta_scan(const char* fasta_path, int k, const char* genome_len_path, 
 
 int lhgt_index_load_shard(lhgt_ctx* ctx, const char* index_path, int shard_rank, int shard_world, long* n_contigs, long* n_bases) {
     LHGT_DEVICE_ENTRY(ctx);
+    NodeAffinity near_gpu(ctx ? ctx->device : 0);   // the upload's host threads and staging next to the GPU (see NodeAffinity)
     if (!ctx || !index_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
     Mapped m;
     LHGT_TRY(m.open(index_path));

@@ -56,7 +56,7 @@ if os.environ.get("E2E_KNOBS"):      # "name=VAR:val,VAR:val;name2=..." environm
     for spec in os.environ["E2E_KNOBS"].split(";"):
         name, _, kv = spec.partition("=")
         sets = dict(x.split(":") for x in kv.split(",") if x)
-        for kk in ("LHGT_INGEST_THREADS", "LHGT_MMAP_ADVICE", "LHGT_MMAP_POPULATE", "LHGT_INGEST_CHUNK_BYTES", "LHGT_ONE_COPY_STREAM", "LHGT_INGEST_STREAM", "LHGT_INGEST_IO"):
+        for kk in ("LHGT_INGEST_THREADS", "LHGT_MMAP_ADVICE", "LHGT_MMAP_POPULATE", "LHGT_INGEST_CHUNK_BYTES", "LHGT_ONE_COPY_STREAM", "LHGT_INGEST_STREAM", "LHGT_INGEST_IO", "LHGT_INGEST_NUMA"):
             os.environ.pop(kk, None)
         os.environ.update(sets)
         for i in range(2):

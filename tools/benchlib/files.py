@@ -48,6 +48,40 @@ def synth_files(tmp, k, e, n_contigs, contig_len, n_pairs, device, seed_ref=1, s
     return fa, f1, f2
 
 
+class near_gpu:
+    """while the input files are written: this process on the CPUs of the GPU's NUMA node, so that their pages land in that node's page
+    cache -- the container has a CPU quota, not a CPU set, and where a file's pages sit decides a good part of the from-files rate
+    (Which socket).  Does nothing where the node cannot be found."""
+
+    def __init__(self, device=0, away=False):
+        self.device, self.old, self.away = device, None, away
+
+    def __enter__(self):
+        try:
+            if self.device < 0:
+                return self
+            import torch
+            pr = torch.cuda.get_device_properties(self.device)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cpus = set()
+            for tok in open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip().split(","):
+                a, _, b = tok.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            cur = os.sched_getaffinity(0)
+            pick = cur - cpus if self.away else cur & cpus
+            if len(pick) >= 4 and pick != cur:
+                os.sched_setaffinity(0, pick)
+                self.old = cur
+        except Exception:
+            pass
+        return self
+
+    def __exit__(self, *exc):
+        if self.old:
+            os.sched_setaffinity(0, self.old)
+        return False
+
+
 def synth_files_sliced(tmp, k, e, n_contigs, contig_len, n_pairs, device, slice_pairs=4_000_000):
     """like synth_files for inputs of tens of GB: the pairs generated and written slice by slice"""
     from localhgt_amd.engine import Engine

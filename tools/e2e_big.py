@@ -19,6 +19,12 @@ os.system("free -g | head -2; df -h /tmp | tail -1; nproc")
 tmp = tempfile.mkdtemp(prefix="lhgt_e2e_", dir="/tmp")
 fa, f1, f2 = (os.path.join(tmp, x) for x in ("ref.fa", "s.1.fq", "s.2.fq"))
 t0 = time.time()
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from benchlib.files import near_gpu
+# E2E_FILES=far|anywhere: write the files from the OTHER socket / wherever the scheduler puts this process (default: the GPU's socket)
+_where = os.environ.get("E2E_FILES", "near")
+_ctx = near_gpu(0) if _where == "near" else near_gpu(0, away=True) if _where == "far" else near_gpu(-1)
+_ctx.__enter__()
 with Engine(K, E) as eng:
     eng.rng_seed(1); eng.coder_generate()
     ref = eng.synth_reference(1, n_contigs, CL, want_host=True)
@@ -36,7 +42,8 @@ with Engine(K, E) as eng:
             with open(path, "ab") as dst, open(part, "rb") as src:
                 shutil.copyfileobj(src, dst, 1 << 24)
             os.remove(part)
-print(f"inputs written in {time.time() - t0:.0f} s: fasta {os.path.getsize(fa) / 1e6:.0f} MB, fastq 2 x {os.path.getsize(f1) / 1e9:.2f} GB", flush=True)
+_ctx.__exit__(None, None, None)
+print(f"inputs written in {time.time() - t0:.0f} s ({_where} the GPU's NUMA node): fasta {os.path.getsize(fa) / 1e6:.0f} MB, fastq 2 x {os.path.getsize(f1) / 1e9:.2f} GB", flush=True)
 
 
 def run(tag, threads, **kw):

@@ -1289,11 +1289,12 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
 // sums.  Here the flags are preset to "single" (0x01), and three small kernels take back what is not:
 //   no_kmer_flags      positions without a k-mer -- a not-a-base inside the window, the last k - 1 of a contig -- get 0x80 (exact zeros);
 //   ref_single_slots   the list, kept under every position's SMALLEST hash: an entry whose slot reads 3 is done without being touched;
-//                      the others (a few per cent) are followed to their other hashes, and only a position none of whose hashes
-//                      reads 3 is written (0x80);
+//                      the others (a few per mille) are followed to their other hashes and written exactly: 0x80 when none reads 3,
+//                      0x81 (single, not trio) otherwise;
 //   ref_trio_runs      the lower bound: 32 consecutive positions of every 250 (64 of any 500-position window, as many as every 8th
-//                      position gave; consecutive ones share their lines of bases) are probed largest hash first until one does not
-//                      read 3, and those whose e hashes all do are written 0x83.
+//                      position gave; consecutive ones share their lines of bases).  A position not yet marked exact has a smallest
+//                      hash that reads 3 -- the sweep just said so -- so only its other hashes are probed, largest first, until one
+//                      does not read 3; those whose e hashes all do are written 0x83.
 // window_lite, the fill of the tiles it cannot settle and window_good follow as in the single-first form (the probe-state bytes of
 // those tiles cleared first: nothing is known of them).  Same peaks, ids and votes; e <= 3, packed form only (which positions hold
 // no k-mer is read off the not-a-base plane; the index form would have to stream its 12 bytes per base for it).
@@ -1391,7 +1392,9 @@ __global__ void __launch_bounds__(ST) ref_single_slots(const unsigned long long*
                 probes++;
                 none[u] = ((c2[u] >> ((h2[u] & 15u) * 2u)) & 3u) != 3u;
             }
-            if (none[u]) flags[x[u]] = 0x80;                    // no hash of the position reads 3: exact zeros
+            // exact either way (bit 7): no hash reads 3 -> zeros; another one does -> single, and NOT trio -- which also tells ref_trio_runs
+            // that this position's listed hash does not read 3 (it takes every position without the bit for one whose listed hash does)
+            if (on[u]) flags[x[u]] = none[u] ? 0x80 : 0x81;
         }
     };
     uint32_t head = 0;
@@ -1455,19 +1458,22 @@ __global__ void __launch_bounds__(BT) ref_trio_runs(const TileDev* __restrict__ 
     const long nk = (long)c.len - k + 1;
     const long j = (long)t.j0 + (threadIdx.x >> 5) * RUN_PERIOD + (threadIdx.x & 31);
     unsigned long long probes = 0;
-    if (j < nk) {
+    // ref_single_slots has run: a position whose listed hash -- its smallest -- does not read 3 carries the exact bit by now (0x80 /
+    // 0x81: not trio), and so does one without a k-mer; every other position's smallest hash READS 3 and need not be asked again:
+    // largest hash first (the likeliest "not 3"), then the middle one -- 1.9 probes per position of a run where all three took 2.9
+    if (j < nk && !(flags[c.flat_base + j] & 0x80)) {
         const RefKmer km = ref_kmer(rs, c, j, k, e);
         uint32_t h[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) h[i] = i < e ? ref_hash(rs, km, i) : 0u;
-        const ProbeOrder po = probe_order(h, e);                  // largest hash first: the likeliest "not 3"
-        bool all3 = true;
+        const ProbeOrder po = probe_order(h, e);
+        bool all3 = h[0] != 0u && (e < 2 || h[1] != 0u) && (e < 3 || h[2] != 0u);   // a hash that is none never reads 3 (and the listed one is the smallest that is one)
 #pragma unroll
-        for (int q = 0; q < 3; q++)
-            if (q < e && all3) {
-                const uint32_t hv = pick3(h, q == 0 ? po.hi : q == 1 ? (e == 2 ? po.lo : po.mid) : po.lo);
-                if (hv != 0) probes++;
-                all3 = hv != 0 && count_of(counts, hv) == 3u;
+        for (int q = 0; q < 2; q++)
+            if (q < e - 1 && all3) {
+                const uint32_t hv = pick3(h, q == 0 ? po.hi : po.mid);
+                probes++;
+                all3 = count_of(counts, hv) == 3u;
             }
         if (all3) flags[c.flat_base + j] = 0x83;                  // single, trio, exact
     }

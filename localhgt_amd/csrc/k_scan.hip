@@ -1125,8 +1125,9 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
 // them against the counters in LDS and appends those whose slot reads 3 to a ring in LDS; whenever the ring holds 4 ST of them every
 // thread follows FOUR at once -- their four lines of hashes / bases are requested together, then their four probes -- so the
 // dependent chain of a survivor runs with all lanes busy and four requests per lane in flight (a wave that followed 64 survivors one
-// per lane, between two loads of its stream, reached 33 G lines/s of the fabric's 56; waves with rings of their own, no barrier: 38).
-template <bool PACKED, int ST>
+// per lane, between two loads of its stream, reached 33 G lines/s of the fabric's 56; waves with rings of their own, no barrier: 38;
+// U = 8 at a time and 512 or 1024 threads: the same time to a tenth of a millisecond -- what is left is not latency).
+template <bool PACKED, int ST, int U>
 __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
                                                       const uint16_t* __restrict__ hi, const RefSource rs, const ContigDev* __restrict__ contigs,
                                                       int n_contigs, const uint32_t* __restrict__ counts, int slice_words, int k, int e,
@@ -1134,7 +1135,7 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
                                                       unsigned long long* __restrict__ stats /* nullable: [0] probes of the table, [1] positions followed */, long n_buckets,
                                                       int ablate /* timing only (debug bit 26, LHGT_SLOTS_ABLATE): 1 no survivor is followed, 2 none probes the table */) {
     __shared__ uint32_t slice[SL_SLOTS / 16];
-    constexpr int SL_CHUNK = 4 * ST, SL_RING = 2 * SL_CHUNK;
+    constexpr int SL_CHUNK = U * ST, SL_RING = 2 * SL_CHUNK;
     __shared__ uint32_t ring_lo[SL_RING];
     __shared__ uint8_t ring_hi[SL_RING];
     __shared__ uint32_t s_tail;
@@ -1157,10 +1158,10 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
         if (ablate == 1) return;
         const uint32_t first = from & (SL_RING - 1);
         const uint64_t x_first = (uint64_t)ring_lo[first] | ((uint64_t)ring_hi[first] << 32);   // n >= 1: a listed position, safe to read for idle lanes
-        uint64_t x[4];
-        bool on[4];
+        uint64_t x[U];
+        bool on[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const uint32_t idx = threadIdx.x + (uint32_t)u * ST, at = (from + idx) & (SL_RING - 1);
             on[u] = idx < n;
             x[u] = on[u] ? (uint64_t)ring_lo[at] | ((uint64_t)ring_hi[at] << 32) : x_first;
@@ -1168,31 +1169,31 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
         // the four lines first, all requested before any is looked at: a k-mer's 2 x 2 interleaved words of bases (packed form)
         // or its e stored hashes (index form); then the hashes, the listed one (the largest) aside -- it reads 3 --
         // and the others sorted, the larger one first
-        uint32_t w[4][4];
+        uint32_t w[U][4];
         if (PACKED) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
                 const uint32_t* p = rs.planes + 2 * (x[u] >> 5);   // [hi, lo] of word x >> 5, [hi, lo] of the next: 16 bytes, one load (a listed position holds a k-mer: no look at the not-a-base plane)
 #pragma unroll
                 for (int q = 0; q < 4; q++) w[u][q] = p[q];
             }
         } else {
-            const uint32_t* p[4];
+            const uint32_t* p[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
                 int a = 0, z = n_contigs;                       // last contig with flat_base <= x
                 while (z - a > 1) { const int mid = (a + z) >> 1; if (contigs[mid].flat_base <= x[u]) a = mid; else z = mid; }
                 const ContigDev c = contigs[a];
                 p[u] = rs.index + c.hash_word + (x[u] - c.flat_base) * (uint64_t)e;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int q = 0; q < 3; q++) w[u][q] = p[u][q < e ? q : e - 1];
         }
-        uint32_t h1[4], h2[4], c1[4];
+        uint32_t h1[U], h2[U], c1[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             uint32_t a0, a1, a2;
             if (PACKED) {
                 const int r = (int)(x[u] & 31);
@@ -1214,19 +1215,19 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
         // the four first probes together, then the four second ones: a lane with nothing to ask reads word 0 (a line every
         // wave shares -- a cache hit, not a line fill; the branches the compiler made of "only if" probes waited one by one)
 #pragma unroll
-        for (int u = 0; u < 4; u++) c1[u] = counts[e > 1 && on[u] && ablate != 2 ? h1[u] >> 4 : 0u];
-        bool all3[4];
-        uint32_t c2[4];
+        for (int u = 0; u < U; u++) c1[u] = counts[e > 1 && on[u] && ablate != 2 ? h1[u] >> 4 : 0u];
+        bool all3[U];
+        uint32_t c2[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             all3[u] = on[u] && (e < 2 || (h1[u] != 0u && ((c1[u] >> ((h1[u] & 15u) * 2u)) & 3u) == 3u));
             if (on[u]) followed++;
             if (on[u] && e > 1) probes++;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) c2[u] = counts[e > 2 && all3[u] && ablate != 2 ? h2[u] >> 4 : 0u];
+        for (int u = 0; u < U; u++) c2[u] = counts[e > 2 && all3[u] && ablate != 2 ? h2[u] >> 4 : 0u];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             if (e > 2 && all3[u]) {
                 probes++;
                 all3[u] = h2[u] != 0u && ((c2[u] >> ((h2[u] & 15u) * 2u)) & 3u) == 3u;
@@ -1236,29 +1237,31 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
     };
     uint32_t head = 0;
     for (unsigned long long c0 = begin; c0 < end; c0 += SL_CHUNK) {
-        uint32_t lo4[4], hi4[4];
+        uint32_t lo4[U], hi4[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const unsigned long long i = c0 + threadIdx.x + (unsigned long long)u * ST;
             const bool ok = i < end;
             lo4[u] = ok ? lo[i] : 0u;
             hi4[u] = ok ? (uint32_t)hi[i] : 0x10000u;           // bit 16: no entry
         }
-        unsigned long long m[4];
+        unsigned long long m[U];
         uint32_t mine = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const uint32_t sl = hi4[u] & (SL_SLOTS - 1u);
             const bool pass = !(hi4[u] & 0x10000u) && ((slice[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) == 3u;
             m[u] = __ballot(pass);
             mine |= pass ? 1u << u : 0u;
         }
-        const uint32_t total = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+        uint32_t total = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) total += (uint32_t)__popcll(m[u]);
         uint32_t base = 0;
         if (lane == 0 && total) base = atomicAdd(&s_tail, total);
         base = (uint32_t)__shfl((int)base, 0, 64);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             if ((mine >> u) & 1u) {
                 const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u))) & (SL_RING - 1);
                 ring_lo[at] = lo4[u];
@@ -1676,10 +1679,10 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
         const int ablate = (ctx->debug & (1 << 26)) && getenv("LHGT_SLOTS_ABLATE") ? atoi(getenv("LHGT_SLOTS_ABLATE")) : 0;
         if (ctx->ref_packed)
-            hipLaunchKernelGGL((ref_flags_slots<true, BT>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+            hipLaunchKernelGGL((ref_flags_slots<true, BT, 4>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
                                ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
         else
-            hipLaunchKernelGGL((ref_flags_slots<false, BT>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+            hipLaunchKernelGGL((ref_flags_slots<false, BT, 4>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
                                ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
     } else if (sparse_form) {

@@ -237,6 +237,8 @@ def main():
     verify, stats = None, None
     if world == 1 and not args.debug and not args.force_dist and not args.no_stats:
         stats = wl.stats_step()                              # untimed: the run's own key and probe counts (needed-bytes model)
+        if args.ref_form == "packed" and eng.slot_list()["bytes"]:
+            stats["slot_list_bytes"] = eng.slot_list()["bytes"]
         if not args.no_verify:
             verify = verify_forms(eng)
     dt, per_ms, n_peaks, nf = wl.run(args.steps, args.warmup)

@@ -1101,7 +1101,7 @@ __global__ void __launch_bounds__(1024) slot_list_offsets(uint32_t* __restrict__
 }
 __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
                                                      int k, int e, int smallest, const unsigned long long* __restrict__ off, uint32_t* __restrict__ cur,
-                                                     uint32_t* __restrict__ lo, uint16_t* __restrict__ hi, long n_blk) {
+                                                     uint32_t* __restrict__ lo, uint16_t* __restrict__ hi, uint32_t* __restrict__ mid /* nullable */, long n_blk) {
     const long blk = block2d();
     if (blk >= n_blk) return;
     const TileDev t = tiles[blk];
@@ -1118,6 +1118,12 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
         const uint64_t x = c.flat_base + (uint64_t)j;
         lo[at] = (uint32_t)x;
         hi[at] = (uint16_t)((h & (SL_SLOTS - 1u)) | ((uint32_t)(x >> 32) << SL_BITS));
+        if (mid) {                                       // the second-largest of the e hashes (the listed one is the largest)
+            uint32_t a0 = ref_hash(rs, km, 0), a1 = e > 1 ? ref_hash(rs, km, 1) : 0u, a2 = e > 2 ? ref_hash(rs, km, 2) : 0u;
+            if (a1 > a0) { const uint32_t t = a0; a0 = a1; a1 = t; }
+            if (a2 > a0) { const uint32_t t = a0; a0 = a2; a2 = t; }
+            mid[at] = a2 > a1 ? a2 : a1;
+        }
     }
 }
 
@@ -1127,9 +1133,10 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
 // dependent chain of a survivor runs with all lanes busy and four requests per lane in flight (a wave that followed 64 survivors one
 // per lane, between two loads of its stream, reached 33 G lines/s of the fabric's 56; waves with rings of their own, no barrier: 38;
 // U = 8 at a time and 512 or 1024 threads: the same time to a tenth of a millisecond -- what is left is not latency).
-template <bool PACKED, int ST, int U>
+template <bool PACKED, int ST, int U, bool MID>
 __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
-                                                      const uint16_t* __restrict__ hi, const RefSource rs, const ContigDev* __restrict__ contigs,
+                                                      const uint16_t* __restrict__ hi, const uint32_t* __restrict__ mid /* MID: every entry's second-largest hash */,
+                                                      const RefSource rs, const ContigDev* __restrict__ contigs,
                                                       int n_contigs, const uint32_t* __restrict__ counts, int slice_words, int k, int e,
                                                       uint8_t* __restrict__ flags,
                                                       unsigned long long* __restrict__ stats /* nullable: [0] probes of the table, [1] positions followed */, long n_buckets,
@@ -1138,6 +1145,7 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
     constexpr int SL_CHUNK = U * ST, SL_RING = 2 * SL_CHUNK;
     __shared__ uint32_t ring_lo[SL_RING];
     __shared__ uint8_t ring_hi[SL_RING];
+    __shared__ uint32_t ring_mid[MID ? SL_RING : 1];
     __shared__ uint32_t s_tail;
     const long b = block2d();
     if (b >= n_buckets) return;
@@ -1159,71 +1167,97 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
         const uint32_t first = from & (SL_RING - 1);
         const uint64_t x_first = (uint64_t)ring_lo[first] | ((uint64_t)ring_hi[first] << 32);   // n >= 1: a listed position, safe to read for idle lanes
         uint64_t x[U];
-        bool on[U];
+        bool on[U], all3[U];
+        uint32_t hm[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t idx = threadIdx.x + (uint32_t)u * ST, at = (from + idx) & (SL_RING - 1);
             on[u] = idx < n;
             x[u] = on[u] ? (uint64_t)ring_lo[at] | ((uint64_t)ring_hi[at] << 32) : x_first;
+            hm[u] = MID && on[u] ? ring_mid[at] : 0u;
+            all3[u] = on[u];
+            if (on[u]) followed++;
         }
-        // the four lines first, all requested before any is looked at: a k-mer's 2 x 2 interleaved words of bases (packed form)
-        // or its e stored hashes (index form); then the hashes, the listed one (the largest) aside -- it reads 3 --
-        // and the others sorted, the larger one first
-        uint32_t w[U][4];
-        if (PACKED) {
+        if (MID) {
+            // the entry brought the position's second-largest hash along: its probe first -- four at once, no look at the reference --
+            // and only the third of the positions that pass it (or all, at e = 2: they are trio) go on to their line of bases / hashes
+            uint32_t cm[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) cm[u] = counts[on[u] && hm[u] != 0u && e > 1 && ablate != 2 ? hm[u] >> 4 : 0u];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t* p = rs.planes + 2 * (x[u] >> 5);   // [hi, lo] of word x >> 5, [hi, lo] of the next: 16 bytes, one load (a listed position holds a k-mer: no look at the not-a-base plane)
+                if (on[u] && e > 1) {
+                    probes++;
+                    all3[u] = hm[u] != 0u && ((cm[u] >> ((hm[u] & 15u) * 2u)) & 3u) == 3u;
+                }
+            }
+        }
+        // the four lines, all requested before any is looked at: a k-mer's 2 x 2 interleaved words of bases (packed form) or its e
+        // stored hashes (index form); a lane with nothing to ask reads the first survivor's line (one line for all of them: a cache hit)
+        const bool need_ref = MID ? e > 2 : e > 1;
+        uint32_t h1[U], h2[U];
+        if (need_ref) {
+            uint32_t w[U][4];
+            if (PACKED) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) w[u][q] = p[q];
+                for (int u = 0; u < U; u++) {
+                    const uint32_t* p = rs.planes + 2 * ((all3[u] ? x[u] : x_first) >> 5);   // [hi, lo] of word x >> 5, [hi, lo] of the next: 16 bytes, one load (a listed position holds a k-mer: no look at the not-a-base plane)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w[u][q] = p[q];
+                }
+            } else {
+                const uint32_t* p[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint64_t xx = all3[u] ? x[u] : x_first;
+                    int a = 0, z = n_contigs;                   // last contig with flat_base <= x
+                    while (z - a > 1) { const int md = (a + z) >> 1; if (contigs[md].flat_base <= xx) a = md; else z = md; }
+                    const ContigDev c = contigs[a];
+                    p[u] = rs.index + c.hash_word + (xx - c.flat_base) * (uint64_t)e;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) w[u][q] = p[u][q < e ? q : e - 1];
+            }
+            // the hashes, the listed one (the largest) aside -- it reads 3 --, the others sorted, the larger one first
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                uint32_t a0, a1, a2;
+                if (PACKED) {
+                    const int r = (int)((all3[u] ? x[u] : x_first) & 31);
+                    const uint32_t whi = window32(w[u][0], w[u][2], r) >> (32 - k), wlo = window32(w[u][1], w[u][3], r) >> (32 - k);
+                    const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
+                    a0 = hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[0]);
+                    a1 = e > 1 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[1]) : 0u;
+                    a2 = e > 2 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[2]) : 0u;
+                } else {
+                    a0 = w[u][0];
+                    a1 = e > 1 ? w[u][1] : 0u;
+                    a2 = e > 2 ? w[u][2] : 0u;
+                }
+                if (a1 > a0) { const uint32_t t = a0; a0 = a1; a1 = t; }
+                if (a2 > a0) { const uint32_t t = a0; a0 = a2; a2 = t; }
+                if (a2 > a1) { const uint32_t t = a1; a1 = a2; a2 = t; }
+                h1[u] = a1; h2[u] = a2;
             }
         } else {
-            const uint32_t* p[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) h1[u] = h2[u] = 0u;
+        }
+        // the probes that are left, four at once each time: a lane with nothing to ask reads word 0 (a line every wave shares -- a
+        // cache hit, not a line fill; the branches the compiler made of "only if" probes waited one by one)
+        if (!MID) {
+            uint32_t c1[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) c1[u] = counts[e > 1 && on[u] && ablate != 2 ? h1[u] >> 4 : 0u];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                int a = 0, z = n_contigs;                       // last contig with flat_base <= x
-                while (z - a > 1) { const int mid = (a + z) >> 1; if (contigs[mid].flat_base <= x[u]) a = mid; else z = mid; }
-                const ContigDev c = contigs[a];
-                p[u] = rs.index + c.hash_word + (x[u] - c.flat_base) * (uint64_t)e;
+                all3[u] = on[u] && (e < 2 || (h1[u] != 0u && ((c1[u] >> ((h1[u] & 15u) * 2u)) & 3u) == 3u));
+                if (on[u] && e > 1) probes++;
             }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) w[u][q] = p[u][q < e ? q : e - 1];
         }
-        uint32_t h1[U], h2[U], c1[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t a0, a1, a2;
-            if (PACKED) {
-                const int r = (int)(x[u] & 31);
-                const uint32_t whi = window32(w[u][0], w[u][2], r) >> (32 - k), wlo = window32(w[u][1], w[u][3], r) >> (32 - k);
-                const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
-                a0 = hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[0]);
-                a1 = e > 1 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[1]) : 0u;
-                a2 = e > 2 ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[2]) : 0u;
-            } else {
-                a0 = w[u][0];
-                a1 = e > 1 ? w[u][1] : 0u;
-                a2 = e > 2 ? w[u][2] : 0u;
-            }
-            if (a1 > a0) { const uint32_t t = a0; a0 = a1; a1 = t; }
-            if (a2 > a0) { const uint32_t t = a0; a0 = a2; a2 = t; }
-            if (a2 > a1) { const uint32_t t = a1; a1 = a2; a2 = t; }
-            h1[u] = a1; h2[u] = a2;
-        }
-        // the four first probes together, then the four second ones: a lane with nothing to ask reads word 0 (a line every
-        // wave shares -- a cache hit, not a line fill; the branches the compiler made of "only if" probes waited one by one)
-#pragma unroll
-        for (int u = 0; u < U; u++) c1[u] = counts[e > 1 && on[u] && ablate != 2 ? h1[u] >> 4 : 0u];
-        bool all3[U];
         uint32_t c2[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            all3[u] = on[u] && (e < 2 || (h1[u] != 0u && ((c1[u] >> ((h1[u] & 15u) * 2u)) & 3u) == 3u));
-            if (on[u]) followed++;
-            if (on[u] && e > 1) probes++;
-        }
 #pragma unroll
         for (int u = 0; u < U; u++) c2[u] = counts[e > 2 && all3[u] && ablate != 2 ? h2[u] >> 4 : 0u];
 #pragma unroll
@@ -1237,13 +1271,14 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
     };
     uint32_t head = 0;
     for (unsigned long long c0 = begin; c0 < end; c0 += SL_CHUNK) {
-        uint32_t lo4[U], hi4[U];
+        uint32_t lo4[U], hi4[U], mid4[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const unsigned long long i = c0 + threadIdx.x + (unsigned long long)u * ST;
             const bool ok = i < end;
             lo4[u] = ok ? lo[i] : 0u;
             hi4[u] = ok ? (uint32_t)hi[i] : 0x10000u;           // bit 16: no entry
+            mid4[u] = MID && ok ? mid[i] : 0u;
         }
         unsigned long long m[U];
         uint32_t mine = 0;
@@ -1266,6 +1301,7 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
                 const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u))) & (SL_RING - 1);
                 ring_lo[at] = lo4[u];
                 ring_hi[at] = (uint8_t)(hi4[u] >> SL_BITS);
+                if (MID) ring_mid[at] = mid4[u];
             }
             base += (uint32_t)__popcll(m[u]);
         }
@@ -1513,8 +1549,8 @@ static RefSource ref_source(const lhgt_ctx* ctx) {
 // it would leave less than LHGT_SLOT_LIST_HEADROOM_GB (default 40) of the device's memory free.
 namespace lhgt {
 void slot_list_drop(lhgt_ctx* ctx) {
-    for (void* p : {(void*)ctx->d_sl_lo, (void*)ctx->d_sl_hi, (void*)ctx->d_sl_off}) if (p) lhgt::dev_free(p);
-    ctx->d_sl_lo = nullptr; ctx->d_sl_hi = nullptr; ctx->d_sl_off = nullptr;
+    for (void* p : {(void*)ctx->d_sl_lo, (void*)ctx->d_sl_hi, (void*)ctx->d_sl_off, (void*)ctx->d_sl_mid}) if (p) (void)lhgt::dev_free(p);
+    ctx->d_sl_lo = nullptr; ctx->d_sl_hi = nullptr; ctx->d_sl_off = nullptr; ctx->d_sl_mid = nullptr;
     ctx->sl_entries = 0; ctx->sl_buckets = 0; ctx->sl_state = 0; ctx->sl_sparse_scans = 0; ctx->sl_need_share = 0.0;
 }
 }  // namespace lhgt
@@ -1558,8 +1594,18 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
         if (trace) fprintf(stderr, "[lhgt] slot list: no memory for %llu entries -- not built\n", n_entries);
         return LHGT_OK;
     }
+    // the sparse-table list (largest hash) takes every entry's second-largest hash along when there is room for it (4 more bytes per
+    // position: 130 GB in all for 13 Gbase; LHGT_SLOT_LIST_MID=0: never): the followed positions then ask the table before the reference
+    static const bool mid_ok = !(getenv("LHGT_SLOT_LIST_MID") && atoi(getenv("LHGT_SLOT_LIST_MID")) == 0);
+    if (!smallest && ctx->e >= 2 && mid_ok) {
+        size_t f2 = 0, t2 = 0;
+        LHGT_HIP(hipMemGetInfo(&f2, &t2));
+        if ((double)f2 - 4.0 * (double)n_entries >= headroom_gb * 1e9 || (double)f2 - 4.0 * (double)n_entries >= 0.25 * (double)f2) {
+            if (lhgt::dev_malloc(&ctx->d_sl_mid, (size_t)(n_entries + 64) * 4) != hipSuccess) { ctx->d_sl_mid = nullptr; (void)hipGetLastError(); }
+        }
+    }
     hipLaunchKernelGGL(slot_list_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, smallest ? 1 : 0, ctx->d_sl_off, d_hist,
-                       ctx->d_sl_lo, ctx->d_sl_hi, ctx->n_tiles);
+                       ctx->d_sl_lo, ctx->d_sl_hi, ctx->d_sl_mid, ctx->n_tiles);
     LHGT_HIP(hipGetLastError());
     LHGT_HIP(hipStreamSynchronize(ctx->stream));
     lhgt::dev_free(d_hist);
@@ -1568,7 +1614,7 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
     ctx->sl_state = 1;
     ctx->sl_smallest = smallest;
     ctx->sl_unlisted = unlisted;
-    if (trace) fprintf(stderr, "[lhgt] slot list (by the %s hash): %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", smallest ? "smallest" : "largest", n_entries, nb, 6.0 * (double)n_entries / 1e9, wall_s() - t0);
+    if (trace) fprintf(stderr, "[lhgt] slot list (by the %s hash%s): %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", smallest ? "smallest" : "largest", ctx->d_sl_mid ? ", with the second-largest" : "", n_entries, nb, (ctx->d_sl_mid ? 10.0 : 6.0) * (double)n_entries / 1e9, wall_s() - t0);
     return LHGT_OK;
 }
 
@@ -1678,12 +1724,13 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (st) LHGT_HIP(hipMemsetAsync(st, 0, 16, ctx->stream));
         const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
         const int ablate = (ctx->debug & (1 << 26)) && getenv("LHGT_SLOTS_ABLATE") ? atoi(getenv("LHGT_SLOTS_ABLATE")) : 0;
-        if (ctx->ref_packed)
-            hipLaunchKernelGGL((ref_flags_slots<true, BT, 4>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ctx->d_sl_mid, ref_source(ctx),
                                ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
-        else
-            hipLaunchKernelGGL((ref_flags_slots<false, BT, 4>), blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx),
-                               ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
+        };
+        if (ctx->ref_packed) { if (ctx->d_sl_mid) launch(ref_flags_slots<true, BT, 4, true>); else launch(ref_flags_slots<true, BT, 4, false>); }
+        else if (ctx->d_sl_mid) launch(ref_flags_slots<false, BT, 4, true>);
+        else launch(ref_flags_slots<false, BT, 4, false>);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));
     } else if (sparse_form) {
         hipLaunchKernelGGL(ref_flags_trio, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags,

@@ -160,6 +160,7 @@ struct lhgt_ctx {
     // the slot list of the resident reference: every position with a k-mer, grouped by the top bits of its hash 0
     uint32_t* d_sl_lo = nullptr;             // low 32 bits of the flat position
     uint16_t* d_sl_hi = nullptr;             // low 14 bits of the slot | position bits 32-33 << 14
+    uint32_t* d_sl_mid = nullptr;            // (list under the largest hash, when there is room) every entry's second-largest hash
     unsigned long long* d_sl_off = nullptr;  // [sl_buckets + 1]
     unsigned long long sl_entries = 0;
     long sl_buckets = 0;

@@ -113,6 +113,7 @@ def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_co
     dt, per_ms, n_peaks, nf = w.run(steps, 1)       # (round 5: always a warm-up step -- a context's second scan of a resident reference may build its slot list)
     if want_stats and engine.scan_info()["form"] in ("slot-first", "slot-single"):
         stats = w.stats_step()                      # the counts of the form the timed steps took, not of the first scan's
+        stats["slot_list_bytes"] = engine.slot_list()["bytes"]
     d = {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
          "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
          "scan_B_form": engine.scan_info(), "vote_form": engine.vote_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs,

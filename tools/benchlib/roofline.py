@@ -92,9 +92,12 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
         # the slot list streamed (6 B per position with a k-mer), one line of hashes / bases per position followed, their probes, the
         # flags cleared and the trio positions written (counted with the clearing)
         followed = stats.get("scan_followed", 0)
-        out["ref_flags"] = (6 * n_pos + (followed + probes) * LINE + ref_bases,
-                            f"slot list 6 B x {n_pos} positions + {followed} positions followed ({followed / max(1, n_pos):.3f} of them) x {LINE} B of "
-                            f"{'bases' if packed else 'stored hashes'} + {probes} table probes x {LINE} B + flag bytes cleared {ref_bases}")
+        list_b = stats.get("slot_list_bytes") or 6 * n_pos
+        with_mid = list_b > 8 * n_pos                       # the entries carry their second-largest hash: a followed position asks the table first,
+        ref_lines = max(0, probes - followed) if with_mid and e > 2 else followed     # and only those that pass (= the second probes) read the reference
+        out["ref_flags"] = (list_b + (ref_lines + probes) * LINE + ref_bases,
+                            f"slot list {list_b} B ({list_b / max(1, n_pos):.0f} B x {n_pos} positions) + {followed} positions followed ({followed / max(1, n_pos):.3f} of them), "
+                            f"{ref_lines} of them read {LINE} B of {'bases' if packed else 'stored hashes'} + {probes} table probes x {LINE} B + flag bytes cleared {ref_bases}")
     else:
         out["ref_flags"] = (probes * LINE + stream + 2 * ref_bases,
                             f"{probes} table probes x {LINE} B ({scan_form}: {probes / max(1, n_pos):.3f} per position) + "

@@ -246,6 +246,7 @@ def main():
     vote_form = eng.vote_info()
     xch_main = dict(wl.xch)
     moved_main = dict(dist.moved) if dist else None
+    sl_info = eng.slot_list() if args.ref_form == "packed" else {"entries": 0, "bytes": 0}      # of the form the timed steps ran on
     other_form = None
     if len(forms) > 1:                                   # the other form of phase B, a few steps, same reads
         if args.ref_form == "packed":
@@ -292,7 +293,6 @@ def main():
         print("bench: exchanges of rank 0 per step (" + dist.backend + "): " + "; ".join(
             f"{kk} {v['bytes_per_step'] / 1e6:.1f} MB in {xch_ms[kk]:.2f} ms" + (f" = {v['GB_per_s']} GB/s" if v["GB_per_s"] else "") for kk, v in xch_bytes.items()),
             file=sys.stderr, flush=True)
-    sl_info = eng.slot_list() if args.ref_form == "packed" else {"entries": 0, "bytes": 0}
     resident_txt = ("index resident" if args.ref_form != "packed" else
                     f"resident as packed bases + slot list = its k-mer positions by hash bucket, {(sl_info['bytes'] + ref_bases * 3 // 8) / 1e9:.0f} GB" if sl_info["entries"] else "packed bases resident")
     cfg_no = 2 if headline else 1 if workload_key(args) == (1000, 10_000_000, 0, False, 0) else "-"

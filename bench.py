@@ -227,7 +227,8 @@ def main():
     if args.ref_form == "packed":
         # the slot list of the resident reference (include/localhgt_hip.h: lhgt_slot_list): built before the first scan that has a
         # use for it -- untimed, like the reference load it belongs to -- instead of before the second (the engine's own rule)
-        eng.slot_list(2 if use_list and not forms[0] else 1 if use_list else 0)
+        big_ref = args.contigs * args.contig_len >= 1 << 32      # below that the engine's own rule leaves the list alone
+        eng.slot_list(2 if use_list and not forms[0] and big_ref else 1 if use_list else 0)
     eng.synth_options(args.snp, 20, args.sample_contigs)
     eng.synth_pairs(1, 2, args.contigs, args.contig_len, rank * args.pairs, args.pairs, L)   # this rank's shard, packed, resident
     eng.synchronize()
@@ -250,7 +251,7 @@ def main():
     other_form = None
     if len(forms) > 1:                                   # the other form of phase B, a few steps, same reads
         if args.ref_form == "packed":
-            eng.slot_list(2 if use_list and not forms[1] else 1 if use_list else 0)   # a shard of 1/N of the reference: the engine's own rule (lists from 2^32 positions on)
+            eng.slot_list(2 if use_list and not forms[1] and big_ref else 1 if use_list else 0)   # a shard of 1/N of the reference: the engine's own rule (lists from 2^32 positions on)
         load_reference(forms[1])
         wl2 = Workload(eng, dist, rank, world, forms[1], out_path)
         st2 = min(args.steps, 5)

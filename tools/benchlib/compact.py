@@ -21,6 +21,13 @@ def _roof(r):
     return out
 
 
+def _roof_short(r):
+    """a secondary roofline entry: what ran, what bounds it, how close"""
+    if not isinstance(r, dict):
+        return None
+    return {k: r[k] for k in ("kernel", "bound", "launch_ms", "launches_per_step", "frac", "frac_needed", "frac_of_bound") if r.get(k) is not None}
+
+
 def _num(x, nd=3):
     return round(x, nd) if isinstance(x, float) else x
 
@@ -54,13 +61,16 @@ def compact_line(detail):
     if isinstance(pt, dict):
         line["planted_transfers"] = {"recall": pt.get("recall"), "breakpoints": pt.get("breakpoints")}
     line["roofline"] = _roof(detail.get("roofline"))
+    rb = (detail.get("roofline_other") or {}).get("ref_flags")
+    if isinstance(rb, dict):                                # the k-mer-scan kernel of the reference side (north_star's HBM target), when it is not the dominant one
+        line["scan_roofline"] = _roof_short(rb)
     found = (detail.get("secondary") or {}).get("uhgg_deep_focused_sample")
     if isinstance(found, dict) and "value" in found:      # the same read count where the path finds its planted transfers
         line["value_found"] = _num(found["value"])
         line["found"] = {"workload": found.get("workload_short", "13 Gbase ref, 100 M pairs from 300 of its contigs (100x)"),
                          "ms_per_step": found.get("ms_per_step"), "phase_ms": {k: _num(v, 1) for k, v in found.get("phase_ms", {}).items()},
                          "recall": (found.get("planted_transfers") or {}).get("recall"), "filtered_peaks": found.get("filtered_peaks"),
-                         "roofline": _roof(found.get("roofline"))}
+                         "roofline": _roof_short(found.get("roofline"))}
     ix = (detail.get("secondary") or {}).get("uhgg_index_form")
     if isinstance(ix, dict) and "value" in ix:            # the same workload with the index file's hashes resident: what rounds 1-4 led with
         line["value_index_form"] = _num(ix["value"])

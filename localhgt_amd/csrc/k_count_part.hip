@@ -1244,8 +1244,13 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
             auto run = [&](auto G_) {
                 using G = decltype(G_);
                 const uint32_t piece = piece_keys(pc.n, G::GRID);
-                hipLaunchKernelGGL((part_reads_direct<G, false>), dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
-                                   ctx->d_counts, ablate & 3, (const uint32_t*)nullptr);
+                // (a batch of long reads only -- 250-base reads throughout -- has nothing for the first launch but a walk over its lengths:
+                // 2.5 ms per chunk, 72 ms per 100 M pairs; the pieces' cursors, which it leaves for the list launch, are cleared instead)
+                if (have_long && b.n_long == 2 * b.d.n_pairs)
+                    hipMemsetAsync(cur1, 0, (size_t)NBK * G::GRID * 4, ctx->stream);
+                else
+                    hipLaunchKernelGGL((part_reads_direct<G, false>), dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
+                                       ctx->d_counts, ablate & 3, (const uint32_t*)nullptr);
                 if (have_long) {          // the long reads of the chunk, segment by segment, behind the short ones in the same pieces
                     hipMemsetAsync(d_list, 0, 4, ctx->stream);
                     hipLaunchKernelGGL(long_read_segments, dim3((unsigned)((2 * np + 255) / 256)), dim3(256), 0, ctx->stream, b.d, p0, np, ctx->k, d_list, list_cap);

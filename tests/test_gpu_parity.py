@@ -381,6 +381,35 @@ def test_direct_form_of_the_partition_equals_direct_count(Engine):
     assert got[0][1][3] > 0 and sum(got[0][1]) == 1 << 32
 
 
+def test_batch_of_long_reads_only_counts_like_the_direct_kernel(Engine):
+    """a batch in which EVERY read has more than 128 k-mer offsets (250-base reads throughout): phase A's direct form skips its
+    short-read launch and sends everything through the segment list (round 5) -- against the compare-and-swap kernel and the sorted
+    tiles; ragged lengths 160..420, N's, a hot read, mates not counted"""
+    k, e = 32, 3
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    def rd(n):
+        return [acgt[rng.choice(5, size=int(rng.integers(160, 421)), p=[.248, .248, .248, .248, .008])].tobytes() for _ in range(n)]
+    hot = acgt[rng.choice(4, size=250)].tobytes()
+    reads1 = rd(9001) + [b"A" * 250, hot] * 300 + rd(1000)
+    reads2 = rd(9001) + [b"T" * 250, hot] * 300 + rd(1000)
+    c2 = (rng.random(len(reads1)) < 0.9).astype(np.uint8)
+    got = []
+    for mode, dbg in ((0, 0), (1, 0), (1, 65536), (1, 1 << 21)):
+        with Engine(k, e) as eng:
+            eng.rng_seed(11)
+            eng.coder_generate()
+            eng.set_count_mode(mode)
+            eng.set_debug(dbg)
+            eng.pairs_append(*_pairs(reads1, reads2), count_mate2=c2)
+            eng.count_kmers()
+            eng.count_kmers()
+            got.append((eng.digest(eng.DIGEST_COUNTS), tuple(int(x) for x in eng.counts_histogram())))
+    for other in got[1:]:
+        assert other == got[0]
+    assert got[0][1][3] > 0 and sum(got[0][1]) == 1 << 32
+
+
 def test_more_voted_peaks_than_the_first_buffer_holds(Engine, tmp_path):
     """phase D compacts the voted peaks into a buffer that starts at 4096 records and grows once when more peaks were voted (round
     4: the grown buffer's 64-bit counter sat at an odd multiple of 12 bytes and the first sample with > 4096 voted peaks -- the

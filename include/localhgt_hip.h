@@ -30,7 +30,9 @@ enum {
     LHGT_E_STATE = 5,      /* call order violated (e.g. ref_scan before index_load) */
     LHGT_E_TOO_MANY_PEAKS = 6, /* E:272-274 "Too many peaks!" (the reference overruns its arrays) */
     LHGT_E_NOMEM = 7,
-    LHGT_E_NO_DEVICE = 8
+    LHGT_E_NO_DEVICE = 8,
+    LHGT_E_EMULATION = 9   /* only the -t N emulation refuses this input (the reference's -t N run is undefined on it); the
+                              -t 1 result is defined: `extract_ref` falls back to it with a warning */
 };
 
 typedef struct lhgt_ctx lhgt_ctx;
@@ -147,8 +149,8 @@ int lhgt_fastq_parse_digest_planned(const char* fq1, const char* fq2, double rat
  * across the ranks: lhgt_ref_scan_local, lhgt_ref_scan_group_counts, [sum over ranks], lhgt_set_group_totals, lhgt_ref_scan_emit,
  * lhgt_peaks_install.  Inputs on which the reference's behaviour is undefined (a chunk entered within 1000 bytes of EOF,
  * overlapping chunks, a thread's peaks overflowing its id range, threads that re-synchronise fq2 at different line offsets) are
- * refused with an error whose text starts with "-t N emulation" / "Too many peaks! thread": `extract_ref` then falls back to the
- * -t 1 result with a warning. */
+ * refused with LHGT_E_EMULATION (round 6: a code of its own; the text starts with "-t N emulation" / "Too many peaks! thread"):
+ * `extract_ref` then falls back to the -t 1 result with a warning. */
 int lhgt_set_thread_emulation(lhgt_ctx* ctx, int threads);
 /* where thread i of `threads` enters a FASTQ (byte), the global index of its first line and the lines it consumes;
  * size_for_chunks = size of fq1 (also for fq2, E:1419), < 0 = this file's */

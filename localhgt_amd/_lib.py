@@ -16,7 +16,7 @@ CODER_SLOTS = 300
 MAX_RANDOM = 50_000_000
 
 ERRORS = {0: "OK", 1: "E_ARG", 2: "E_IO", 3: "E_HIP", 4: "E_FORMAT", 5: "E_STATE", 6: "E_TOO_MANY_PEAKS",
-          7: "E_NOMEM", 8: "E_NO_DEVICE"}
+          7: "E_NOMEM", 8: "E_NO_DEVICE", 9: "E_EMULATION"}
 
 _vp, _i, _l, _d, _f = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 _u8p, _u16p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)

@@ -33,48 +33,95 @@ __global__ void __launch_bounds__(256) digest_kernel(const T* __restrict__ v, ui
 #include <unordered_map>
 namespace lhgt {
 namespace {
-struct DevBlock { int device; size_t bytes; void* p; };
+// A parked block remembers the park "generation"; a device that has been synchronised since (g_dev_synced) has finished every
+// kernel that could still have been reading or writing the block when its owner let go of it.  hipFree used to give that guarantee
+// implicitly (it synchronises the device); the cache gives it when the block is handed out again -- a block parked by one
+// context's regrowth in mid-stream (key buffers, d_revote, staging) must not reach another context's stream while the first
+// one's queued kernels still use it (two contexts on one GPU: tools/benchlib/legs.py pipelined_samples).
+struct DevBlock { int device; size_t bytes; void* p; unsigned long long gen; };
 std::mutex g_dev_mu;
 std::vector<DevBlock> g_dev_free;                                   // cached blocks, oldest first
 std::unordered_map<void*, std::pair<int, size_t>> g_dev_live;       // blocks handed out by dev_alloc_raw: device, class size
+std::unordered_map<int, unsigned long long> g_dev_synced;           // per device: every block parked at or before this generation is quiescent
+unsigned long long g_dev_gen = 0;
 size_t g_dev_cached = 0;
-const size_t DEV_CACHE_CAP = (size_t)96 << 30;                      // more than this is not kept (a context's tables, buffers and batches at configs[1]..[2] sizes)
+size_t g_dev_cap = 0;                                               // 0 = not decided yet (dev_cache_cap)
+thread_local lhgt_ctx* t_entry_ctx = nullptr;                       // the context of the C-ABI call running on this thread (LHGT_DEVICE_ENTRY)
+// what is kept at most: a context's tables, buffers and batches at configs[1]..[2] sizes (96 GB) -- but never more than a third of
+// the device (LHGT_DEV_CACHE_GB overrides; ranks that share a GPU, torch and RCCL do not see parked blocks as reclaimable)
+size_t dev_cache_cap() {
+    if (g_dev_cap) return g_dev_cap;
+    size_t cap = (size_t)96 << 30;
+    if (const char* s = getenv("LHGT_DEV_CACHE_GB")) cap = (size_t)(atof(s) * (double)(1ull << 30));
+    else {
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess && t / 3 < cap) cap = t / 3;
+        else (void)hipGetLastError();
+        if (const char* w = getenv("WORLD_SIZE")) if (atoi(w) > 1) cap = std::min(cap, (size_t)24 << 30);   // ranks may share this GPU (gloo mode)
+    }
+    g_dev_cap = cap ? cap : 1;
+    return g_dev_cap;
+}
 size_t size_class(size_t bytes) {                                   // next eighth-step of a power of two, steps of at most 256 MiB
     size_t top = (size_t)1 << 26;                                   // (a 156 GB index must not grow by 16 GB for the sake of reuse)
     while ((top << 1) <= bytes) top <<= 1;
     const size_t step = std::min(top >> 3, (size_t)256 << 20);
     return (bytes + step - 1) / step * step;
 }
+// last resort of an allocation that would fail: the optional slot list (78-130 GB) of the context whose call is running on this
+// thread, when no scan is using it.  Other threads' contexts are left alone (their lists may be in use).
+bool drop_optional(void) {
+    lhgt_ctx* c = t_entry_ctx;
+    if (!c || c->sl_state != 1 || c->sl_in_use) return false;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    slot_list_drop(c);
+    (void)big_release_all();                                        // the list's blocks were parked by slot_list_drop
+    if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] out of device memory: the slot list was dropped\n");
+    return true;
+}
+hipError_t malloc_hard(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && big_release_all()) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+    if (e == hipErrorOutOfMemory && drop_optional()) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+    return e;
+}
 }  // namespace
+void entry_context(lhgt_ctx* ctx) { t_entry_ctx = ctx; }
 hipError_t dev_alloc_raw(void** p, size_t bytes) {
     *p = nullptr;
-    if (bytes < DEV_CACHE_MIN) {
-        hipError_t e = hipMalloc(p, bytes);
-        if (e == hipErrorOutOfMemory && big_release_all()) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
-        return e;
-    }
+    if (bytes < DEV_CACHE_MIN) return malloc_hard(p, bytes);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     const size_t cls = size_class(bytes);
     {
-        std::lock_guard<std::mutex> lk(g_dev_mu);
+        std::unique_lock<std::mutex> lk(g_dev_mu);
         for (size_t i = 0; i < g_dev_free.size(); i++)
             if (g_dev_free[i].device == dev && g_dev_free[i].bytes == cls) {
-                *p = g_dev_free[i].p;
+                const DevBlock b = g_dev_free[i];
                 g_dev_cached -= cls;
                 g_dev_free.erase(g_dev_free.begin() + (long)i);
-                g_dev_live[*p] = {dev, cls};
+                g_dev_live[b.p] = {dev, cls};
+                const bool quiet = g_dev_synced[dev] >= b.gen;
+                const unsigned long long now = g_dev_gen;
+                lk.unlock();
+                if (!quiet) {                                       // work queued before the block was parked may still touch it
+                    const hipError_t se = hipDeviceSynchronize();
+                    if (se != hipSuccess) return se;
+                    lk.lock();
+                    if (g_dev_synced[dev] < now) g_dev_synced[dev] = now;
+                }
+                *p = b.p;
                 return hipSuccess;
             }
     }
-    hipError_t e = hipMalloc(p, cls);
-    if (e == hipErrorOutOfMemory && big_release_all()) { (void)hipGetLastError(); e = hipMalloc(p, cls); }
+    hipError_t e = malloc_hard(p, cls);
     if (e == hipErrorOutOfMemory && cls > bytes) { (void)hipGetLastError(); e = hipMalloc(p, bytes); if (e == hipSuccess) return e; }   // no room for the rounding: an exact, uncached block
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_dev_mu); g_dev_live[*p] = {dev, cls}; }
     return e;
 }
 hipError_t dev_free(void* p) {
     if (!p) return hipSuccess;
+    const size_t cap = dev_cache_cap();
     {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         auto it = g_dev_live.find(p);
@@ -82,8 +129,8 @@ hipError_t dev_free(void* p) {
             const int dev = it->second.first;
             const size_t cls = it->second.second;
             g_dev_live.erase(it);
-            if (g_dev_cached + cls <= DEV_CACHE_CAP) {
-                g_dev_free.push_back({dev, cls, p});
+            if (g_dev_cached + cls <= cap) {
+                g_dev_free.push_back({dev, cls, p, ++g_dev_gen});
                 g_dev_cached += cls;
                 return hipSuccess;
             }

@@ -169,9 +169,9 @@ static int thread_part(const Mapped& m, const ChunkPlan& pl, long size_for_chunk
     for (int i = 0; i < threads; i++) {
         const long start = (long)i * each, end = i == threads - 1 ? size_for_chunks : (long)(i + 1) * each;
         const long pos = thread_entry(m.p, (long)m.n, start);
-        if (pos < 0) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: thread %d would enter %s within 1000 bytes of its end (the reference reads stale bytes there)", threads, i, path);
+        if (pos < 0) LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: thread %d would enter %s within 1000 bytes of its end (the reference reads stale bytes there)", threads, i, path);
         const long first = line_index_of(m, pl, (size_t)pos);
-        if (first % 4) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: thread %d enters %s at line %ld, not at a record (the reference would take quality lines for reads)", threads, i, path, first);
+        if (first % 4) LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: thread %d enters %s at line %ld, not at a record (the reference would take quality lines for reads)", threads, i, path, first);
         const size_t next = line_start_at_or_after(m.p, m.n, (size_t)end + 1);    // first line the chunk does NOT consume
         const long stop = (size_t)end + 1 >= m.n ? pl.line0.back() : line_index_of(m, pl, next);
         out->first.push_back(first);
@@ -180,7 +180,7 @@ static int thread_part(const Mapped& m, const ChunkPlan& pl, long size_for_chunk
     }
     for (int i = 0; i + 1 < threads; i++)   // the reference would count such reads twice; only files of a few records per thread get here
         if (out->first[i + 1] < out->first[i] + out->count[i])
-            LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: the chunks of threads %d and %d of %s overlap (file too small for that many threads)", threads, i, i + 1, path);
+            LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: the chunks of threads %d and %d of %s overlap (file too small for that many threads)", threads, i, i + 1, path);
     return LHGT_OK;
 }
 
@@ -347,14 +347,14 @@ static int parse_setup(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, 
                 if (same_id(a, la, m2.p + pos, nl ? (size_t)(nl - (m2.p + pos)) : m2.n - pos)) g2 = line_index_of(m2, p2, pos);
             }
             if (g2 < 0) g2 = find_id_line(m2, p2, pos > 1000000001UL ? pos - 1000000000UL : 1, a, read_id_len(a, la));
-            if (g2 < 0) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: no line of %s carries the read ID of thread %d's first record (the reference spins through 10^9 failed reads)", emulate_threads, fq2, i);
-            if (have && g2 - g != lay->shift) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: the threads find their first records at different line offsets in %s (%ld and %ld)", emulate_threads, fq2, lay->shift, g2 - g);
+            if (g2 < 0) LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: no line of %s carries the read ID of thread %d's first record (the reference spins through 10^9 failed reads)", emulate_threads, fq2, i);
+            if (have && g2 - g != lay->shift) LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: the threads find their first records at different line offsets in %s (%ld and %ld)", emulate_threads, fq2, lay->shift, g2 - g);
             lay->shift = g2 - g;
             have = true;
         }
         if (lay->lines2 < lay->lines1 + lay->shift)
             for (long g = lay->lines2 - lay->shift; g < lay->lines1; g++)
-                if (g % 4 == 1) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: %s has fewer records than %s", emulate_threads, fq2, fq1);
+                if (g % 4 == 1) LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: %s has fewer records than %s", emulate_threads, fq2, fq1);
     } else if (lay->lines1 > 0) {
         line_at(m1, p1, 0, &a, &la, &sa);
         const bool have2 = line_at(m2, p2, 0, &b, &lb, &sb);
@@ -364,9 +364,9 @@ static int parse_setup(const Mapped& m1, const Mapped& m2, const ChunkPlan& p1, 
             lay->shift = g2;
         }
     }
-    if (lay->shift % 4) LHGT_FAIL(LHGT_E_FORMAT, "%s%s pairs with %s at line offset %ld, inside a record (the reference would take quality lines for reads)",
+    if (lay->shift % 4) LHGT_FAIL(emulate_threads > 1 ? LHGT_E_EMULATION : LHGT_E_FORMAT, "%s%s pairs with %s at line offset %ld, inside a record (the reference would take quality lines for reads)",
                                   emulate_threads > 1 ? "-t N emulation: " : "", fq2, fq1, lay->shift);
-    if (lay->shift < 0) LHGT_FAIL(LHGT_E_FORMAT, "-t %d emulation: %s is %ld lines behind %s", emulate_threads, fq2, -lay->shift, fq1);
+    if (lay->shift < 0) LHGT_FAIL(LHGT_E_EMULATION, "-t %d emulation: %s is %ld lines behind %s", emulate_threads, fq2, -lay->shift, fq1);
     return LHGT_OK;
 }
 

@@ -101,6 +101,12 @@ int lhgt_coder_set(lhgt_ctx* ctx, const int16_t* cc) {
     if (!ctx || !cc) LHGT_FAIL(LHGT_E_ARG, "null argument");
     HashParams hp;
     LHGT_TRY(build_hash_params(cc, ctx->k, ctx->e, &hp));
+    // the slot list groups the reference's positions by the hashes of the coder it was built under: a packed reference may
+    // legitimately be scanned under a new coder (phase B recomputes the hashes), its list may not
+    if (ctx->device >= 0 && ctx->sl_state != 0 && (!ctx->have_coder || memcmp(&ctx->hp, &hp, sizeof hp) != 0)) {
+        if (hipSetDevice(ctx->device) == hipSuccess && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        slot_list_drop(ctx);
+    }
     memcpy(ctx->cc, cc, sizeof ctx->cc);
     ctx->hp = hp;
     ctx->have_coder = true;

@@ -1566,7 +1566,7 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
     const double need = 6.0 * (double)ctx->n_pos + 12.0 * (double)nb;
     if ((double)free_b - need < headroom_gb * 1e9 && lhgt::big_release_all())     // blocks parked by earlier contexts of the process count as free
         LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
-    if ((double)free_b - need < headroom_gb * 1e9 && (double)free_b - need < 0.25 * (double)free_b) {
+    if ((double)free_b - need < headroom_gb * 1e9) {   // (round 6: the absolute headroom alone -- "or a quarter of what is free" could leave a few GB for the next, larger sample)
         if (trace) fprintf(stderr, "[lhgt] slot list: %.1f GB wanted, %.1f GB free -- not built\n", need / 1e9, (double)free_b / 1e9);
         return LHGT_OK;
     }
@@ -1600,7 +1600,7 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
     if (!smallest && ctx->e >= 2 && mid_ok) {
         size_t f2 = 0, t2 = 0;
         LHGT_HIP(hipMemGetInfo(&f2, &t2));
-        if ((double)f2 - 4.0 * (double)n_entries >= headroom_gb * 1e9 || (double)f2 - 4.0 * (double)n_entries >= 0.25 * (double)f2) {
+        if ((double)f2 - 4.0 * (double)n_entries >= headroom_gb * 1e9) {
             if (lhgt::dev_malloc(&ctx->d_sl_mid, (size_t)(n_entries + 64) * 4) != hipSuccess) { ctx->d_sl_mid = nullptr; (void)hipGetLastError(); }
         }
     }
@@ -1714,6 +1714,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (ctx->sl_state == 0 && (asked || (ctx->sl_mode == 1 && ctx->sl_sparse_scans >= 1 && pays))) LHGT_TRY(slot_list_build(ctx, want_smallest));
         ctx->scan_slots = ctx->sl_state == 1 && ctx->sl_smallest == want_smallest && (asked || pays) && (sparse_form || ctx->sl_unlisted == 0);
     }
+    struct InUse { lhgt_ctx* c; ~InUse() { c->sl_in_use = false; } } in_use{ctx};   // every return below ends with the stream drained
+    ctx->sl_in_use = ctx->scan_slots;
     if (list_form) ctx->sl_sparse_scans++;
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] table: %.1f %% of the slots at 3, trial settles %.1f %% -> %s B1\n", 100.0 * frac3, 100.0 * pilot_settled, sparse_form ? "trio-first" : ctx->scan_lite ? "single-first (lite)" : "exact");
     LHGT_HIP(hipEventRecord(ctx->ev2, ctx->stream));
@@ -1909,7 +1911,7 @@ static int thread_id_ranges(lhgt_ctx* ctx, long max_peak, const std::vector<long
     long total = 0;
     for (int j = 0; j < N; j++) {
         if (totals[j] > each_peaks)
-            LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! thread %d of %d found %ld, its id range holds %ld (the reference runs into the next thread's ids): appoint a larger max_peak_num (see --max_peak).", j, N, totals[j], each_peaks);
+            LHGT_FAIL(LHGT_E_EMULATION, "Too many peaks! thread %d of %d found %ld, its id range holds %ld (the reference runs into the next thread's ids): appoint a larger max_peak_num (see --max_peak).", j, N, totals[j], each_peaks);
         total += totals[j];
     }
     *first_id = total > 0 && totals[0] == 0 ? 1 : 0;

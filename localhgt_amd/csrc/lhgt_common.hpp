@@ -15,6 +15,7 @@ namespace lhgt {
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
 const char* last_error();
+void entry_context(::lhgt_ctx* ctx);   // cabi.hip: the context whose call runs on this thread (whose optional structures an allocation may drop)
 #define LHGT_HIP(expr)                                                                      \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -41,6 +42,7 @@ const char* last_error();
         if ((ctx) && (ctx)->device < 0)                                                                               \
             LHGT_FAIL(LHGT_E_NO_DEVICE, "host-only context: no GPU work possible (no CPU fallback)");                 \
         if (ctx) LHGT_HIP(hipSetDevice((ctx)->device));                                                               \
+        lhgt::entry_context(ctx);                                                                                     \
     } while (0)
 
 // ---------------------------------------------------------------- hash parameters (by value to kernels)
@@ -164,6 +166,7 @@ struct lhgt_ctx {
     unsigned long long* d_sl_off = nullptr;  // [sl_buckets + 1]
     unsigned long long sl_entries = 0;
     long sl_buckets = 0;
+    bool sl_in_use = false;                  // a scan is running on the list: an allocation out of memory must not drop it (cabi.hip: drop_optional)
     int sl_state = 0;                        // 0 not tried for this reference, 1 built, -1 tried and left (no memory, e > 3, positions beyond 2^34)
     int sl_mode = 1;                         // lhgt_slot_list / LHGT_SLOT_LIST: 0 never, 1 before the second sparse scan of a reference, 2 before the first
     int sl_sparse_scans = 0;                 // sparse-form scans of the resident reference so far

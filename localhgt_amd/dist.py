@@ -142,7 +142,12 @@ class Exchange:
             dist.destroy_process_group()
 
     def barrier(self):
-        dist.barrier()
+        """never through NCCL when the ranks may share a GPU: with the gloo backend (and its 'cpu:gloo,cuda:nccl' group) the
+        barrier is an all-reduce of one host integer -- dist.barrier() picks its device by the torch version's own rule"""
+        if self.backend == "gloo":
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32))
+        else:
+            dist.barrier(device_ids=[self.device])
 
     def _dev(self):
         return torch.device("cuda", self.device) if self.backend == "nccl" else torch.device("cpu")
@@ -261,14 +266,14 @@ class Exchange:
         try:
             n_new, n_sel = self.adapter.scan_local(eng, hit_ratio, match_ratio)
         except LocalHGTError as e:                         # 1: only the -t N emulation refuses (the caller falls back to -t 1 -- on EVERY rank), 2: anything else
-            err, mine = e, (1 if (e.code == 4 and "emulation:" in str(e)) or (e.code == 6 and "Too many peaks! thread" in str(e)) else 2)
+            err, mine = e, (1 if e.code == 9 else 2)   # LHGT_E_EMULATION
         except Exception as e:                             # noqa: BLE001 -- a rank that failed alone must not leave the others in the gather below
             err, mine = e, 2
         worst = self.agree(mine)
         if worst:                                          # the same class and code on every rank, so that all fall back or all stop
             if mine == worst:
                 raise err
-            raise LocalHGTError(4 if worst == 1 else 5, "-t N emulation: refused on another rank" if worst == 1 else
+            raise LocalHGTError(9 if worst == 1 else 5, "-t N emulation: refused on another rank" if worst == 1 else
                                 f"reference-sharded scan failed on another rank (rank {self.rank} stops with it)")
         allc = self._gather_small([n_new, n_sel])
         news = [c[0] for c in allc]

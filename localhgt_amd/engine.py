@@ -127,6 +127,13 @@ class Engine:
                                                       C.byref(nc), C.byref(nb)))
         return nc.value, nb.value
 
+    def fasta_scan(self, fasta: str, genome_len_path: Optional[str] = None) -> Tuple[int, int, int]:
+        """host-only: (sequences, indexed contigs, their bases) of a FASTA as read_ref sees it; writes genome.len.txt when asked"""
+        ns, nc, nb = C.c_long(0), C.c_long(0), C.c_long(0)
+        _lib.check(self.lib.lhgt_fasta_scan(fasta.encode(), self.k, genome_len_path.encode() if genome_len_path else None,
+                                            C.byref(ns), C.byref(nc), C.byref(nb)))
+        return ns.value, nc.value, nb.value
+
     def index_from_memory(self, ascii_bases: np.ndarray, offsets: np.ndarray):
         a = np.ascontiguousarray(ascii_bases, dtype=np.uint8)
         o = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -69,9 +69,54 @@ def _warn_if_ids_desynchronise(genome_len_path: str, k: int, log) -> None:
 
 
 def _emulation_refused(err) -> bool:
-    """errors with which only the -t N emulation refuses an input (include/localhgt_hip.h: lhgt_set_thread_emulation)"""
-    msg = str(err)
-    return (err.code == 4 and "emulation:" in msg and "-t " in msg) or (err.code == 6 and "Too many peaks! thread" in msg)
+    """the error with which only the -t N emulation refuses an input (include/localhgt_hip.h: LHGT_E_EMULATION)"""
+    return err.code == 9
+
+
+class Session:
+    """One process that handles sample after sample (round 6: `extract_ref --batch`).  The reference runs one sample per process
+    (scripts/pipeline.sh:35) and pays the reference load every time; a session keeps ONE context per (k, e) and with it whatever
+    a next sample of the same reference can reuse: the resident reference (index hashes or packed bases), the slot list the
+    second sparse-table scan of that reference builds (include/localhgt_hip.h: lhgt_slot_list), the 16 GiB peak_kmer table and
+    the key buffers.  Every sample still gets exactly the files a process of its own would have written -- the per-sample state
+    (seed, coder draws, sampling array, reads, count table, thread emulation) is set up from scratch as `run` does."""
+
+    def __init__(self, device: int = 0, dist=None, log=print):
+        self.device, self.dist, self.log = device, dist, log
+        self.eng = None
+        self.resident = None        # identity of the reference the context holds: (path, size, mtime_ns, form, shard) [+ the index file's]
+        self.ref_shape = (0, 0)     # its (contigs, bases)
+        self.samples = 0
+
+    def _engine(self, k: int, e: int) -> Engine:
+        if self.eng is not None and (self.eng.k, self.eng.e) != (k, e):
+            self.close()
+        if self.eng is None:
+            self.eng = Engine(k, e, self.device)
+            self.resident = None
+        return self.eng
+
+    def close(self):
+        if self.eng is not None:
+            self.eng.close()
+        self.eng, self.resident = None, None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def run(self, a: Args, emulate_threads=None, ref_form=None, log=None) -> dict:
+        t0 = time.time()
+        eng = self._engine(a.k, a.e)
+        try:
+            rep = _run(eng, a, t0, self.dist, log or self.log, emulate_threads, ref_form, self)
+        except BaseException:
+            self.close()     # also on an error: a long-lived caller must not keep a 16 GiB peak_kmer table (and the reads) per failed
+            raise            # call, and the next sample must not inherit half a sample's state
+        self.samples += 1
+        return rep
 
 
 def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, ref_form=None) -> dict:
@@ -86,22 +131,27 @@ def run(a: Args, device: int = 0, dist=None, log=print, emulate_threads=None, re
     produced (under sampling the kept reads, and with them the .bed, differ between -t 1 and -t N, E:1037).  Where the emulation
     refuses an input -- one on which the reference reads stale bytes or overruns a thread's id range -- the run falls back to
     the -t 1 result with one warning line."""
-    t0 = time.time()
-    eng = Engine(a.k, a.e, device)
-    try:
-        return _run(eng, a, t0, dist, log, emulate_threads, ref_form)
-    finally:
-        eng.close()      # also on an error: a long-lived caller must not keep a 16 GiB peak_kmer table (and the reads) per failed call
+    with Session(device, dist, log) as ses:
+        return ses.run(a, emulate_threads, ref_form)
 
 
-def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form) -> dict:
+def _file_id(path: str):
+    st = os.stat(path)
+    return (os.path.realpath(path), st.st_size, st.st_mtime_ns)
+
+
+def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form, ses: Session) -> dict:
     from ._lib import LocalHGTError
     rank, world = (dist.rank, dist.world) if dist else (0, 1)
+    if ses.samples:                                            # a context that has seen a sample: nothing of it may reach this one
+        eng.pairs_clear()
+        eng.counts_clear()
+        eng.sampling_reserve(0)                                # (the entries the LAST sample's reads could look at: get_random fills all of them until told otherwise)
     if emulate_threads is None:
         emulate_threads = os.environ.get("LHGT_EMULATE_THREADS", "1") != "0"
     emulating = bool(emulate_threads) and a.threads > 1
+    eng.set_thread_emulation(a.threads if emulating else 1)
     if emulating:
-        eng.set_thread_emulation(a.threads)
         log(f"reproducing the reference's -t {a.threads} read partition and peak id ranges")
     log(f"kmer length is {a.k}\nseed is {a.seed}\nnum of hash functions is {a.e}")
     eng.rng_seed(a.seed)                                       # E:1386
@@ -150,16 +200,29 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form) 
     # (Uploading the index on a second host thread next to the FASTQ pipeline was tried and lost: 0.23 s instead of 0.17 s for
     # 4 M pairs + a 1.2 GB index -- the page faults and the pinning of the index mapping fight the parse threads.)
     t_i0 = time.time()
-    if packed:
-        eng.set_reference_form(True)
-        log("reference form: packed bases from the FASTA, hashes recomputed in the scan")
-        n_contigs, n_bases = eng.reference_load_fasta(a.fasta, a.fasta + ".genome.len.txt" if built and rank == 0 else None)
-        if dist and built:
-            dist.barrier()
-    elif shard_index:
-        n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
+    # a session's next sample of the same reference finds it resident (same file by path, size and mtime; same form and shard)
+    want = _file_id(a.fasta) + (ref_form, (rank, world) if shard_index else None) + (() if packed else _file_id(idx))
+    reused = ses.resident == want
+    if reused:
+        n_contigs, n_bases = ses.ref_shape
+        log("reference: resident from the previous sample of this session")
+        if packed and built and rank == 0 and not os.path.exists(a.fasta + ".genome.len.txt"):
+            eng.fasta_scan(a.fasta, a.fasta + ".genome.len.txt")   # what a run of its own would have (re)written (E:773, 878)
     else:
-        n_contigs, n_bases = eng.index_load(idx)               # E:1417 (+ resident copy of the hashes)
+        ses.resident = None
+        if packed:
+            eng.set_reference_form(True)
+            log("reference form: packed bases from the FASTA, hashes recomputed in the scan")
+            n_contigs, n_bases = eng.reference_load_fasta(a.fasta, a.fasta + ".genome.len.txt" if built and rank == 0 else None)
+        elif shard_index:
+            eng.set_reference_form(False)
+            n_contigs, n_bases = eng.index_load_shard(idx, rank, world)
+        else:
+            eng.set_reference_form(False)
+            n_contigs, n_bases = eng.index_load(idx)           # E:1417 (+ resident copy of the hashes)
+        ses.resident, ses.ref_shape = want, (n_contigs, n_bases)
+    if packed and dist and built:
+        dist.barrier()
     t_i1 = time.time()
     _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
     if plan1 is not None:                                      # reads per file are known: only the entries they can look at are filled
@@ -187,7 +250,7 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form) 
                 raise err
             raise LocalHGTError(5, f"another rank failed (rank {rank} stops with it)")
         if worst == 1:
-            return err if mine == 1 else LocalHGTError(4, "-t N emulation: refused on another rank")
+            return err if mine == 1 else LocalHGTError(9, "-t N emulation: refused on another rank")
         return None
 
     def load_and_count():
@@ -252,7 +315,7 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form) 
     log(f"Finish with time:\t{t5 - t0:.2f}")
     rep = dict(pairs_seen=seen, pairs_kept=kept, n_contigs=n_contigs, n_bases=n_bases, n_peaks=n_peaks,
                n_filtered=n_filtered, ratio=ratio, index_built=built and not packed, ref_form=ref_form, emulated_threads=a.threads if emulating else 1,
-               ref_resident_bytes=eng.reference_info()["resident_bytes"], ingest_s=t_r0 + state["t_reads"] - t0, index_s=t_i1 - t_i0,
+               ref_resident_bytes=eng.reference_info()["resident_bytes"], ref_reused=reused, scan_form=eng.scan_info()["form"], slot_list_bytes=eng.slot_list()["bytes"], ingest_s=t_r0 + state["t_reads"] - t0, index_s=t_i1 - t_i0,
                reads_s=state["t_reads"], count_s=t2 - t_r0 - state["t_reads"], scan_s=t3 - t2,
                vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
                vote_kernel_ms=eng.phase_ms(2), world=world, staged_bytes=dist.staged_bytes if dist else 0)
@@ -271,9 +334,53 @@ def _collective(fn, emulating, LocalHGTError):
     return None
 
 
+def read_manifest(path: str):
+    """one sample per line: the 12 arguments of an `extract_ref` call as scripts/pipeline.sh:35 passes them (shell quoting allowed,
+    `#` starts a comment, blank lines are skipped)"""
+    import shlex
+    samples = []
+    with open(path) as f:
+        for no, line in enumerate(f, 1):
+            tok = shlex.split(line, comments=True)
+            if not tok:
+                continue
+            if len(tok) != 12:
+                raise SystemExit(f"{path}:{no}: {len(tok)} arguments, an extract_ref call has 12 "
+                                 "(fq1 fq2 ref.fa interval_out hit_ratio match_ratio threads k max_peak coder_num seed base_num)")
+            samples.append(parse_argv(tok))
+    return samples
+
+
+def run_batch(samples, device: int = 0, dist=None, log=print, ref_form=None, emulate_threads=None, keep_going=True):
+    """the samples one after the other in ONE session (class Session): the files of every sample are those of a call of its
+    own.  A sample that fails is reported and -- on one GPU -- the batch goes on with a fresh context; returns the per-sample
+    reports (None for a failed one)."""
+    reps = []
+    with Session(device, dist, log) as ses:
+        for i, a in enumerate(samples):
+            log(f"---- batch sample {i + 1} of {len(samples)}: {a.interval}")
+            try:
+                reps.append(ses.run(a, emulate_threads, ref_form))
+            except Exception as ex:                            # noqa: BLE001 -- reported; the others still run
+                if dist or not keep_going:
+                    raise
+                log(f"error: sample {i + 1} ({a.interval}) failed: {ex}")
+                reps.append(None)
+    return reps
+
+
 def main(argv=None) -> int:
+    """extract_ref <12 arguments>             one sample, as scripts/pipeline.sh:35 calls it
+    extract_ref --batch MANIFEST            one process for many samples: MANIFEST holds the 12 arguments of each call, one per line;
+                                            the reference of consecutive samples stays resident on the GPU (round 6)"""
     argv = sys.argv[1:] if argv is None else argv
-    a = parse_argv(argv)
+    batch = None
+    if argv and argv[0] == "--batch":
+        if len(argv) != 2:
+            raise SystemExit("usage: extract_ref --batch MANIFEST   (one extract_ref argument list per line)")
+        batch = read_manifest(argv[1])
+    else:
+        a = parse_argv(argv)
     dist = None
     device = 0
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -281,6 +388,9 @@ def main(argv=None) -> int:
         dist = Exchange.from_env()
         device = dist.device
     try:
+        if batch is not None:
+            reps = run_batch(batch, device=device, dist=dist)
+            return 1 if any(r is None for r in reps) else 0
         run(a, device=device, dist=dist)
     finally:
         if dist:

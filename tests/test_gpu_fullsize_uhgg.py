@@ -29,6 +29,32 @@ def eng():
     e.close()
 
 
+def _regular_index_form(eng):
+    """the module's reference as most tests want it: 13000 x 1 Mbp, the index file's hashes resident"""
+    if eng.reference_info()["form"] != "index" or eng.reference_info()["resident_bytes"] < 150e9 or eng.scan_info()["tiles"] != NC * CL // 2000:
+        eng.slot_list(0)
+        eng.slot_list(1)
+        eng.set_reference_form(False)
+        eng.synth_reference(1, NC, CL)
+
+
+_LIGHT = {"pairs": 25_000_000, "contigs": 1000}
+
+
+def _light_sample(eng):
+    """25 M pairs drawn from 1000 contigs (7.5x), resident and counted -- kept across tests that want the same sample (the count
+    table does not depend on the reference)"""
+    if getattr(eng, "_resident_sample", None) == _LIGHT and eng.pairs_count() == _LIGHT["pairs"]:
+        return
+    eng.pairs_clear()
+    eng.synth_options(0, 20, _LIGHT["contigs"])
+    eng.synth_pairs(1, 2, NC, CL, 0, _LIGHT["pairs"])
+    eng.synth_options(0, 20, 0)
+    eng.counts_clear()
+    eng.count_kmers()
+    eng._resident_sample = dict(_LIGHT)
+
+
 def _scan(eng, debug):
     eng.set_debug(debug)
     n = eng.ref_scan(0.1, 0.08, 300_000_000)
@@ -94,6 +120,7 @@ def _count_both_ways(eng):
                          [(25_000_000, 0, False, False), (35_000_000, 0, None, False), (100_000_000, 0, True, False),
                           (25_000_000, 1000, None, True), (50_000_000, 300, None, True)])
 def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_votes):
+    eng._resident_sample = None
     eng.pairs_clear()
     eng.synth_options(0, 20, sample_contigs)
     eng.synth_pairs(1, 2, NC, CL, 0, pairs)
@@ -145,64 +172,12 @@ def test_oracle_revotes_a_subset_of_pairs_at_full_table_size(eng, oracle, tmp_pa
     assert n_peaks >= 10 and n_votes >= 1
 
 
-from localhgt_amd.synth import ragged_cuts as _ragged_cuts  # noqa: E402
-
-
-def test_ragged_reference_forms_agree(eng):
-    """the same base stream cut into ~117 k ragged contigs, under the 100 M pairs of the headline workload (the count table
-    does not depend on the reference): per-contig tiles mostly shorter than 2000 positions, windows and contrast halos that
-    hang over contig ends everywhere"""
-    eng.pairs_clear()
-    eng.synth_pairs(1, 2, NC, CL, 0, 100_000_000)
-    eng.counts_clear()
-    eng.count_kmers()
-    cuts = _ragged_cuts(NC * CL)
-    lens = np.diff(cuts.astype(np.int64))
-    assert lens.size >= 100_000 and (lens <= K).sum() > 100 and lens.max() > 1_500_000
-    eng.synth_reference_cuts(1, NC, CL, cuts)
-    exact, info, votes = _check_scans_and_votes(eng, None, "ragged")
-    assert info["tiles"] == int(np.ceil(lens[lens > K] / 2000).sum())
-    n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
-    loci, _ = eng.peaks_export(n_peaks)
-    contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
-    assert (np.diff(contig * (1 << 32) + pos) > 0).all()
-    indexed = lens[lens > K]
-    assert contig.max() <= indexed.size and (pos < indexed[contig - 1]).all()          # sequential ids of indexed contigs (quirk Q7)
-    # a lighter sample on the same ragged reference: the exact form's territory
-    eng.pairs_clear()
-    eng.synth_options(0, 20, 1000)
-    eng.synth_pairs(1, 2, NC, CL, 0, 25_000_000)
-    eng.synth_options(0, 20, 0)
-    eng.counts_clear()
-    eng.count_kmers()
-    exact, _, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
-    assert votes[1] >= 1
-    # the packed form of the same ragged reference: contigs start anywhere inside a plane word (shared words are OR-ed together by
-    # neighbouring spans), contigs <= k are absent from the planes as they are from the index
-    try:
-        eng.set_reference_form(True)
-        eng.synth_reference_cuts(1, NC, CL, cuts)
-        assert eng.reference_info()["form"] == "packed"
-        for dbg, form in ((8192, "exact"), (0, None), (1 << 24, "slot-first"), (4096 | (1 << 24), "slot-single")):
-            # the list forms (round 5) on contigs that start anywhere inside a plane word, many shorter than a tile, some shorter than k
-            got, sinfo = _scan(eng, dbg)
-            assert got == exact and form in (None, sinfo["form"]), ("ragged packed", dbg, sinfo, got, exact)
-        assert _vote(eng, 0) == votes
-    finally:
-        eng.set_reference_form(False)
-        eng.synth_reference(1, NC, CL)                               # the module's other tests expect the regular reference, index form
-
-
 def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
     """SURVEY.md 8f rank 1 at full size: the 13 Gbase reference resident as bit-planes (4.9 GB) instead of the index file's
     hashes (156 GB), hashes recomputed inside every form of B1 and in the peak registry -- the same flags, loci, peak_kmer and
     votes, table by table"""
-    eng.pairs_clear()
-    eng.synth_options(0, 20, 1000)
-    eng.synth_pairs(1, 2, NC, CL, 0, 25_000_000)
-    eng.synth_options(0, 20, 0)
-    eng.counts_clear()
-    eng.count_kmers()
+    _light_sample(eng)
+    _regular_index_form(eng)
     info = eng.reference_info()
     assert info["form"] == "index" and info["resident_bytes"] > 150e9
     assert eng.scan_info()["tiles"] == NC * CL // 2000, "another test left its own reference resident"
@@ -243,6 +218,49 @@ def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
         checked, n_peaks, _ = bigaddr.check_against_oracle(eng, oracle, str(tmp_path), NC, CL, K, E, bigaddr.boundary_contigs(NC, CL, K, E, True))
         assert checked > 0 and n_peaks > 100
     finally:
-        eng.slot_list(1)
-        eng.set_reference_form(False)
-        eng.synth_reference(1, NC, CL)                               # the module's other tests expect the index form
+        eng.slot_list(1)                                             # (the reference stays packed: _regular_index_form is what a later test calls)
+
+
+from localhgt_amd.synth import ragged_cuts as _ragged_cuts  # noqa: E402
+
+
+def test_ragged_reference_forms_agree(eng):
+    """the same base stream cut into ~117 k ragged contigs, under the 100 M pairs of the headline workload (the count table
+    does not depend on the reference): per-contig tiles mostly shorter than 2000 positions, windows and contrast halos that
+    hang over contig ends everywhere"""
+    cuts = _ragged_cuts(NC * CL)
+    lens = np.diff(cuts.astype(np.int64))
+    assert lens.size >= 100_000 and (lens <= K).sum() > 100 and lens.max() > 1_500_000
+    eng.set_reference_form(False)
+    eng.synth_reference_cuts(1, NC, CL, cuts)
+    indexed = lens[lens > K]
+    # a light sample on the ragged reference first (the one the test before left resident and counted): the exact form's territory
+    _light_sample(eng)
+    exact, info, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
+    assert votes[1] >= 1
+    assert info["tiles"] == int(np.ceil(indexed / 2000).sum())
+    # the packed form of the same ragged reference: contigs start anywhere inside a plane word (shared words are OR-ed together by
+    # neighbouring spans), contigs <= k are absent from the planes as they are from the index
+    eng.set_reference_form(True)
+    eng.synth_reference_cuts(1, NC, CL, cuts)
+    assert eng.reference_info()["form"] == "packed"
+    for dbg, form in ((8192, "exact"), (0, None), (1 << 24, "slot-first"), (4096 | (1 << 24), "slot-single")):
+        # the list forms (round 5) on contigs that start anywhere inside a plane word, many shorter than a tile, some shorter than k
+        got, sinfo = _scan(eng, dbg)
+        assert got == exact and form in (None, sinfo["form"]), ("ragged packed", dbg, sinfo, got, exact)
+    assert _vote(eng, 0) == votes
+    # ... then the headline's 100 M pairs on it (round 6: on the packed form, which the light sample has just tied to the index form)
+    eng._resident_sample = None
+    eng.pairs_clear()
+    eng.synth_pairs(1, 2, NC, CL, 0, 100_000_000)
+    eng.counts_clear()
+    eng.count_kmers()
+    _check_scans_and_votes(eng, None, "ragged")
+    n_peaks = eng.ref_scan(0.1, 0.08, 300_000_000)
+    loci, _ = eng.peaks_export(n_peaks)
+    contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)
+    assert (np.diff(contig * (1 << 32) + pos) > 0).all()
+    assert contig.max() <= indexed.size and (pos < indexed[contig - 1]).all()          # sequential ids of indexed contigs (quirk Q7)
+    # (last test of the module: the reference stays ragged and packed; _regular_index_form is what any other test would call)
+
+

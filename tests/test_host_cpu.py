@@ -521,7 +521,7 @@ def test_thread_partition_flags_and_refusals(lib, oracle, case_inputs, tmp_path)
     open(tiny1, "wb").write(b"\n".join(open(f1, "rb").read().split(b"\n")[:24]) + b"\n")
     open(tiny2, "wb").write(b"\n".join(open(f2, "rb").read().split(b"\n")[:24]) + b"\n")
     assert h.lhgt_fastq_parse_digest_threads(tiny1.encode(), tiny2.encode(), 100.0, None, 0, 1, 4096, 2, 5000, 40, C.byref(seen),
-                                             C.byref(kept), C.byref(dig), None) == 4
+                                             C.byref(kept), C.byref(dig), None) == 9      # LHGT_E_EMULATION: only the -t N emulation refuses (extract_ref falls back to -t 1)
 
 
 def test_parallel_sam_ratio_equals_the_getline_pass(lib, oracle, case_inputs, tmp_path):

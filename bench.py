@@ -248,6 +248,22 @@ def main():
     xch_main = dict(wl.xch)
     moved_main = dict(dist.moved) if dist else None
     sl_info = eng.slot_list() if args.ref_form == "packed" else {"entries": 0, "bytes": 0}      # of the form the timed steps ran on
+    sl_cost = None
+    if sl_info["entries"] and world == 1 and not args.debug and scan["form"] in ("slot-first", "slot-single"):
+        # the list is a per-reference precompute built OUTSIDE the timed steps (like the reference load): what it cost, the same steps
+        # without it (debug bit 25: phase B's position-ordered kernels on the same packed reference), and after how many samples of one
+        # resident reference it has paid for itself.  `bin/extract_ref --batch` is the shipped entry point that reaches this state.
+        eng.set_debug(1 << 25)
+        dt0, per0, n0, nf0 = wl.run(2, 0)
+        eng.set_debug(0)
+        ms0, ms1 = dt0 / 2 * 1e3, dt / args.steps * 1e3
+        sl_cost = {"slot_list_build_ms": sl_info.get("build_ms"), "slot_list_GB": round(sl_info["bytes"] / 1e9, 1),
+                   "value_without_list": round(args.pairs * 2 / dt0 / 1e6, 3), "ms_per_step_without_list": round(ms0, 2),
+                   "scan_B_ms_without_list": round(per0[1], 2), "same_peaks": (n0, nf0) == (n_peaks, nf),
+                   "break_even_samples": round(sl_info.get("build_ms", 0.0) / (ms0 - ms1), 1) if ms0 > ms1 else None,
+                   "note": "value is measured with the reference AND its slot list resident (the list is built once per resident reference, untimed); value_without_list = "
+                           "the same steps on phase B's position-ordered kernels; break_even_samples = build time / time saved per sample.  One process per sample "
+                           "(scripts/pipeline.sh:35) never reaches the list; `extract_ref --batch MANIFEST` does (secondary.batch_13g_from_files, from FASTQ files)"}
     other_form = None
     if len(forms) > 1:                                   # the other form of phase B, a few steps, same reads
         if args.ref_form == "packed":
@@ -295,7 +311,7 @@ def main():
             f"{kk} {v['bytes_per_step'] / 1e6:.1f} MB in {xch_ms[kk]:.2f} ms" + (f" = {v['GB_per_s']} GB/s" if v["GB_per_s"] else "") for kk, v in xch_bytes.items()),
             file=sys.stderr, flush=True)
     resident_txt = ("index resident" if args.ref_form != "packed" else
-                    f"resident as packed bases + slot list = its k-mer positions by hash bucket, {(sl_info['bytes'] + ref_bases * 3 // 8) / 1e9:.0f} GB" if sl_info["entries"] else "packed bases resident")
+                    f"resident as packed bases + slot list = its k-mer positions by hash bucket, {(sl_info['bytes'] + ref_bases * 3 // 8) / 1e9:.0f} GB, list built once per resident reference outside the timed steps: slot_list_build_ms; reached by extract_ref --batch" if sl_info["entries"] else "packed bases resident")
     cfg_no = 2 if headline else 1 if workload_key(args) == (1000, 10_000_000, 0, False, 0) else "-"
     sample_txt = (f"drawn from {args.sample_contigs} of its contigs" if args.sample_contigs else "drawn from half of its contigs") + (f", SNP {args.snp / 10:g} %" if args.snp else "")
     detail = {
@@ -312,7 +328,7 @@ def main():
         "exchange_ms": xch_ms, "exchange_bytes": xch_bytes,
         "n1_equivalent_ms": round(step_s * 1e3 - sum(xch_ms.values()), 3) if xch_ms else round(step_s * 1e3, 3),
         "sharded_index" if (other_form and forms[1]) else "replicated_index": other_form,
-        "scan_B_form": scan, "vote_form": vote_form, "work_stats": stats, "memory_plan_bytes": plan, "slot_list": sl_info,
+        "scan_B_form": scan, "vote_form": vote_form, "work_stats": stats, "memory_plan_bytes": plan, "slot_list": sl_info, "slot_list_cost": sl_cost,
         "raw_peaks": n_peaks, "filtered_peaks": nf, "setup_s": round(setup_s, 2),
         "planted_transfers": interval_recall(out_path, planted_breakpoints(args.contigs, args.contig_len, args.sample_contigs)) if world == 1 and not args.ragged else None,
         "verify": verify,

@@ -304,7 +304,8 @@ int lhgt_synth_read_mix(lhgt_ctx* ctx, int long_permille, int long_len);
  * trio-first probe kernels recorded (outputs unchanged); bit24: lhgt_ref_scan takes the trio-first form answered from the slot
  * list, which it builds at once if there is none (lhgt_slot_list; outputs unchanged); bit25: a slot list that exists is not used;
  * bit26: stage ablation of the slot-first kernel, the stage named by LHGT_SLOTS_ABLATE (1: no listed position is followed, 2: none
- * probes the table; timing only, the flags come out WRONG).
+ * probes the table; timing only, the flags come out WRONG); bit27: a dense peak set (no bitmap) is voted in the shared-line-fill form
+ * (k_vote_shared.hip) whatever the store's size and grouping (e <= 3; outputs unchanged); bit28: never in that form.
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts
@@ -329,9 +330,14 @@ int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_ti
  * use it always; -1: leave the mode.  entries / bytes (nullable): the list as it stands (0 = none: not built yet, no memory for
  * it, e > 3, or positions beyond 2^34).  No reference counterpart (the reference walks its index file once per run, E:888-979). */
 int lhgt_slot_list(lhgt_ctx* ctx, int mode, unsigned long long* entries, unsigned long long* bytes);
+/* what the last build of a slot list cost (ms on the host clock: its histogram, offsets and fill kernels and its allocations); 0 if
+ * this context has built none.  Measurement only (bench.py: slot_list_build_ms, break_even_samples). */
+int lhgt_slot_list_build_ms(lhgt_ctx* ctx, double* ms);
 /* ---- which kernel the last lhgt_vote took (k_vote.hip): *form = 0 the generic kernel probing peak_kmer itself (dense peak sets), 1 the
  *      generic kernel behind the L2-resident bitmap, 2 the queued sparse kernel behind the bitmap, 3 the 128 KiB LDS fold in front of
- *      bitmap and peak_kmer; *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only
+ *      bitmap and peak_kmer, 4 (round 6) the shared-line-fill form of a dense peak set under a deep sample: reads grouped by their
+ *      smallest hash, a workgroup fetches every DISTINCT slot its 32 reads probe once (k_vote_shared.hip; environment
+ *      LHGT_SHARED_VOTE=0 never, =1 whenever e <= 3, default: when the grouping finds LHGT_SHARED_MIN = 8 reads per occupied bucket); *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only
  *      three quarters of them are used (3 MiB instead of 4).  Measurement only. */
 int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarter);
 /* ---- work counters for the roofline's "bytes the implemented algorithm must move" (bench.py).  enable = 1: count from
@@ -343,7 +349,8 @@ int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarte
  *      ref_flags_lite / ref_flags_trio marked as probed, summed before the fill of the unsettled tiles; the slot-first form: the
  *      probes of the positions it followed beyond the slot list, their number in [2]); [3] probes that
  *      went on from the LDS fold to the L2 bitmap; [4] probes that went on from the bitmap to peak_kmer; [5] pairs voted in the
- *      lane-per-offset form behind the filters; the others 0.  No reference counterpart: measurement only. */
+ *      lane-per-offset form behind the filters; [6] distinct peak_kmer slots the shared-line-fill vote fetched (its line fills) and [7] the probes it answered outside its LDS sets (one line fill each;
+ *      [5] then counts the pairs whose events were walked).  No reference counterpart: measurement only. */
 int lhgt_work_stats(lhgt_ctx* ctx, int enable, unsigned long long out[8]);
 int lhgt_stream(lhgt_ctx* ctx, void** hip_stream);
 int lhgt_synchronize(lhgt_ctx* ctx);

@@ -105,6 +105,7 @@ SIGNATURES = {
     "lhgt_phase_ms": [_vp, _i, _fp],
     "lhgt_scan_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), _lp, _lp],
     "lhgt_slot_list": [_vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "lhgt_slot_list_build_ms": [_vp, _dp],
     "lhgt_work_stats": [_vp, _i, _u64p],
     "lhgt_vote_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lhgt_stream": [_vp, C.POINTER(_vp)],

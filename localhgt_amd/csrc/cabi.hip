@@ -298,6 +298,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt::ingest_free(c);
     lhgt_ingest_pool_free(c);
     lhgt::slot_list_drop(c);
+    lhgt::vshared_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
                     (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words,
@@ -396,6 +397,12 @@ int lhgt_slot_list(lhgt_ctx* ctx, int mode, unsigned long long* entries, unsigne
     }
     if (entries) *entries = ctx->sl_state == 1 ? ctx->sl_entries : 0ull;
     if (bytes) *bytes = ctx->sl_state == 1 ? (ctx->d_sl_mid ? 10ull : 6ull) * ctx->sl_entries + 8ull * (unsigned long long)(ctx->sl_buckets + 1) : 0ull;
+    return LHGT_OK;
+}
+
+int lhgt_slot_list_build_ms(lhgt_ctx* ctx, double* ms) {
+    if (!ctx || !ms) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    *ms = ctx->sl_build_ms;
     return LHGT_OK;
 }
 

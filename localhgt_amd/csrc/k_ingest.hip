@@ -463,6 +463,7 @@ int install_pairs_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, const uint64_
     b.d.flags = d_cnt;
     b.d.n_pairs = n;
     ctx->batches.push_back(b);
+    ctx->store_gen++;
     ctx->n_pairs += n;
     return LHGT_OK;
 }
@@ -533,6 +534,7 @@ int install_pairs_chunked(lhgt_ctx* ctx, const uint8_t* d_ascii, const ChunkPair
     b.d.flags = d_fl;
     b.d.n_pairs = n;
     ctx->batches.push_back(b);
+    ctx->store_gen++;
     ctx->n_pairs += n;
     return LHGT_OK;
 }
@@ -542,6 +544,7 @@ void pairs_truncate(lhgt_ctx* ctx, size_t n_batches) {
         ctx->n_pairs -= ctx->batches.back().d.n_pairs;
         free_batch(ctx->batches.back());
         ctx->batches.pop_back();
+        ctx->store_gen++;
     }
 }
 
@@ -712,6 +715,7 @@ int lhgt_pairs_clear(lhgt_ctx* ctx) {
     for (auto& b : ctx->batches) free_batch(b);
     ctx->batches.clear();
     ctx->n_pairs = 0;
+    ctx->store_gen++;
     return LHGT_OK;
 }
 

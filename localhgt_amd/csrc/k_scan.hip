@@ -1614,6 +1614,7 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
     ctx->sl_state = 1;
     ctx->sl_smallest = smallest;
     ctx->sl_unlisted = unlisted;
+    ctx->sl_build_ms = (wall_s() - t0) * 1e3;
     if (trace) fprintf(stderr, "[lhgt] slot list (by the %s hash%s): %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", smallest ? "smallest" : "largest", ctx->d_sl_mid ? ", with the second-largest" : "", n_entries, nb, (ctx->d_sl_mid ? 10.0 : 6.0) * (double)n_entries / 1e9, wall_s() - t0);
     return LHGT_OK;
 }

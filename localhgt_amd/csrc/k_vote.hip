@@ -7,114 +7,9 @@
 // order-dependent judge_base logic, sequentially on lane 0 over the few events.
 #include <algorithm>
 #include "lhgt_hash.hpp"
+#include "k_vote_judge.hpp"
 
 namespace lhgt {
-
-// Per-wave LDS: events[max_ev][e] of (peak id, contig); the contig of a hit is fetched by the lane
-// that found it.  judge_base then runs out of registers: lane l holds events l, l+64, .. of the
-// current 64-event chunk and entries l, l+64, .. of the contig table (TR registers deep); an event
-// is broadcast with readlane, the table searched with one compare + ballot per register row.
-// EC = compile-time number of hashes (3), or 0 for the generic runtime-e form: the judge is bound by
-// instruction issue (mostly scalar control flow), so dead iterations and row walks are compiled away.
-template <int TR, int EC>
-__device__ __forceinline__ void judge_pair(const uint32_t* ev, int n_ev, int e_rt, int lane, uint32_t* __restrict__ filter) {
-    constexpr int EM = EC ? EC : 9;
-    const int e = EC ? EC : e_rt;
-    int tchr[TR], tcnt[TR], tfirst[TR];
-#pragma unroll
-    for (int r = 0; r < TR; r++) { tchr[r] = 0; tcnt[r] = 0; tfirst[r] = 0; }
-    int n_tab = 0;
-    for (int q0 = 0; q0 < n_ev; q0 += 64) {
-        uint32_t eid[EM], echr[EM];
-        const int myq = q0 + lane;
-#pragma unroll
-        for (int i = 0; i < EM; i++)
-            if (i < e) {
-                eid[i] = myq < n_ev ? ev[((size_t)myq * e + i) * 2] : 0u;
-                echr[i] = myq < n_ev ? ev[((size_t)myq * e + i) * 2 + 1] : 0u;
-            }
-        const int nq = n_ev - q0 < 64 ? n_ev - q0 : 64;
-        for (int qq = 0; qq < nq; qq++) {
-            const int q = __builtin_amdgcn_readfirstlane(qq);
-            int sel_chr = 0, sel_id = 0, sel_num = 0, sel_slot = -1;
-            int last_chr = -1, s = -1, cnt = 0;   // lookup of the previous hash of this event (counts do not move inside an event)
-#pragma unroll
-            for (int i = 0; i < EM; i++) {
-                if (!EC && i >= e) continue;
-                const int id = __builtin_amdgcn_readlane((int)eid[i], q);
-                if (!id) continue;
-                const int chr = __builtin_amdgcn_readlane((int)echr[i], q);
-                if (chr != last_chr) {
-                    last_chr = chr;
-                    s = -1;
-                    cnt = 0;
-                    {   // row 0: the whole table while it has <= 64 entries (the usual case)
-                        const unsigned long long bal = __ballot(lane < n_tab && tchr[0] == chr);
-                        if (bal) {
-                            s = __ffsll((long long)bal) - 1;
-                            cnt = __builtin_amdgcn_readlane(tcnt[0], s);
-                        }
-                    }
-                    if (TR > 1 && s < 0 && n_tab > 64) {
-#pragma unroll
-                        for (int r = 1; r < TR; r++) {
-                            if (s >= 0 || r * 64 >= n_tab) continue;
-                            const unsigned long long bal = __ballot(r * 64 + lane < n_tab && tchr[r] == chr);
-                            if (bal) {
-                                const int l = __ffsll((long long)bal) - 1;
-                                s = r * 64 + l;
-                                cnt = __builtin_amdgcn_readlane(tcnt[r], l);
-                            }
-                        }
-                    }
-                }
-                // among the hashes that hit, prefer the contig with the largest running count (ties: later
-                // hash, `>=` at E:131); an unseen contig is taken only if nothing is selected yet (E:140-144)
-                if (s >= 0) {
-                    if (cnt >= sel_num) { sel_id = id; sel_chr = chr; sel_num = cnt; sel_slot = s; }
-                } else if (sel_id == 0) { sel_id = id; sel_chr = chr; sel_num = 0; sel_slot = -1; }
-            }
-            const int slot = sel_slot >= 0 ? sel_slot : n_tab;
-            const bool mine = lane == (slot & 63);
-#pragma unroll
-            for (int r = 0; r < TR; r++)
-                if ((slot >> 6) == r) {                 // wave-uniform: only the owning row is touched
-                    if (sel_slot >= 0) tcnt[r] = mine ? sel_num + 1 : tcnt[r];
-                    else {                              // first peak of the contig (E:150-152)
-                        tchr[r] = mine ? sel_chr : tchr[r];
-                        tcnt[r] = mine ? 1 : tcnt[r];
-                        tfirst[r] = mine ? sel_id : tfirst[r];
-                    }
-                }
-            if (sel_slot < 0) n_tab++;
-        }
-    }
-    // check_split: contigs with >= 6 offsets; the two largest counts (with multiplicity) vote (E:161-202)
-    int largest = 0, n_f = 0;
-#pragma unroll
-    for (int r = 0; r < TR; r++) {
-        const int c = (r * 64 + lane < n_tab && tcnt[r] >= 6) ? tcnt[r] : 0;
-        n_f += __popcll(__ballot(c > 0));
-        largest = c > largest ? c : largest;
-    }
-    for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(largest, d); largest = o > largest ? o : largest; }
-    if (n_f > 1) {
-        int n_at = 0, second = 0;
-#pragma unroll
-        for (int r = 0; r < TR; r++) {
-            const int c = (r * 64 + lane < n_tab && tcnt[r] >= 6) ? tcnt[r] : 0;
-            n_at += __popcll(__ballot(c == largest));
-            second = (c < largest && c > second) ? c : second;
-        }
-        for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(second, d); second = o > second ? o : second; }
-        if (n_at > 1) second = largest;
-#pragma unroll
-        for (int r = 0; r < TR; r++) {
-            const int c = (r * 64 + lane < n_tab) ? tcnt[r] : 0;
-            if (c >= 6 && (c == largest || c == second)) atomicAdd(&filter[tfirst[r]], 1u);  // clamped to 254 at export (E:194)
-        }
-    }
-}
 
 // Any read length up to 500, probes of one 64-offset slice at a time.  PF: consult the L2-resident folded bitmap
 // first (exact negatives: a clear bit means no slot folding onto it holds a peak), so sparse peak sets never
@@ -124,7 +19,7 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                                                    const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
                                                    int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2,
-                                                   const uint32_t* __restrict__ pair_list) {
+                                                   const uint32_t* __restrict__ pair_list, long list_base) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
@@ -137,7 +32,9 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     // pair_list (vote_kernel_fold's deferred pairs): [0] = how many, then the pairs; null = every pair of the batch
     const long n_items = pair_list ? (long)pair_list[0] : b.n_pairs;
     for (long it = wave; it < n_items; it += n_waves) {
-        const long p = pair_list ? (long)pair_list[1 + it] : it;
+        // (list_base: a list of GLOBAL pair numbers over all resident batches -- k_vote_shared.hip -- holds other batches' pairs too)
+        const long p = pair_list ? (long)pair_list[1 + it] - list_base : it;
+        if (p < 0 || p >= b.n_pairs) continue;
         if (b.flags && !(b.flags[p] & PAIR_VOTE)) continue;   // counted only (surplus fq2 record, thread-chunk emulation)
         int n_ev = 0;
         for (int m = 0; m < 2; m++) {
@@ -664,6 +561,8 @@ __global__ void __launch_bounds__(256) compact_voted(const uint32_t* __restrict_
 
 using namespace lhgt;
 
+int lhgt_vote_shared(lhgt_ctx* ctx, bool* done, const uint32_t** d_list, unsigned long long* d_stats);   // k_vote_shared.hip
+
 extern "C" {
 
 int lhgt_vote(lhgt_ctx* ctx) {
@@ -672,9 +571,37 @@ int lhgt_vote(lhgt_ctx* ctx) {
     if (ctx->n_peaks < 0) LHGT_FAIL(LHGT_E_STATE, "lhgt_ref_scan must precede lhgt_vote");
     LHGT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     unsigned long long* d_stats = ctx->stats_on ? ctx->d_stats : nullptr;
+    // a dense peak set under a deep sample: the probes of overlapping reads share their line fills (k_vote_shared.hip); what that
+    // form leaves over -- pairs with a long read, pairs whose events found no room -- comes back as a list of global pair numbers
+    bool shared_done = false;
+    const uint32_t* shared_list = nullptr;
+    if (!ctx->prefilter_on) LHGT_TRY(lhgt_vote_shared(ctx, &shared_done, &shared_list, d_stats));
+    long pair_base = 0;
     for (const ReadBatch& b : ctx->batches) {
+        const long base_here = pair_base;
+        pair_base += b.d.n_pairs;
         int nk = b.max_len - ctx->k + 1;
         if (nk <= 0) continue;
+        if (shared_done) {
+            ctx->vote_form = 4;
+            const int ev_all = 2 * nk;
+            const size_t pw = ((size_t)ev_all * ctx->e * 2 + 64) * 4 + (ev_all > 256 ? 512 * 4 : 0);
+            int w = (int)(65536 / pw);
+            w = w > 4 ? 4 : w < 1 ? 1 : w;
+            long nb = (b.d.n_pairs + w - 1) / w;
+            if (nb > 256L * 16) nb = 256L * 16;
+#define LHGT_VOTE_REST(TR_)                                                                                                          \
+    do {                                                                                                                             \
+        if (pw * w > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((vote_kernel<TR_, 0, true>), dim3((unsigned)nb), dim3(64 * w), pw * w, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, \
+                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, 0u, 0, shared_list, base_here);  \
+    } while (0)
+            if (ev_all <= 256) LHGT_VOTE_REST(4);
+            else if (ev_all <= 512) LHGT_VOTE_REST(8);
+            else LHGT_VOTE_REST(16);
+#undef LHGT_VOTE_REST
+            continue;
+        }
         // a batch of short reads with a few long ones (lhgt_common.hpp: ReadBatch::n_long): the sparse forms take the pairs of short
         // reads and list the others, which the generic kernel votes behind them (votes are sums: the order is free)
         const bool mixed = nk > FAST_NK && b.n_long >= 0 && b.n_long * 8 <= 2 * b.d.n_pairs && ctx->e <= 3 && ctx->prefilter_on && !(ctx->debug & 32);
@@ -702,7 +629,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, PF_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                            ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr);          \
+                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr, 0L);      \
     } while (0)
         const bool nt = ctx->k >= 28;
         // the pairs on a list (the fold form's deferred pairs; a mixed batch's pairs with a long read) in the generic form, sized for
@@ -718,7 +645,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
     do {                                                                                                                             \
         if (pw * w > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, 1, false>), dim3((unsigned)nb), dim3(64 * w), pw * w, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, \
-                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, list);   \
+                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, list, 0L);   \
     } while (0)
             if (ev_all <= 256) LHGT_VOTE_LIST(4);
             else if (ev_all <= 512) LHGT_VOTE_LIST(8);

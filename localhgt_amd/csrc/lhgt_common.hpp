@@ -166,6 +166,7 @@ struct lhgt_ctx {
     unsigned long long* d_sl_off = nullptr;  // [sl_buckets + 1]
     unsigned long long sl_entries = 0;
     long sl_buckets = 0;
+    double sl_build_ms = 0.0;                // wall time of the last slot_list_build that built a list (host clock around its three kernels and allocations)
     bool sl_in_use = false;                  // a scan is running on the list: an allocation out of memory must not drop it (cabi.hip: drop_optional)
     int sl_state = 0;                        // 0 not tried for this reference, 1 built, -1 tried and left (no memory, e > 3, positions beyond 2^34)
     int sl_mode = 1;                         // lhgt_slot_list / LHGT_SLOT_LIST: 0 never, 1 before the second sparse scan of a reference, 2 before the first
@@ -177,6 +178,8 @@ struct lhgt_ctx {
     // reads
     std::vector<lhgt::ReadBatch> batches;
     long n_pairs = 0;
+    unsigned long long store_gen = 0;   // counts every change of the resident read store (what k_vote_shared.hip keeps per store is stale after one)
+    void* vshared = nullptr;            // lhgt_vshared* (k_vote_shared.hip): keys and order of the store's reads, arena
     // B/C
     uint32_t* d_peak_kmer = nullptr;
     int32_t* d_loci = nullptr;
@@ -190,7 +193,7 @@ struct lhgt_ctx {
     size_t revote_cap = 0;                 // words
     bool prefilter_on = false;
     uint32_t pf_mask = 0;             // low address bits indexing the prefilter
-    int vote_form = 0;                // which kernel the last lhgt_vote took: 0 generic on peak_kmer, 1 generic behind the bitmap, 2 queued behind the bitmap, 3 LDS fold + bitmap
+    int vote_form = 0;                // which kernel the last lhgt_vote took: 0 generic on peak_kmer, 1 generic behind the bitmap, 2 queued behind the bitmap, 3 LDS fold + bitmap, 4 shared line fills (k_vote_shared.hip)
     bool pf_q3 = false;               // the bitmap is three quarters of what pf_mask spans (lhgt_hash.hpp: PF_Q3)
     int pf2 = 0;                      // folded prefilter: shift of the address bits picking a key's second bit (0 = one bit per key)
     unsigned long long n_selected = 0;  // peak positions inside good intervals (new + merged) of the last scan
@@ -277,6 +280,7 @@ int index_install(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, boo
 int index_install_shard(lhgt_ctx* ctx, const uint32_t* host_words, size_t n_words, int rank, int world);
 int ws_reserve(lhgt_ctx* ctx, size_t ascii_bytes, size_t plane_words);
 void slot_list_drop(lhgt_ctx* ctx);   // k_scan.hip: the resident reference changes
+void vshared_free(lhgt_ctx* ctx);     // k_vote_shared.hip
 int hash_contig_to_device(lhgt_ctx* ctx, const uint8_t* ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_contig_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long len, uint32_t* d_out, uint8_t* d_valid);
 int hash_span_dev_ascii(lhgt_ctx* ctx, const uint8_t* d_ascii, long span_len, const uint64_t* coff, const uint64_t* out_word,

@@ -380,9 +380,11 @@ class Engine:
         sparse-form scan of a reference (default), 2 before the first, -1 query"""
         n, b = C.c_uint64(0), C.c_uint64(0)
         _lib.check(self.lib.lhgt_slot_list(self.h, int(mode), C.byref(n), C.byref(b)))
-        return {"entries": n.value, "bytes": b.value}
+        ms = C.c_double(0)
+        _lib.check(self.lib.lhgt_slot_list_build_ms(self.h, C.byref(ms)))
+        return {"entries": n.value, "bytes": b.value, "build_ms": round(ms.value, 1)}
 
-    WORK_STATS = ("count_keys", "scan_probes", "scan_followed", "vote_l2_probes", "vote_hbm_probes", "vote_revoted_pairs", None, None)
+    WORK_STATS = ("count_keys", "scan_probes", "scan_followed", "vote_l2_probes", "vote_hbm_probes", "vote_revoted_pairs", "vote_shared_fetches", "vote_shared_outside")
 
     def work_stats(self, enable: int = -1) -> dict:
         """work counters of the phases run since work_stats(1) (include/localhgt_hip.h: lhgt_work_stats); measurement only"""
@@ -395,7 +397,7 @@ class Engine:
         f, b, q = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.check(self.lib.lhgt_vote_info(self.h, C.byref(f), C.byref(b), C.byref(q)))
         mib = (1 << b.value) / 8 / (1 << 20) * (0.75 if q.value else 1.0) if b.value else 0.0
-        return {"form": ("dense", "bitmap", "queued", "fold")[f.value], "bitmap_MiB": round(mib, 3)}
+        return {"form": ("dense", "bitmap", "queued", "fold", "shared")[f.value], "bitmap_MiB": round(mib, 3)}
 
     def synchronize(self):
         _lib.check(self.lib.lhgt_synchronize(self.h))

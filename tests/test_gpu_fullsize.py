@@ -147,3 +147,33 @@ def test_count_on_load_equals_count_after_load(eng, tmp_path):
     eng.set_count_on_load(False)
     assert got[0] == got[1]
     assert got[0][1][0] < (1 << 32) and got[0][1][1] > 0
+
+
+def test_deep_sample_on_a_dense_peak_set_shares_its_line_fills(eng):
+    """round 6: 10 M pairs from 30 genomes of the 1 Gbase reference (100x) with SNPs at 1 % of the sample genomes' bases -- the
+    reference's own read model (test/run_BKP_detection.sh: species20_snp0.01) -- against a peak set voted without a bitmap (debug
+    bit 2).  The engine picks the shared-line-fill form by itself (40 reads per champion k-mer), mixes two batches (a 250-base pair
+    in each goes to the generic kernel behind it), and the votes are those of the dense generic kernel (bit 28: never shared)."""
+    eng.pairs_clear()
+    eng.synth_options(10, 20, 30)
+    eng.synth_read_mix(1, 250)                    # one pair in a thousand with 250-base reads: the form's fallback list
+    eng.synth_pairs(1, 2, NC, CL, 0, 6_000_000)
+    eng.synth_pairs(1, 3, NC, CL, 6_000_000, 4_000_000)
+    eng.synth_read_mix(0, 0)
+    eng.synth_options(0, 20, 0)
+    eng.counts_clear()
+    eng.count_kmers()
+    got = {}
+    for name, dbg in (("shared", 4), ("dense", 4 | (1 << 28)), ("picked", 0)):
+        eng.set_debug(dbg)
+        n = eng.ref_scan(0.1, 0.08, 300_000_000)
+        eng.work_stats(1)
+        eng.vote()
+        st = eng.work_stats(0)
+        got[name] = (n, eng.digest(eng.DIGEST_VOTES), eng.vote_info()["form"], st["vote_shared_fetches"])
+        eng.set_debug(0)
+    assert got["shared"][2] == "shared" and got["dense"][2] == "dense", got
+    assert got["shared"][:2] == got["dense"][:2] == got["picked"][:2], got
+    assert got["shared"][1][1] >= 10, "nothing voted: the check would be empty"
+    probes = 10_000_000 * 714
+    assert 0 < got["shared"][3] < probes / 4, f"{got['shared'][3]} line fills for {probes} probes: the reads do not share"

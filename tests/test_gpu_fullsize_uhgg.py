@@ -38,11 +38,12 @@ def _regular_index_form(eng):
         eng.synth_reference(1, NC, CL)
 
 
-_LIGHT = {"pairs": 25_000_000, "contigs": 1000}
+_LIGHT = {"pairs": 12_500_000, "contigs": 500}
 
 
 def _light_sample(eng):
-    """25 M pairs drawn from 1000 contigs (7.5x), resident and counted -- kept across tests that want the same sample (the count
+    """12.5 M pairs drawn from 500 contigs (7.5x; round 6: half of round 5's 25 M from 1000 -- 242 M raw peaks made every scan of it take
+    two seconds), resident and counted -- kept across tests that want the same sample (the count
     table does not depend on the reference)"""
     if getattr(eng, "_resident_sample", None) == _LIGHT and eng.pairs_count() == _LIGHT["pairs"]:
         return
@@ -74,7 +75,7 @@ def _vote(eng, debug):
     return d
 
 
-def _check_scans_and_votes(eng, expect_lite, tag):
+def _check_scans_and_votes(eng, expect_lite, tag, shared=False):
     exact, info_x = _scan(eng, 8192)
     assert not info_x["lite"]
     assert exact[0] > 1000, (tag, exact[0])
@@ -95,6 +96,9 @@ def _check_scans_and_votes(eng, expect_lite, tag):
     nofilter = _vote(eng, 4)                           # every probe goes to peak_kmer
     nofold = _vote(eng, 16)                            # never an LDS fold in front of the bitmap (the queued kernel)
     assert queued == generic == direct == nofilter == nofold, (tag, queued, generic, direct, nofilter, nofold)
+    if shared:                                         # the shared-line-fill form of a dense peak set (round 6), forced: same votes
+        sh = _vote(eng, 4 | (1 << 27))
+        assert eng.vote_info()["form"] == "shared" and sh == queued, (tag, eng.vote_info(), sh, queued)
     return exact, info_t, queued
 
 
@@ -118,7 +122,7 @@ def _count_both_ways(eng):
 # 128 KiB LDS fold with the deferred judge (vote_kernel_fold): the form `0` of the vote comparison is that kernel there.
 @pytest.mark.parametrize("pairs,sample_contigs,expect_lite,expect_votes",
                          [(25_000_000, 0, False, False), (35_000_000, 0, None, False), (100_000_000, 0, True, False),
-                          (25_000_000, 1000, None, True), (50_000_000, 300, None, True)])
+                          (12_500_000, 500, None, True), (50_000_000, 300, None, True)])
 def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_votes):
     eng._resident_sample = None
     eng.pairs_clear()
@@ -127,7 +131,7 @@ def test_uhgg_scale_forms_agree(eng, pairs, sample_contigs, expect_lite, expect_
     eng.synth_options(0, 20, 0)
     digest, hist = _count_both_ways(eng)               # leaves the direct kernel's table: same bits
     frac3 = hist[3] / float(1 << 32)
-    exact, info, votes = _check_scans_and_votes(eng, expect_lite, f"{pairs} pairs")
+    exact, info, votes = _check_scans_and_votes(eng, expect_lite, f"{pairs} pairs", shared=bool(sample_contigs))
     assert abs(info["frac_slots_at_3"] - frac3) < 0.01
     assert info["tiles"] == NC * CL // 2000
     if expect_votes:
@@ -236,7 +240,7 @@ def test_ragged_reference_forms_agree(eng):
     indexed = lens[lens > K]
     # a light sample on the ragged reference first (the one the test before left resident and counted): the exact form's territory
     _light_sample(eng)
-    exact, info, votes = _check_scans_and_votes(eng, None, "ragged 25 M")
+    exact, info, votes = _check_scans_and_votes(eng, None, "ragged 12.5 M", shared=True)
     assert votes[1] >= 1
     assert info["tiles"] == int(np.ceil(indexed / 2000).sum())
     # the packed form of the same ragged reference: contigs start anywhere inside a plane word (shared words are OR-ed together by

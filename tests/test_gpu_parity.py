@@ -115,10 +115,13 @@ def test_phases_match_oracle(Engine, oracle, case_inputs, name, tmp_path):
         assert (pf_g == pf_o[:n_g]).all()
         # every vote kernel (queued with its direct branch forced, generic with / without the bitmap, no LDS fold); the form of the scan the
         # engine picks by itself (0), the single-first ("lite") form, also with no tile settled early, and the trio-first form
-        for flags in (0, 2048, 32, 4, 16, 4096, 4096 | 256, 16384, 16384 | 256, 1 << 24, (1 << 24) | 256, 16384 | (1 << 25)):
+        # ... and (round 6) the shared-line-fill form of a dense peak set (bit 27: forced on this small store; bit 2: no bitmap)
+        for flags in (0, 2048, 32, 4, 16, 4096, 4096 | 256, 16384, 16384 | 256, 1 << 24, (1 << 24) | 256, 16384 | (1 << 25), 4 | (1 << 27)):
             eng.set_debug(flags)
             assert eng.ref_scan(case.hit_ratio, case.match_ratio, case.max_peak) == n_o     # clears the votes
             eng.vote()
+            if flags & (1 << 27):
+                assert eng.vote_info()["form"] == ("shared" if e <= 3 else "dense"), eng.vote_info()
             assert (eng.peaks_export(n_g)[1] == pf_o[:n_g]).all(), f"votes differ with debug flags {flags}"
             assert (eng.peaks_export(n_g)[0] == loci_o[:2 * n_o]).all() and (eng.peak_kmer_export() == pk_o).all(), flags
             form = eng.scan_info()["form"]
@@ -215,6 +218,25 @@ def test_extract_ref_matches_reference_golden(case_inputs, name, ref_form, tmp_p
     else:
         with pytest.raises(get_bed_file.InconsistentReferenceIds):
             get_bed_file.write_bed(fa2, interval)
+
+
+def test_shared_vote_with_no_room_for_its_events(case_inputs, tmp_path, monkeypatch):
+    """the shared-line-fill vote (k_vote_shared.hip) keeps the offsets with a hit in an arena; with an arena of four blocks nearly
+    every pair overflows and is voted by the generic kernel behind it: the reference's files all the same"""
+    from localhgt_amd import extract_ref
+    monkeypatch.setenv("LHGT_SHARED_ARENA", "0.0001")
+    monkeypatch.setenv("LHGT_DEBUG", str(4 | (1 << 27)))
+    for name in ("k24_base", "k24_t4", "k32_base"):
+        case = cases.CASES[name]
+        fa, f1, f2, meta = case_inputs(name)
+        d = tmp_path / name
+        d.mkdir()
+        fa2 = str(d / "ref.fa")
+        shutil.copy(fa, fa2)
+        interval = str(d / "interval.txt")
+        rep = extract_ref.run(extract_ref.parse_argv(cases.extract_ref_argv(case, f1, f2, fa2, interval)), log=lambda *a: None)
+        assert rep["n_peaks"] == meta["raw_peaks"]
+        assert open(interval).read() == open(os.path.join(cases.GOLDEN_DIR, name, "interval.txt")).read(), name
 
 
 # ------------------------------------------------------------------ edge cases

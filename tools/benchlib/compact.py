@@ -71,6 +71,11 @@ def compact_line(detail):
                          "ms_per_step": found.get("ms_per_step"), "phase_ms": {k: _num(v, 1) for k, v in found.get("phase_ms", {}).items()},
                          "recall": (found.get("planted_transfers") or {}).get("recall"), "filtered_peaks": found.get("filtered_peaks"),
                          "roofline": _roof_short(found.get("roofline"))}
+    sl = detail.get("slot_list_cost")
+    if isinstance(sl, dict):                              # the headline runs on a per-reference precompute: what it costs, when it has paid for itself
+        for kk in ("slot_list_build_ms", "value_without_list", "break_even_samples"):
+            if sl.get(kk) is not None:
+                line[kk] = sl[kk]
     ix = (detail.get("secondary") or {}).get("uhgg_index_form")
     if isinstance(ix, dict) and "value" in ix:            # the same workload with the index file's hashes resident: what rounds 1-4 led with
         line["value_index_form"] = _num(ix["value"])
@@ -109,6 +114,11 @@ def compact_line(detail):
         for tag, d in (e2e.get("big") or {}).items():
             if isinstance(d, dict) and "value" in d:
                 sec[f"e2e_32m_{tag}"] = {"value": d["value"]}
+        bt = e2e.get("batch_13g")
+        if isinstance(bt, dict) and "value" in bt:        # extract_ref --batch from files at 13 Gbase, reference load and list build included
+            sec["batch_13g_from_files"] = {"value": bt["value"], "steady": bt.get("steady_input_pairs_per_s_M"), "break_even_samples": bt.get("break_even_samples")}
+        elif isinstance(bt, dict):
+            sec["batch_13g_from_files"] = str(bt.get("error") or bt.get("skipped"))[:80]
         if "error" in e2e:
             sec["e2e_error"] = str(e2e["error"])[:80]
     if sec:

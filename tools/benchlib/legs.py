@@ -192,6 +192,69 @@ def e2e_from_files(k, e, device, n_contigs=100, contig_len=1_000_000, n_pairs=4_
     return out
 
 
+def e2e_batch(k, e, device, n_contigs=13000, contig_len=1_000_000, n_samples=5, pairs_per_sample=8_000_000, sample_contigs=300, time_budget_s=240):
+    """`extract_ref --batch` at the headline's reference size (round 6): n_samples samples as FASTQ files against the 13 Gbase
+    reference as a FASTA file, through localhgt_amd.extract_ref.run_batch -- what `bin/extract_ref --batch MANIFEST` calls -- with
+    LHGT_REF_FORM=packed: ONE context, the reference loaded by the first sample, its slot list built before the second sparse scan (the
+    engine's own rule), both kept for the rest.  Every sample's 12 arguments are those of scripts/pipeline.sh:35 (-t 10, sample = 1).
+    Reported: input pairs/s over the whole batch INCLUDING the reference load and the list build, the per-sample times, and the same
+    first sample as a call of its own (what one process per sample pays every time)."""
+    from localhgt_amd import extract_ref
+    from localhgt_amd.engine import Engine
+    from .files import write_fasta, write_fastq
+    t_all = time.time()
+    need = 1.1 * (n_contigs * (contig_len + 8) + n_samples * 2 * 320 * pairs_per_sample)
+    if shutil.disk_usage(tempfile.gettempdir()).free < need:
+        return {"skipped": f"needs {need / 1e9:.0f} GB of scratch space"}
+    with tempfile.TemporaryDirectory(prefix="lhgt_batch_") as tmp:
+        fa = os.path.join(tmp, "ref.fa")
+        samples = []
+        with near_gpu(device), Engine(k, e, device=device) as eng:
+            eng.rng_seed(1)
+            eng.coder_generate()
+            eng.set_reference_form(True)
+            write_fasta(fa, eng.synth_reference(1, n_contigs, contig_len, want_host=True), n_contigs, contig_len)
+            eng.synth_options(0, 20, sample_contigs)
+            for i in range(n_samples):
+                eng.pairs_clear()
+                m1, m2 = eng.synth_pairs(1, 100 + i, n_contigs, contig_len, 0, pairs_per_sample, 150, want_host=True)
+                f1, f2 = os.path.join(tmp, f"s{i}.1.fq"), os.path.join(tmp, f"s{i}.2.fq")
+                write_fastq(f1, m1, pairs_per_sample, 150, "1")
+                write_fastq(f2, m2, pairs_per_sample, 150, "2")
+                samples.append(extract_ref.Args(f1, f2, fa, os.path.join(tmp, f"s{i}.interval.txt"), 0.1, 0.08, 10, k, 300_000_000, e, 1, 1.0))
+        gen_s = time.time() - t_all
+        fq_bytes = sum(os.path.getsize(a.fq1) + os.path.getsize(a.fq2) for a in samples)
+        quiet = lambda *x: None                                   # noqa: E731
+        t0 = time.time()
+        reps = extract_ref.run_batch(samples, device=device, log=quiet, ref_form="packed")
+        batch_s = time.time() - t0
+        outs = [open(a.interval, "rb").read() for a in samples]
+        single = None
+        if time.time() - t_all < time_budget_s:                   # the first sample again as a process-per-sample call pays it (warm page cache, like the batch's later samples)
+            os.remove(samples[0].interval)
+            single = extract_ref.run(samples[0], device=device, log=quiet, ref_form="packed")
+            single["same_file"] = open(samples[0].interval, "rb").read() == outs[0]
+        per = [{"total_s": round(r["total_s"], 3), "reference_s": round(r["index_s"], 3), "reads_s": round(r["reads_s"], 3), "scan_s": round(r["scan_s"], 3),
+                "vote_s": round(r["vote_s"], 3), "scan_form": r["scan_form"], "ref_reused": r["ref_reused"], "raw_peaks": r["n_peaks"], "filtered_peaks": r["n_filtered"],
+                "slot_list_GB": round(r["slot_list_bytes"] / 1e9, 1)} for r in reps]
+        steady = [p["total_s"] for p in per[2:]] or [per[-1]["total_s"]]
+        out = {"value": round(n_samples * pairs_per_sample / batch_s / 1e6, 2), "unit": "M input pairs/s",
+               "what": f"extract_ref --batch: {n_samples} samples x {pairs_per_sample} pairs (FASTQ files, {fq_bytes / 1e9:.1f} GB, page cache; each drawn from {sample_contigs} genomes, sample = 1, -t 10) "
+                       f"against the {n_contigs * contig_len / 1e9:.0f} Gbase reference as a FASTA file, LHGT_REF_FORM=packed, ONE process and context; the time INCLUDES the "
+                       "reference load (first sample) and the slot list build (second sample)",
+               "batch_s": round(batch_s, 3), "samples": per, "steady_sample_s": round(sum(steady) / len(steady), 3),
+               "steady_input_pairs_per_s_M": round(pairs_per_sample / (sum(steady) / len(steady)) / 1e6, 2),
+               "files_written_s": round(gen_s, 1)}
+        if single:
+            out["one_process_per_sample"] = {"total_s": round(single["total_s"], 3), "reference_s": round(single["index_s"], 3), "scan_s": round(single["scan_s"], 3),
+                                             "scan_form": single["scan_form"], "value": round(pairs_per_sample / single["total_s"] / 1e6, 2),
+                                             "same_interval_file_as_in_the_batch": single["same_file"]}
+            gain = single["total_s"] - out["steady_sample_s"]
+            extra = sum(p["total_s"] for p in per[:2]) - 2 * single["total_s"]       # what the first two samples of the batch cost beyond two calls of their own
+            out["break_even_samples"] = round(2 + max(0.0, extra) / gain, 1) if gain > 0 else None
+    return out
+
+
 def pipelined_samples(k, e, device, n_contigs, contig_len, pairs, n_samples=4):
     """(--full only; measured in round 3: gain 0.998.)  Two contexts on one GPU (each with its own stream, tables and read store;
     the reference resident as packed bases in both), two host threads: a sample's phase A may run while the other context is in

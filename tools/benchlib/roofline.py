@@ -107,6 +107,13 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
         out["vote_kernel"] = (reads + hb * LINE,
                               f"reads {reads} + {hb} probes of peak_kmer x {LINE} B ({hb / max(1, pairs):.2f} per pair survive the "
                               f"{'LDS fold and the ' if vote_form == 'fold' else ''}L2-resident bitmap, which costs no HBM byte)")
+    elif vote_form == "shared":
+        # round 6: reads grouped by their smallest hash, a workgroup fetches every distinct slot of its 32 reads once; the records are
+        # read three times (keys -- once per store --, insert pass, lookup pass), the events written and read back by the judge
+        fetched = stats.get("vote_shared_fetches", 0) + stats.get("vote_shared_outside", 0)
+        out["vote_kernel"] = (2 * reads + fetched * LINE + pairs * 2 * 8,
+                              f"reads twice 2 x {reads} + {fetched} distinct slots of peak_kmer x {LINE} B ({fetched / max(1, pairs):.1f} line fills per pair for "
+                              f"{keys / max(1, pairs):.0f} probes: overlapping reads share them) + per-read event records {pairs * 2 * 8}")
     else:
         out["vote_kernel"] = (reads + keys * LINE, f"reads {reads} + {keys} probes of peak_kmer x {LINE} B (no on-chip filter: dense peak set)")
     return out
@@ -160,7 +167,7 @@ def roofline_entry(kernel, desc, ms_step, launches, model_b, needed, traffic_rec
 def vote_form_of(vote, stats):
     """which vote kernel lhgt_vote took: from Engine.vote_info(), else from what it counted"""
     if vote:
-        return vote["form"] if vote["form"] in ("fold", "queued") else "dense"
+        return vote["form"] if vote["form"] in ("fold", "queued", "shared") else "dense"
     if stats.get("vote_l2_probes"):
         return "fold"
     if stats.get("vote_hbm_probes") or stats.get("vote_revoted_pairs"):
@@ -182,7 +189,7 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
     scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio", "slot-first": "ref_flags_slots",
                    "slot-single": "no_kmer_flags+ref_single_slots+ref_trio_runs"}.get(scan["form"], "ref_flags")
-    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued"}.get(vform, "vote_kernel")
+    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued", "shared": "vs_probe+vs_judge"}.get(vform, "vote_kernel")
     info = {
         "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
                     f"phase A kernel family, {n_chunks} chunks of <= {8 if direct else 4} Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",
@@ -196,9 +203,10 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
                       model_ref, 1, HBM_CEILING, "hbm_lines"),
         "vote_kernel": (vote_kernel, f"phase C read re-scan, {2 * (L - k + 1) * e} probes per pair "
                         + {"fold": "screened by a 128 KiB LDS fold, then the L2-resident bitmap, then peak_kmer",
-                           "queued": "answered by the L2-resident bitmap except for its survivors"}.get(vform, "into peak_kmer")
-                        + f"; {n_batches} launches per step", model_pairs, n_batches, HBM_CEILING if vform == "dense" else L2_CEILING,
-                        "hbm_lines" if vform == "dense" else "l2_requests"),
+                           "queued": "answered by the L2-resident bitmap except for its survivors",
+                           "shared": "answered from LDS sets of the distinct slots of 32 reads that share a champion k-mer, each slot fetched once"}.get(vform, "into peak_kmer")
+                        + f"; {1 if vform == 'shared' else n_batches} launches per step", model_pairs, 1 if vform == "shared" else n_batches,
+                        HBM_CEILING if vform in ("dense", "shared") else L2_CEILING, "hbm_lines" if vform in ("dense", "shared") else "l2_requests"),
     }
     keys_a = (stats or {}).get("count_keys") or pairs * 2 * (L - k + 1) * e
     roof = {ph: roofline_entry(info[ph][0], info[ph][1], kern[ph], info[ph][3], info[ph][2], need.get(ph), traffic.get(ph) if src else None, src, info[ph][4],

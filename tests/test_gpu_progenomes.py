@@ -55,6 +55,30 @@ def test_progenomes_scale_reference_on_one_gpu(k, oracle, tmp_path):
             assert got == exact, (dbg, sinfo)
         votes = _vote(e, 0)
         assert votes == _vote(e, 32) == _vote(e, 4) == _vote(e, 1 << 19) and (votes[1] >= 1 or k < 32), votes   # bit 19: every pair walked, no bound
+        # configs[4] AS NAMED (round 6): 200 M input pairs under the CLI's default --sample 2000000000 -- the reference's own answer to a
+        # sample too dense for max_peak (E:1392-1398, scripts/infer_HGT_breakpoint.py:209): ratio = 2e9 / (2 x 200 M x 150) = 3.33 %, i.e.
+        # 6 666 666 pairs pass the sampling array whatever the input size; a subset of iid pairs is iid, so the kept pairs are generated
+        # directly.  The same properties on that sample: forms of the scan and of the vote agree, max_peak (the default 3 x 10^8) holds
+        kept = int(2e9 / (2 * 150))
+        e.pairs_clear()
+        e.synth_options(0, 20, 300)
+        e.synth_pairs(1, 3, nc, CL, 0, kept)
+        e.synth_options(0, 20, 0)
+        e.counts_clear()
+        e.count_kmers()
+        named, _ = _scan(e, 8192)
+        assert 0 < named[0] < 300_000_000
+        for dbg in (0, 16384):
+            got, sinfo = _scan(e, dbg)
+            assert got == named, ("as named", dbg, sinfo)
+        assert _vote(e, 0) == _vote(e, 4), "as named"
+        # (back to the 10 M-pair sample for the address checks below)
+        e.pairs_clear()
+        e.synth_options(0, 20, 300)
+        e.synth_pairs(1, 2, nc, CL, 0, 10_000_000)
+        e.synth_options(0, 20, 0)
+        e.counts_clear()
+        e.count_kmers()
         n_peaks = e.ref_scan(0.1, 0.08, 300_000_000)
         loci, _ = e.peaks_export(n_peaks)
         contig, pos = loci[0::2].astype(np.int64), loci[1::2].astype(np.int64)

@@ -99,10 +99,13 @@ def compact_line(detail):
     for name, d in (detail.get("secondary") or {}).items():
         if name == "uhgg_deep_focused_sample":
             continue
-        if name == "configs4_progenomes_1gpu" and isinstance(d, dict):
+        if name in ("configs4_progenomes_1gpu", "configs4_as_named") and isinstance(d, dict):
             for kk in ("k32", "k21"):
                 if _leg(d.get(kk)):
-                    sec[f"configs4_{kk}"] = _leg(d[kk])
+                    tag = f"configs4_{kk}" if name == "configs4_progenomes_1gpu" else f"configs4_named_{kk}"
+                    sec[tag] = _leg(d[kk])
+                    if "input_pairs_per_s_M" in d[kk]:
+                        sec[tag]["input"] = d[kk]["input_pairs_per_s_M"]
         elif _leg(d):
             sec[name] = _leg(d)
         elif isinstance(d, str):

@@ -249,7 +249,7 @@ def main():
     moved_main = dict(dist.moved) if dist else None
     sl_info = eng.slot_list() if args.ref_form == "packed" else {"entries": 0, "bytes": 0}      # of the form the timed steps ran on
     sl_cost = None
-    if sl_info["entries"] and world == 1 and not args.debug and scan["form"] in ("slot-first", "slot-single"):
+    if sl_info["entries"] and world == 1 and not args.debug and not args.no_stats and scan["form"] in ("slot-first", "slot-single"):   # (not in the PMC children: their counters must see the timed step alone)
         # the list is a per-reference precompute built OUTSIDE the timed steps (like the reference load): what it cost, the same steps
         # without it (debug bit 25: phase B's position-ordered kernels on the same packed reference), and after how many samples of one
         # resident reference it has paid for itself.  `bin/extract_ref --batch` is the shipped entry point that reaches this state.

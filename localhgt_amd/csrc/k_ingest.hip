@@ -716,6 +716,7 @@ int lhgt_pairs_clear(lhgt_ctx* ctx) {
     ctx->batches.clear();
     ctx->n_pairs = 0;
     ctx->store_gen++;
+    lhgt::vshared_free(ctx);      // what the shared-line-fill vote kept about this store's reads (15 GB per 100 M pairs; the blocks stay with the process)
     return LHGT_OK;
 }
 

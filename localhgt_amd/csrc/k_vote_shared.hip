@@ -33,11 +33,11 @@ namespace lhgt {
 
 constexpr int VS_G = 64;                  // reads per work item at most (one bucket of the grouping, or a piece of a large one)
 constexpr int VS_WAVES = 8;
-constexpr int VS_SET = 4096;              // entries of the LDS set: (slot, id) pairs, 32 KiB -- 64 overlapping reads probe ~1500 distinct slots
-constexpr int VS_SET_BITS = 12;
+constexpr int VS_SET = 2048;              // entries of the LDS set: a k-mer (8 bytes) and the contigs its e <= 3 slots name (12 bytes), 40 KiB -- the
+constexpr int VS_SET_BITS = 11;           // <= 64 reads of a bucket hold ~240 distinct k-mers per champion locus, a few hundred more where keys share a bucket
 constexpr int VS_PROBES = 8;
 constexpr int VS_REC = 20;                // LDS words per staged record (three planes of <= 6 words: reads of <= FAST_NK offsets)
-constexpr uint32_t VS_EMPTY = 0xffffffffu;
+constexpr unsigned long long VS_EMPTY64 = ~0ull;      // no canonical k-mer: all ones is poly-T, whose reverse complement (poly-A, all zeros) is the smaller
 constexpr uint32_t VS_NOKEY = 0xffffffffu;
 // what a read leaves for the pair filter: 48 bytes
 struct VsReadRec {
@@ -80,6 +80,27 @@ __device__ __forceinline__ bool vs_hashes(const uint32_t* rec, const VsRead& rd,
 #pragma unroll
     for (int i = 0; i < 3; i++) h[i] = i < e ? hash_from_windows(whi, wlo, rhi, rlo, hp.mask[i]) : 0u;
     return j < rd.nk && wnb == 0;
+}
+
+// the k-mer at offset s * 64 + lane as ONE key: the smaller of its 2-bit code (hi plane << 32 | lo plane) and its reverse
+// complement's.  A k-mer and its reverse complement have the same e hashes (each hash is min(forward, reverse), E:447-452), so the
+// set can hold k-mers instead of slots: one entry, one compare-and-swap and one lookup per k-mer instead of e, and the hashes are
+// only computed once per DISTINCT k-mer of a work item (from the key: vs_key_hash).
+__device__ __forceinline__ bool vs_kmer(const uint32_t* rec, const VsRead& rd, int s, int lane, int k, unsigned long long* key) {
+    const int j = s * 64 + lane, r = j & 31;
+    const uint32_t* q = rec + (j < rd.nk ? (j >> 5) : 0);
+    const int wp = rd.wpr;
+    auto win = [&](uint32_t a, uint32_t c) { return window32(a, c, r) >> (32 - k); };
+    const uint32_t whi = win(q[0], q[1]), wlo = win(q[wp], q[wp + 1]), wnb = win(q[2 * wp], q[2 * wp + 1]);
+    const uint32_t kmask = k >= 32 ? 0xffffffffu : (1u << k) - 1u;
+    const uint32_t chi = ~brev_k(whi, k) & kmask, clo = ~brev_k(wlo, k) & kmask;
+    const unsigned long long f = ((unsigned long long)whi << 32) | wlo, c = ((unsigned long long)chi << 32) | clo;
+    *key = f < c ? f : c;
+    return j < rd.nk && wnb == 0;
+}
+__device__ __forceinline__ uint32_t vs_key_hash(unsigned long long key, int k, const uint32_t* __restrict__ m) {
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    return hash_from_windows(hi, lo, brev_k(hi, k), brev_k(lo, k), m);
 }
 
 // ---------------------------------------------------------------- keys
@@ -223,35 +244,36 @@ __global__ void __launch_bounds__(256) vs_make_items(const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------- probe
-__device__ __forceinline__ uint32_t vs_slot(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - VS_SET_BITS); }
-// The six probes of a lane (two slices of 64 offsets x three hashes) walk the set TOGETHER: one LDS round trip serves all six --
-// taken one after the other the walks were the kernel's time (profiles/r06: 127 us per work item, 6 x the estimate).  A probe is
-// one compare-and-swap: it finds the slot empty (and takes it), or holding its own key, or moves on.  `todo` = the probes still
-// looking for their place (bit i); where[i] = the entry a probe ended at, VS_OUT if the set had no room for it within VS_PROBES
-// entries (it then asks peak_kmer itself), VS_DEAD for a probe that is not live (offset beyond the read, k-mer with an N, hash i >= e).
+__device__ __forceinline__ uint32_t vs_slot(unsigned long long key) {
+    return (((uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - VS_SET_BITS);
+}
+// The k-mers of a lane (two slices of 64 offsets) walk the set TOGETHER, in straight-line selects: one LDS round trip serves both
+// (rounds 6's earlier forms: the probes one after the other were the kernel's time -- 127 us per work item, 6 x the estimate --, and
+// written with `if`s every probe became an exec region with its own copies of the slot registers, 250 instructions per round:
+// profiles/r06).  A probe is one 64-bit compare-and-swap: it finds the entry empty (and takes it), or holding its own k-mer, or moves
+// on; a probe that is done plays its compare-and-swap on the lane's dummy word, which never matches.  where[i] = the entry a k-mer
+// ended at, VS_OUT if the set had no room for it within VS_PROBES entries (it then asks peak_kmer itself), VS_DEAD for an offset
+// beyond the read or a k-mer with an N.
 constexpr uint32_t VS_OUT = 0xfffeu, VS_DEAD = 0xffffu;
 template <int N>
-__device__ __forceinline__ void vs_insert_n(uint32_t* set, uint32_t* dummy /* one word per lane that never reads VS_EMPTY */, const uint32_t (&h)[N],
-                                            uint32_t live, uint32_t (&where)[N]) {
-    // straight-line selects, no branch per probe: written with `if`s the compiler made an exec region with its own copies of the six
-    // slot registers out of every probe (250 instructions per round, profiles/r06); a probe that is done plays its compare-and-swap
-    // on the lane's dummy word, which never matches
+__device__ __forceinline__ void vs_insert_n(unsigned long long* keys, unsigned long long* dummy /* one per lane, never VS_EMPTY64 */,
+                                            const unsigned long long (&key)[N], uint32_t live, uint32_t (&where)[N]) {
     uint32_t s[N], todo[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        s[i] = vs_slot(h[i]);
-        const uint32_t lv = (live >> i) & 1u;
-        where[i] = lv ? VS_OUT : VS_DEAD;
-        todo[i] = lv & (uint32_t)(h[i] != VS_EMPTY);
+        s[i] = vs_slot(key[i]);
+        todo[i] = (live >> i) & 1u;
+        where[i] = todo[i] ? VS_OUT : VS_DEAD;
     }
 #pragma unroll 1
     for (int t = 0; t < VS_PROBES; t++) {
-        uint32_t old[N], left = 0u;
+        unsigned long long old[N];
+        uint32_t left = 0u;
 #pragma unroll
-        for (int i = 0; i < N; i++) old[i] = atomicCAS(todo[i] ? &set[2 * s[i]] : dummy, VS_EMPTY, h[i]);
+        for (int i = 0; i < N; i++) old[i] = atomicCAS(todo[i] ? &keys[s[i]] : dummy, VS_EMPTY64, key[i]);
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            const uint32_t fin = todo[i] & (uint32_t)((old[i] == VS_EMPTY) | (old[i] == h[i]));
+            const uint32_t fin = todo[i] & (uint32_t)((old[i] == VS_EMPTY64) | (old[i] == key[i]));
             where[i] = fin ? s[i] : where[i];
             todo[i] &= ~fin;
             s[i] = todo[i] ? ((s[i] + 1) & (VS_SET - 1)) : s[i];
@@ -267,13 +289,15 @@ __device__ __forceinline__ void vs_insert_n(uint32_t* set, uint32_t* dummy /* on
 __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, const uint2* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ order,
                                                           const unsigned long long* __restrict__ desc, const uint32_t* __restrict__ peak_kmer,
                                                           const int32_t* __restrict__ loci, VsReadRec* __restrict__ read_rec,
-                                                          unsigned long long* __restrict__ stats /* nullable: [0] distinct slots fetched, [1] lanes with a probe answered outside the set */,
+                                                          unsigned long long* __restrict__ stats /* nullable: [0] slots fetched for the sets, [1] probes answered outside them */,
                                                           int ablate /* stage timing (LHGT_VS_ABLATE; outputs wrong): 1 no inserts, 2 no fetches, 4 no lookups, 8 no records, 16 nothing after the reads' records */) {
-    __shared__ __align__(16) uint32_t set[2 * VS_SET];
+    __shared__ __align__(16) unsigned long long skey[VS_SET];   // the set's k-mers
+    __shared__ uint32_t sval[3 * VS_SET];            // per entry: the contig each of its e slots names (0: the slot holds no id)
     __shared__ uint32_t recs[VS_G * VS_REC];
     __shared__ unsigned long long rdesc[VS_G];
     __shared__ uint32_t rid[VS_G + 2];              // [VS_G], [VS_G + 1]: the item's sums for lhgt_work_stats
-    __shared__ uint32_t counters[VS_WAVES * 128];     // per wave: 64 contig buckets, 64 dummy words (one per lane) for the probes and hits that do not count
+    __shared__ __align__(8) unsigned long long dummy[64 * VS_WAVES];   // one word per lane for the compare-and-swaps and counts that do not count (never all ones)
+    __shared__ uint32_t counters[VS_WAVES * 64];     // per wave: the 64 contig buckets of the read at hand
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int k = hp.k, e = hp.e;
     const long item = block2d();
@@ -285,8 +309,8 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
         rid[threadIdx.x] = r;
         rdesc[threadIdx.x] = desc[r];
     }
-    for (int i = threadIdx.x; i < VS_SET; i += 64 * VS_WAVES) { set[2 * i] = VS_EMPTY; set[2 * i + 1] = 0u; }
-    counters[wib * 128 + 64 + lane] = 0u;
+    for (int i = threadIdx.x; i < VS_SET; i += 64 * VS_WAVES) skey[i] = VS_EMPTY64;
+    dummy[threadIdx.x] = 0ull;
     if (threadIdx.x < 2) rid[VS_G + threadIdx.x] = 0u;
     __syncthreads();
     for (int idx = threadIdx.x; idx < n_here * VS_REC; idx += 64 * VS_WAVES) {
@@ -297,48 +321,50 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
     }
     __syncthreads();
     if (ablate & 16) return;
-    // 1. every slot the item's reads probe enters the set; a lane remembers WHERE each of its probes ended (16 bits per probe, three
-    //    registers per read, a wave has at most VS_G / VS_WAVES = 8 reads) so that step 3 neither hashes nor searches again
+    // 1. every k-mer of the item's reads enters the set; a lane remembers WHERE each of its two k-mers ended (16 bits each, one
+    //    register per read, a wave has at most VS_G / VS_WAVES = 8 reads) so that step 3 neither builds nor searches them again
     constexpr int RPW = VS_G / VS_WAVES;
-    uint32_t wh[RPW][3];
+    uint32_t wh[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; rr++) {
-        wh[rr][0] = wh[rr][1] = wh[rr][2] = VS_DEAD | (VS_DEAD << 16);
+        wh[rr] = VS_DEAD | (VS_DEAD << 16);
         const int q = wib + rr * VS_WAVES;
         if (q < n_here && !(ablate & 1)) {
             const VsRead rd = vs_shape((int)(rdesc[q] >> 48), k);
-            uint32_t h[6], where[6], live = 0u;
+            unsigned long long key[2];
+            uint32_t where[2], live = 0u;
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                uint32_t hs[3];
-                const bool ok = vs_hashes(recs + q * VS_REC, rd, s, lane, k, e, hp, hs);
-#pragma unroll
-                for (int i = 0; i < 3; i++) { h[3 * s + i] = hs[i]; if (ok && i < e) live |= 1u << (3 * s + i); }
-            }
-            vs_insert_n<6>(set, counters + wib * 128 + 64 + lane, h, live, where);
-#pragma unroll
-            for (int i = 0; i < 3; i++) wh[rr][i] = where[2 * i] | (where[2 * i + 1] << 16);
+            for (int s = 0; s < 2; s++)
+                if (vs_kmer(recs + q * VS_REC, rd, s, lane, k, &key[s])) live |= 1u << s;
+            vs_insert_n<2>(skey, dummy + threadIdx.x, key, live, where);
+            wh[rr] = where[0] | (where[1] << 16);
         }
     }
     __syncthreads();
-    // 2. one fetch per distinct slot, all of a thread's in flight together; the set's value becomes the CONTIG of the id found
-    //    (count_peak_kmer's peak_chr, E:455; contigs number from 1), 0 where the slot holds no id
+    // 2. per distinct k-mer: its e hashes (from the key), one fetch per slot, all of a thread's in flight together; the set's values
+    //    become the CONTIG of the id each slot holds (count_peak_kmer's peak_chr, E:455; contigs number from 1), 0 where it holds none
     {
         constexpr int U = VS_SET / (64 * VS_WAVES);
         int n_mine = 0;
-        uint32_t key[U], val[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) key[u] = set[2 * (u * 64 * VS_WAVES + threadIdx.x)];
+        uint32_t val[U][3];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            val[u] = 0u;
-            if (key[u] != VS_EMPTY && !(ablate & 2)) { val[u] = __builtin_nontemporal_load(peak_kmer + key[u]); n_mine++; }
+            const unsigned long long key = skey[u * 64 * VS_WAVES + threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                val[u][i] = 0u;
+                if (key != VS_EMPTY64 && i < e && !(ablate & 2)) { val[u][i] = __builtin_nontemporal_load(peak_kmer + vs_key_hash(key, k, hp.mask[i])); n_mine++; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (val[u]) val[u] = (uint32_t)loci[2 * (long)val[u]];
 #pragma unroll
-        for (int u = 0; u < U; u++) set[2 * (u * 64 * VS_WAVES + threadIdx.x) + 1] = val[u];
+            for (int i = 0; i < 3; i++)
+                if (val[u][i]) val[u][i] = (uint32_t)loci[2 * (long)val[u][i]];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) sval[3 * (u * 64 * VS_WAVES + threadIdx.x) + i] = val[u][i];
         if (stats) {       // (one global atomic per workgroup: 48 M waves adding to one address took 300 ms)
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) n_mine += __shfl_xor(n_mine, d, 64);
@@ -347,8 +373,9 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
     }
     __syncthreads();
     if (stats && threadIdx.x == 0) atomicAdd(stats, (unsigned long long)rid[VS_G]);
-    // 3. the reads again: the contig of every probe from where step 1 left it, summed up per read
-    uint32_t* cnt = counters + wib * 128;
+    // 3. the reads again: the contigs of every k-mer's slots from where step 1 left it, summed up per read
+    uint32_t* cnt = counters + wib * 64;
+    uint32_t* my_dummy = reinterpret_cast<uint32_t*>(dummy + threadIdx.x);       // its low half (the high half stays zero)
     unsigned long long st_out = 0;
 #pragma unroll
     for (int rr = 0; rr < RPW; rr++) {
@@ -357,26 +384,29 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
         const uint32_t r = rid[q];
         uint32_t chr[6], outside = 0u;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const uint32_t w = (wh[rr][i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-            chr[i] = set[2 * (w < (uint32_t)VS_SET ? w : 0u) + 1];      // unconditional load, masked afterwards
-            if (w >= (uint32_t)VS_SET) chr[i] = 0u;
-            if (w == VS_OUT) outside |= 1u << i;
+        for (int s = 0; s < 2; s++) {
+            const uint32_t w = (wh[rr] >> (s * 16)) & 0xffffu;
+            const uint32_t at = 3u * (w < (uint32_t)VS_SET ? w : 0u);          // unconditional loads, masked afterwards
+#pragma unroll
+            for (int i = 0; i < 3; i++) chr[3 * s + i] = (w < (uint32_t)VS_SET && i < e) ? sval[at + i] : 0u;
+            if (w == VS_OUT) outside |= 1u << s;
         }
-        if (__any(outside != 0u)) {       // the set had no room for this probe: its key again, peak_kmer itself, then the contig of the id
+        if (__any(outside != 0u)) {       // the set had no room for this k-mer: its key again, peak_kmer itself, then the contig of the id
             const VsRead rd = vs_shape((int)(rdesc[q] >> 48), k);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                uint32_t hs[3];
-                vs_hashes(recs + q * VS_REC, rd, s, lane, k, e, hp, hs);
+                unsigned long long key;
+                vs_kmer(recs + q * VS_REC, rd, s, lane, k, &key);
+                if ((outside >> s) & 1u) {
 #pragma unroll
-                for (int i = 0; i < 3; i++)
-                    if ((outside >> (3 * s + i)) & 1u) {
-                        const uint32_t id = __builtin_nontemporal_load(peak_kmer + hs[i]);
-                        chr[3 * s + i] = id ? (uint32_t)loci[2 * (long)id] : 0u;
-                    }
+                    for (int i = 0; i < 3; i++)
+                        if (i < e) {
+                            const uint32_t id = __builtin_nontemporal_load(peak_kmer + vs_key_hash(key, k, hp.mask[i]));
+                            chr[3 * s + i] = id ? (uint32_t)loci[2 * (long)id] : 0u;
+                        }
+                }
             }
-            if (stats) st_out += (unsigned long long)__popcll(__ballot(outside != 0u));
+            if (stats) st_out += (unsigned long long)(__popcll(__ballot(outside & 1u)) + __popcll(__ballot(outside & 2u))) * (unsigned long long)e;
         }
         if (ablate & 8) continue;
         const unsigned long long any0 = __ballot((chr[0] | chr[1] | chr[2]) != 0u), any1 = __ballot((chr[3] | chr[4] | chr[5]) != 0u);
@@ -404,7 +434,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
             const bool hit = chr[i] != 0u, st = chr[i] == star;
             mine_hits += hit;
             mine_star += hit & st;
-            atomicAdd(&cnt[hit && !st ? vs_contig_bucket(chr[i]) : 64u + (uint32_t)lane], 1u);
+            atomicAdd(hit && !st ? &cnt[vs_contig_bucket(chr[i])] : my_dummy, 1u);
         }
         int both = mine_hits | (mine_star << 16);
 #pragma unroll

@@ -13,7 +13,7 @@
 //            A pair votes only if TWO contigs collect six hit offsets each (check_split E:161-202), and judge_base credits every hit
 //            offset to one of the contigs its hashes name (E:118-159): what a read keeps is therefore what an upper bound of "which
 //            contigs can reach six" needs -- its hits and hit offsets, the contig most of its hits name (exactly counted), and the hits
-//            on all other contigs in 64 hashed 4-bit counters (32 bytes).
+//            on all other contigs in 128 hashed 4-bit counters (64 bytes).
 //   filter   per PAIR (one lane): the two reads' records added up; a pair in which at most one contig can reach six is done.
 //   vote     the pairs that are left -- a few per cent where the sample's reads sit on their own contigs -- are voted from scratch by
 //            the generic kernel (vote_kernel on a pair list): the same hits in the same order through the same judge_pair, so the
@@ -39,15 +39,16 @@ constexpr int VS_PROBES = 8;
 constexpr int VS_REC = 20;                // LDS words per staged record (three planes of <= 6 words: reads of <= FAST_NK offsets)
 constexpr unsigned long long VS_EMPTY64 = ~0ull;      // no canonical k-mer: all ones is poly-T, whose reverse complement (poly-A, all zeros) is the smaller
 constexpr uint32_t VS_NOKEY = 0xffffffffu;
-// what a read leaves for the pair filter: 48 bytes
+// what a read leaves for the pair filter: 80 bytes
+constexpr int VS_CB = 128;      // contig buckets of the filter (64: 5 % of the SNP leg's pairs passed, most of them on foreign hits that met in a bucket)
 struct VsReadRec {
-    unsigned long long sk[4];   // bit b of sk[j] = bit j of bucket b's count (saturating at 15) of the hits NOT on `star`
-    uint32_t star;              // the contig most hits name (the contig of a hit near the middle of the read; 0: no hit)
+    unsigned long long sk[VS_CB / 64][4];   // bit b of sk[w][j] = bit j of bucket 64 w + b's count (saturating at 15) of the hits NOT on `star`
+    uint32_t star;              // the contig most hits name (the contig of an offset whose e hashes agree; 0: no hit)
     uint32_t n_star;            // hits on it, exactly
     uint32_t n_hits;            // probes that found an id
     uint32_t n_ev;              // offsets with a hit
 };
-__device__ __forceinline__ uint32_t vs_contig_bucket(uint32_t chr) { return (chr * 0x9E3779B1u) >> 26; }
+__device__ __forceinline__ uint32_t vs_contig_bucket(uint32_t chr) { return (chr * 0x9E3779B1u) >> 25; }     // 7 bits: VS_CB buckets
 
 struct VsBatches {                         // the resident batches as one numbering of pairs
     const ReadBatchDev* d;
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
     __shared__ unsigned long long rdesc[VS_G];
     __shared__ uint32_t rid[VS_G + 2];              // [VS_G], [VS_G + 1]: the item's sums for lhgt_work_stats
     __shared__ __align__(8) unsigned long long dummy[64 * VS_WAVES];   // one word per lane for the compare-and-swaps and counts that do not count (never all ones)
-    __shared__ uint32_t counters[VS_WAVES * 64];     // per wave: the 64 contig buckets of the read at hand
+    __shared__ uint32_t counters[VS_WAVES * 64];     // per wave: the VS_CB = 128 contig buckets of the read at hand, 16 bits each (bucket b in half b >> 6 of word b & 63; a read has <= 384 hits)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int k = hp.k, e = hp.e;
     const long item = block2d();
@@ -434,17 +435,25 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
             const bool hit = chr[i] != 0u, st = chr[i] == star;
             mine_hits += hit;
             mine_star += hit & st;
-            atomicAdd(hit && !st ? &cnt[vs_contig_bucket(chr[i])] : my_dummy, 1u);
+            const uint32_t bk = vs_contig_bucket(chr[i]);
+            atomicAdd(hit && !st ? &cnt[bk & 63u] : my_dummy, 1u << ((bk >> 6) * 16u));
         }
         int both = mine_hits | (mine_star << 16);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) both += __shfl_xor(both, d, 64);
         __builtin_amdgcn_wave_barrier();
-        const uint32_t c = cnt[lane] < 15u ? cnt[lane] : 15u;
-        const unsigned long long s0 = __ballot(c & 1u), s1 = __ballot(c & 2u), s2 = __ballot(c & 4u), s3 = __ballot(c & 8u);
+        unsigned long long sl[VS_CB / 64][4];
+#pragma unroll
+        for (int w = 0; w < VS_CB / 64; w++) {
+            const uint32_t cw = (cnt[lane] >> (16 * w)) & 0xffffu, c = cw < 15u ? cw : 15u;
+            sl[w][0] = __ballot(c & 1u); sl[w][1] = __ballot(c & 2u); sl[w][2] = __ballot(c & 4u); sl[w][3] = __ballot(c & 8u);
+        }
         if (lane == 0) {
             VsReadRec o;
-            o.sk[0] = s0; o.sk[1] = s1; o.sk[2] = s2; o.sk[3] = s3;
+#pragma unroll
+            for (int w = 0; w < VS_CB / 64; w++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) o.sk[w][j] = sl[w][j];
             o.star = star;
             o.n_star = (uint32_t)(both >> 16);
             o.n_hits = (uint32_t)(both & 0xffff);
@@ -463,7 +472,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES, 6) vs_probe(HashParams hp, cons
 // ---------------------------------------------------------------- filter
 // One lane per pair: can two different contigs collect six hit offsets each?  Upper bounds only: a contig's count is at most the
 // hits that name it (judge_base credits an offset to ONE contig, E:118-159).  Known per read: the hits on its star contig, exactly;
-// the hits on all other contigs by hashed bucket (saturated at 15, which reads as "enough").  Per bucket b: O_b = the two reads'
+// the hits on all other contigs by hashed bucket (VS_CB = 128 of them; saturated at 15, which reads as "enough").  Per bucket b: O_b = the two reads'
 // other-hits added, and the stars that hash there with their exact counts; the most contigs of bucket b that can reach six:
 //   two  if O_b >= 12 (two others), or a star s with max(0, 6 - s) + 6 <= O_b (it and an other), or two different stars s1, s2 with
 //        max(0, 6 - s1) + max(0, 6 - s2) <= O_b
@@ -481,38 +490,41 @@ __global__ void __launch_bounds__(256) vs_filter(uint32_t n_pairs, const VsReadR
     if (P < (long)n_pairs) {
         const VsReadRec a = read_rec[2 * P], b = read_rec[2 * P + 1];
         if (a.n_hits + b.n_hits >= 12u && a.n_ev + b.n_ev >= 6u) {
-            // bit-sliced sum of the 64 pairs of 4-bit counters: five planes
-            unsigned long long o[5], carry = 0ull;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned long long x = a.sk[j], y = b.sk[j];
-                o[j] = x ^ y ^ carry;
-                carry = (x & y) | (carry & (x ^ y));
-            }
-            o[4] = carry;
-            // a saturated counter (15) stands for "15 or more": read it as large
-            const unsigned long long sat = (a.sk[0] & a.sk[1] & a.sk[2] & a.sk[3]) | (b.sk[0] & b.sk[1] & b.sk[2] & b.sk[3]);
-            // >= 6: bit 4, or bit 3, or bits 2 and 1;  >= 12: bit 4, or bits 3 and 2
-            const unsigned long long ge6 = o[4] | o[3] | (o[2] & o[1]) | sat, ge12 = o[4] | (o[3] & o[2]) | sat;
             const uint32_t ba = vs_contig_bucket(a.star), bb = vs_contig_bucket(b.star);
             const bool has_a = a.n_star > 0u, has_b = b.n_star > 0u && !(has_a && a.star == b.star);
             const uint32_t sa = a.n_star + (has_a && b.n_star > 0u && a.star == b.star ? b.n_star : 0u), sb = b.n_star;
-            unsigned long long star_mask = 0ull;
-            if (has_a) star_mask |= 1ull << ba;
-            if (has_b) star_mask |= 1ull << bb;
-            int total = __popcll(ge6 & ~star_mask) + __popcll(ge12 & ~star_mask);          // buckets without a star: one, or two
+            int total = 0;
+            uint32_t Oa = 0u, Ob = 0u;           // the other-hits of the stars' buckets (64: saturated)
+#pragma unroll
+            for (int w = 0; w < VS_CB / 64; w++) {
+                // bit-sliced sum of 64 pairs of 4-bit counters: five planes
+                unsigned long long o[5], carry = 0ull;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned long long x = a.sk[w][j], y = b.sk[w][j];
+                    o[j] = x ^ y ^ carry;
+                    carry = (x & y) | (carry & (x ^ y));
+                }
+                o[4] = carry;
+                // a saturated counter (15) stands for "15 or more": read it as large
+                const unsigned long long sat = (a.sk[w][0] & a.sk[w][1] & a.sk[w][2] & a.sk[w][3]) | (b.sk[w][0] & b.sk[w][1] & b.sk[w][2] & b.sk[w][3]);
+                // >= 6: bit 4, or bit 3, or bits 2 and 1;  >= 12: bit 4, or bits 3 and 2
+                const unsigned long long ge6 = o[4] | o[3] | (o[2] & o[1]) | sat, ge12 = o[4] | (o[3] & o[2]) | sat;
+                unsigned long long star_mask = 0ull;
+                if (has_a && (int)(ba >> 6) == w) { star_mask |= 1ull << (ba & 63u); Oa = ((sat >> (ba & 63u)) & 1ull) ? 64u : vs_sliced_at(o, ba & 63u); }
+                if (has_b && (int)(bb >> 6) == w) { star_mask |= 1ull << (bb & 63u); Ob = ((sat >> (bb & 63u)) & 1ull) ? 64u : vs_sliced_at(o, bb & 63u); }
+                total += __popcll(ge6 & ~star_mask) + __popcll(ge12 & ~star_mask);          // buckets without a star: one contig, or two
+            }
             auto need = [](uint32_t s) { return s >= 6u ? 0u : 6u - s; };
-            auto bucket_with = [&](uint32_t bk, uint32_t s1, bool two, uint32_t s2) {
-                const bool big = (sat >> bk) & 1ull;
-                const uint32_t O = big ? 64u : vs_sliced_at(o, bk);
+            auto bucket_with = [&](uint32_t O, uint32_t s1, bool two, uint32_t s2) {
                 if (O >= 12u || need(s1) + 6u <= O || (two && (need(s2) + 6u <= O || need(s1) + need(s2) <= O))) return 2;
                 if (O >= 6u || s1 + O >= 6u || (two && s2 + O >= 6u)) return 1;
                 return 0;
             };
-            if (has_a && has_b && ba == bb) total += bucket_with(ba, sa, true, sb);
+            if (has_a && has_b && ba == bb) total += bucket_with(Oa, sa, true, sb);
             else {
-                if (has_a) total += bucket_with(ba, sa, false, 0u);
-                if (has_b) total += bucket_with(bb, sb, false, 0u);
+                if (has_a) total += bucket_with(Oa, sa, false, 0u);
+                if (has_b) total += bucket_with(Ob, sb, false, 0u);
             }
             keep = total >= 2 || (debug & (1 << 19));
         }

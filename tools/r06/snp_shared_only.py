@@ -12,7 +12,7 @@ eng = Engine(K, E); eng.rng_seed(1); eng.coder_generate(); eng.set_reference_for
 eng.synth_reference(1, NC, CL)
 eng.synth_options(10, 20, sc); eng.synth_pairs(1, 2, NC, CL, 0, pairs); eng.synth_options(0, 20, 0)
 eng.counts_clear(); eng.count_kmers()
-eng.set_debug(1 << 25)
+eng.set_debug((1 << 25) | int(os.environ.get("LHGT_DEBUG", "0")))
 eng.ref_scan(0.1, 0.08, 300_000_000)
 for _ in range(votes):
     eng.vote()

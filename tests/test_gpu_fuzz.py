@@ -104,6 +104,11 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     # a third of the cases each: the form the engine picks, single-first, trio-first (when e <= 3) -- every other of those answered
     # from the slot list (bit 24, round 5); every fourth case with the vote bitmap in its three-quarter form (bit 20; k > 25)
     dbg = (0, 4096, 16384, 0, 4096 | (1 << 24), 1 << 24)[idx % 6] | ((1 << 20) if idx % 4 == 3 else 0)   # 4096 | bit 24: slot-single where the reference is packed
+    # every fifth case (round 6), or every case under LHGT_FUZZ_SHARED=1: no vote bitmap (bit 2) and the shared-line-fill form of the dense vote
+    # forced on these small stores (bit 27; e <= 3: otherwise the dense kernel) -- ragged reads (the long ones go on its list), chimeric
+    # pairs that do vote (its filter must keep them), N's and lower case
+    if idx % 5 == 2 or os.environ.get("LHGT_FUZZ_SHARED", "0") == "1":
+        dbg |= 4 | (1 << 27)
     if dbg:
         monkeypatch.setenv("LHGT_DEBUG", str(dbg))
     g, c = tmp_path / "gpu", tmp_path / "cpu"

@@ -153,3 +153,32 @@ def test_random_case_with_several_ranks_matches_oracle(oracle, tmp_path, idx):
     names = ("i.txt", "ref.fa.genome.len.txt") + (() if mode == "packed" else (f"ref.fa.k{k}.h{e}.index.dat",))
     for name in names:
         assert open(g / name, "rb").read() == open(c / name, "rb").read(), (name, mode, world, threads, k, e, seed, sample, hit, match)
+
+
+@pytest.mark.parametrize("mode", ["replicated", "packed"])
+def test_two_ranks_run_a_batch(case_inputs, tmp_path, mode):
+    """`extract_ref --batch MANIFEST` (round 6) under two ranks: three samples of one reference in one process group -- every rank keeps
+    the reference resident between the samples, the exchanges of every sample run in turn -- and every sample's files are the goldens
+    (the first sample builds the index with every read kept; the sampled one is the golden made on an index in place)"""
+    names = ["k24_base", "k24_sample_half_cached", "k24_t4"]
+    fa2 = str(tmp_path / "ref.fa")
+    lines, outs = [], []
+    for i, name in enumerate(names):
+        case = cases.CASES[name]
+        fa, f1, f2, meta = case_inputs(name)
+        if i == 0:
+            shutil.copy(fa, fa2)
+        interval = str(tmp_path / f"s{i}.interval.txt")
+        lines.append(" ".join(cases.extract_ref_argv(case, f1, f2, fa2, interval)))
+        outs.append((name, interval))
+    if mode == "packed":       # the coder header the cached golden was made with: an index in place before the batch
+        from localhgt_amd import extract_ref
+        a0 = extract_ref.parse_argv(lines[0].split())
+        extract_ref.run(a0, log=lambda *a: None)
+        os.remove(a0.interval)
+    manifest = tmp_path / "batch.txt"
+    manifest.write_text("\n".join(lines) + "\n")
+    res = _launch(2, ["--batch", str(manifest)], MODES[mode])
+    assert res.stdout.count("reference: resident from the previous sample") >= 2, res.stdout[-3000:]     # samples 2 and 3 (on every rank whose stdout the launcher passes on)
+    for name, interval in outs:
+        _check_against_golden(name, fa2, interval, expect_index=True)

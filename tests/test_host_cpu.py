@@ -213,6 +213,26 @@ def _digest(lib, f1, f2, ratio=100.0, rnd=None, rank=0, world=1, block=64, threa
     return rc, seen.value, kept.value, dig.value
 
 
+def test_batch_manifest_holds_one_extract_ref_call_per_line(tmp_path):
+    """`extract_ref --batch MANIFEST` (round 6): the 12 arguments of scripts/pipeline.sh:35 per line, parsed like argv (stod then
+    truncation, E:1352-1371); comments, blank lines and shell quoting; a line with another number of arguments is refused with its number"""
+    from localhgt_amd import extract_ref
+    m = tmp_path / "batch.txt"
+    m.write_text("# two samples of one reference\n\n"
+                 "a.1.fq a.2.fq ref.fa out/a.interval.txt 0.1 0.08 10 32 300000000 3 1 2000000000\n"
+                 "'b 1.fq' b.2.fq ref.fa out/b.interval.txt 0.1 0.08 10.9 32 3e8 3 7 0.5   # a path with a blank, threads 10.9 -> 10\n")
+    got = extract_ref.read_manifest(str(m))
+    assert [a.fq1 for a in got] == ["a.1.fq", "b 1.fq"] and [a.threads for a in got] == [10, 10]
+    assert got[0] == extract_ref.parse_argv("a.1.fq a.2.fq ref.fa out/a.interval.txt 0.1 0.08 10 32 300000000 3 1 2000000000".split())
+    assert (got[1].max_peak, got[1].seed, got[1].sample) == (300000000, 7, 0.5)
+    m.write_text("a.1.fq a.2.fq ref.fa out 0.1 0.08 10 32 300000000 3 1\n")
+    with pytest.raises(SystemExit) as ei:
+        extract_ref.read_manifest(str(m))
+    assert "batch.txt:1" in str(ei.value) and "11 arguments" in str(ei.value)
+    with pytest.raises(SystemExit):
+        extract_ref.main(["--batch"])
+
+
 def test_parallel_fastq_parser_is_split_invariant(lib, oracle, case_inputs, tmp_path):
     """any chunk size / thread count gives the same kept pairs, in the same order, with the same mate-2 flags"""
     fa, f1, f2, _ = case_inputs("k24_fq2_longer")          # fq2 longer than fq1: exercises the Q4 flag

@@ -904,8 +904,12 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                                                      uint32_t* __restrict__ prefilter /* nullable */, uint32_t pf_mask, int pf2,
                                                      uint32_t first_id /* 1 under -t N emulation when thread 0 finds no peak, else 0 */, long n_blk) {
     __shared__ int incl[TILE], part[BT];
-    const long blk = block2d();
-    if (blk >= n_blk) return;
+    if (block2d() >= n_blk) return;
+    // the tiles from the LAST one down (round 6): ids ascend with the tiles and the larger id wins a slot, so the tiles that run first
+    // now hold the ids that stay -- a later, smaller id finds `peak_kmer[h] >= id` with a plain load and leaves the slot alone, which
+    // is a line read instead of the read-modify-write of an atomic (7.7 G registrations into 4.3 G slots in the CLI's default regime:
+    // more than half of them lose).  A stale load only ever shows a SMALLER id: the atomic then decides, as before.
+    const long blk = n_blk - 1 - block2d();
     const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
     const long len = c.len, nk = len - k + 1;
@@ -952,7 +956,7 @@ __global__ void __launch_bounds__(BT) register_peaks(const TileDev* __restrict__
                 // hit > 0 for this hash: the bit the probe kernels recorded, where they did (hashes 8.., and those the single-first /
                 // trio-first forms left unprobed or without a record, are probed again)
                 if (i < 8 && ((have >> i) & 1u) ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
-                    atomicMax(&peak_kmer[h], id);  // later (larger) id wins
+                    if (__builtin_nontemporal_load(peak_kmer + h) < id) atomicMax(&peak_kmer[h], id);  // later (larger) id wins
                     if (prefilter) {
                         atomicOr(&prefilter[pf_word(h, pf_mask)], pf_word_bits(h, pf2));
                     }

@@ -75,12 +75,17 @@ bool drop_optional(void) {
     if (!c || c->sl_state != 1 || c->sl_in_use) return false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     slot_list_drop(c);
+    c->sl_state = -1;                                               // not built again for this reference: the memory is wanted elsewhere
     (void)big_release_all();                                        // the list's blocks were parked by slot_list_drop
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] out of device memory: the slot list was dropped\n");
     return true;
 }
 hipError_t malloc_hard(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
+    // test hook (tests/test_gpu_devcache.py): LHGT_TEST_FAIL_ALLOC=<bytes> makes the first attempt of an allocation of that size or more
+    // fail as if the device were full WHILE the calling context holds an idle slot list -- the path that drops the list and tries again
+    static const long fail_from = getenv("LHGT_TEST_FAIL_ALLOC") ? atol(getenv("LHGT_TEST_FAIL_ALLOC")) : 0;
+    const bool pretend = fail_from > 0 && bytes >= (size_t)fail_from && t_entry_ctx && t_entry_ctx->sl_state == 1 && !t_entry_ctx->sl_in_use;
+    hipError_t e = pretend ? hipErrorOutOfMemory : hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory && big_release_all()) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
     if (e == hipErrorOutOfMemory && drop_optional()) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
     return e;
@@ -244,6 +249,7 @@ int lhgt_device_count(int* n) {
 int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
     if (!out) LHGT_FAIL(LHGT_E_ARG, "null argument");
     *out = nullptr;
+    lhgt::entry_context(nullptr);
     if (k < 8 || k > 32) LHGT_FAIL(LHGT_E_ARG, "k = %d outside [8, 32] (hashes are 32-bit, E:1012)", k);
     if (e < 1 || e > 9) LHGT_FAIL(LHGT_E_ARG, "e = %d outside [1, 9]", e);
     if (k * e > LHGT_CODER_SLOTS) LHGT_FAIL(LHGT_E_ARG, "k*e = %d exceeds the %d coder slots (E:1186)", k * e, LHGT_CODER_SLOTS);
@@ -290,6 +296,7 @@ int lhgt_ctx_create(int device, int k, int e, lhgt_ctx** out) {
 
 int lhgt_ctx_destroy(lhgt_ctx* c) {
     if (!c) return LHGT_OK;
+    lhgt::entry_context(nullptr);       // (an allocation that runs out of memory looks at the calling thread's context: not at this one any more)
     lhgt::sampling_join(c);
     if (c->device < 0) { free(c->rng); delete c; return LHGT_OK; }
     hipSetDevice(c->device);

@@ -3,11 +3,13 @@ GPU: a block one context parks while its kernels are still queued --
 mid-stream -- may be handed to the other context only once the device has drained what was queued before the park.  Two host
 threads, each with a context of its own, grow their batches step by step (every step frees and re-allocates blocks of 64 MiB and
 more, of size classes the two contexts share) and count; every table must equal the one a lone context computes."""
+import os
 import threading
 
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K, E, NC, CL = 26, 3, 40, 100_000
 STEPS = [60_000, 150_000, 90_000, 400_000, 250_000, 700_000]
 
@@ -52,3 +54,46 @@ def test_two_contexts_share_the_block_cache_while_regrowing():
     for (seed, n, rnd), d in got.items():
         assert d == want[(seed, n)], (seed, n, rnd)
     pool_trim()
+
+
+def test_an_allocation_out_of_memory_drops_the_idle_slot_list(case_inputs, tmp_path):
+    """the slot list is optional (78-130 GB on a catalogue) and a later, larger sample must not fail where it would have fit
+    without it.  With LHGT_TEST_FAIL_ALLOC the first attempt of a larger allocation fails as on a full device while the context holds an
+    idle list: the list goes, the allocation succeeds, the next scan takes the position-ordered kernel -- same interval file.
+    (A subprocess: the hook is read once per process.)"""
+    import subprocess
+    import sys
+    import cases
+    case = cases.CASES["k24_base"]
+    fa, f1, f2, meta = case_inputs("k24_base")
+    script = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+from localhgt_amd.engine import Engine
+eng = Engine(24, 3)
+eng.rng_seed(1); eng.coder_generate(); eng.set_reference_form(True)
+eng.reference_load_fasta({fa!r})
+eng.slot_list(2)
+eng.sampling_init(100.0)
+eng.pairs_load_fastq({f1!r}, {f2!r}, 100.0)
+eng.count_kmers()
+n = eng.ref_scan(0.1, 0.08, 1000000)
+a_entries = eng.slot_list()["entries"]                       # (the probe kernels ran on the list; the first allocation behind them -- the peak registry's -- already dropped it)
+eng.vote()
+a = (n, eng.scan_info()["form"], a_entries, eng.digest(eng.DIGEST_VOTES), eng.digest(eng.DIGEST_PEAK_KMER))
+eng.pairs_clear()                                            # the next sample: its batches are new allocations
+eng.pairs_load_fastq({f1!r}, {f2!r}, 100.0)
+b_entries = eng.slot_list()["entries"]
+eng.counts_clear(); eng.count_kmers()
+n2 = eng.ref_scan(0.1, 0.08, 1000000); eng.vote()
+b = (n2, eng.scan_info()["form"], eng.slot_list()["entries"], eng.digest(eng.DIGEST_VOTES), eng.digest(eng.DIGEST_PEAK_KMER))
+print(a); print(b_entries); print(b)
+assert a[1] == "slot-first" and a[2] == 0, a
+assert b_entries == 0, "the list should have been dropped by the failed allocation"
+assert b[1] == "trio-first" and b[2] == 0, b        # ... and is not built again for this reference
+assert (a[0], a[3], a[4]) == (b[0], b[3], b[4]), (a, b)
+"""
+    env = dict(os.environ, LHGT_TEST_FAIL_ALLOC="4096", LHGT_TRACE="1")
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "the slot list was dropped" in res.stderr

@@ -337,7 +337,7 @@ int lhgt_slot_list_build_ms(lhgt_ctx* ctx, double* ms);
  *      generic kernel behind the L2-resident bitmap, 2 the queued sparse kernel behind the bitmap, 3 the 128 KiB LDS fold in front of
  *      bitmap and peak_kmer, 4 (round 6) the shared-line-fill form of a dense peak set under a deep sample: reads grouped by their
  *      smallest hash, a workgroup fetches every DISTINCT slot its 32 reads probe once (k_vote_shared.hip; environment
- *      LHGT_SHARED_VOTE=0 never, =1 whenever e <= 3, default: when the grouping finds LHGT_SHARED_MIN = 8 reads per occupied bucket); *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only
+ *      LHGT_SHARED_VOTE=0 never, =1 whenever e <= 3, default: when the grouping finds LHGT_SHARED_MIN = 3 reads per occupied bucket); *bitmap_bits = log2 of the bits the bitmap's mask spans (0: no bitmap), *three_quarter = 1 when only
  *      three quarters of them are used (3 MiB instead of 4).  Measurement only. */
 int lhgt_vote_info(lhgt_ctx* ctx, int* form, int* bitmap_bits, int* three_quarter);
 /* ---- work counters for the roofline's "bytes the implemented algorithm must move" (bench.py).  enable = 1: count from

@@ -22,7 +22,7 @@
 // (Two earlier forms of this round, measured and dropped -- DESIGN.md 4: per-read hit lists in an arena, judged per pair -- at the
 // SNP leg's 125 true hits per read the arena wants 200 GB --; and the set walked hash by hash instead of six probes together.)
 // Pairs the form does not take (a read of more than FAST_NK offsets) go to the generic kernel as well.  The engine picks the form when
-// the dense form would run, e <= 3, the grouping finds at least LHGT_SHARED_MIN (8) reads per occupied bucket and the peak set is
+// the dense form would run, e <= 3, the grouping finds at least LHGT_SHARED_MIN (3) reads per occupied bucket and the peak set is
 // not so dense that foreign hits alone fill the counters; keys and order are kept while the read store does not change.
 #include <algorithm>
 #include <cstring>
@@ -671,7 +671,10 @@ static int vshared_prepare(lhgt_ctx* ctx, bool* use) {
             fprintf(stderr, "[lhgt] shared vote: %u of %ld reads keyed, %llu of %ld buckets occupied (%.1f reads per bucket, %u work items), %u pairs with a long read, %.1f ms\n",
                     v->n_listed, 2 * np, occ, n_buckets, v->reads_per_bucket, v->n_items, v->n_list_keys, v->keys_ms);
     }
-    static const double min_share = getenv("LHGT_SHARED_MIN") ? atof(getenv("LHGT_SHARED_MIN")) : 8.0;
+    // from 3 reads per occupied bucket on (measured: 10 M pairs from 300 genomes, 5.6 reads per bucket, 203 line fills per pair instead of 714:
+    // 59.8 against the dense kernel's 136.5 ms, plus 20 ms of keys and grouping once per store; per pair the form costs ~1.6 ns + 0.02 ns per
+    // line fill against 14.3 ns, so it still pays where two reads in three share nothing -- below that the grouping is not worth its pass)
+    static const double min_share = getenv("LHGT_SHARED_MIN") ? atof(getenv("LHGT_SHARED_MIN")) : 3.0;
     *use = forced || (v->reads_per_bucket >= min_share && (double)v->n_list_keys * 8.0 <= (double)np);
     return LHGT_OK;
 }

@@ -20,3 +20,6 @@ tools/r06/pmc_kernel.sh r06/pmc_sq1 vs_probe "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SA
 tools/r06/pmc_kernel.sh r06/pmc_sq2 vs_probe "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" -- python3 $GRAFT_REPO_ROOT/tools/r06/snp_shared_only.py 30000000 90 1 > $out/sq_vs_probe_2.txt
 rm -rf gpurun_out/r06/pmc_* 
 ls -la $out
+# the shared form at lower coverage: 10 M pairs from 300 genomes (5.6 reads per bucket), 50 M pairs with SNPs (23.8)
+( LHGT_TRACE=1 python3 tools/r06/snp_leg.py 10000000 300 0 2>&1 | grep "form\|can vote\|keyed"; LHGT_TRACE=1 python3 tools/r06/snp_leg.py 50000000 300 10 2>&1 | grep "form\|can vote\|keyed" ) > $out/shared_vote_at_lower_coverage.txt
+ls -la $out

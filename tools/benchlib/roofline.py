@@ -108,12 +108,16 @@ def needed_bytes(L, k, e, pairs, ref_bases, n_contigs, packed, stats, partitione
                               f"reads {reads} + {hb} probes of peak_kmer x {LINE} B ({hb / max(1, pairs):.2f} per pair survive the "
                               f"{'LDS fold and the ' if vote_form == 'fold' else ''}L2-resident bitmap, which costs no HBM byte)")
     elif vote_form == "shared":
-        # round 6: reads grouped by their smallest hash, a workgroup fetches every distinct slot of its 32 reads once; the records are
-        # read three times (keys -- once per store --, insert pass, lookup pass), the events written and read back by the judge
+        # round 6: reads grouped by their smallest hash, a workgroup fetches every slot of the distinct k-mers of its <= 64 reads once; the
+        # records are read by the grouping (once per store) and by the probe kernel, an 80-byte record per read is written and read by the
+        # filter, and the pairs that can vote are probed again, every probe, by the generic kernel
         fetched = stats.get("vote_shared_fetches", 0) + stats.get("vote_shared_outside", 0)
-        out["vote_kernel"] = (2 * reads + fetched * LINE + pairs * 2 * 8,
-                              f"reads twice 2 x {reads} + {fetched} distinct slots of peak_kmer x {LINE} B ({fetched / max(1, pairs):.1f} line fills per pair for "
-                              f"{keys / max(1, pairs):.0f} probes: overlapping reads share them) + per-read event records {pairs * 2 * 8}")
+        again = stats.get("vote_revoted_pairs", 0)
+        probes_pp = 2 * (L - k + 1) * e
+        out["vote_kernel"] = (reads + fetched * LINE + pairs * 2 * 2 * 80 + again * probes_pp * LINE,
+                              f"reads {reads} + {fetched} slots of peak_kmer x {LINE} B ({fetched / max(1, pairs):.1f} line fills per pair for "
+                              f"{keys / max(1, pairs):.0f} probes: overlapping reads share them) + per-read records written and read {pairs * 2 * 2 * 80} + "
+                              f"{again} pairs that can vote ({100.0 * again / max(1, pairs):.1f} %) x {probes_pp} probes x {LINE} B in the generic kernel")
     else:
         out["vote_kernel"] = (reads + keys * LINE, f"reads {reads} + {keys} probes of peak_kmer x {LINE} B (no on-chip filter: dense peak set)")
     return out
@@ -189,7 +193,7 @@ def rooflines(k, e, L, pairs, ref_bases, n_contigs, packed, per_ms, scan, n_peak
     kern = {"count_A": per_ms[0], "ref_flags": per_ms[3], "vote_kernel": per_ms[2]}
     scan_kernel = {"single-first": "ref_flags_lite", "trio-first": "ref_flags_trio", "slot-first": "ref_flags_slots",
                    "slot-single": "no_kmer_flags+ref_single_slots+ref_trio_runs"}.get(scan["form"], "ref_flags")
-    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued", "shared": "vs_probe+vs_judge"}.get(vform, "vote_kernel")
+    vote_kernel = {"fold": "vote_kernel_fold", "queued": "vote_kernel_queued", "shared": "vs_probe+vs_filter+vote_kernel"}.get(vform, "vote_kernel")
     info = {
         "count_A": (("part_reads_direct+part_keys16_direct+part_apply2" if direct else "part_scatter_reads+part_scatter_keys16+part_apply") if partitioned else "count_direct",
                     f"phase A kernel family, {n_chunks} chunks of <= {8 if direct else 4} Mi pairs per step: {2 * (L - k + 1) * e} table updates per pair",

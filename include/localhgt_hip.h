@@ -191,6 +191,24 @@ int lhgt_pairs_append(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, 
  * fq2 adds (E:1438-1445) is expressed this way by lhgt_pairs_load_fastq. */
 int lhgt_pairs_append_flags(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const uint8_t* seq2,
                             const uint64_t* off2, long n_pairs, const uint8_t* pair_flags);
+/* ---- a sample kept PACKED on disk (round 6; no reference counterpart: the reference reads FASTQ text, E:1020-1044, 350-419).
+ * `localhgt_pack fq1 fq2 out.lhgp` loads a record-aligned pair of files whole (every read kept, no thread emulation) and writes the
+ * resident store's own records at a fixed stride -- [u16 len1][u16 len2][mate 1: hi, lo, not-a-base planes of len1 / 32 + 1 words]
+ * [mate 2 likewise], 148 bytes for 150-base pairs against ~640 of text -- behind a header that holds what the loader decides from
+ * the TEXT: the lines each thread of the reference's -t N consumes for every N (lhgt_fastq_thread_chunks), the first pair whose mate 2
+ * lies behind size(fq1) (quirk Q4), the bases of fq1 (cal_sam_ratio).  lhgt_pairs_load_packed reads part `part` of `n_parts` of the
+ * records into pinned memory (pread on all host threads, nothing parsed), and the GPU decides which pairs the run keeps -- the sampling
+ * array by global ordinal and Q4 at threads = 1, the thread chunks otherwise: the rules of lhgt_pairs_load_fastq -- and lays them out
+ * as batches.  Same resident pairs (in another order: phases A and C do not depend on it), same tables, same files.
+ * lhgt_pairs_batches / _batch_info: the resident store as it stands; lhgt_pairs_store_write: its records to `path` from data_offset on
+ * (refused unless the store is that of a clean pair of files read whole). */
+int lhgt_pairs_batches(lhgt_ctx* ctx, long* n_batches);
+int lhgt_pairs_batch_info(lhgt_ctx* ctx, long batch, long* n_pairs, unsigned long long* n_words, int* max_len);
+int lhgt_pairs_store_write(lhgt_ctx* ctx, const char* path, unsigned long long data_offset, long stride, long* n_pairs, long* q4_first_pair,
+                           unsigned long long* bases1);
+int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long data_offset, long stride, long n_pairs_total, long q4_first_pair,
+                           double ratio_percent, int threads, const long* first1, const long* count1, const long* first2, const long* count2,
+                           int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept);
 /* with count-on-load lhgt_pairs_load_fastq closes a batch every Mi pairs and runs phase A on it at once, behind the parsing of the
  * next batch (the coder must be set: load or build the index first); lhgt_count_kmers then only counts what is not counted yet and
  * reports the whole kernel time.  lhgt_counts_clear makes every batch uncounted again. */

@@ -66,6 +66,10 @@ SIGNATURES = {
     "lhgt_fastq_parse_digest_threads": [_cs, _cs, _d, _fp, _i, _i, _l, _i, _l, _i, _lp, _lp, _u64p, _lp],
     "lhgt_pairs_append": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
     "lhgt_pairs_append_flags": [_vp, _u8p, _u64p, _u8p, _u64p, _l, _u8p],
+    "lhgt_pairs_batches": [_vp, _lp],
+    "lhgt_pairs_batch_info": [_vp, _l, _lp, _u64p, C.POINTER(C.c_int)],
+    "lhgt_pairs_store_write": [_vp, _cs, C.c_uint64, _l, _lp, _lp, _u64p],
+    "lhgt_pairs_load_packed": [_vp, _cs, C.c_uint64, _l, _l, _l, _d, _i, _lp, _lp, _lp, _lp, _i, _i, _lp, _lp],
     "lhgt_set_count_on_load": [_vp, _i],
     "lhgt_pairs_clear": [_vp],
     "lhgt_pairs_count": [_vp, _lp],

@@ -632,6 +632,8 @@ static int usable_cpus() {
     return n;
 }
 
+static int default_threads();
+int ingest_default_threads() { return default_threads(); }     // (k_packed.hip)
 static int default_threads() {
     const char* e = getenv("LHGT_INGEST_THREADS");
     if (e && atoi(e) > 0) return atoi(e);

@@ -295,6 +295,7 @@ struct ParseShare {
 
 // host_fastx.cpp
 long thread_entry(const uint8_t* p, long n, long start);   // get_fq_start (E:44-89)
+int ingest_default_threads();                              // the CPUs the process may use (affinity mask, cgroup quota), at most 48; LHGT_INGEST_THREADS
 // host_fastq_stream.cpp: the single-pass loader.  LHGT_OK: every pair of the files went through consume(), plan1 / plan2 hold the
 // line plans made on the way.  STREAM_RETRY (not an error code of the C-ABI): this pass does not decide the input -- *why says what
 // it met -- and whatever consume() has seen must be dropped and the files given to the planned loader.

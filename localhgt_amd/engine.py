@@ -208,6 +208,19 @@ class Engine:
                                                           C.byref(seen), C.byref(kept)))
         return seen.value, kept.value
 
+    def pairs_load_packed(self, hdr, ratio_percent: float, threads: int = 1, part: int = 0, parts: int = 1) -> Tuple[int, int]:
+        """part `part` of `parts` of a packed sample (localhgt_amd/pack.py: Header) becomes resident; threads > 1: the reference's -t
+        threads read partition from the header's thread chunks (raises LocalHGTError 9 where the emulation refuses the files)"""
+        seen, kept = C.c_long(0), C.c_long(0)
+        tabs = [None] * 4
+        if threads > 1:
+            tabs = [np.ascontiguousarray(x, dtype=np.int64) for x in hdr.thread_chunks(threads)]
+        ptr = [None if t is None else _ptr(t, C.c_long) for t in tabs]
+        _lib.check(self.lib.lhgt_pairs_load_packed(self.h, hdr.path.encode(), hdr.data_offset, hdr.stride, hdr.n_pairs, hdr.q4_first_pair,
+                                                   float(ratio_percent), int(threads), ptr[0], ptr[1], ptr[2], ptr[3], part, parts,
+                                                   C.byref(seen), C.byref(kept)))
+        return seen.value, kept.value
+
     def pairs_append(self, seq1: np.ndarray, off1: np.ndarray, seq2: np.ndarray, off2: np.ndarray,
                      count_mate2: Optional[np.ndarray] = None, flags: Optional[np.ndarray] = None):
         """flags (one byte per pair: 1 = mate 1 counted in phase A, 2 = mate 2 counted, 4 = pair voted in phase C) overrides

@@ -175,13 +175,20 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form, 
     if a.sample != 1 and os.environ.get("LHGT_SYNC_SAMPLING", "0") != "1":   # =1: draw them where the reference does (A/B timing)
         eng.sampling_begin()
     plan1 = plan2 = None
-    if dist:                                                   # every rank counts the lines of 1/world of both files (dist.fastq_plan)
+    from . import pack as _pack
+    packed_sample = _pack.read_header(a.fq1) if _pack.is_packed(a.fq1) else None    # a sample packed by localhgt_pack (fq2 is then ignored: "-")
+    if packed_sample:
+        log(f"reads: {a.fq1} is a packed sample ({packed_sample.n_pairs} pairs, {packed_sample.stride} bytes each)")
+    elif dist:                                                 # every rank counts the lines of 1/world of both files (dist.fastq_plan)
         ch1, ch2 = eng.fastq_pair_chunks(a.fq1, a.fq2)          # fq2 in as many chunks as fq1: the parse can then take whole columns
         plan1 = dist.fastq_plan(eng, a.fq1, want_len_sums=a.sample > 1, chunk=ch1)
         plan2 = dist.fastq_plan(eng, a.fq2, chunk=ch2)
     elif a.sample > 1:                                         # the CLI's default --sample 2000000000: the line count the loader needs
         plan1, plan2 = eng.fastq_plan(a.fq1, True, other=a.fq2)   # anyway also yields cal_sam_ratio's base count (no extra pass over fq1)
-    ratio = eng.sam_ratio_from_plan(plan1, a.sample) if plan1 is not None else eng.sam_ratio(a.fq1, a.sample)   # E:1392-1398
+    if packed_sample:
+        ratio = packed_sample.ratio(a.sample)
+    else:
+        ratio = eng.sam_ratio_from_plan(plan1, a.sample) if plan1 is not None else eng.sam_ratio(a.fq1, a.sample)   # E:1392-1398
     log(f"down-sampling ratio: {ratio}%.")
     if built:
         if rank == 0 and not packed:
@@ -225,7 +232,9 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form, 
         dist.barrier()
     t_i1 = time.time()
     _warn_if_ids_desynchronise(a.fasta + ".genome.len.txt", a.k, log)
-    if plan1 is not None:                                      # reads per file are known: only the entries they can look at are filled
+    if packed_sample:
+        eng.sampling_reserve(packed_sample.n_pairs)
+    elif plan1 is not None:                                    # reads per file are known: only the entries they can look at are filled
         eng.sampling_reserve(max((int(plan1[1].sum()) + 2) // 4, (int(plan2[1].sum()) + 2) // 4))
     eng.sampling_init(ratio)                                   # E:1422
     t_r0 = time.time()
@@ -255,7 +264,10 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form, 
 
     def load_and_count():
         t = time.time()
-        if plan1 is not None:                                  # this rank's contiguous run of fq1's chunks, paired through the whole plan
+        if packed_sample:                                      # this rank's contiguous run of the packed pairs; the GPU decides which the run keeps
+            _, state["kept"] = eng.pairs_load_packed(packed_sample, ratio, a.threads if emulating else 1, rank, world)
+            state["seen"] = packed_sample.n_pairs
+        elif plan1 is not None:                                # this rank's contiguous run of fq1's chunks, paired through the whole plan
             state["seen"], state["kept"] = eng.pairs_load_fastq_planned(a.fq1, a.fq2, ratio, plan1[:2], plan2[:2], rank, world)
         else:
             state["seen"], state["kept"] = eng.pairs_load_fastq(a.fq1, a.fq2, ratio)

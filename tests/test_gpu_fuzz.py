@@ -165,6 +165,23 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
         assert rep["pairs_kept"] == orep.pairs_voted
     else:
         assert rep["pairs_kept"] >= orep.pairs_voted
+    # every third case (round 6), or every case under LHGT_FUZZ_PACKED=1: the same run from the sample PACKED by localhgt_pack, where the
+    # packer takes the files (record-aligned pairs): same interval file, same pairs kept -- sampling, -t N and quirk Q4 from the header
+    if idx % 3 == 1 or os.environ.get("LHGT_FUZZ_PACKED", "0") == "1":
+        from localhgt_amd import pack
+        h = tmp_path / "packed"
+        h.mkdir()
+        try:
+            pack.pack(str(g / "s.1.fq"), str(g / "s.2.fq"), str(h / "s.lhgp"), max_threads=10, log=lambda *x: None)
+        except (SystemExit, _lib.LocalHGTError):
+            return                            # unequal files, foreign first IDs, a line beyond the reference's buffers: they stay FASTQ
+        shutil.copy(g / "ref.fa", h / "ref.fa")
+        for _ in range(runs):
+            a = list(args)
+            a[0:4] = [str(h / "s.lhgp"), "-", str(h / "ref.fa"), str(h / "i.txt")]
+            rep_p = extract_ref.run(extract_ref.parse_argv(a), log=lambda *x: None, ref_form="packed" if packed else "index")
+        assert open(h / "i.txt", "rb").read() == open(g / "i.txt", "rb").read(), ("packed sample", k, e, seed, sample, threads)
+        assert (rep_p["pairs_kept"], rep_p["n_peaks"], rep_p["emulated_threads"]) == (rep["pairs_kept"], rep["n_peaks"], rep["emulated_threads"])
 
 
 def test_nine_hashes_and_500_base_reads(oracle, tmp_path):

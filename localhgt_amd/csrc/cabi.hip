@@ -304,6 +304,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt_pairs_clear(c);
     lhgt::ingest_free(c);
     lhgt_ingest_pool_free(c);
+    if (c->h_packed_stage) { (void)hipHostFree(c->h_packed_stage); c->h_packed_stage = nullptr; }
     lhgt::slot_list_drop(c);
     lhgt::vshared_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,

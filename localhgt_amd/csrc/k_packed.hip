@@ -260,20 +260,27 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
         LHGT_HIP(dev_malloc(&d_random, n_ent * 4));
         LHGT_HIP(hipMemcpyAsync(d_random, ctx->random_array.data(), n_ent * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    // chunks of <= 4 Mi pairs through two pinned buffers: the records of chunk c + 1 are read while chunk c is on its way
-    const long CH = std::min<long>(4L << 20, std::max<long>(1, (long)(((size_t)1 << 30) / (size_t)stride)));
-    uint8_t* h_raw[2] = {nullptr, nullptr};
-    uint8_t* d_raw = nullptr;
-    uint8_t* d_fl = nullptr;
-    unsigned long long* d_tot = nullptr;
+    // chunks of <= 2 Mi pairs through two pinned host buffers and two device buffers: while chunk c is copied and its flags are
+    // made, the host reads chunk c + 1; the one wait per chunk is for its totals (kept pairs and words size the batch), and behind
+    // it the next chunk's copy and the gather of this one are queued together.  The pinned buffers stay with the context (a
+    // session loads sample after sample; pinning 600 MB costs ~0.1 s).
+    const long CH = std::min<long>(2L << 20, std::max<long>(1, (long)(((size_t)1 << 29) / (size_t)stride)));
+    const size_t raw_bytes = (size_t)CH * (size_t)stride;
+    uint8_t* d_raw[2] = {nullptr, nullptr};
+    uint8_t* d_fl[2] = {nullptr, nullptr};
+    unsigned long long* d_tot = nullptr;        // [c & 1][8]: totals of chunk c, gather cursors behind them
     int rc = LHGT_OK;
-    auto fail = [&](int code) { rc = code; };
-    for (int i = 0; i < 2 && rc == LHGT_OK; i++) {
-        if (hipHostMalloc((void**)&h_raw[i], (size_t)CH * (size_t)stride, hipHostMallocDefault) != hipSuccess) { set_error("no pinned memory for the packed records"); fail(LHGT_E_NOMEM); }
+    if (ctx->packed_stage_bytes < 2 * raw_bytes) {
+        if (ctx->h_packed_stage) { (void)hipHostFree(ctx->h_packed_stage); ctx->h_packed_stage = nullptr; ctx->packed_stage_bytes = 0; }
+        if (hipHostMalloc((void**)&ctx->h_packed_stage, 2 * raw_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("no pinned memory for the packed records"); rc = LHGT_E_NOMEM; }
+        else ctx->packed_stage_bytes = 2 * raw_bytes;
     }
-    if (rc == LHGT_OK && dev_malloc(&d_raw, (size_t)CH * (size_t)stride) != hipSuccess) { set_error("no device memory for the packed records"); fail(LHGT_E_NOMEM); }
-    if (rc == LHGT_OK && dev_malloc(&d_fl, (size_t)CH) != hipSuccess) { set_error("no device memory"); fail(LHGT_E_NOMEM); }
-    if (rc == LHGT_OK && dev_malloc(&d_tot, 64) != hipSuccess) { set_error("no device memory"); fail(LHGT_E_NOMEM); }
+    uint8_t* h_raw[2] = {ctx->h_packed_stage, ctx->h_packed_stage ? ctx->h_packed_stage + raw_bytes : nullptr};
+    for (int i = 0; i < 2 && rc == LHGT_OK; i++)
+        if (dev_malloc(&d_raw[i], raw_bytes) != hipSuccess || dev_malloc(&d_fl[i], (size_t)CH) != hipSuccess) { set_error("no device memory for the packed records"); rc = LHGT_E_NOMEM; }
+    if (rc == LHGT_OK && dev_malloc(&d_tot, 256) != hipSuccess) { set_error("no device memory"); rc = LHGT_E_NOMEM; }
+    unsigned long long* h_tot = nullptr;        // pinned: the totals come back without a staging copy
+    if (rc == LHGT_OK && hipHostMalloc((void**)&h_tot, 256, hipHostMallocDefault) != hipSuccess) { set_error("no pinned memory"); rc = LHGT_E_NOMEM; }
     const int nthreads = ingest_default_threads();
     auto read_chunk = [&](long p0, long m, uint8_t* dst) -> int {
         std::atomic<int> bad{0};
@@ -290,35 +297,43 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
         if (bad) { set_error("%s: the packed records end before pair %ld", path, p0 + m); return LHGT_E_IO; }
         return LHGT_OK;
     };
+    // chunk c: copy + flags + totals, all queued
+    auto enqueue = [&](int c, long p0, long m) -> int {
+        const int s = c & 1;
+        if (hipMemcpyAsync(d_raw[s], h_raw[s], (size_t)m * (size_t)stride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(d_tot + 16 * s, 0, 128, ctx->stream) != hipSuccess) { set_error("upload of the packed records failed"); return LHGT_E_HIP; }
+        hipLaunchKernelGGL(pk_flags, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_raw[s], stride, p0, m, rule, d_random, d_fl[s], d_tot + 16 * s, ctx->k);
+        if (hipMemcpyAsync(h_tot + 16 * s, d_tot + 16 * s, 40, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipEventRecord(s ? ctx->ev3 : ctx->ev2, ctx->stream) != hipSuccess) { set_error("copy"); return LHGT_E_HIP; }
+        return LHGT_OK;
+    };
     long kept_total = 0;
     double t_read = 0, t_dev = 0;
     const double t_all = now_s();
     if (rc == LHGT_OK && p_hi > p_lo) {
-        long next = p_lo;
-        int cur = 0;
-        long m_cur = std::min(CH, p_hi - next);
+        long p_at = p_lo;
+        int c = 0;
+        long m_cur = std::min(CH, p_hi - p_at);
         double t0 = now_s();
-        rc = read_chunk(next, m_cur, h_raw[0]);
+        rc = read_chunk(p_at, m_cur, h_raw[0]);
         t_read += now_s() - t0;
+        if (rc == LHGT_OK) rc = enqueue(0, p_at, m_cur);
         while (rc == LHGT_OK && m_cur > 0) {
-            const long p0 = next, m = m_cur;
-            next += m;
-            // this chunk to the device, its flags and totals
-            if (hipMemcpyAsync(d_raw, h_raw[cur], (size_t)m * (size_t)stride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipMemsetAsync(d_tot, 0, 64, ctx->stream) != hipSuccess) { set_error("upload of the packed records failed"); rc = LHGT_E_HIP; break; }
-            hipLaunchKernelGGL(pk_flags, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, stride, p0, m, rule, d_random, d_fl, d_tot, ctx->k);
-            unsigned long long tot[5] = {0, 0, 0, 0, 0};
-            if (hipMemcpyAsync(tot, d_tot, 40, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { set_error("copy"); rc = LHGT_E_HIP; break; }
-            // the next chunk's records meanwhile (into the other buffer: its last copy has left it long ago)
-            const long m_next = std::min(CH, p_hi - next);
-            if (m_next > 0) {
+            const long m = m_cur;
+            const int s = c & 1;
+            p_at += m;
+            const long m_next = std::min(CH, p_hi - p_at);
+            if (m_next > 0) {         // the next chunk's records meanwhile (its host buffer's last copy was waited for two chunks ago)
                 t0 = now_s();
-                rc = read_chunk(next, m_next, h_raw[cur ^ 1]);
+                rc = read_chunk(p_at, m_next, h_raw[s ^ 1]);
                 t_read += now_s() - t0;
                 if (rc != LHGT_OK) break;
             }
             t0 = now_s();
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("the packed records' flags kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = LHGT_E_HIP; break; }
+            if (hipEventSynchronize(s ? ctx->ev3 : ctx->ev2) != hipSuccess) { set_error("the packed records' flags kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = LHGT_E_HIP; break; }
+            unsigned long long tot[5];
+            memcpy(tot, h_tot + 16 * s, 40);
+            if (m_next > 0) { rc = enqueue(c + 1, p_at, m_next); if (rc != LHGT_OK) break; }      // behind this chunk's flags, in front of its gather
             const long nb = (long)tot[0];
             if (nb > 0) {
                 if (tot[1] >= (1ull << 32)) { set_error("batch too large: %llu plane words", tot[1]); rc = LHGT_E_ARG; break; }
@@ -326,6 +341,7 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
                 b.n_words = tot[1];
                 b.n_kmers = tot[2];
                 b.n_long = (long)tot[3];
+                b.max_len = (int)tot[4];
                 const size_t words_b = (tot[1] * 4 + 16 + 255) & ~(size_t)255, off_b = ((size_t)2 * nb * 4 + 255) & ~(size_t)255, len_b = ((size_t)2 * nb * 2 + 255) & ~(size_t)255;
                 uint8_t* blk = nullptr;
                 if (dev_malloc(&blk, words_b + off_b + len_b + (size_t)nb) != hipSuccess) { set_error("no device memory for a batch of %ld pairs", nb); rc = LHGT_E_NOMEM; break; }
@@ -334,10 +350,8 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
                 uint32_t* d_off = (uint32_t*)(blk + words_b);
                 uint16_t* d_len = (uint16_t*)(blk + words_b + off_b);
                 uint8_t* d_flags = blk + words_b + off_b + len_b;
-                hipMemsetAsync(d_tot + 6, 0, 16, ctx->stream);
-                hipLaunchKernelGGL(pk_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, stride, m, d_fl, nb, d_tot + 6, d_words, d_off, d_len, d_flags);
-                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { dev_free(blk); set_error("the packed records' gather failed"); rc = LHGT_E_HIP; break; }
-                b.max_len = (int)tot[4];
+                hipLaunchKernelGGL(pk_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_raw[s], stride, m, d_fl[s], nb, d_tot + 16 * s + 8, d_words, d_off, d_len, d_flags);
+                if (hipGetLastError() != hipSuccess) { dev_free(blk); set_error("the packed records' gather failed"); rc = LHGT_E_HIP; break; }
                 b.d.words = d_words;
                 b.d.off[0] = d_off;
                 b.d.off[1] = d_off + nb;
@@ -351,13 +365,13 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
                 kept_total += nb;
             }
             t_dev += now_s() - t0;
-            cur ^= 1;
+            c++;
             m_cur = m_next;
         }
     }
-    if (rc != LHGT_OK) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; i++) if (h_raw[i]) hipHostFree(h_raw[i]);
-    for (void* p : {(void*)d_raw, (void*)d_fl, (void*)d_tot, (void*)d_random}) if (p) dev_free(p);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == LHGT_OK) { set_error("the packed records' gather failed: %s", hipGetErrorString(hipGetLastError())); rc = LHGT_E_HIP; }
+    if (h_tot) (void)hipHostFree(h_tot);
+    for (void* p : {(void*)d_raw[0], (void*)d_raw[1], (void*)d_fl[0], (void*)d_fl[1], (void*)d_tot, (void*)d_random}) if (p) dev_free(p);
     if (rc != LHGT_OK) return rc;
     if (ingest_trace())
         fprintf(stderr, "[lhgt ingest] packed part %d/%d: pairs [%ld, %ld) of %ld, %.1f MB of records: read %.3fs (%d threads), device %.3fs, %ld kept, %.3fs in all\n",

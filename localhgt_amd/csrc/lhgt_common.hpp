@@ -241,6 +241,8 @@ struct lhgt_ctx {
     uint32_t* h_ingest_meta = nullptr;       // hipHostMalloc: the open batch's chunk descriptors (lhgt::ChunkDesc x ingest_meta_cap)
     long ingest_meta_cap = 0;
     std::vector<hipEvent_t> ingest_events;
+    uint8_t* h_packed_stage = nullptr;       // hipHostMalloc: two chunks of packed records on their way to the device (k_packed.hip)
+    size_t packed_stage_bytes = 0;
     uint32_t* d_ingest_start = nullptr;      // device copy of the start offsets of the batch being packed
     long ingest_start_cap = 0;
     // grow-only device workspaces (ASCII staging and packed planes of one contig / one upload)

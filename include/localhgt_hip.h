@@ -209,6 +209,10 @@ int lhgt_pairs_store_write(lhgt_ctx* ctx, const char* path, unsigned long long d
 int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long data_offset, long stride, long n_pairs_total, long q4_first_pair,
                            double ratio_percent, int threads, const long* first1, const long* count1, const long* first2, const long* count2,
                            int part, int n_parts, long* n_pairs_seen, long* n_pairs_kept);
+/* measurement handle (tools/ingest_scaling.py), no GPU: the host side of lhgt_pairs_load_packed alone -- the records of part `part`
+ * of `n_parts` read in the loader's chunks into two host buffers by `threads` threads (0: the loader's own choice) */
+int lhgt_packed_read_rate(const char* path, unsigned long long data_offset, long stride, long n_pairs_total, int part, int n_parts, int threads,
+                          double* seconds);
 /* with count-on-load lhgt_pairs_load_fastq closes a batch every Mi pairs and runs phase A on it at once, behind the parsing of the
  * next batch (the coder must be set: load or build the index first); lhgt_count_kmers then only counts what is not counted yet and
  * reports the whole kernel time.  lhgt_counts_clear makes every batch uncounted again. */

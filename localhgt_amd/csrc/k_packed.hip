@@ -228,6 +228,47 @@ int lhgt_pairs_store_write(lhgt_ctx* ctx, const char* path, unsigned long long d
     return LHGT_OK;
 }
 
+}  // extern "C"
+
+// records [p0, p0 + m) of the file into dst, by all host threads
+static bool packed_read(int fd, unsigned long long data_offset, long stride, long p0, long m, uint8_t* dst, int nthreads) {
+    std::atomic<int> bad{0};
+    const long pieces = std::min<long>(4L * nthreads, std::max<long>(1, m / 4096));
+    parallel_for(pieces, nthreads, [&](long q) {
+        const long a = m * q / pieces, b = m * (q + 1) / pieces;
+        size_t want = (size_t)(b - a) * (size_t)stride, done = 0;
+        while (done < want) {
+            const ssize_t r = pread(fd, dst + (size_t)a * (size_t)stride + done, want - done, (off_t)(data_offset + (unsigned long long)(p0 + a) * (unsigned long long)stride + done));
+            if (r <= 0) { bad = 1; return; }
+            done += (size_t)r;
+        }
+    });
+    return !bad;
+}
+
+extern "C" {
+
+// Measurement handle (tools/ingest_scaling.py), no GPU: the host side of lhgt_pairs_load_packed alone -- part `part` of `n_parts` of the
+// records read in the loader's chunks into two buffers by `threads` host threads (0: the loader's own choice).
+int lhgt_packed_read_rate(const char* path, unsigned long long data_offset, long stride, long n_pairs_total, int part, int n_parts, int threads, double* seconds) {
+    if (!path || stride < 8 || n_pairs_total < 0 || n_parts < 1 || part < 0 || part >= n_parts) LHGT_FAIL(LHGT_E_ARG, "bad argument");
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) LHGT_FAIL(LHGT_E_IO, "cannot open %s", path);
+    const long p_lo = (long)((__int128)n_pairs_total * part / n_parts), p_hi = (long)((__int128)n_pairs_total * (part + 1) / n_parts);
+    const long CH = std::min<long>(2L << 20, std::max<long>(1, (long)(((size_t)1 << 29) / (size_t)stride)));
+    const size_t raw_bytes = (size_t)CH * (size_t)stride;
+    std::vector<uint8_t> buf(2 * raw_bytes, 1);          // touched: a loader's pinned buffers are
+    const int nthreads = threads > 0 ? threads : ingest_default_threads();
+    const double t0 = now_s();
+    int c = 0;
+    bool ok = true;
+    for (long p = p_lo; p < p_hi && ok; p += CH, c++) ok = packed_read(fd, data_offset, stride, p, std::min(CH, p_hi - p), buf.data() + (size_t)(c & 1) * raw_bytes, nthreads);
+    if (seconds) *seconds = now_s() - t0;
+    close(fd);
+    if (!ok) LHGT_FAIL(LHGT_E_IO, "%s: the packed records end early", path);
+    return LHGT_OK;
+}
+
 // Part `part` of `n_parts` of a packed sample (a contiguous run of its pairs: read ordinals are global) becomes resident: the records
 // are read into pinned memory by all host threads, go to the GPU as they are, and the GPU decides which pairs the run keeps (the
 // sampling array by global ordinal and quirk Q4 at threads = 1; the thread chunks first1 / count1 / first2 / count2 of the reference's
@@ -283,18 +324,7 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
     if (rc == LHGT_OK && hipHostMalloc((void**)&h_tot, 256, hipHostMallocDefault) != hipSuccess) { set_error("no pinned memory"); rc = LHGT_E_NOMEM; }
     const int nthreads = ingest_default_threads();
     auto read_chunk = [&](long p0, long m, uint8_t* dst) -> int {
-        std::atomic<int> bad{0};
-        const long pieces = std::min<long>(4L * nthreads, std::max<long>(1, m / 4096));
-        parallel_for(pieces, nthreads, [&](long q) {
-            const long a = m * q / pieces, b = m * (q + 1) / pieces;
-            size_t want = (size_t)(b - a) * (size_t)stride, done = 0;
-            while (done < want) {
-                const ssize_t r = pread(fd, dst + (size_t)a * (size_t)stride + done, want - done, (off_t)(data_offset + (unsigned long long)(p0 + a) * (unsigned long long)stride + done));
-                if (r <= 0) { bad = 1; return; }
-                done += (size_t)r;
-            }
-        });
-        if (bad) { set_error("%s: the packed records end before pair %ld", path, p0 + m); return LHGT_E_IO; }
+        if (!packed_read(fd, data_offset, stride, p0, m, dst, nthreads)) { set_error("%s: the packed records end before pair %ld", path, p0 + m); return LHGT_E_IO; }
         return LHGT_OK;
     };
     // chunk c: copy + flags + totals, all queued

@@ -8,7 +8,7 @@ slowest rank's parse).  The consumer only hands slabs back (lhgt_fastq_parse_rat
 GPUs, not an end-to-end figure.
 
 usage: ingest_scaling.py [n_pairs=32000000] [out.txt]      (writes the files with the device generator first: needs the GPU for that)
-       ingest_scaling.py --files fq1 fq2 [out.txt]
+       ingest_scaling.py --files fq1 fq2 [packed.lhgp] [out.txt]
 """
 import ctypes as C
 import json
@@ -52,6 +52,12 @@ def worker(argv):
         print(json.dumps({"step": "plan", "part": part, "s": dt}), flush=True)
         return
     seen, kept, bases, secs = C.c_long(0), C.c_long(0), C.c_long(0), C.c_double(0)
+    if step == "packed":          # fq1 = the packed sample: the loader's host side is pread of its records, nothing else
+        from localhgt_amd import pack
+        hdr = pack.read_header(fq1)
+        rc = h.lhgt_packed_read_rate(fq1.encode(), hdr.data_offset, hdr.stride, hdr.n_pairs, part, parts, threads, C.byref(secs))
+        print(json.dumps({"step": "packed", "part": part, "rc": rc, "s": secs.value, "pairs": hdr.n_pairs}), flush=True)
+        return
     if step == "single":
         os.environ["LHGT_INGEST_STREAM"] = "1"
         rc = h.lhgt_fastq_parse_rate(fq1.encode(), fq2.encode(), 100.0, None, threads, CHUNK, emulate, None, None, 0, None, None, 0, 0, 1,
@@ -85,9 +91,12 @@ def main():
     if args and args[0] == "--worker":
         return worker(args[1:])
     work = tempfile.mkdtemp(prefix="lhgt_ingest_", dir="/tmp")
+    packed = None
     if args and args[0] == "--files":
         fq1, fq2 = args[1], args[2]
         out_path = args[3] if len(args) > 3 else None
+        if out_path and out_path.endswith(".lhgp"):
+            packed, out_path = out_path, (args[4] if len(args) > 4 else None)
     else:
         import bench
         n_pairs = int(args[0]) if args else 32_000_000
@@ -95,6 +104,9 @@ def main():
         t0 = time.time()
         _, fq1, fq2 = bench.synth_files_sliced(work, 32, 3, 100, 1_000_000, n_pairs, 0)
         print(f"files written in {time.time() - t0:.0f} s", flush=True)
+        from localhgt_amd import pack
+        packed = os.path.join(work, "s.lhgp")
+        pack.pack(fq1, fq2, packed, max_threads=10)
     size = os.path.getsize(fq1) + os.path.getsize(fq2)
     n_pairs = sum(1 for _ in open(fq1, "rb")) // 4 if size < 1 << 28 else os.path.getsize(fq1) // 318     # bench's records are 318 bytes
     hw = os.cpu_count() or 8
@@ -126,6 +138,18 @@ def main():
                 how = {2: "columns on the plans' line numbers", 0: "chunk loop"}.get(b[0].get("path"), "?")
                 lines.append(f"{parts} x {t:3d}, planned (count, exchange, parse 1/{parts}: {how}) | {tp:.3f} | {tq:.3f} | {n_pairs / (tp + tq) / 1e6:.1f} | {size / (tp + tq) / 1e9:.1f}")
                 print(lines[-1], flush=True)
+    if packed:
+        psize = os.path.getsize(packed)
+        lines.append(f"the same pairs as a packed sample (localhgt_pack: {psize / 1e9:.2f} GB, {size / psize:.1f} x less than the text): the host side of its load is pread of "
+                     f"1/N of the records into two buffers (lhgt_packed_read_rate; the loader's are pinned)")
+        for parts in (1, 2, 4, 8):
+            for t in sorted({max(2, base // parts), max(2, base * 3 // 2 // parts)}):
+                for rep in range(2):
+                    b = run_step("packed", packed, "-", parts, t, 1, work)
+                    assert all(x["rc"] == 0 for x in b), b
+                    tq = max(x["s"] for x in b)
+                    lines.append(f"{parts} x {t:3d}, packed records (pread 1/{parts}) | - | {tq:.3f} | {n_pairs / tq / 1e6:.1f} | {psize / tq / 1e9:.1f} (of records)")
+                    print(lines[-1], flush=True)
     if out_path:
         open(out_path, "w").write("\n".join(lines) + "\n")
     import shutil

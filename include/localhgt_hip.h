@@ -327,7 +327,7 @@ int lhgt_synth_read_mix(lhgt_ctx* ctx, int long_permille, int long_len);
  * list, which it builds at once if there is none (lhgt_slot_list; outputs unchanged); bit25: a slot list that exists is not used;
  * bit26: stage ablation of the slot-first kernel, the stage named by LHGT_SLOTS_ABLATE (1: no listed position is followed, 2: none
  * probes the table; timing only, the flags come out WRONG); bit27: a dense peak set (no bitmap) is voted in the shared-line-fill form
- * (k_vote_shared.hip) whatever the store's size and grouping (e <= 3; outputs unchanged); bit28: never in that form.
+ * (k_vote_shared.hip) whatever the store's size and grouping (e <= 3; outputs unchanged); bit28: never in that form; bit29: the peaks' k-mers are registered by partition (lhgt_registry_info) whatever their number (k >= 20), bit30: never.
  * The environment variable LHGT_DEBUG presets the flags of every new context. */
 int lhgt_set_debug(lhgt_ctx* ctx, int flags);
 /* the context's kernels run only on the CUs whose bits are set in mask[0 .. n_words) (n_words = 0: all CUs again): two contexts
@@ -341,6 +341,12 @@ int lhgt_phase_ms(lhgt_ctx* ctx, int phase /*0=A 1=B 2=C (all kernels of the pha
  *      be settled from that); 2 trio-first, for a sparse table (probes until a hash does not read 3; complete probes only near
  *      windows that reach the trio threshold).  n_tiles_exact = tiles that got the exact treatment. */
 int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_tiles, long* n_tiles_exact);
+/* ---- how the last lhgt_ref_scan registered its peaks' k-mers in peak_kmer (add_peak, E:247-267; k_scan.hip): *chunks = 0 with one atomicMax
+ *      per (slot, id) from the walk over the reference (register_peaks), n > 0 (round 6) routed by slot through two scatter passes and
+ *      applied per 2^(k-17)-slot slice of the table in LDS, in n chunks of the reference (a dense peak set without a vote bitmap: half a G of
+ *      records or more; LHGT_REGISTER_PART=0 never, =1 whenever k >= 20; debug bit 29 / 30 likewise).  records_bound = selected
+ *      positions x e, records_direct = records that found their region full and went to the table at once.  Measurement only. */
+int lhgt_registry_info(lhgt_ctx* ctx, int* chunks, unsigned long long* records_bound, unsigned long long* records_direct);
 /* The slot list of the resident reference: every position with a k-mer, grouped by the top bits of the slot its largest hash
  * addresses (6 bytes per position; 10 when the list under the largest hash also carries every position's second-largest hash, which
  * it does when that leaves room on the device).  A context that scans sample after sample against one resident reference answers the first

@@ -72,6 +72,14 @@ size_t size_class(size_t bytes) {                                   // next eigh
 // thread, when no scan is using it.  Other threads' contexts are left alone (their lists may be in use).
 bool drop_optional(void) {
     lhgt_ctx* c = t_entry_ctx;
+    if (c && c->d_rg_buf) {                                         // the registry by partition's record buffers: idle outside register_partitioned, sized again by the next scan
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        (void)dev_free(c->d_rg_buf);
+        c->d_rg_buf = nullptr;
+        c->rg_buf_bytes = 0;
+        (void)big_release_all();
+        return true;
+    }
     if (!c || c->sl_state != 1 || c->sl_in_use) return false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     slot_list_drop(c);
@@ -143,6 +151,7 @@ hipError_t dev_free(void* p) {
     }
     return hipFree(p);
 }
+size_t dev_cached_bytes() { std::lock_guard<std::mutex> lk(g_dev_mu); return g_dev_cached; }
 bool big_release_all() {
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
@@ -308,7 +317,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt::slot_list_drop(c);
     lhgt::vshared_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
-                    (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count,
+                    (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count, (void*)c->d_tile_sel, (void*)c->d_rg_buf,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words,
                     (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_revote, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest, (void*)c->d_stats})
         if (p) lhgt::dev_free(p);

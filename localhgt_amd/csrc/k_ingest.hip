@@ -594,10 +594,10 @@ int upload_pairs(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* off1, const
 int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t first_ref_index) {
     const int k = ctx->k, e = ctx->e;
     slot_list_drop(ctx);
-    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_ref_planes, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count})
+    for (void* p : {(void*)ctx->d_index, (void*)ctx->d_ref_planes, (void*)ctx->d_contigs, (void*)ctx->d_tiles, (void*)ctx->d_flags, (void*)ctx->d_nzmask, (void*)ctx->d_tile_good, (void*)ctx->d_active_tiles, (void*)ctx->d_tile_count, (void*)ctx->d_tile_sel, (void*)ctx->d_rg_buf})
         if (p) lhgt::dev_free(p);
     ctx->d_ref_planes = nullptr; ctx->ref_plane_words = 0;
-    ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr;
+    ctx->d_index = nullptr; ctx->d_contigs = nullptr; ctx->d_tiles = nullptr; ctx->d_flags = nullptr; ctx->d_nzmask = nullptr; ctx->d_tile_good = nullptr; ctx->d_active_tiles = nullptr; ctx->d_tile_count = nullptr; ctx->d_tile_sel = nullptr; ctx->d_rg_buf = nullptr; ctx->rg_buf_bytes = 0;
     ctx->contigs.clear();
     ctx->contig_first_tile.clear();
     ctx->all_lens.clear();
@@ -636,6 +636,7 @@ int index_layout(lhgt_ctx* ctx, const std::vector<uint32_t>& lens, uint32_t firs
     LHGT_HIP(lhgt::dev_malloc(&ctx->d_nzmask, flat));
     LHGT_HIP(lhgt::dev_malloc(&ctx->d_tile_good, tiles.size() + 8));
     LHGT_HIP(lhgt::dev_malloc(&ctx->d_active_tiles, (tiles.size() + 1) * 4));
+    LHGT_HIP(lhgt::dev_malloc(&ctx->d_tile_sel, (tiles.size() + 16) * 4));
     LHGT_HIP(lhgt::dev_malloc(&ctx->d_tile_count, (tiles.size() + 16) * 4));  // counts, total, then small counters (selected positions, active tiles, saturated lines)
     LHGT_HIP(hipMemcpyAsync(ctx->d_contigs, ctx->contigs.data(), ctx->contigs.size() * sizeof(ContigDev), hipMemcpyHostToDevice, ctx->copy_stream));
     LHGT_HIP(hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice, ctx->copy_stream));

@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) mark_active_tiles(const TileDev* __restri
 // that return at once costs ~25 ns each in the dispatcher); tile_count of the others was zeroed by the caller
 __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, int k,
                                                       const uint32_t* __restrict__ active,
-                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count,
+                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_sel,
                                                       unsigned long long* __restrict__ n_selected, long n_blk) {
     __shared__ unsigned long long gw[NW3];
     __shared__ int prevw[NW3], nextw[NW3];       // last good index in words <= w / first good index in words >= w
@@ -797,6 +797,7 @@ __global__ void __launch_bounds__(BT) interval_select(const TileDev* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         tile_count[tile] = (uint32_t)n_new;
+        tile_sel[tile] = (uint32_t)n_sel;
         if (n_sel) atomicAdd(n_selected, (unsigned long long)n_sel);
     }
 }
@@ -1033,6 +1034,244 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
             atomicOr(&prefilter[pf_word(h, pf_mask)], pf_word_bits(h, pf2));
         }
     }
+}
+
+// ---- B5 by partition (round 6).  In the regime `localhgt bkp` runs by default (--sample 2000000000 on a half-of-the-
+// catalogue sample) the peak set is dense: 55 M peaks register 7.7 G (hash, id) pairs into a 16 GiB table, and register_peaks above is
+// what the fabric allows for that many random line fills and write-backs (12 G line transactions, 261 ms).  "The larger id wins a
+// slot" does not depend on the order of the registrations (E:247-267: every thread of the reference overwrites in its own order, the
+// emulation's rule is the last writer = the largest id), so they are routed by slot like phase A's keys:
+//   rg_emit   a workgroup walks RG_TILES tiles twice -- first counting its records per top-8-bit bucket of the slot in LDS, then,
+//             with one global cursor bump per bucket, writing each record (slot << 32 | id) to its place: the 8-byte stores of one run land
+//             next to each other within microseconds and leave L2 as whole lines;
+//   rg_split  a slab of 16 Ki records of one bucket, held in registers, goes to the 512 sub-buckets of the next nine bits the same way;
+//   rg_apply  a final bucket = 2^(k-17) slots of peak_kmer (128 KiB at k = 32) lives in LDS while its records are applied with
+//             ds_max_u32, and goes back as it came: one sequential sweep of the table per chunk instead of a line fill per record.
+// A slot is min(forward, reverse complement), so its density falls linearly (2(1-x)): bucket q of nb expects the share
+// (2(nb-q)-1)/nb^2 of the records, regions are laid out by that expectation + 1/16 + a pad (rg_base), and a record that finds its
+// region full (repeats) is applied to the table at once -- rg_apply loads its slice behind the scatters, so the table is exact whatever
+// overflows.  The records of the whole reference need 17 bytes each in flight; what fits decides the number of CHUNKS (runs of tile
+// groups with equal shares of the selected positions, from interval_select's per-tile counts), each with its own emit / split /
+// apply and table sweep.
+constexpr int RG_TILES = 16, RG_BT = 512;
+constexpr int RG_B1 = 256, RG_B2 = 512, RG_L2 = 17;            // 8 + 9 bits of fan-out
+constexpr int RG_SBT = 1024, RG_PER = 16, RG_SLAB = RG_SBT * RG_PER;
+constexpr unsigned long long RG_PAD1 = 8192, RG_PAD2 = 64;
+// first record of bucket q of 2^nb_log: floor(ucap * q (2 nb - q) / nb^2) + q * pad, even (16-byte aligned) -- integer arithmetic, the same
+// value in every kernel and on the host
+__host__ __device__ inline unsigned long long rg_base(unsigned long long ucap, unsigned long long q, int nb_log, unsigned long long pad) {
+    const unsigned long long nb = 1ull << nb_log, A = q * (2 * nb - q);
+    const int S = 2 * nb_log;
+    unsigned long long v;
+    if (S < 20) v = (A * ucap) >> S;
+    else v = (A * (ucap >> 20) + ((A * (ucap & 0xfffffull)) >> 20)) >> (S - 20);
+    return (v + q * pad) & ~1ull;
+}
+
+__global__ void __launch_bounds__(1024) rg_group_prefix(const uint32_t* __restrict__ tile_sel, long n_tiles, long n_groups, unsigned long long* __restrict__ pre) {
+    __shared__ unsigned long long sh[16];
+    unsigned long long carry = 0;
+    for (long base = 0; base < n_groups; base += 1024) {
+        const long g = base + threadIdx.x;
+        unsigned long long x = 0;
+        if (g < n_groups)
+            for (int q = 0; q < RG_TILES; q++) { const long t = g * RG_TILES + q; if (t < n_tiles) x += tile_sel[t]; }
+        unsigned long long total;
+        const unsigned long long ex = block_excl_sum_u64(x, sh, &total);
+        if (g < n_groups) pre[g] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) pre[n_groups] = carry;
+}
+
+__global__ void __launch_bounds__(RG_BT) rg_emit(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
+                                                 const uint32_t* __restrict__ counts, const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
+                                                 const uint8_t* __restrict__ pstate, const uint32_t* __restrict__ tile_base, int k, int e,
+                                                 int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer, uint32_t first_id, long n_tiles, long n_groups,
+                                                 const unsigned long long* __restrict__ group_pre, unsigned long long sel_per_chunk, unsigned long long chunk,
+                                                 unsigned long long ucap, unsigned long long pad1, unsigned long long* __restrict__ cur1, unsigned long long* __restrict__ buf1,
+                                                 unsigned long long* __restrict__ n_direct,
+                                                 uint32_t* __restrict__ prefilter /* nullable: the vote's bitmap, where a forced run has one */, uint32_t pf_mask, int pf2) {
+    __shared__ int incl[TILE], part[RG_BT];
+    __shared__ unsigned int hist[RG_B1];
+    __shared__ unsigned long long gpos[RG_B1], glim[RG_B1];
+    const long g = block2d();
+    if (g >= n_groups) return;
+    const unsigned long long s0 = group_pre[g];
+    if (group_pre[g + 1] == s0 || s0 / sel_per_chunk != chunk) return;     // nothing selected here, or another chunk's group
+    for (int b = threadIdx.x; b < RG_B1; b += RG_BT) hist[b] = 0;
+    __syncthreads();
+    const int shift1 = k - 8;
+    unsigned int direct = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int ti = 0; ti < RG_TILES; ti++) {
+            const long blk = g * RG_TILES + ti;
+            if (blk >= n_tiles) break;
+            uint32_t base = tile_base[blk];
+            if (tile_base[blk + 1] == base) continue;  // no peak in this tile (uniform)
+            base += first_id;
+            const TileDev t = tiles[blk];
+            const ContigDev c = contigs[t.contig];
+            const long len = c.len, nk = len - k + 1;
+            const uint8_t* F = flags + c.flat_base;
+            constexpr int CH = (TILE + RG_BT - 1) / RG_BT;
+            const int b0 = threadIdx.x * CH, en = b0 + CH < TILE ? b0 + CH : TILE;
+            int s = 0;
+            for (int jj = b0; jj < en; jj++) {
+                const long j = (long)t.j0 + jj;
+                s += (j < len) ? (F[j] >> 6) & 1 : 0;
+                incl[jj] = s;
+            }
+            const int off = block_excl_sum(s, part);
+            for (int jj = b0; jj < en; jj++) incl[jj] += off;
+            __syncthreads();
+            for (int jj = threadIdx.x; jj < TILE; jj += RG_BT) {
+                const long j = (long)t.j0 + jj;
+                if (j >= len) break;
+                const uint8_t f = F[j];
+                if (!((f >> 5) & 1)) continue;
+                const uint32_t id = base + (uint32_t)incl[jj] - 1u;  // merged peaks take the id of their bucket's first peak
+                if (pass == 1 && ((f >> 6) & 1)) {
+                    loci[2 * (long)id] = (int32_t)c.ref_index;
+                    loci[2 * (long)id + 1] = (int32_t)j;
+                }
+                if (j >= nk) continue;
+                const RefKmer km = ref_kmer(rs, c, j, k, e);
+                uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u, have = nzmask ? 0xffu : 0u;
+                if (pstate) {                 // as in register_peaks: what the probe kernels already know about "count > 0" per hash
+                    const uint32_t ps = pstate[c.flat_base + j];
+                    if ((f & 0x82u) == 0x82u) { nz = 7u; have = 7u; }
+                    else if (ps & 0x80u) { nz = (ps >> 4) & 7u; have = 7u; }
+                    else {
+                        const uint32_t known = (ps >> 4) & 7u, is3 = ps & 7u;
+                        nz = is3 | (((ps >> 3) & 1u) ? (known & ~is3) : 0u);
+                        have = known;
+                    }
+                }
+                for (int i = 0; i < e; i++) {
+                    const uint32_t h = ref_hash(rs, km, i);
+                    if (i < 8 && ((have >> i) & 1u) ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
+                        const uint32_t b = h >> shift1;
+                        if (pass == 0) atomicAdd(&hist[b], 1u);
+                        else {
+                            const unsigned long long pos = gpos[b] + atomicAdd(&hist[b], 1u);
+                            if (pos < glim[b]) buf1[pos] = ((unsigned long long)h << 32) | id;
+                            else { atomicMax(&peak_kmer[h], id); direct++; }
+                            if (prefilter) atomicOr(&prefilter[pf_word(h, pf_mask)], pf_word_bits(h, pf2));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (pass == 0) {
+            for (int b = threadIdx.x; b < RG_B1; b += RG_BT) {
+                const unsigned int n = hist[b];
+                hist[b] = 0;
+                gpos[b] = n ? rg_base(ucap, b, 8, pad1) + atomicAdd(&cur1[b], (unsigned long long)n) : 0ull;
+                glim[b] = rg_base(ucap, b + 1, 8, pad1);
+            }
+            __syncthreads();
+        }
+    }
+    if (direct) atomicAdd(n_direct, (unsigned long long)direct);
+}
+
+__global__ void __launch_bounds__(RG_SBT) rg_split(const unsigned long long* __restrict__ buf1, const unsigned long long* __restrict__ cur1, unsigned long long ucap,
+                                                   unsigned long long pad1, unsigned long long pad2, int k,
+                                                   unsigned long long* __restrict__ cur2, unsigned long long* __restrict__ buf2, uint32_t* __restrict__ peak_kmer,
+                                                   unsigned long long* __restrict__ n_direct) {
+    __shared__ unsigned long long cnt[RG_B1], before[RG_B1 + 1];
+    __shared__ unsigned int hist[RG_B2];
+    __shared__ unsigned long long gpos[RG_B2], glim[RG_B2];
+    for (int b = threadIdx.x; b < RG_B1; b += RG_SBT) {
+        const unsigned long long lo = rg_base(ucap, b, 8, pad1), cap = rg_base(ucap, b + 1, 8, pad1) - lo;
+        const unsigned long long n = cur1[b];
+        cnt[b] = n < cap ? n : cap;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int b = 0; b < RG_B1; b++) { before[b] = run; run += (cnt[b] + RG_SLAB - 1) / RG_SLAB; }
+        before[RG_B1] = run;
+    }
+    __syncthreads();
+    const unsigned long long items = before[RG_B1];
+    const int shift2 = k - RG_L2;
+    unsigned int direct = 0;
+    for (unsigned long long item = blockIdx.x; item < items; item += gridDim.x) {
+        int lo = 0, hi = RG_B1;                 // the bucket of this slab: the last q with before[q] <= item
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (before[mid] <= item) lo = mid; else hi = mid; }
+        const int q = lo;
+        const unsigned long long slab = item - before[q], first = slab * RG_SLAB;
+        const unsigned long long n = cnt[q] - first < (unsigned long long)RG_SLAB ? cnt[q] - first : (unsigned long long)RG_SLAB;
+        const unsigned long long* src = buf1 + rg_base(ucap, q, 8, pad1) + first;
+        for (int s = threadIdx.x; s < RG_B2; s += RG_SBT) hist[s] = 0;
+        __syncthreads();
+        unsigned long long rec[RG_PER];
+        unsigned int rank[RG_PER];
+#pragma unroll
+        for (int r = 0; r < RG_PER; r++) {
+            const unsigned long long i = (unsigned long long)r * RG_SBT + threadIdx.x;
+            rec[r] = i < n ? __builtin_nontemporal_load(src + i) : ~0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < RG_PER; r++)
+            if (rec[r] != ~0ull) rank[r] = atomicAdd(&hist[((uint32_t)(rec[r] >> 32) >> shift2) & (RG_B2 - 1)], 1u);
+        __syncthreads();
+        for (int s = threadIdx.x; s < RG_B2; s += RG_SBT) {
+            const unsigned int m = hist[s];
+            const unsigned long long fb = (unsigned long long)q * RG_B2 + s;
+            gpos[s] = m ? rg_base(ucap, fb, RG_L2, pad2) + atomicAdd(&cur2[fb], (unsigned long long)m) : 0ull;
+            glim[s] = rg_base(ucap, fb + 1, RG_L2, pad2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RG_PER; r++)
+            if (rec[r] != ~0ull) {
+                const uint32_t h = (uint32_t)(rec[r] >> 32);
+                const int s = (h >> shift2) & (RG_B2 - 1);
+                const unsigned long long pos = gpos[s] + rank[r];
+                if (pos < glim[s]) buf2[pos] = rec[r];
+                else { atomicMax(&peak_kmer[h], (uint32_t)rec[r]); direct++; }
+            }
+        __syncthreads();
+    }
+    if (direct) atomicAdd(n_direct, (unsigned long long)direct);
+}
+
+__global__ void __launch_bounds__(1024) rg_apply(const unsigned long long* __restrict__ buf2, const unsigned long long* __restrict__ cur2, unsigned long long ucap,
+                                                 unsigned long long pad2, int k,
+                                                 uint32_t* __restrict__ peak_kmer, long n_final) {
+    extern __shared__ uint32_t rg_tab[];
+    const long fb = block2d();
+    if (fb >= n_final) return;
+    const unsigned long long lo = rg_base(ucap, (unsigned long long)fb, RG_L2, pad2), cap = rg_base(ucap, (unsigned long long)fb + 1, RG_L2, pad2) - lo;
+    unsigned long long n = cur2[fb];
+    if (n > cap) n = cap;
+    if (n == 0) return;
+    const int sb = k - RG_L2;
+    const uint32_t slots = 1u << sb, mask = slots - 1u;
+    uint32_t* T = peak_kmer + ((size_t)fb << sb);
+    const unsigned long long* R = buf2 + lo;
+    if (n * 64 < slots) {                       // a handful of records: not worth the slice
+        for (unsigned long long i = threadIdx.x; i < n; i += 1024) { const unsigned long long rec = R[i]; atomicMax(&T[(uint32_t)(rec >> 32) & mask], (uint32_t)rec); }
+        return;
+    }
+    for (uint32_t i = threadIdx.x * 4; i < slots; i += 4096) *(uint4*)&rg_tab[i] = *(const uint4*)&T[i];
+    __syncthreads();
+    unsigned long long i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        const unsigned long long r0 = __builtin_nontemporal_load(R + i), r1 = __builtin_nontemporal_load(R + i + 1024), r2 = __builtin_nontemporal_load(R + i + 2048),
+                                 r3 = __builtin_nontemporal_load(R + i + 3072);
+        atomicMax(&rg_tab[(uint32_t)(r0 >> 32) & mask], (uint32_t)r0);
+        atomicMax(&rg_tab[(uint32_t)(r1 >> 32) & mask], (uint32_t)r1);
+        atomicMax(&rg_tab[(uint32_t)(r2 >> 32) & mask], (uint32_t)r2);
+        atomicMax(&rg_tab[(uint32_t)(r3 >> 32) & mask], (uint32_t)r3);
+    }
+    for (; i < n; i += 1024) { const unsigned long long rec = R[i]; atomicMax(&rg_tab[(uint32_t)(rec >> 32) & mask], (uint32_t)rec); }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x * 4; j < slots; j += 4096) *(uint4*)&T[j] = *(const uint4*)&rg_tab[j];
 }
 
 // ---- B1 for a sparse table with the reference resident across samples ("slot-first", round 5).  The trio-first kernel above asks
@@ -1831,6 +2070,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     unsigned int* d_nact = (unsigned int*)(d_nsel + 1);
     LHGT_HIP(hipMemsetAsync(d_nact, 0, 4, ctx->stream));
     LHGT_HIP(hipMemsetAsync(ctx->d_tile_count, 0, (size_t)(ctx->n_tiles + 1) * 4, ctx->stream));
+    LHGT_HIP(hipMemsetAsync(ctx->d_tile_sel, 0, (size_t)(ctx->n_tiles + 1) * 4, ctx->stream));
     hipLaunchKernelGGL(mark_active_tiles, dim3((unsigned)((ctx->n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs,
                        ctx->d_tile_good, ctx->n_tiles, ctx->d_active_tiles, d_nact, ctx->debug & 256);
     unsigned int n_active = 0;
@@ -1839,7 +2079,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
     if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] tiles %ld, for interval_select %u\n", ctx->n_tiles, n_active);
     if (n_active)
         hipLaunchKernelGGL(interval_select, blocks2d(n_active), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, k, ctx->d_active_tiles,
-                           ctx->d_flags, ctx->d_tile_count, d_nsel, (long)n_active);
+                           ctx->d_flags, ctx->d_tile_count, ctx->d_tile_sel, d_nsel, (long)n_active);
     if (ctx->n_tiles <= 4L * SCAN_CHUNK && !((ctx->debug & 128) && ctx->n_tiles >= 3))
         hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_count, ctx->n_tiles);
     else {   // the active-tile list is free again: its first words hold the chunk sums (u64, far fewer than n_tiles / 2)
@@ -1994,6 +2234,96 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     return LHGT_OK;
 }
 
+// The registry by partition (rg_emit / rg_split / rg_apply above) in front of the vote of a DENSE peak set: *done = false when the
+// direct kernel is the better (or the only possible) way -- few records (a bitmap in front of the vote says so, too), no memory for a
+// tenth of the records in flight.  LHGT_REGISTER_PART=0 never, =1 whenever k >= 20; debug bit 29 / bit 30 likewise;
+// LHGT_REGISTER_CHUNKS / LHGT_REGISTER_TIGHT (tests): that many chunks; regions sized for a 1/TIGHT of the records, so that most find them full.
+static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long long n_sel, bool* done) {
+    *done = false;
+    ctx->rg_chunks = 0;
+    ctx->rg_bound = 0;
+    ctx->rg_direct = 0;
+    static const int mode = getenv("LHGT_REGISTER_PART") ? atoi(getenv("LHGT_REGISTER_PART")) : -1;
+    const bool forced = mode == 1 || (ctx->debug & (1 << 29));
+    if (mode == 0 || (ctx->debug & (1 << 30)) || (ctx->prefilter_on && !forced) || ctx->k < 20 || ctx->k > 32 || ctx->n_tiles == 0 || n_sel == 0) return LHGT_OK;
+    const unsigned long long e = (unsigned long long)ctx->e;
+    if (!forced && n_sel * e < (1ull << 29)) return LHGT_OK;          // half a G of records: 20 ms of the direct kernel
+    if (n_sel * e >= (1ull << 35)) return LHGT_OK;                    // (rg_base's arithmetic)
+    const int want_chunks = getenv("LHGT_REGISTER_CHUNKS") ? atoi(getenv("LHGT_REGISTER_CHUNKS")) : 0;      // (read per scan: the tests vary them)
+    const int tight = getenv("LHGT_REGISTER_TIGHT") ? atoi(getenv("LHGT_REGISTER_TIGHT")) : 0;
+    const long n_groups = (ctx->n_tiles + RG_TILES - 1) / RG_TILES;
+    const long n_final = (long)RG_B1 * RG_B2;
+    const unsigned long long pad1 = tight > 1 ? 2 : RG_PAD1, pad2 = tight > 1 ? 2 : RG_PAD2;
+    const size_t fixed = (((size_t)n_groups + 1) * 8 + 255 & ~(size_t)255) + (size_t)(RG_B1 + n_final + 8) * 8;     // group prefix, cursors, counter
+    // bytes of the two record buffers for `nc` chunks
+    auto plan = [&](int nc, unsigned long long* sel_per, unsigned long long* ucap, size_t* b1, size_t* b2) {
+        *sel_per = (n_sel + (unsigned long long)nc - 1) / (unsigned long long)nc;
+        unsigned long long u = (*sel_per + (unsigned long long)RG_TILES * TILE) * e;      // a group belongs to the chunk its first position falls into
+        u += u / 16;
+        if (tight > 1) u = u / (unsigned long long)tight + 1;
+        *ucap = u;
+        *b1 = (size_t)(rg_base(u, RG_B1, 8, pad1) + 16) * 8;
+        *b2 = (size_t)(rg_base(u, (unsigned long long)n_final, RG_L2, pad2) + 16) * 8;
+    };
+    unsigned long long sel_per = 0, ucap = 0;
+    size_t b1 = 0, b2 = 0;
+    int nc = want_chunks > 0 ? want_chunks : 1;
+    plan(nc, &sel_per, &ucap, &b1, &b2);
+    if (want_chunks <= 0 && ctx->rg_buf_bytes < fixed + b1 + b2) {
+        // what the device can spare: free and parked blocks less 8 GB, and no more than 32 GB (LHGT_REGISTER_GB) -- inside the 40 GB the
+        // slot list leaves free, which is worth more than fewer chunks (a chunk more = a sweep of the table more, ~10 ms); up to 8 chunks
+        static const double cap_gb = getenv("LHGT_REGISTER_GB") ? atof(getenv("LHGT_REGISTER_GB")) : 32.0;
+        size_t free_b = 0, total_b = 0;
+        LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t avail = free_b + lhgt::dev_cached_bytes() + ctx->rg_buf_bytes;
+        const size_t room = std::min(avail > ((size_t)8 << 30) ? avail - ((size_t)8 << 30) : 0, (size_t)(cap_gb * 1e9));
+        while (nc < 8 && fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) { nc++; plan(nc, &sel_per, &ucap, &b1, &b2); }
+        if (fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) {
+            if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: %.1f GB wanted for 8 chunks, %.1f GB to spare -- the direct kernel\n", (double)(fixed + b1 + b2) / 1e9, (double)room / 1e9);
+            return LHGT_OK;
+        }
+    }
+    if (ctx->rg_buf_bytes < fixed + b1 + b2) {
+        if (ctx->d_rg_buf) { lhgt::dev_free(ctx->d_rg_buf); ctx->d_rg_buf = nullptr; ctx->rg_buf_bytes = 0; }
+        if (lhgt::dev_malloc(&ctx->d_rg_buf, fixed + b1 + b2) != hipSuccess) {
+            (void)hipGetLastError();
+            if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: no %.1f GB -- the direct kernel\n", (double)(fixed + b1 + b2) / 1e9);
+            return LHGT_OK;
+        }
+        ctx->rg_buf_bytes = fixed + b1 + b2;
+    }
+    unsigned long long* d_pre = (unsigned long long*)ctx->d_rg_buf;
+    unsigned long long* d_cur1 = (unsigned long long*)(ctx->d_rg_buf + (((size_t)n_groups + 1) * 8 + 255 & ~(size_t)255));
+    unsigned long long* d_cur2 = d_cur1 + RG_B1;
+    unsigned long long* d_direct = d_cur2 + n_final;
+    unsigned long long* d_buf1 = (unsigned long long*)(ctx->d_rg_buf + fixed);
+    unsigned long long* d_buf2 = (unsigned long long*)(ctx->d_rg_buf + fixed + b1);
+    hipLaunchKernelGGL(rg_group_prefix, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_sel, ctx->n_tiles, n_groups, d_pre);
+    LHGT_HIP(hipMemsetAsync(d_direct, 0, 8, ctx->stream));
+    const size_t lds = (size_t)4 << (ctx->k - RG_L2);
+    if (lds > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)rg_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) n_cu = prop.multiProcessorCount; else (void)hipGetLastError(); }
+    const uint8_t* pstate = ctx->scan_form == 2 && !(ctx->debug & (1 << 23)) ? ctx->d_nzmask : nullptr;
+    for (int c = 0; c < nc; c++) {
+        LHGT_HIP(hipMemsetAsync(d_cur1, 0, (size_t)(RG_B1 + n_final) * 8, ctx->stream));
+        hipLaunchKernelGGL(rg_emit, blocks2d(n_groups), dim3(RG_BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, ctx->d_flags,
+                           ctx->scan_lite ? nullptr : ctx->d_nzmask, pstate, ctx->d_tile_count, ctx->k, ctx->e, ctx->d_loci, ctx->d_peak_kmer, first_id, ctx->n_tiles, n_groups,
+                           d_pre, sel_per, (unsigned long long)c, ucap, pad1, d_cur1, d_buf1, d_direct,
+                           ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2);
+        hipLaunchKernelGGL(rg_split, dim3((unsigned)(2 * n_cu)), dim3(RG_SBT), 0, ctx->stream, d_buf1, d_cur1, ucap, pad1, pad2, ctx->k, d_cur2, d_buf2, ctx->d_peak_kmer, d_direct);
+        hipLaunchKernelGGL(rg_apply, blocks2d(n_final), dim3(1024), lds, ctx->stream, d_buf2, d_cur2, ucap, pad2, ctx->k, ctx->d_peak_kmer, n_final);
+    }
+    LHGT_HIP(hipGetLastError());
+    LHGT_HIP(hipMemcpyAsync(&ctx->rg_direct, d_direct, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->rg_chunks = nc;
+    ctx->rg_bound = n_sel * e;
+    *done = true;
+    if (getenv("LHGT_TRACE"))
+        fprintf(stderr, "[lhgt] registry by partition: <= %llu records in %d chunk(s), %.1f GB of record buffers\n", n_sel * e, nc, (double)(b1 + b2) / 1e9);
+    return LHGT_OK;
+}
+
 extern "C" {
 
 int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_peak, long* n_peaks) {
@@ -2020,7 +2350,9 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     const long id_end = (long)total + first_id;
     LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, max_peak + first_id));
-    if (ctx->n_tiles > 0)
+    bool by_partition = false;
+    LHGT_TRY(register_partitioned(ctx, (uint32_t)first_id, n_sel, &by_partition));
+    if (ctx->n_tiles > 0 && !by_partition)
         hipLaunchKernelGGL(register_peaks, blocks2d(ctx->n_tiles), dim3(BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx),
                        ctx->d_counts, ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask,
                        ctx->scan_form == 2 && !(ctx->debug & (1 << 23)) ? ctx->d_nzmask : nullptr /* debug bit 23: look every count up (A/B) */,
@@ -2035,6 +2367,15 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
     ctx->max_peak = max_peak;
     ctx->voted = false;
     if (n_peaks) *n_peaks = total;
+    return LHGT_OK;
+}
+
+// which way the last lhgt_ref_scan registered its peaks: *chunks = 0 the direct kernel, n = by partition in n chunks
+int lhgt_registry_info(lhgt_ctx* ctx, int* chunks, unsigned long long* records_bound, unsigned long long* records_direct) {
+    if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");
+    if (chunks) *chunks = ctx->rg_chunks;
+    if (records_bound) *records_bound = ctx->rg_bound;
+    if (records_direct) *records_direct = ctx->rg_direct;
     return LHGT_OK;
 }
 

@@ -185,6 +185,11 @@ struct lhgt_ctx {
     int32_t* d_loci = nullptr;
     uint32_t* d_filter = nullptr;
     uint32_t* d_tile_count = nullptr;
+    uint32_t* d_tile_sel = nullptr;     // selected positions per tile (interval_select): what the registry by partition sizes its chunks by
+    uint8_t* d_rg_buf = nullptr;        // the registry by partition's record buffers + cursors (k_scan.hip: register_partitioned), kept between scans
+    size_t rg_buf_bytes = 0;
+    int rg_chunks = 0;                  // chunks of the last registry by partition (0: the direct kernel ran)
+    unsigned long long rg_bound = 0, rg_direct = 0;   // its record bound, and the records that found their region full
     long n_peaks = -1, max_peak = 0;
     long id_end = 0;   // one past the largest peak id in use (= n_peaks, + 1 under -t N emulation when thread 0 found no peak: then no peak holds id 0)
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
@@ -271,6 +276,7 @@ void sampling_join(lhgt_ctx* ctx);   // waits for a fill started by lhgt_samplin
 // reason a 156 GB index does not fit).
 constexpr size_t DEV_CACHE_MIN = (size_t)64 << 20;
 hipError_t dev_alloc_raw(void** p, size_t bytes);
+size_t dev_cached_bytes();        // what the process keeps parked (reusable by the next dev_malloc of the same size class, released by an allocation that would fail)
 hipError_t dev_free(void* p);          // blocks that came from dev_malloc go back to the cache; anything else to hipFree
 bool big_release_all();               // frees every cached block; true if there was one
 template <class T>

@@ -388,6 +388,12 @@ class Engine:
         return {"lite": lite.value in (1, 4), "form": ("exact", "single-first", "trio-first", "slot-first", "slot-single")[lite.value], "frac_slots_at_3": round(frac.value, 4),
                 "tiles": nt.value, "tiles_exact": ne.value}
 
+    def registry_info(self) -> dict:
+        """how the last ref_scan registered its peaks' k-mers (include/localhgt_hip.h: lhgt_registry_info): chunks 0 = the direct kernel"""
+        ch, bound, direct = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.lhgt_registry_info(self.h, C.byref(ch), C.byref(bound), C.byref(direct)))
+        return {"chunks": ch.value, "records_bound": bound.value, "records_direct": direct.value}
+
     def slot_list(self, mode: int = -1) -> dict:
         """the slot list of the resident reference (include/localhgt_hip.h: lhgt_slot_list): mode 0 never / drop, 1 before the second
         sparse-form scan of a reference (default), 2 before the first, -1 query"""

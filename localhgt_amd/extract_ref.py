@@ -327,7 +327,7 @@ def _run(eng: Engine, a: Args, t0: float, dist, log, emulate_threads, ref_form, 
     log(f"Finish with time:\t{t5 - t0:.2f}")
     rep = dict(pairs_seen=seen, pairs_kept=kept, n_contigs=n_contigs, n_bases=n_bases, n_peaks=n_peaks,
                n_filtered=n_filtered, ratio=ratio, index_built=built and not packed, ref_form=ref_form, emulated_threads=a.threads if emulating else 1,
-               ref_resident_bytes=eng.reference_info()["resident_bytes"], ref_reused=reused, scan_form=eng.scan_info()["form"], slot_list_bytes=eng.slot_list()["bytes"], ingest_s=t_r0 + state["t_reads"] - t0, index_s=t_i1 - t_i0,
+               ref_resident_bytes=eng.reference_info()["resident_bytes"], ref_reused=reused, scan_form=eng.scan_info()["form"], registry_chunks=eng.registry_info()["chunks"], slot_list_bytes=eng.slot_list()["bytes"], ingest_s=t_r0 + state["t_reads"] - t0, index_s=t_i1 - t_i0,
                reads_s=state["t_reads"], count_s=t2 - t_r0 - state["t_reads"], scan_s=t3 - t2,
                vote_s=t4 - t3, total_s=t5 - t0, count_kernel_ms=eng.phase_ms(0), scan_kernel_ms=eng.phase_ms(1),
                vote_kernel_ms=eng.phase_ms(2), world=world, staged_bytes=dist.staged_bytes if dist else 0)

@@ -109,6 +109,13 @@ def test_random_case_matches_oracle(oracle, tmp_path, idx, monkeypatch):
     # pairs that do vote (its filter must keep them), N's and lower case
     if idx % 5 == 2 or os.environ.get("LHGT_FUZZ_SHARED", "0") == "1":
         dbg |= 4 | (1 << 27)
+    # every seventh case (round 6), or every case under LHGT_FUZZ_REGISTRY=1: the peaks' k-mers registered by partition (bit 29; k >= 20:
+    # otherwise the direct kernel), in 1 .. 3 chunks, every other of them with regions most records find full
+    if idx % 7 == 3 or os.environ.get("LHGT_FUZZ_REGISTRY", "0") == "1":
+        dbg |= 1 << 29
+        monkeypatch.setenv("LHGT_REGISTER_CHUNKS", str(1 + idx % 3))
+        if idx % 2:
+            monkeypatch.setenv("LHGT_REGISTER_TIGHT", "30")
     if dbg:
         monkeypatch.setenv("LHGT_DEBUG", str(dbg))
     g, c = tmp_path / "gpu", tmp_path / "cpu"

@@ -12,6 +12,7 @@
 //   B5 register       peak_loci + peak_kmer[h] = max id (ids grow in write order) (E:247-267)
 // flags byte per reference position: bit0 single, bit1 trio, bit2 good window, bit3 peak (computed inside intervals only),
 // bit4 inside a good interval, bit5 selected (peak & interval), bit6 new peak.
+#include <type_traits>
 #include <chrono>
 #include "lhgt_hash.hpp"
 
@@ -1053,7 +1054,7 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
 // overflows.  The records of the whole reference need 17 bytes each in flight; what fits decides the number of CHUNKS (runs of tile
 // groups with equal shares of the selected positions, from interval_select's per-tile counts), each with its own emit / split /
 // apply and table sweep.
-constexpr int RG_TILES = 16, RG_BT = 512;
+constexpr int RG_TILES = 8, RG_BT = 512;
 constexpr int RG_B1 = 256, RG_B2 = 512, RG_L2 = 17;            // 8 + 9 bits of fan-out
 constexpr int RG_SBT = 1024, RG_PER = 16, RG_SLAB = RG_SBT * RG_PER;
 constexpr unsigned long long RG_PAD1 = 8192, RG_PAD2 = 64;
@@ -1068,91 +1069,227 @@ __host__ __device__ inline unsigned long long rg_base(unsigned long long ucap, u
     return (v + q * pad) & ~1ull;
 }
 
-__global__ void __launch_bounds__(1024) rg_group_prefix(const uint32_t* __restrict__ tile_sel, long n_tiles, long n_groups, unsigned long long* __restrict__ pre) {
+// selected positions in front of every group of RG_TILES tiles (three small kernels: sums of 1024 groups, their prefix, the groups)
+__device__ __forceinline__ unsigned long long rg_group_sel(const uint32_t* __restrict__ tile_sel, long n_tiles, long g) {
+    unsigned long long x = 0;
+    for (int q = 0; q < RG_TILES; q++) { const long t = g * RG_TILES + q; if (t < n_tiles) x += tile_sel[t]; }
+    return x;
+}
+__global__ void __launch_bounds__(1024) rg_group_sums(const uint32_t* __restrict__ tile_sel, long n_tiles, long n_groups, unsigned long long* __restrict__ sums) {
     __shared__ unsigned long long sh[16];
-    unsigned long long carry = 0;
-    for (long base = 0; base < n_groups; base += 1024) {
-        const long g = base + threadIdx.x;
-        unsigned long long x = 0;
-        if (g < n_groups)
-            for (int q = 0; q < RG_TILES; q++) { const long t = g * RG_TILES + q; if (t < n_tiles) x += tile_sel[t]; }
-        unsigned long long total;
-        const unsigned long long ex = block_excl_sum_u64(x, sh, &total);
-        if (g < n_groups) pre[g] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) pre[n_groups] = carry;
+    const long g = (long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned long long total;
+    block_excl_sum_u64(g < n_groups ? rg_group_sel(tile_sel, n_tiles, g) : 0ull, sh, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) rg_group_prefix(const uint32_t* __restrict__ tile_sel, long n_tiles, long n_groups, const unsigned long long* __restrict__ sums,
+                                                        unsigned long long* __restrict__ pre) {
+    __shared__ unsigned long long sh[16];
+    const long g = (long)blockIdx.x * 1024 + threadIdx.x;
+    const unsigned long long ex = block_excl_sum_u64(g < n_groups ? rg_group_sel(tile_sel, n_tiles, g) : 0ull, sh, nullptr);
+    if (g < n_groups) pre[g] = sums[blockIdx.x] + ex;
+    if (g == 0) pre[n_groups] = sums[gridDim.x];
+}
+// first group of every chunk: the first g with pre[g] >= c * sel_per_chunk (a group belongs to the chunk pre[g] / sel_per_chunk)
+__global__ void rg_chunk_bounds(const unsigned long long* __restrict__ pre, long n_groups, unsigned long long sel_per_chunk, int n_chunks, long* __restrict__ bounds) {
+    const int c = threadIdx.x;
+    if (c > n_chunks) return;
+    if (c == n_chunks) { bounds[c] = n_groups; return; }
+    const unsigned long long want = (unsigned long long)c * sel_per_chunk;
+    long lo = 0, hi = n_groups;            // first g in [0, n_groups] with pre[g] >= want
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (pre[mid] >= want) hi = mid; else lo = mid + 1; }
+    bounds[c] = lo;
 }
 
-__global__ void __launch_bounds__(RG_BT) rg_emit(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
+// A WAVE per tile.  Everything a tile's walk reads from memory is fetched in the wave's prologue, in batches of independent loads: the
+// flag bytes (their ballots give the list of SELECTED positions -- bit 5; 44 % of an active tile's in the default regime --, the ballot
+// words of "opens a peak", bit 6, with their running counts: the ids, and of "exact trio", bits 7 and 1), the probe-state (or nz) byte of
+// every selected position, and the tile's words of the packed planes.  Both passes then run dense over the list out of LDS -- pass 0
+// counts the group's records per bucket, one cursor bump per bucket reserves the runs, pass 1 hashes again and writes -- with no load
+// to wait for in pass 1, so its scattered stores are never waited for either.
+constexpr int RG_WORDS = (TILE + 63) / 64;     // 32 ballot words per tile
+constexpr int RG_PW = (TILE + 31) / 32 + 3;    // plane words a tile's windows can touch
+static_assert(RG_TILES == RG_BT / 64, "a tile per wave");
+// STAGED: the packed reference (the index form reads its stored hashes inside the loops); E: the number of hashes when it is 1 .. 3, so
+// that the loop over them unrolls and the masks stay in scalar registers (0: any e) -- with the general loop the compiler waits for
+// every outstanding memory operation, the previous records' stores included, before each hash
+template <bool STAGED, int E>
+__global__ void __launch_bounds__(RG_BT, 4) rg_emit(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
                                                  const uint32_t* __restrict__ counts, const uint8_t* __restrict__ flags, const uint8_t* __restrict__ nzmask,
                                                  const uint8_t* __restrict__ pstate, const uint32_t* __restrict__ tile_base, int k, int e,
-                                                 int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer, uint32_t first_id, long n_tiles, long n_groups,
+                                                 int32_t* __restrict__ loci, uint32_t* __restrict__ peak_kmer, uint32_t first_id, long n_tiles, long g_first, long g_end,
                                                  const unsigned long long* __restrict__ group_pre, unsigned long long sel_per_chunk, unsigned long long chunk,
                                                  unsigned long long ucap, unsigned long long pad1, unsigned long long* __restrict__ cur1, unsigned long long* __restrict__ buf1,
                                                  unsigned long long* __restrict__ n_direct,
-                                                 uint32_t* __restrict__ prefilter /* nullable: the vote's bitmap, where a forced run has one */, uint32_t pf_mask, int pf2) {
-    __shared__ int incl[TILE], part[RG_BT];
+                                                 uint32_t* __restrict__ prefilter /* nullable: the vote's bitmap, where a forced run has one */, uint32_t pf_mask, int pf2,
+                                                 int ablate /* timing only (LHGT_RG_ABLATE): 1 no record is stored, 2 no pass 1, 3 the prologue alone, 4 no cursor bumps */) {
+    __shared__ unsigned short list[RG_TILES][RG_WORDS * 64];
+    __shared__ uint8_t laux[RG_TILES][RG_WORDS * 64];
+    __shared__ uint32_t lpl[RG_TILES][3 * RG_PW];             // hi / lo interleaved, then the not-a-base words
+    __shared__ unsigned long long m6[RG_TILES][RG_WORDS], m82[RG_TILES][RG_WORDS];
+    __shared__ unsigned short c6[RG_TILES][RG_WORDS];
+    __shared__ int n_list[RG_TILES];
     __shared__ unsigned int hist[RG_B1];
     __shared__ unsigned long long gpos[RG_B1], glim[RG_B1];
-    const long g = block2d();
-    if (g >= n_groups) return;
+    const long g = g_first + block2d();
+    if (g >= g_end) return;
     const unsigned long long s0 = group_pre[g];
-    if (group_pre[g + 1] == s0 || s0 / sel_per_chunk != chunk) return;     // nothing selected here, or another chunk's group
+    if (group_pre[g + 1] == s0 || s0 / sel_per_chunk != chunk) return;     // nothing selected here (or not this chunk's group)
     for (int b = threadIdx.x; b < RG_B1; b += RG_BT) hist[b] = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, ti = threadIdx.x >> 6;
     const int shift1 = k - 8;
-    unsigned int direct = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int ti = 0; ti < RG_TILES; ti++) {
-            const long blk = g * RG_TILES + ti;
-            if (blk >= n_tiles) break;
-            uint32_t base = tile_base[blk];
-            if (tile_base[blk + 1] == base) continue;  // no peak in this tile (uniform)
-            base += first_id;
-            const TileDev t = tiles[blk];
-            const ContigDev c = contigs[t.contig];
-            const long len = c.len, nk = len - k + 1;
-            const uint8_t* F = flags + c.flat_base;
-            constexpr int CH = (TILE + RG_BT - 1) / RG_BT;
-            const int b0 = threadIdx.x * CH, en = b0 + CH < TILE ? b0 + CH : TILE;
-            int s = 0;
-            for (int jj = b0; jj < en; jj++) {
-                const long j = (long)t.j0 + jj;
-                s += (j < len) ? (F[j] >> 6) & 1 : 0;
-                incl[jj] = s;
+    const long blk = g * RG_TILES + ti;
+    uint32_t base = 0;
+    bool live = blk < n_tiles;
+    if (live) { base = tile_base[blk]; live = tile_base[blk + 1] != base; }   // no peak in this tile (wave-uniform)
+    base += first_id;
+    TileDev t{};
+    ContigDev c{};
+    if (live) { t = tiles[blk]; c = contigs[t.contig]; }
+    const long len = c.len, nk = len - k + 1;
+    const uint8_t* aux = pstate ? pstate : nzmask;       // one byte per position, or none (single-first form: every count is looked up)
+    const uint64_t x0 = c.flat_base + (uint64_t)t.j0;    // flat position of the tile's first
+    if (live) {
+        const uint8_t* F = flags + x0;
+        const uint8_t* A = aux ? aux + x0 : nullptr;
+        const long left = len - (long)t.j0;              // positions of the contig from the tile's first on
+        const int last = (int)((left < TILE ? left : (long)TILE) - 1);
+        unsigned int r5 = 0, r6 = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint8_t fb[RG_WORDS / 2], ab[RG_WORDS / 2];
+#pragma unroll
+            for (int q = 0; q < RG_WORDS / 2; q++) {                 // unconditional loads on an index clamped into the tile
+                const int jj = (half * (RG_WORDS / 2) + q) * 64 + lane;
+                fb[q] = F[jj <= last ? jj : last];
+                if (jj > last) fb[q] = 0;
             }
-            const int off = block_excl_sum(s, part);
-            for (int jj = b0; jj < en; jj++) incl[jj] += off;
-            __syncthreads();
-            for (int jj = threadIdx.x; jj < TILE; jj += RG_BT) {
-                const long j = (long)t.j0 + jj;
-                if (j >= len) break;
-                const uint8_t f = F[j];
-                if (!((f >> 5) & 1)) continue;
-                const uint32_t id = base + (uint32_t)incl[jj] - 1u;  // merged peaks take the id of their bucket's first peak
-                if (pass == 1 && ((f >> 6) & 1)) {
-                    loci[2 * (long)id] = (int32_t)c.ref_index;
-                    loci[2 * (long)id + 1] = (int32_t)j;
+#pragma unroll
+            for (int q = 0; q < RG_WORDS / 2; q++) {
+                const int jj = (half * (RG_WORDS / 2) + q) * 64 + lane;
+                ab[q] = A ? A[jj <= last ? jj : last] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int q = 0; q < RG_WORDS / 2; q++) {
+                const int it = half * (RG_WORDS / 2) + q;
+                const unsigned long long b5 = __ballot((fb[q] >> 5) & 1), b6 = __ballot((fb[q] >> 5) & (fb[q] >> 6) & 1), b82 = __ballot((fb[q] & 0x82u) == 0x82u);
+                if ((fb[q] >> 5) & 1) {
+                    const unsigned int slot = r5 + (unsigned int)__popcll(b5 & ((1ull << lane) - 1ull));
+                    list[ti][slot] = (unsigned short)(it * 64 + lane);
+                    laux[ti][slot] = ab[q];
                 }
-                if (j >= nk) continue;
-                const RefKmer km = ref_kmer(rs, c, j, k, e);
-                uint32_t nz = nzmask ? nzmask[c.flat_base + j] : 0u, have = nzmask ? 0xffu : 0u;
-                if (pstate) {                 // as in register_peaks: what the probe kernels already know about "count > 0" per hash
-                    const uint32_t ps = pstate[c.flat_base + j];
-                    if ((f & 0x82u) == 0x82u) { nz = 7u; have = 7u; }
-                    else if (ps & 0x80u) { nz = (ps >> 4) & 7u; have = 7u; }
+                if (lane == 0) { m6[ti][it] = b6; m82[ti][it] = b82; c6[ti][it] = (unsigned short)r6; }
+                r5 += (unsigned int)__popcll(b5);
+                r6 += (unsigned int)__popcll(b6);
+            }
+        }
+        if (lane == 0) n_list[ti] = (int)r5;
+        if (STAGED) {
+            // plane words (x0 >> 5) .. of the tile, as far as the windows of its positions reach (ref_kmer reads word q and q + 1 of each plane)
+            const uint64_t w0 = x0 >> 5, w_last = ((x0 + (uint64_t)last) >> 5) + 1;
+            for (int wi = lane; wi < RG_PW; wi += 64) {
+                const uint64_t w = w0 + (uint64_t)wi <= w_last ? w0 + (uint64_t)wi : w_last;
+                const uint2 hl = *(const uint2*)(rs.planes + 2 * w);
+                lpl[ti][2 * wi] = hl.x;
+                lpl[ti][2 * wi + 1] = hl.y;
+                lpl[ti][2 * RG_PW + wi] = rs.planes[2 * rs.plane_words + w];
+            }
+        }
+    }
+    __syncthreads();
+    unsigned int direct = 0;
+    const int n_sel = live && ablate != 3 ? n_list[ti] : 0;
+    const int nk_rel = (int)(nk - (long)t.j0 < (long)TILE ? nk - (long)t.j0 : (long)TILE);      // tile-relative positions below this have a k-mer (E:247,262; beyond nk the hit array is zero anyway)
+    const int xr = (int)(x0 & 31);
+    // k-mer windows of tile-relative position jj out of the staged plane words
+    auto kmer_at = [&](int jj) {
+        RefKmer km{};
+        const int q = (xr + jj) >> 5, r = (xr + jj) & 31;
+        const uint32_t* P = &lpl[ti][2 * q];
+        const uint32_t* NB = &lpl[ti][2 * RG_PW + q];
+        km.whi = window32(P[0], P[2], r) >> (32 - k);
+        km.wlo = window32(P[1], P[3], r) >> (32 - k);
+        km.valid = (window32(NB[0], NB[1], r) >> (32 - k)) == 0u;
+        km.rhi = brev_k(km.whi, k);
+        km.rlo = brev_k(km.wlo, k);
+        return km;
+    };
+    // "count > 0" per hash from the state byte (as in register_peaks): nz where the probe kernels left a record, have = which hashes they did
+    auto decode = [&](uint32_t ax, bool trio, uint32_t* have) -> uint32_t {
+        if (!pstate) { *have = nzmask ? 0xffu : 0u; return nzmask ? ax : 0u; }
+        const uint32_t known = (ax >> 4) & 7u, is3 = ax & 7u;
+        const bool filled = (ax & 0x80u) != 0u;
+        const uint32_t part = is3 | (((ax >> 3) & 1u) ? (known & ~is3) : 0u);
+        *have = trio || filled ? 7u : known;
+        return trio ? 7u : filled ? known : part;
+    };
+    // RESOLVED (packed reference, e <= 3): pass 0 also settles the look-ups -- where the probe kernels left no record of a hash its count
+    // is read from the table, a random access -- and leaves "hash i registers" in the state byte's place, so that pass 1 loads nothing:
+    // with the look-ups inside pass 1 every one of them also waited for the stores of the positions before it (gfx950 counts loads and
+    // stores in one counter; 126 ms instead of 85 for 7.7 G records).  The loads of one step of pass 0 are independent and leave together.
+    constexpr bool RESOLVED = STAGED && E >= 1 && E <= 3;
+    constexpr int EN = E ? E : 1;
+    // one dense pass over the selected positions: PASS 0 counts per bucket, PASS 1 writes
+    auto walk = [&](auto pass_tag) {
+        constexpr int PASS = decltype(pass_tag)::value;
+        for (int n0 = 0; n0 < n_sel; n0 += 64) {
+            const int n = n0 + lane;
+            const bool in = n < n_sel;
+            const int jj = in ? list[ti][n] : 0, w = jj >> 6, bit = jj & 63;
+            uint32_t id = 0;
+            if (PASS == 1 && in) {
+                const unsigned long long w6 = m6[ti][w];
+                id = base + (uint32_t)c6[ti][w] + (uint32_t)__popcll(w6 & ((2ull << bit) - 1ull)) - 1u;  // merged peaks take the id of their bucket's first peak
+                if ((w6 >> bit) & 1ull) {
+                    loci[2 * (long)id] = (int32_t)c.ref_index;
+                    loci[2 * (long)id + 1] = (int32_t)(t.j0 + jj);
+                }
+            }
+            const bool has_kmer = in && jj < nk_rel;
+            const uint32_t ax = in ? laux[ti][n] : 0u;
+            if (RESOLVED && PASS == 1 && ax == 0u) continue;
+            if (!RESOLVED && !has_kmer) continue;
+            const RefKmer km = STAGED ? kmer_at(jj) : ref_kmer(rs, c, (long)t.j0 + jj, k, e);
+            uint32_t have = 7u, nz = ax;
+            if (!(RESOLVED && PASS == 1)) nz = decode(ax, (m82[ti][w] >> bit) & 1ull, &have);
+            if constexpr (RESOLVED) {
+                uint32_t h[EN];
+#pragma unroll
+                for (int i = 0; i < EN; i++) h[i] = km.valid ? hash_from_windows(km.whi, km.wlo, km.rhi, km.rlo, rs.hp.mask[i]) : 0u;
+                if (PASS == 0) {
+                    uint32_t need = has_kmer ? ~have & ((1u << EN) - 1u) : 0u;
+#pragma unroll
+                    for (int i = 0; i < EN; i++) if (h[i] == 0u) need &= ~(1u << i);
+                    if (__any(need != 0u)) {
+                        uint32_t word[EN];
+#pragma unroll
+                        for (int i = 0; i < EN; i++) word[i] = counts[((need >> i) & 1u) ? h[i] >> 4 : 0u];          // unconditional: the loads of a step leave together
+#pragma unroll
+                        for (int i = 0; i < EN; i++)
+                            if (((need >> i) & 1u) && ((word[i] >> ((h[i] & 15u) * 2u)) & 3u) != 0u) nz |= 1u << i;
+                    }
+                    nz = has_kmer ? nz & ((1u << EN) - 1u) : 0u;
+                    if (in) laux[ti][n] = (uint8_t)nz;
+                }
+#pragma unroll
+                for (int i = 0; i < EN; i++) {
+                    if (!((nz >> i) & 1u)) continue;
+                    const uint32_t b = h[i] >> shift1;
+                    if (PASS == 0) atomicAdd(&hist[b], 1u);
                     else {
-                        const uint32_t known = (ps >> 4) & 7u, is3 = ps & 7u;
-                        nz = is3 | (((ps >> 3) & 1u) ? (known & ~is3) : 0u);
-                        have = known;
+                        const unsigned long long pos = gpos[b] + atomicAdd(&hist[b], 1u);
+                        if (ablate == 1) { direct += (unsigned int)(pos & 1); continue; }
+                        if (pos < glim[b]) buf1[pos] = ((unsigned long long)h[i] << 32) | id;
+                        else { atomicMax(&peak_kmer[h[i]], id); direct++; }
+                        if (prefilter) atomicOr(&prefilter[pf_word(h[i], pf_mask)], pf_word_bits(h[i], pf2));
                     }
                 }
+            } else {
                 for (int i = 0; i < e; i++) {
                     const uint32_t h = ref_hash(rs, km, i);
                     if (i < 8 && ((have >> i) & 1u) ? ((nz >> i) & 1u) != 0u : (h != 0 && count_of(counts, h) > 0)) {
                         const uint32_t b = h >> shift1;
-                        if (pass == 0) atomicAdd(&hist[b], 1u);
+                        if (PASS == 0) atomicAdd(&hist[b], 1u);
                         else {
                             const unsigned long long pos = gpos[b] + atomicAdd(&hist[b], 1u);
                             if (pos < glim[b]) buf1[pos] = ((unsigned long long)h << 32) | id;
@@ -1162,18 +1299,18 @@ __global__ void __launch_bounds__(RG_BT) rg_emit(const TileDev* __restrict__ til
                     }
                 }
             }
-            __syncthreads();
         }
-        if (pass == 0) {
-            for (int b = threadIdx.x; b < RG_B1; b += RG_BT) {
-                const unsigned int n = hist[b];
-                hist[b] = 0;
-                gpos[b] = n ? rg_base(ucap, b, 8, pad1) + atomicAdd(&cur1[b], (unsigned long long)n) : 0ull;
-                glim[b] = rg_base(ucap, b + 1, 8, pad1);
-            }
-            __syncthreads();
-        }
+    };
+    walk(std::integral_constant<int, 0>{});
+    __syncthreads();
+    for (int b = threadIdx.x; b < RG_B1; b += RG_BT) {
+        const unsigned int n = hist[b];
+        hist[b] = 0;
+        gpos[b] = n ? rg_base(ucap, b, 8, pad1) + (ablate == 4 ? (unsigned long long)(blockIdx.x & 1023) * n : atomicAdd(&cur1[b], (unsigned long long)n)) : 0ull;
+        glim[b] = rg_base(ucap, b + 1, 8, pad1);
     }
+    __syncthreads();
+    if (ablate != 2) walk(std::integral_constant<int, 1>{});
     if (direct) atomicAdd(n_direct, (unsigned long long)direct);
 }
 
@@ -1232,7 +1369,7 @@ __global__ void __launch_bounds__(RG_SBT) rg_split(const unsigned long long* __r
                 const uint32_t h = (uint32_t)(rec[r] >> 32);
                 const int s = (h >> shift2) & (RG_B2 - 1);
                 const unsigned long long pos = gpos[s] + rank[r];
-                if (pos < glim[s]) buf2[pos] = rec[r];
+                if (pos < glim[s]) buf2[pos] = rec[r];       // (id and slot bits as two arrays, 6 bytes: the 2-byte scattered stores made this pass 2.8 x slower)
                 else { atomicMax(&peak_kmer[h], (uint32_t)rec[r]); direct++; }
             }
         __syncthreads();
@@ -1240,9 +1377,8 @@ __global__ void __launch_bounds__(RG_SBT) rg_split(const unsigned long long* __r
     if (direct) atomicAdd(n_direct, (unsigned long long)direct);
 }
 
-__global__ void __launch_bounds__(1024) rg_apply(const unsigned long long* __restrict__ buf2, const unsigned long long* __restrict__ cur2, unsigned long long ucap,
-                                                 unsigned long long pad2, int k,
-                                                 uint32_t* __restrict__ peak_kmer, long n_final) {
+__global__ void __launch_bounds__(1024) rg_apply(const unsigned long long* __restrict__ buf2, const unsigned long long* __restrict__ cur2,
+                                                 unsigned long long ucap, unsigned long long pad2, int k, uint32_t* __restrict__ peak_kmer, long n_final) {
     extern __shared__ uint32_t rg_tab[];
     const long fb = block2d();
     if (fb >= n_final) return;
@@ -2254,7 +2390,9 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
     const long n_groups = (ctx->n_tiles + RG_TILES - 1) / RG_TILES;
     const long n_final = (long)RG_B1 * RG_B2;
     const unsigned long long pad1 = tight > 1 ? 2 : RG_PAD1, pad2 = tight > 1 ? 2 : RG_PAD2;
-    const size_t fixed = (((size_t)n_groups + 1) * 8 + 255 & ~(size_t)255) + (size_t)(RG_B1 + n_final + 8) * 8;     // group prefix, cursors, counter
+    const long n_gblk = (n_groups + 1023) / 1024;
+    const size_t pre_bytes = ((size_t)(n_groups + 1 + n_gblk + 1 + 16) * 8 + 255) & ~(size_t)255;                   // group prefix, the sums of 1024 groups, chunk bounds
+    const size_t fixed = pre_bytes + (size_t)(RG_B1 + n_final + 8) * 8;                                               // + cursors, counter
     // bytes of the two record buffers for `nc` chunks
     auto plan = [&](int nc, unsigned long long* sel_per, unsigned long long* ucap, size_t* b1, size_t* b2) {
         *sel_per = (n_sel + (unsigned long long)nc - 1) / (unsigned long long)nc;
@@ -2267,12 +2405,12 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
     };
     unsigned long long sel_per = 0, ucap = 0;
     size_t b1 = 0, b2 = 0;
-    int nc = want_chunks > 0 ? want_chunks : 1;
+    int nc = want_chunks > 0 ? std::min(want_chunks, 32) : 1;
     plan(nc, &sel_per, &ucap, &b1, &b2);
     if (want_chunks <= 0 && ctx->rg_buf_bytes < fixed + b1 + b2) {
-        // what the device can spare: free and parked blocks less 8 GB, and no more than 32 GB (LHGT_REGISTER_GB) -- inside the 40 GB the
-        // slot list leaves free, which is worth more than fewer chunks (a chunk more = a sweep of the table more, ~10 ms); up to 8 chunks
-        static const double cap_gb = getenv("LHGT_REGISTER_GB") ? atof(getenv("LHGT_REGISTER_GB")) : 32.0;
+        // what the device can spare: free and parked blocks less 8 GB, and no more than 34 GB (LHGT_REGISTER_GB) -- inside the 40 GB the
+        // slot list leaves free (it goes first when an allocation fails: cabi.hip), which is worth more than fewer chunks (a chunk more = a sweep of the table more, ~10 ms); up to 8 chunks
+        static const double cap_gb = getenv("LHGT_REGISTER_GB") ? atof(getenv("LHGT_REGISTER_GB")) : 34.0;
         size_t free_b = 0, total_b = 0;
         LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t avail = free_b + lhgt::dev_cached_bytes() + ctx->rg_buf_bytes;
@@ -2293,13 +2431,21 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
         ctx->rg_buf_bytes = fixed + b1 + b2;
     }
     unsigned long long* d_pre = (unsigned long long*)ctx->d_rg_buf;
-    unsigned long long* d_cur1 = (unsigned long long*)(ctx->d_rg_buf + (((size_t)n_groups + 1) * 8 + 255 & ~(size_t)255));
+    unsigned long long* d_sums = d_pre + n_groups + 1;
+    long* d_bounds = (long*)(d_sums + n_gblk + 1);
+    unsigned long long* d_cur1 = (unsigned long long*)(ctx->d_rg_buf + pre_bytes);
     unsigned long long* d_cur2 = d_cur1 + RG_B1;
     unsigned long long* d_direct = d_cur2 + n_final;
     unsigned long long* d_buf1 = (unsigned long long*)(ctx->d_rg_buf + fixed);
     unsigned long long* d_buf2 = (unsigned long long*)(ctx->d_rg_buf + fixed + b1);
-    hipLaunchKernelGGL(rg_group_prefix, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tile_sel, ctx->n_tiles, n_groups, d_pre);
+    hipLaunchKernelGGL(rg_group_sums, dim3((unsigned)n_gblk), dim3(1024), 0, ctx->stream, ctx->d_tile_sel, ctx->n_tiles, n_groups, d_sums);
+    hipLaunchKernelGGL(chunk_bases, dim3(1), dim3(1024), 0, ctx->stream, d_sums, n_gblk);
+    hipLaunchKernelGGL(rg_group_prefix, dim3((unsigned)n_gblk), dim3(1024), 0, ctx->stream, ctx->d_tile_sel, ctx->n_tiles, n_groups, d_sums, d_pre);
+    hipLaunchKernelGGL(rg_chunk_bounds, dim3(1), dim3(64), 0, ctx->stream, d_pre, n_groups, sel_per, nc, d_bounds);
+    long bounds[65];
+    LHGT_HIP(hipMemcpyAsync(bounds, d_bounds, (size_t)(nc + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     LHGT_HIP(hipMemsetAsync(d_direct, 0, 8, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
     const size_t lds = (size_t)4 << (ctx->k - RG_L2);
     if (lds > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)rg_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int n_cu = 256;
@@ -2307,10 +2453,21 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
     const uint8_t* pstate = ctx->scan_form == 2 && !(ctx->debug & (1 << 23)) ? ctx->d_nzmask : nullptr;
     for (int c = 0; c < nc; c++) {
         LHGT_HIP(hipMemsetAsync(d_cur1, 0, (size_t)(RG_B1 + n_final) * 8, ctx->stream));
-        hipLaunchKernelGGL(rg_emit, blocks2d(n_groups), dim3(RG_BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, ctx->d_flags,
-                           ctx->scan_lite ? nullptr : ctx->d_nzmask, pstate, ctx->d_tile_count, ctx->k, ctx->e, ctx->d_loci, ctx->d_peak_kmer, first_id, ctx->n_tiles, n_groups,
-                           d_pre, sel_per, (unsigned long long)c, ucap, pad1, d_cur1, d_buf1, d_direct,
-                           ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2);
+        if (bounds[c + 1] <= bounds[c]) continue;
+        const int ablate = getenv("LHGT_RG_ABLATE") ? atoi(getenv("LHGT_RG_ABLATE")) : 0;
+#define RG_EMIT(ST_, E_)                                                                                                                                               \
+        hipLaunchKernelGGL((rg_emit<ST_, E_>), blocks2d(bounds[c + 1] - bounds[c]), dim3(RG_BT), 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, rsrc, ctx->d_counts,    \
+                           ctx->d_flags, ctx->scan_lite ? nullptr : ctx->d_nzmask, pstate, ctx->d_tile_count, ctx->k, ctx->e, ctx->d_loci, ctx->d_peak_kmer, first_id,  \
+                           ctx->n_tiles, bounds[c], bounds[c + 1], d_pre, sel_per, (unsigned long long)c, ucap, pad1, d_cur1, d_buf1, d_direct,                         \
+                           ctx->prefilter_on ? ctx->d_prefilter : nullptr, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, ablate)
+        const RefSource rsrc = ref_source(ctx);
+        if (rsrc.index) { RG_EMIT(false, 0); }
+        else if (ctx->e == 3) { RG_EMIT(true, 3); }
+        else if (ctx->e == 2) { RG_EMIT(true, 2); }
+        else if (ctx->e == 1) { RG_EMIT(true, 1); }
+        else { RG_EMIT(true, 0); }
+#undef RG_EMIT
+        if (ablate) continue;          // (timing runs of rg_emit alone: its records are not all there)
         hipLaunchKernelGGL(rg_split, dim3((unsigned)(2 * n_cu)), dim3(RG_SBT), 0, ctx->stream, d_buf1, d_cur1, ucap, pad1, pad2, ctx->k, d_cur2, d_buf2, ctx->d_peak_kmer, d_direct);
         hipLaunchKernelGGL(rg_apply, blocks2d(n_final), dim3(1024), lds, ctx->stream, d_buf2, d_cur2, ucap, pad2, ctx->k, ctx->d_peak_kmer, n_final);
     }

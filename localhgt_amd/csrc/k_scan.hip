@@ -1042,18 +1042,20 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
 // what the fabric allows for that many random line fills and write-backs (12 G line transactions, 261 ms).  "The larger id wins a
 // slot" does not depend on the order of the registrations (E:247-267: every thread of the reference overwrites in its own order, the
 // emulation's rule is the last writer = the largest id), so they are routed by slot like phase A's keys:
-//   rg_emit   a workgroup walks RG_TILES tiles twice -- first counting its records per top-8-bit bucket of the slot in LDS, then,
-//             with one global cursor bump per bucket, writing each record (slot << 32 | id) to its place: the 8-byte stores of one run land
-//             next to each other within microseconds and leave L2 as whole lines;
+//   rg_emit   a workgroup takes RG_TILES tiles, a wave each, and goes over their selected positions twice -- first counting its records
+//             per top-8-bit bucket of the slot in LDS, then, with one global cursor bump per bucket, writing each record
+//             (slot << 32 | id) to its place: the 8-byte stores of one run land next to each other within microseconds and leave L2
+//             as whole lines (the pass is bound by their number: 220 G stores/s);
 //   rg_split  a slab of 16 Ki records of one bucket, held in registers, goes to the 512 sub-buckets of the next nine bits the same way;
 //   rg_apply  a final bucket = 2^(k-17) slots of peak_kmer (128 KiB at k = 32) lives in LDS while its records are applied with
 //             ds_max_u32, and goes back as it came: one sequential sweep of the table per chunk instead of a line fill per record.
 // A slot is min(forward, reverse complement), so its density falls linearly (2(1-x)): bucket q of nb expects the share
 // (2(nb-q)-1)/nb^2 of the records, regions are laid out by that expectation + 1/16 + a pad (rg_base), and a record that finds its
 // region full (repeats) is applied to the table at once -- rg_apply loads its slice behind the scatters, so the table is exact whatever
-// overflows.  The records of the whole reference need 17 bytes each in flight; what fits decides the number of CHUNKS (runs of tile
-// groups with equal shares of the selected positions, from interval_select's per-tile counts), each with its own emit / split /
-// apply and table sweep.
+// overflows.  The records of the whole reference need 17 bytes each in flight; what the device can spare decides the number of CHUNKS
+// (runs of tile groups with equal shares of the selected positions, from interval_select's per-tile counts), each with its own emit /
+// split / apply and table sweep.  Default regime, 7.68 G records in 4 chunks of 32.7 GB: 81 + 38 + 35 = 154 ms instead of 261
+// (profiles/r06/kernel_stats_default_sample_registry_by_partition.txt).
 constexpr int RG_TILES = 8, RG_BT = 512;
 constexpr int RG_B1 = 256, RG_B2 = 512, RG_L2 = 17;            // 8 + 9 bits of fan-out
 constexpr int RG_SBT = 1024, RG_PER = 16, RG_SLAB = RG_SBT * RG_PER;
@@ -1943,6 +1945,12 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
     size_t free_b = 0, total_b = 0;
     LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
     const double need = 6.0 * (double)ctx->n_pos + 12.0 * (double)nb;
+    if ((double)free_b - need < headroom_gb * 1e9 && ctx->d_rg_buf) {              // the registry by partition's record buffers (idle between scans): the list is worth more
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        lhgt::dev_free(ctx->d_rg_buf);
+        ctx->d_rg_buf = nullptr;
+        ctx->rg_buf_bytes = 0;
+    }
     if ((double)free_b - need < headroom_gb * 1e9 && lhgt::big_release_all())     // blocks parked by earlier contexts of the process count as free
         LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
     if ((double)free_b - need < headroom_gb * 1e9) {   // (round 6: the absolute headroom alone -- "or a quarter of what is free" could leave a few GB for the next, larger sample)
@@ -2414,7 +2422,8 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
         size_t free_b = 0, total_b = 0;
         LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t avail = free_b + lhgt::dev_cached_bytes() + ctx->rg_buf_bytes;
-        const size_t room = std::min(avail > ((size_t)8 << 30) ? avail - ((size_t)8 << 30) : 0, (size_t)(cap_gb * 1e9));
+        const size_t spare = avail > ((size_t)8 << 30) ? avail - ((size_t)8 << 30) : 0;
+        const size_t room = std::max(std::min(spare, (size_t)(cap_gb * 1e9)), spare > ((size_t)60 << 30) ? spare - ((size_t)60 << 30) : 0);   // (more where even a slot list to come would leave it; slot_list_build takes the buffers back if it must)
         while (nc < 8 && fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) { nc++; plan(nc, &sel_per, &ucap, &b1, &b2); }
         if (fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) {
             if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: %.1f GB wanted for 8 chunks, %.1f GB to spare -- the direct kernel\n", (double)(fixed + b1 + b2) / 1e9, (double)room / 1e9);
@@ -2423,7 +2432,10 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
     }
     if (ctx->rg_buf_bytes < fixed + b1 + b2) {
         if (ctx->d_rg_buf) { lhgt::dev_free(ctx->d_rg_buf); ctx->d_rg_buf = nullptr; ctx->rg_buf_bytes = 0; }
-        if (lhgt::dev_malloc(&ctx->d_rg_buf, fixed + b1 + b2) != hipSuccess) {
+        const double t_alloc = wall_s();
+        const hipError_t ae = lhgt::dev_malloc(&ctx->d_rg_buf, fixed + b1 + b2);
+        if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: %.1f GB taken or allocated in %.3f s\n", (double)(fixed + b1 + b2) / 1e9, wall_s() - t_alloc);
+        if (ae != hipSuccess) {
             (void)hipGetLastError();
             if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: no %.1f GB -- the direct kernel\n", (double)(fixed + b1 + b2) / 1e9);
             return LHGT_OK;

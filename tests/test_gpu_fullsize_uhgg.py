@@ -200,6 +200,15 @@ def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
             assert got == expect, (dbg, sinfo, got, expect)
         assert _vote(eng, 0) == want_votes
         assert _vote(eng, 4) == want_votes
+        # round 6: the peaks' k-mers registered by partition (k_scan.hip: rg_emit / rg_split / rg_apply) against the direct kernel, 16 GiB
+        # table, ids beyond 2^26, with the vote's bitmap (forced) and without
+        got, _ = _scan(eng, 1 << 30)
+        assert eng.registry_info()["chunks"] == 0 and got == want[0]
+        for dbg in (1 << 29, 4 | (1 << 29)):
+            got, _ = _scan(eng, dbg)
+            reg = eng.registry_info()
+            assert reg["chunks"] >= 1 and reg["records_direct"] == 0 and got == want[0], (dbg, reg, got, want[0])
+        assert _vote(eng, 4 | (1 << 29)) == want_votes
         # round 5: the trio-first form answered from the slot list (13 G positions by the bucket of their hash 0, 78 GB next to the
         # 4.9 GB of planes): built by the first scan that asks for it, taken by itself from then on; positions beyond 2^32 in its entries
         assert eng.slot_list()["entries"] == 0                       # (mode 0 above: the second sparse scan of the loop did not build it)

@@ -303,114 +303,9 @@ __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__
     }
 }
 
-// The same fill for the packed reference and e <= 3 (round 6), rearranged around the memory system: as written above a position costs
-// up to seven DEPENDENT round trips -- its flag byte, its state byte, its plane words, then one count look-up after the other, each under a
-// branch of its own -- and the next position's first load also waits for this one's stores (gfx950 counts loads and stores in one
-// counter).  Here the workgroup's plane words go to LDS once, a thread's flag and state bytes of the tile BODY are all fetched first,
-// the look-ups of a position leave together (unconditional loads, a dead one reads word 0), and those of the next position are on
-// their way before this one's bytes are stored.  The look-back positions (another tile's body, as a rule filled by that tile's
-// workgroup) come last, with their bytes read then.
-constexpr int FILL_IT = (TILE + HL2 + BT - 1) / BT;      // positions per thread
-constexpr int FILL_PW = (TILE + HL2 + 31) / 32 + 3;      // plane words the workgroup's windows can touch
-template <int E>
-__global__ void __launch_bounds__(BT) ref_flags_fill_packed(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
-                                                            const uint32_t* __restrict__ list, const RefSource rs,
-                                                            const uint32_t* __restrict__ counts, int k, uint8_t* __restrict__ flags,
-                                                            uint8_t* __restrict__ pstate, long n_blk, int record_nz) {
-    __shared__ uint32_t lpl[3 * FILL_PW];
-    const long blk = block2d();
-    if (blk >= n_blk) return;
-    const TileDev t = tiles[list[blk]];
-    const ContigDev c = contigs[t.contig];
-    const long len = c.len, nk = len - k + 1;
-    const long jlo = (long)t.j0 - HL2;                    // may lie in front of the contig
-    const long jfirst = jlo < 0 ? 0 : jlo, jlast = ((long)t.j0 + TILE < len ? (long)t.j0 + TILE : len) - 1;
-    const uint64_t xf = c.flat_base + (uint64_t)jfirst, w0 = xf >> 5, w_last = ((c.flat_base + (uint64_t)jlast) >> 5) + 1;
-    for (int wi = threadIdx.x; wi < FILL_PW; wi += BT) {
-        const uint64_t w = w0 + (uint64_t)wi <= w_last ? w0 + (uint64_t)wi : w_last;
-        const uint2 hl = *(const uint2*)(rs.planes + 2 * w);
-        lpl[2 * wi] = hl.x;
-        lpl[2 * wi + 1] = hl.y;
-        lpl[2 * FILL_PW + wi] = rs.planes[2 * rs.plane_words + w];
-    }
-    uint8_t* F = flags + c.flat_base;
-    uint8_t* P = pstate + c.flat_base;
-    constexpr uint32_t full = (1u << E) - 1u;
-    constexpr int HALO_IT = HL2 / BT;                     // the first iterations of a thread are look-back positions
-    static_assert(HL2 % BT == 0, "look-back positions fill whole iterations");
-    // bytes of the body positions, all loads first
-    uint8_t fb[FILL_IT], pb[FILL_IT];
-#pragma unroll
-    for (int it = HALO_IT; it < FILL_IT; it++) {
-        long j = jlo + threadIdx.x + (long)it * BT;
-        j = j < jfirst ? jfirst : j > jlast ? jlast : j;
-        fb[it] = F[j];
-        pb[it] = P[j];
-    }
-    __syncthreads();
-    struct Probe { uint32_t h[E], word[E], need, is3, nz; bool act; long j; uint8_t f; };
-    // everything of position `it` up to its look-ups' loads
-    auto start = [&](int it, uint8_t f, uint8_t ps) {
-        Probe pr{};
-        const int i0 = threadIdx.x + it * BT;
-        const long j = jlo + i0;
-        pr.j = j;
-        pr.f = f;
-        pr.act = i0 < TILE + HL2 && j >= 0 && j < len && !(f & 0x80) && !(ps & 0x80);   // already exact: a neighbouring workgroup has written (or is writing) the same values
-        const uint32_t known = (ps >> 4) & 7u;
-        pr.is3 = ps & 7u;
-        pr.nz = pr.is3 | (((ps >> 3) & 1u) ? (known & ~pr.is3) : 0u);   // trio-first: the one probed hash that did not read 3 has its "> 0" in bit 3
-        pr.need = 0;
-        const bool hashed = pr.act && j < nk;
-        const long jc = j < jfirst ? jfirst : j > jlast ? jlast : j;
-        const uint64_t x = c.flat_base + (uint64_t)jc;
-        const int q = (int)((x >> 5) - w0), r = (int)(x & 31);
-        const uint32_t whi = window32(lpl[2 * q], lpl[2 * q + 2], r) >> (32 - k), wlo = window32(lpl[2 * q + 1], lpl[2 * q + 3], r) >> (32 - k);
-        const bool valid = (window32(lpl[2 * FILL_PW + q], lpl[2 * FILL_PW + q + 1], r) >> (32 - k)) == 0u;
-        const uint32_t rhi = brev_k(whi, k), rlo = brev_k(wlo, k);
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            pr.h[i] = valid ? hash_from_windows(whi, wlo, rhi, rlo, rs.hp.mask[i]) : 0u;
-            if (hashed && !((known >> i) & 1u) && pr.h[i] != 0u) pr.need |= 1u << i;
-            pr.word[i] = counts[((pr.need >> i) & 1u) ? pr.h[i] >> 4 : 0u];
-        }
-        return pr;
-    };
-    auto finish = [&](Probe& pr) {
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            const uint32_t cnt = ((pr.need >> i) & 1u) ? (pr.word[i] >> ((pr.h[i] & 15u) * 2u)) & 3u : 0u;
-            if (cnt == 3u) pr.is3 |= 1u << i;
-            if (cnt > 0u) pr.nz |= 1u << i;
-        }
-        if (pr.act) {
-            F[pr.j] = (uint8_t)((pr.f & 0x7c) | (pr.is3 != 0u) | ((pr.is3 == full) << 1) | 0x80);
-            P[pr.j] = record_nz ? (uint8_t)(pr.is3 | (pr.nz << 4) | 0x80) : (uint8_t)(pr.is3 | (full << 4));
-        }
-    };
-    Probe cur = start(HALO_IT, fb[HALO_IT], pb[HALO_IT]);
-#pragma unroll
-    for (int it = HALO_IT; it < FILL_IT; it++) {
-        Probe nxt{};
-        if (it + 1 < FILL_IT) nxt = start(it + 1, fb[it + 1], pb[it + 1]);
-        finish(cur);
-        cur = nxt;
-    }
-    // the look-back positions: their bytes now
-#pragma unroll
-    for (int it = 0; it < HALO_IT; it++) {
-        long j = jlo + threadIdx.x + (long)it * BT;
-        j = j < jfirst ? jfirst : j > jlast ? jlast : j;
-        fb[it] = F[j];
-        pb[it] = P[j];
-    }
-#pragma unroll
-    for (int it = 0; it < HALO_IT; it++) {
-        Probe pr = start(it, fb[it], pb[it]);
-        finish(pr);
-    }
-}
-
+// (Round 6 tried this kernel rearranged around its memory round trips -- plane words in LDS, a thread's flag and state bytes fetched
+// up front, the look-ups of a position leaving together and the next position's on their way before this one's bytes are stored:
+// 296 -> 294 ms on the default-sample leg.  The fill is bound by the line fills of its ~14 G look-ups, not by their latency.)
 // exclusive prefix over the block's per-thread values: shuffle scan inside each wave, then the few wave totals through LDS
 // (the first version had every thread add up its predecessors: a third of interval_select's instructions)
 __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
@@ -2115,21 +2010,6 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
 }
 
 // B1-B4 on the resident contigs: flags, and tile_count turned into exclusive local ids.
-// the fill of the listed tiles (d_active_tiles): the rearranged kernel for the packed reference and e <= 3 (LHGT_FILL_PLAIN=1: the plain one, A/B)
-static void launch_fill(lhgt_ctx* ctx, long n_need, int record_nz) {
-    static const bool plain = getenv("LHGT_FILL_PLAIN") && atoi(getenv("LHGT_FILL_PLAIN"));
-    const RefSource rs = ref_source(ctx);
-    const dim3 grid = blocks2d(n_need), blk(BT);
-#define FILL_P(E_) hipLaunchKernelGGL((ref_flags_fill_packed<E_>), grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, rs, ctx->d_counts, ctx->k, ctx->d_flags, ctx->d_nzmask, n_need, record_nz)
-    if (!rs.index && !plain && ctx->e == 3) FILL_P(3);
-    else if (!rs.index && !plain && ctx->e == 2) FILL_P(2);
-    else if (!rs.index && !plain && ctx->e == 1) FILL_P(1);
-    else
-        hipLaunchKernelGGL(ref_flags_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, rs, ctx->d_counts, ctx->k, ctx->e, ctx->d_flags,
-                           ctx->d_nzmask, n_need, record_nz);
-#undef FILL_P
-}
-
 static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_t* total_new, unsigned long long* n_selected) {
     const int k = ctx->k, e = ctx->e;
     *total_new = 0;
@@ -2269,7 +2149,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             if (ctx->scan_slots)   // (two launches: a tile's look-back is another tile's body, and the fill tells "written in this launch" by the byte)
                 hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);
-            launch_fill(ctx, (long)n_need, 1);
+            hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 1);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
@@ -2315,7 +2196,8 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         if (n_need) {   // the list sits in d_active_tiles, which mark_active_tiles overwrites only after these two have run
             if (ctx->scan_slots)
                 hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);
-            launch_fill(ctx, (long)n_need, 0);
+            hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 0);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
@@ -2544,7 +2426,8 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
         LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t avail = free_b + lhgt::dev_cached_bytes() + ctx->rg_buf_bytes;
         const size_t spare = avail > ((size_t)8 << 30) ? avail - ((size_t)8 << 30) : 0;
-        const size_t room = std::max(std::min(spare, (size_t)(cap_gb * 1e9)), spare > ((size_t)60 << 30) ? spare - ((size_t)60 << 30) : 0);   // (more where even a slot list to come would leave it; slot_list_build takes the buffers back if it must)
+        // (all of a device without a slot list -- one chunk of 130 GB -- made the first scan 4.6 s slower: that much fresh memory is not free to touch)
+        const size_t room = std::min(spare, (size_t)(cap_gb * 1e9));
         while (nc < 8 && fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) { nc++; plan(nc, &sel_per, &ucap, &b1, &b2); }
         if (fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) {
             if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: %.1f GB wanted for 8 chunks, %.1f GB to spare -- the direct kernel\n", (double)(fixed + b1 + b2) / 1e9, (double)room / 1e9);

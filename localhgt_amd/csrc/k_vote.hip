@@ -24,7 +24,9 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
     if (wib >= waves_per_block) return;
-    constexpr int BOUND_WORDS = TR >= 8 ? 512 : 0;   // long event lists (k <= 23, long reads): 1024 16-bit counters per wave for the bound below
+    // 1024 16-bit counters per wave for the bound below: long event lists (k <= 23, long reads), and (round 6) every dense form -- without a
+    // bitmap in front nearly every offset of a read is an event
+    constexpr int BOUND_WORDS = (TR >= 8 || PF == 0) ? 512 : 0;
     uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64 + BOUND_WORDS);
     uint32_t* stage = ev + (size_t)max_ev * e * 2;   // 64 words: the current read's record, staged once per read
     const long wave = (long)blockIdx.x * waves_per_block + wib;
@@ -86,13 +88,17 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
         }
         if (n_ev < 6 || (debug & 1)) continue;  // base_hits = offsets with any hit (E:149-157, 496)
         __builtin_amdgcn_wave_barrier();
-        if (TR >= 8 && n_ev >= 32 && !(debug & (1 << 19))) {
+        if (BOUND_WORDS && n_ev >= 32 && !(debug & (1 << 19))) {
             // Round 4: bound the outcome before walking the events.  judge_base adds every hit offset to exactly ONE of the contigs its
             // hashes point at (E:118-159), so a contig's final count is at most the number of (event, hash) entries that name it, and
             // check_split votes only if TWO contigs reach six (E:161-202).  The entries' contigs are counted into 1024 hashed 16-bit
             // counters: with at most one counter at six or more, and that one below twelve, at most one contig can reach six -- the
             // pair cannot vote and its walk (one dependent chain over hundreds of events: 2.0 of the 2.3 s of a k = 21 step on a
             // 50 Gbase reference, all of it for pairs that vote nothing) is skipped.  A pair the bound cannot clear is walked as before.
+            // Round 6: ONE counter at twelve or more is the rule where the peak set is dense -- the read's own contig, named by an entry
+            // of nearly every offset, while the other entries scatter over the catalogue.  The contig of the counter's first entry is
+            // then counted exactly and taken out: if what is left of the counter stays below six, still only one contig can reach six
+            // (the dense vote of the CLI's default regime: 262 -> 152 ms; the walk was 14 k instructions per pair, for 1253 votes in 6.67 M pairs).
             uint32_t* hist = stage + 64;
 #pragma unroll
             for (int i = 0; i < BOUND_WORDS / 64; i++) hist[lane + 64 * i] = 0u;
@@ -106,16 +112,43 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
             }
             __builtin_amdgcn_wave_barrier();
             int n6 = 0, n12 = 0;
+            uint32_t big = 0;                   // count << 16 | counter number of the lane's largest counter
 #pragma unroll
             for (int i = 0; i < BOUND_WORDS / 64; i++) {
                 const uint32_t w = hist[lane + 64 * i], lo = w & 0xffffu, hi = w >> 16;
                 n6 += (lo >= 6u) + (hi >= 6u);
                 n12 += (lo >= 12u) + (hi >= 12u);
+                const uint32_t klo = (lo << 16) | (uint32_t)(2 * (lane + 64 * i)), khi = (hi << 16) | (uint32_t)(2 * (lane + 64 * i) + 1);
+                big = klo > big ? klo : big;
+                big = khi > big ? khi : big;
             }
             int both = n6 | (n12 << 16);
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) both += __shfl_xor(both, d, 64);
+            for (int d = 32; d > 0; d >>= 1) {
+                both += __shfl_xor(both, d, 64);
+                const uint32_t o = (uint32_t)__shfl_xor((int)big, d, 64);
+                big = o > big ? o : big;
+            }
             if ((both & 0xffff) <= 1 && (both >> 16) == 0) continue;
+            if ((both & 0xffff) == 1) {         // one counter at six or more, and it is a large one
+                const uint32_t hb = big & 0xffffu, total = big >> 16;
+                uint32_t star = 0, n_star = 0;
+                bool have_star = false;
+                for (int q0 = 0; q0 < n_ev * e; q0 += 64) {
+                    const int q = q0 + lane;
+                    const uint32_t id = q < n_ev * e ? ev[(size_t)q * 2] : 0u, chr = q < n_ev * e ? ev[(size_t)q * 2 + 1] : 0u;
+                    if (!have_star) {
+                        const unsigned long long in_b = __ballot(id != 0u && ((chr * 2654435761u) >> 22) == hb);
+                        if (in_b) {
+                            star = (uint32_t)__builtin_amdgcn_readlane((int)chr, __ffsll((long long)in_b) - 1);
+                            have_star = true;
+                            // (entries before this chunk are not in the counter: none of them is the star's)
+                        }
+                    }
+                    if (have_star) n_star += (uint32_t)__popcll(__ballot(id != 0u && chr == star));
+                }
+                if (have_star && total - n_star < 6u) continue;
+            }
             __builtin_amdgcn_wave_barrier();
         }
         if (e == 3) judge_pair<TR, 3>(ev, n_ev, e, lane, filter);
@@ -585,7 +618,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
         if (shared_done) {
             ctx->vote_form = 4;
             const int ev_all = 2 * nk;
-            const size_t pw = ((size_t)ev_all * ctx->e * 2 + 64) * 4 + (ev_all > 256 ? 512 * 4 : 0);
+            const size_t pw = ((size_t)ev_all * ctx->e * 2 + 64) * 4 + 512 * 4;      // (a dense instance: the counters of the vote bound at every TR)
             int w = (int)(65536 / pw);
             w = w > 4 ? 4 : w < 1 ? 1 : w;
             long nb = (b.d.n_pairs + w - 1) / w;
@@ -723,8 +756,16 @@ int lhgt_vote(lhgt_ctx* ctx) {
             if (mixed) LHGT_TRY(vote_list((const uint32_t*)ctx->d_revote));
         } else if (max_ev <= 256) {
             if (ctx->prefilter_on) LHGT_VOTE(4, 1, false, 64 * wpb, per_wave * wpb);
-            else if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave * wpb);
-            else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave * wpb);
+            else {
+                // a dense instance: every wave also holds the 2 KiB of counters of the vote bound
+                const size_t per_wave_b = per_wave + 512 * 4;
+                wpb = (int)(65536 / per_wave_b);
+                wpb = wpb > 4 ? 4 : wpb < 1 ? 1 : wpb;
+                blocks = (b.d.n_pairs + wpb - 1) / wpb;
+                if (blocks > 256L * 16) blocks = 256L * 16;
+                if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave_b * wpb);
+                else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave_b * wpb);
+            }
         } else {
             // long event lists: every wave also holds the 2 KiB of counters of the vote bound (vote_kernel, TR >= 8)
             const size_t per_wave_b = per_wave + 512 * 4;

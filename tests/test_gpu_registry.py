@@ -90,3 +90,28 @@ def test_the_direct_kernel_stays_where_the_partition_does_not_pay():
         eng.count_kmers()
         eng.ref_scan(0.1, 0.08, 10_000_000)
         assert eng.registry_info()["chunks"] == 0
+
+
+@pytest.mark.parametrize("k,e,pairs", [(26, 3, 3_000), (22, 3, 20_000), (24, 2, 6_000)])
+def test_dense_vote_bound_with_the_reads_own_contig_taken_out(k, e, pairs):
+    """round 6 (k_vote.hip): the dense vote walks a pair's events only if the bound cannot clear it; where one hashed counter holds
+    the read's own contig (named by an entry of nearly every offset) that contig is counted exactly and taken out of the counter.  Same
+    votes as with the bound off (debug bit 19), on a dense peak set where every read has dozens of events"""
+    from localhgt_amd.engine import Engine
+    NC, CL = 60, 50_000
+    got = {}
+    for dbg in (4, 4 | (1 << 19)):
+        with Engine(k, e) as eng:
+            eng.set_debug(dbg)
+            eng.rng_seed(1)
+            eng.coder_generate()
+            eng.set_reference_form(True)
+            eng.synth_reference(1, NC, CL)
+            eng.synth_pairs(1, 5, NC, CL, 0, pairs)
+            eng.count_kmers()
+            n = eng.ref_scan(0.1, 0.08, 10_000_000)
+            eng.vote()
+            assert eng.vote_info()["form"] == "dense"
+            got[dbg] = (n, eng.digest(eng.DIGEST_VOTES))
+    assert got[4] == got[4 | (1 << 19)], got
+    assert got[4][0] > 200

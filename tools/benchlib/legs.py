@@ -116,7 +116,7 @@ def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_co
         stats["slot_list_bytes"] = engine.slot_list()["bytes"]
     d = {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
          "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
-         "scan_B_form": engine.scan_info(), "vote_form": engine.vote_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs,
+         "scan_B_form": engine.scan_info(), "peak_registry": engine.registry_info(), "vote_form": engine.vote_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs,
          "work_stats": stats}
     if recall:
         d["planted_transfers"] = interval_recall(out_path, planted_breakpoints(n_contigs, contig_len, sample_contigs))

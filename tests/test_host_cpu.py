@@ -799,3 +799,42 @@ def test_fasta_line_structure_on_the_host(lib, oracle, tmp_path):
             want[0] = len(text.split(b"\n>")[0].replace(b"\n", b"")) if not text.startswith(b">") else 0
             got = [int(ln.split("\t")[2]) for ln in open(fa + ".len")]
             assert got == [w for w in want if w > k], (name, k)
+
+
+def test_packed_sample_header_on_the_host(lib, tmp_path):
+    """localhgt_amd/pack.py without a GPU: what the loader reads back from a packed sample's header -- cal_sam_ratio from the stored base
+    count (E:1244-1270, 1392-1398), the thread chunks of the reference's -t N or the refusal stored in their place, a thread count the
+    file was not packed for, and the host side of a load (lhgt_packed_read_rate reads the records of part i of n, nothing else)"""
+    import json
+    import struct
+    from localhgt_amd import _lib, pack
+    n_pairs, stride = 1000, 4 + 24 * 6
+    hdr = {"version": 1, "n_pairs": n_pairs, "stride": stride, "max_len": 150, "q4_first_pair": 990, "fq1_bases": 150_000, "data_offset": pack.DATA_OFFSET,
+           "lines": 4000, "max_threads": 3,
+           "threads": {"2": {"first1": [0, 2001], "count1": [2000, 1999], "first2": [0, 2001], "count2": [2000, 1999]},
+                       "3": {"refused": [9, "thread 2 of 3 starts inside a record"]}}}
+    blob = json.dumps(hdr).encode()
+    path = str(tmp_path / "s.lhgp")
+    with open(path, "wb") as f:
+        f.write(pack.MAGIC + struct.pack("<Q", len(blob)) + blob)
+        f.truncate(pack.DATA_OFFSET + n_pairs * stride)
+    assert pack.is_packed(path) and not pack.is_packed(__file__) and not pack.is_packed(str(tmp_path / "absent"))
+    h = pack.read_header(path)
+    assert (h.n_pairs, h.stride, h.q4_first_pair, h.data_offset) == (n_pairs, stride, 990, pack.DATA_OFFSET)
+    assert h.ratio(0.5) == 50.0 and h.ratio(1) == 100.0
+    assert h.ratio(60_000) == 100.0 * 60_000 / (2.0 * 150_000)                 # --sample > 1: bases wanted over twice the bases of fq1
+    f1, c1, f2, c2 = h.thread_chunks(2)
+    assert list(f1) == [0, 2001] and list(c2) == [2000, 1999] and c1.dtype == np.int64
+    for t in (3, 7):                                                           # the stored refusal; a count the sample was not packed for
+        with pytest.raises(_lib.LocalHGTError) as ex:
+            h.thread_chunks(t)
+        assert ex.value.code == 9
+    with pytest.raises(SystemExit):
+        pack.read_header(__file__)
+    h_lib = lib.load(require_gpu=False)
+    secs = ctypes.c_double(-1)
+    for part in range(3):
+        assert h_lib.lhgt_packed_read_rate(path.encode(), pack.DATA_OFFSET, stride, n_pairs, part, 3, 2, ctypes.byref(secs)) == 0 and secs.value >= 0
+    with open(path, "r+b") as f:
+        f.truncate(pack.DATA_OFFSET + (n_pairs - 10) * stride)                 # the records end early: an I/O error, not a short read taken for data
+    assert h_lib.lhgt_packed_read_rate(path.encode(), pack.DATA_OFFSET, stride, n_pairs, 2, 3, 2, ctypes.byref(secs)) != 0

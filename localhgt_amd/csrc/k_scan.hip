@@ -267,14 +267,22 @@ __global__ void __launch_bounds__(BT) clear_pstate_tiles(const TileDev* __restri
 __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs,
                                                      const uint32_t* __restrict__ list, const RefSource rs,
                                                      const uint32_t* __restrict__ counts, int k, int e, uint8_t* __restrict__ flags,
-                                                     uint8_t* __restrict__ pstate, long n_blk, int record_nz /* the trio-first form: see below */) {
+                                                     uint8_t* __restrict__ pstate, long n_blk, int record_nz /* the trio-first form: see below */,
+                                                     const uint32_t* __restrict__ cand /* mark_need_tiles' input, or null */, long n_tiles) {
     const long blk = block2d();
     if (blk >= n_blk) return;
-    const TileDev t = tiles[list[blk]];
+    const long q0 = list[blk];
+    const TileDev t = tiles[q0];
     const ContigDev c = contigs[t.contig];
     const long nk = (long)c.len - k + 1;
     const uint32_t full = (1u << e) - 1u;
-    for (int i0 = threadIdx.x; i0 < TILE + HL2; i0 += BT) {
+    // the look-back positions are the body of the tile in front: if that tile is listed too (mark_need_tiles' rule, asked again here) its
+    // workgroup fills them -- once; without this both did whenever they ran side by side, which neighbours in the list do
+    bool prev_listed = false;
+    if (cand && q0 > 0 && tiles[q0 - 1].contig == t.contig)
+        for (long q = q0 - 4; q <= q0 + 2; q++)
+            if (q >= 0 && q < n_tiles && tiles[q].contig == t.contig && cand[q]) prev_listed = true;
+    for (int i0 = (prev_listed ? HL2 : 0) + threadIdx.x; i0 < TILE + HL2; i0 += BT) {
         const long j = (long)t.j0 - HL2 + i0;
         if (j < 0 || j >= c.len) continue;
         const uint8_t f = flags[c.flat_base + j];
@@ -305,7 +313,8 @@ __global__ void __launch_bounds__(BT) ref_flags_fill(const TileDev* __restrict__
 
 // (Round 6 tried this kernel rearranged around its memory round trips -- plane words in LDS, a thread's flag and state bytes fetched
 // up front, the look-ups of a position leaving together and the next position's on their way before this one's bytes are stored:
-// 296 -> 294 ms on the default-sample leg.  The fill is bound by the line fills of its ~14 G look-ups, not by their latency.)
+// 296 -> 294 ms on the default-sample leg.  The fill is bound by the line fills of its ~11 G look-ups, not by their latency.  Leaving a
+// listed neighbour's body to that neighbour -- below -- took 3 % off: 294 -> 285 ms.)
 // exclusive prefix over the block's per-thread values: shuffle scan inside each wave, then the few wave totals through LDS
 // (the first version had every thread add up its predecessors: a third of interval_select's instructions)
 __device__ __forceinline__ int block_excl_sum(int v, int* sh /*[BT]*/) {
@@ -2150,7 +2159,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
             if (ctx->scan_slots)   // (two launches: a tile's look-back is another tile's body, and the fill tells "written in this launch" by the byte)
                 hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
-                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 1);
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 1, ctx->d_tile_count, ctx->n_tiles);
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }
@@ -2197,7 +2206,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
             if (ctx->scan_slots)
                 hipLaunchKernelGGL(clear_pstate_tiles, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ctx->d_nzmask, (long)n_need);
             hipLaunchKernelGGL(ref_flags_fill, blocks2d(n_need), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, ref_source(ctx),
-                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 0);
+                               ctx->d_counts, k, e, ctx->d_flags, ctx->d_nzmask, (long)n_need, 0, (const uint32_t*)nullptr, ctx->n_tiles);   // (window_lite's list follows no rule the fill could ask again)
             hipLaunchKernelGGL(window_good, blocks2d(((long)n_need + 3) / 4), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ctx->d_active_tiles, 0x80, one_min, three_min,
                                ctx->d_flags, ctx->d_tile_good, (long)n_need);
         }

@@ -317,7 +317,7 @@ int lhgt_ctx_destroy(lhgt_ctx* c) {
     lhgt::slot_list_drop(c);
     lhgt::vshared_free(c);
     for (void* p : {(void*)c->d_counts, (void*)c->d_index, (void*)c->d_ref_planes, (void*)c->d_contigs, (void*)c->d_tiles, (void*)c->d_flags, (void*)c->d_nzmask, (void*)c->d_tile_good, (void*)c->d_satline, (void*)c->d_active_tiles,
-                    (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count, (void*)c->d_tile_sel, (void*)c->d_rg_buf,
+                    (void*)c->d_loci, (void*)c->d_filter, (void*)c->d_tile_count, (void*)c->d_tile_sel, (void*)c->d_rg_buf, (void*)c->d_vote_groups,
                     (void*)c->d_ws_ascii, (void*)c->d_ws_words,
                     (void*)c->d_part_meta, c->d_voted, (void*)c->d_prefilter, (void*)c->d_prefilter_fold, (void*)c->d_revote, (void*)c->d_emit_loci, (void*)c->d_emit_regs, (void*)c->d_digest, (void*)c->d_stats})
         if (p) lhgt::dev_free(p);

@@ -2326,6 +2326,7 @@ static int thread_id_ranges(lhgt_ctx* ctx, long max_peak, const std::vector<long
 static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_selected, long max_peak) {
     const size_t slots = (size_t)1 << ctx->k;
     ctx->n_peaks = -1;
+    ctx->vote_groups_ok = false;          // (lhgt_ref_scan makes the dense vote's contig groups behind this; an installed registry has none)
     ctx->n_selected = n_selected;
     if ((long)total > max_peak)
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
@@ -2388,6 +2389,29 @@ static int peaks_prepare(lhgt_ctx* ctx, uint32_t total, unsigned long long n_sel
     LHGT_HIP(hipMemsetAsync(ctx->d_filter, 0, ((size_t)total + 1) * 4, ctx->stream));  // E:1457
     LHGT_HIP(hipMemsetAsync(ctx->d_loci, 0, ((size_t)total + 1) * 8, ctx->stream));
     return LHGT_OK;
+}
+
+// The contig groups of the dense vote's bound (k_vote.hip): VG_N runs of whole contigs with about equal shares of the peak ids.  Ids
+// ascend with the tiles (register_peaks / rg_emit: tile_base + first_id + running count), so a contig's ids are the run
+// [tile_base[its first tile], tile_base[the next contig's first tile]) + first_id; bounds[j] = the first id of the first contig that starts
+// at or behind j / VG_N of the ids (bounds[0] = 0: ids below first_id belong to nobody), bounds[VG_N] = all ones.
+__global__ void __launch_bounds__(1024) vote_group_bounds(const TileDev* __restrict__ tiles, const uint32_t* __restrict__ tile_base, long n_tiles,
+                                                          uint32_t first_id, uint32_t* __restrict__ bounds) {
+    const int j = threadIdx.x;
+    if (j == 0) { bounds[0] = 0u; bounds[VG_N] = 0xffffffffu; }
+    if (j == 0 || j >= VG_N) return;
+    const uint32_t total = tile_base[n_tiles];
+    const uint32_t want = (uint32_t)(((unsigned long long)total * (unsigned long long)j + VG_N - 1) / VG_N);
+    long lo = 0, hi = n_tiles;                 // first tile whose base is >= want
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (tile_base[mid] >= want) hi = mid; else lo = mid + 1; }
+    long q = lo;
+    if (q < n_tiles && q > 0 && tiles[q - 1].contig == tiles[q].contig) {   // inside a contig: on to the next contig's first tile
+        const uint32_t c = tiles[q].contig;
+        long a = q, b = n_tiles;               // first tile of a later contig (the tiles' contigs ascend)
+        while (a < b) { const long mid = (a + b) >> 1; if (tiles[mid].contig > c) b = mid; else a = mid + 1; }
+        q = a;
+    }
+    bounds[j] = q < n_tiles ? tile_base[q] + first_id : 0xffffffffu;
 }
 
 // The registry by partition (rg_emit / rg_split / rg_apply above) in front of the vote of a DENSE peak set: *done = false when the
@@ -2532,6 +2556,12 @@ int lhgt_ref_scan(lhgt_ctx* ctx, float hit_ratio, float match_ratio, long max_pe
         LHGT_FAIL(LHGT_E_TOO_MANY_PEAKS, "Too many peaks! %u > max_peak %ld: reduce the sampling size, or appoint a larger max_peak_num (see --max_peak).", total, max_peak);
     const long id_end = (long)total + first_id;
     LHGT_TRY(peaks_prepare(ctx, (uint32_t)id_end, n_sel, max_peak + first_id));
+    ctx->vote_groups_ok = false;
+    if (ctx->n_tiles > 0 && !ctx->prefilter_on) {       // a dense vote to come: the contig groups of its bound
+        if (!ctx->d_vote_groups) LHGT_HIP(lhgt::dev_malloc(&ctx->d_vote_groups, (size_t)(VG_N + 1) * 4));
+        hipLaunchKernelGGL(vote_group_bounds, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tiles, ctx->d_tile_count, ctx->n_tiles, (uint32_t)first_id, ctx->d_vote_groups);
+        ctx->vote_groups_ok = true;
+    }
     bool by_partition = false;
     LHGT_TRY(register_partitioned(ctx, (uint32_t)first_id, n_sel, &by_partition));
     if (ctx->n_tiles > 0 && !by_partition)

@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                                                    const uint32_t* __restrict__ prefilter, const uint32_t* __restrict__ lds_fold,
                                                    const int32_t* __restrict__ loci, uint32_t* __restrict__ filter,
                                                    int max_ev, int waves_per_block, int debug, uint32_t pf_mask, int pf2,
-                                                   const uint32_t* __restrict__ pair_list, long list_base) {
+                                                   const uint32_t* __restrict__ pair_list, long list_base,
+                                                   const uint32_t* __restrict__ groups /* PF == 0, nullable: first peak id of VG_N runs of whole contigs (k_scan.hip: vote_group_bounds) */) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int e = hp.e, k = hp.k;
@@ -29,6 +30,21 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
     constexpr int BOUND_WORDS = (TR >= 8 || PF == 0) ? 512 : 0;
     uint32_t* ev = lds + (size_t)wib * (max_ev * e * 2 + 64 + BOUND_WORDS);
     uint32_t* stage = ev + (size_t)max_ev * e * 2;   // 64 words: the current read's record, staged once per read
+    // the group table behind the waves' regions (the workgroup has exactly waves_per_block waves: every one of them gets here)
+    const bool by_groups = PF == 0 && groups != nullptr;
+    uint32_t* gtab = lds + (size_t)waves_per_block * (max_ev * e * 2 + 64 + BOUND_WORDS);
+    if (by_groups) {
+        for (int i = threadIdx.x; i < VG_N; i += 64 * waves_per_block) gtab[i] = groups[i];
+        __syncthreads();
+    }
+    // group of a peak id: the last j with gtab[j] <= id (gtab[0] = 0)
+    auto group_of = [&](uint32_t id) {
+        int g = 0;
+#pragma unroll
+        for (int step = VG_N / 2; step >= 1; step >>= 1)
+            if (gtab[g + step] <= id) g += step;
+        return g;
+    };
     const long wave = (long)blockIdx.x * waves_per_block + wib;
     const long n_waves = (long)gridDim.x * waves_per_block;
     // pair_list (vote_kernel_fold's deferred pairs): [0] = how many, then the pairs; null = every pair of the batch
@@ -67,9 +83,15 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
                             } else ids[i] = peak_kmer[h];  // 0 = no peak (E:454)
                             hit |= ids[i] != 0;
                         }
+                    // (by groups: the contigs are fetched below, and only where the bound over the groups asks for them)
+                    if (!by_groups) {
 #pragma unroll
-                    for (int i = 0; i < 9; i++)
-                        if (i < e) chrs[i] = ids[i] ? (uint32_t)loci[2 * (long)ids[i]] : 0u;  // count_peak_kmer's peak_chr (E:455)
+                        for (int i = 0; i < 9; i++)
+                            if (i < e) chrs[i] = ids[i] ? (uint32_t)loci[2 * (long)ids[i]] : 0u;  // count_peak_kmer's peak_chr (E:455)
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) chrs[i] = 0u;
+                    }
                 }
                 unsigned long long bal = __ballot(hit);
                 if (bal) {
@@ -88,6 +110,71 @@ __global__ void __launch_bounds__(256) vote_kernel(ReadBatchDev b, HashParams hp
         }
         if (n_ev < 6 || (debug & 1)) continue;  // base_hits = offsets with any hit (E:149-157, 496)
         __builtin_amdgcn_wave_barrier();
+        if (by_groups) {
+            // Round 6, late: the bound FIRST, over groups of whole contigs instead of hashed contigs -- a peak's group follows from its id
+            // (ten steps through a table in LDS), its contig costs a random access (loci: 63 of this kernel's 152 ms in the CLI's default
+            // regime).  A contig's final count is at most the entries that name it, hence at most its group's: no group at six -> no
+            // vote.  ONE group at six (the read's own contig and its neighbours): the contigs of THAT group's entries are fetched, the
+            // first one's counted exactly and taken out -- what is left of the group below six -> no vote.  Everything else fetches the
+            // contigs of all entries and goes on as before (the hashed bound, then the walk).
+            bool cleared = false;
+            if (n_ev >= 32 && !(debug & (1 << 19))) {
+                uint32_t* hist = stage + 64;
+#pragma unroll
+                for (int i = 0; i < BOUND_WORDS / 64; i++) hist[lane + 64 * i] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                for (int q = lane; q < n_ev * e; q += 64) {
+                    const uint32_t id = ev[(size_t)q * 2];
+                    if (id) {
+                        const uint32_t g = (uint32_t)group_of(id);
+                        ev[(size_t)q * 2 + 1] = g;                                        // (kept for the second look; a contig takes its place later)
+                        atomicAdd(&hist[g >> 1], 1u << ((g & 1u) * 16u));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                int n6 = 0;
+                uint32_t big = 0;
+#pragma unroll
+                for (int i = 0; i < BOUND_WORDS / 64; i++) {
+                    const uint32_t w = hist[lane + 64 * i], lo = w & 0xffffu, hi = w >> 16;
+                    n6 += (lo >= 6u) + (hi >= 6u);
+                    const uint32_t klo = (lo << 16) | (uint32_t)(2 * (lane + 64 * i)), khi = (hi << 16) | (uint32_t)(2 * (lane + 64 * i) + 1);
+                    big = klo > big ? klo : big;
+                    big = khi > big ? khi : big;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    n6 += __shfl_xor(n6, d, 64);
+                    const uint32_t o = (uint32_t)__shfl_xor((int)big, d, 64);
+                    big = o > big ? o : big;
+                }
+                if (n6 == 0) cleared = true;
+                else if (n6 == 1) {
+                    const uint32_t gsel = big & 0xffffu, total = big >> 16;
+                    uint32_t star = 0, n_star = 0;
+                    bool have_star = false;
+                    for (int q0 = 0; q0 < n_ev * e; q0 += 64) {
+                        const int q = q0 + lane;
+                        const uint32_t id = q < n_ev * e ? ev[(size_t)q * 2] : 0u;
+                        const bool in_g = id != 0u && ev[(size_t)q * 2 + 1] == gsel;
+                        const uint32_t chr = in_g ? (uint32_t)loci[2 * (long)id] : 0u;
+                        const unsigned long long bal = __ballot(in_g);
+                        if (!have_star && bal) {
+                            star = (uint32_t)__builtin_amdgcn_readlane((int)chr, __ffsll((long long)bal) - 1);
+                            have_star = true;
+                        }
+                        if (have_star) n_star += (uint32_t)__popcll(__ballot(in_g && chr == star));
+                    }
+                    if (have_star && total - n_star < 6u) cleared = true;
+                }
+            }
+            if (cleared) continue;
+            for (int q = lane; q < n_ev * e; q += 64) {                                    // the contigs of all entries (count_peak_kmer's peak_chr, E:455)
+                const uint32_t id = ev[(size_t)q * 2];
+                ev[(size_t)q * 2 + 1] = id ? (uint32_t)loci[2 * (long)id] : 0u;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         if (BOUND_WORDS && n_ev >= 32 && !(debug & (1 << 19))) {
             // Round 4: bound the outcome before walking the events.  judge_base adds every hit offset to exactly ONE of the contigs its
             // hashes point at (E:118-159), so a contig's final count is at most the number of (event, hash) entries that name it, and
@@ -627,7 +714,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
     do {                                                                                                                             \
         if (pw * w > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, 0, true>), dim3((unsigned)nb), dim3(64 * w), pw * w, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, \
-                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, 0u, 0, shared_list, base_here);  \
+                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, 0u, 0, shared_list, base_here, (const uint32_t*)nullptr);  \
     } while (0)
             if (ev_all <= 256) LHGT_VOTE_REST(4);
             else if (ev_all <= 512) LHGT_VOTE_REST(8);
@@ -662,9 +749,13 @@ int lhgt_vote(lhgt_ctx* ctx) {
             LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, PF_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, PF_, NT_>), dim3((unsigned)blocks), dim3(THREADS_), LDS_, ctx->stream, b.d, ctx->hp,  \
                            ctx->d_peak_kmer, ctx->d_prefilter, ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, max_ev, wpb,    \
-                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr, 0L);      \
+                           ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, (const uint32_t*)nullptr, 0L, (PF_) == 0 ? vgroups : (const uint32_t*)nullptr); \
     } while (0)
         const bool nt = ctx->k >= 28;
+        // the dense forms' bound over groups of whole contigs (vote_kernel): the table lhgt_ref_scan left, 4 KiB of LDS per workgroup
+        const bool groups_off = getenv("LHGT_VOTE_GROUPS") && !atoi(getenv("LHGT_VOTE_GROUPS"));       // (read per vote: the tests switch it)
+        const uint32_t* vgroups = ctx->vote_groups_ok && !groups_off && !ctx->prefilter_on ? ctx->d_vote_groups : nullptr;
+        const size_t vg_lds = vgroups ? (size_t)VG_N * 4 : 0;
         // the pairs on a list (the fold form's deferred pairs; a mixed batch's pairs with a long read) in the generic form, sized for
         // the batch's longest read
         auto vote_list = [&](const uint32_t* list) -> int {
@@ -678,7 +769,7 @@ int lhgt_vote(lhgt_ctx* ctx) {
     do {                                                                                                                             \
         if (pw * w > 65536) LHGT_HIP(hipFuncSetAttribute((const void*)vote_kernel<TR_, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vote_kernel<TR_, 1, false>), dim3((unsigned)nb), dim3(64 * w), pw * w, ctx->stream, b.d, ctx->hp, ctx->d_peak_kmer, ctx->d_prefilter, \
-                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, list, 0L);   \
+                           ctx->d_prefilter_fold, ctx->d_loci, ctx->d_filter, ev_all, w, ctx->debug, ctx->pf_mask | (ctx->pf_q3 ? PF_Q3 : 0u), ctx->pf2, list, 0L, (const uint32_t*)nullptr);   \
     } while (0)
             if (ev_all <= 256) LHGT_VOTE_LIST(4);
             else if (ev_all <= 512) LHGT_VOTE_LIST(8);
@@ -759,29 +850,29 @@ int lhgt_vote(lhgt_ctx* ctx) {
             else {
                 // a dense instance: every wave also holds the 2 KiB of counters of the vote bound
                 const size_t per_wave_b = per_wave + 512 * 4;
-                wpb = (int)(65536 / per_wave_b);
+                wpb = (int)((65536 - vg_lds) / per_wave_b);
                 wpb = wpb > 4 ? 4 : wpb < 1 ? 1 : wpb;
                 blocks = (b.d.n_pairs + wpb - 1) / wpb;
                 if (blocks > 256L * 16) blocks = 256L * 16;
-                if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave_b * wpb);
-                else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave_b * wpb);
+                if (nt) LHGT_VOTE(4, 0, true, 64 * wpb, per_wave_b * wpb + vg_lds);
+                else LHGT_VOTE(4, 0, false, 64 * wpb, per_wave_b * wpb + vg_lds);
             }
         } else {
             // long event lists: every wave also holds the 2 KiB of counters of the vote bound (vote_kernel, TR >= 8)
             const size_t per_wave_b = per_wave + 512 * 4;
-            wpb = (int)(65536 / per_wave_b);
+            wpb = (int)((65536 - vg_lds) / per_wave_b);
             if (wpb > 4) wpb = 4;
             if (wpb < 1) wpb = 1;
             blocks = (b.d.n_pairs + wpb - 1) / wpb;
             if (blocks > 256L * 16) blocks = 256L * 16;
             if (max_ev <= 512) {   // a table row per 64 events: 8 rows instead of 16 (k = 21 with 150-base reads has 260 events)
                 if (ctx->prefilter_on) LHGT_VOTE(8, 1, false, 64 * wpb, per_wave_b * wpb);
-                else if (nt) LHGT_VOTE(8, 0, true, 64 * wpb, per_wave_b * wpb);
-                else LHGT_VOTE(8, 0, false, 64 * wpb, per_wave_b * wpb);
+                else if (nt) LHGT_VOTE(8, 0, true, 64 * wpb, per_wave_b * wpb + vg_lds);
+                else LHGT_VOTE(8, 0, false, 64 * wpb, per_wave_b * wpb + vg_lds);
             } else {
                 if (ctx->prefilter_on) LHGT_VOTE(16, 1, false, 64 * wpb, per_wave_b * wpb);
-                else if (nt) LHGT_VOTE(16, 0, true, 64 * wpb, per_wave_b * wpb);
-                else LHGT_VOTE(16, 0, false, 64 * wpb, per_wave_b * wpb);
+                else if (nt) LHGT_VOTE(16, 0, true, 64 * wpb, per_wave_b * wpb + vg_lds);
+                else LHGT_VOTE(16, 0, false, 64 * wpb, per_wave_b * wpb + vg_lds);
             }
         }
 #undef LHGT_VOTE

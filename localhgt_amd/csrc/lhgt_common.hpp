@@ -93,6 +93,7 @@ struct ContigDev {
 };
 constexpr int PF_BITS = 25;  // vote prefilter: 2^25 bits = 4 MiB, one XCD's L2
 constexpr int FASTA_BLK = 4096;  // bytes of FASTA text per newline count on the host and per workgroup of strip_fasta_block
+constexpr int VG_N = 1024;  // contig groups of the dense vote's bound (k_vote.hip): one 16-bit counter each
 constexpr int TILE = 2000;  // positions per scan tile; multiple of 50 so peak buckets never straddle tiles
 struct TileDev {
     uint32_t contig;
@@ -194,6 +195,8 @@ struct lhgt_ctx {
     long id_end = 0;   // one past the largest peak id in use (= n_peaks, + 1 under -t N emulation when thread 0 found no peak: then no peak holds id 0)
     uint32_t* d_prefilter = nullptr;  // 2^PF_BITS-bit folded bitmap of slots holding a peak id (L2-resident), or unused
     uint32_t* d_prefilter_fold = nullptr;  // 64 or 128 KiB fold of it, copied into LDS by the fold vote kernels
+    uint32_t* d_vote_groups = nullptr;     // [VG_N + 1] first peak id of every contig group of the dense vote's bound (k_vote.hip), made by lhgt_ref_scan (k_scan.hip)
+    bool vote_groups_ok = false;           // ... and whether it describes the registered peaks (a plain lhgt_ref_scan: ids ascend with the tiles)
     uint32_t* d_revote = nullptr;          // vote_kernel_fold's deferred pairs: [0] = how many, then the pairs of the batch being voted
     size_t revote_cap = 0;                 // words
     bool prefilter_on = false;

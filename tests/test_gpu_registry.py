@@ -92,15 +92,17 @@ def test_the_direct_kernel_stays_where_the_partition_does_not_pay():
         assert eng.registry_info()["chunks"] == 0
 
 
-@pytest.mark.parametrize("k,e,pairs", [(26, 3, 3_000), (22, 3, 20_000), (24, 2, 6_000)])
-def test_dense_vote_bound_with_the_reads_own_contig_taken_out(k, e, pairs):
-    """round 6 (k_vote.hip): the dense vote walks a pair's events only if the bound cannot clear it; where one hashed counter holds
-    the read's own contig (named by an entry of nearly every offset) that contig is counted exactly and taken out of the counter.  Same
-    votes as with the bound off (debug bit 19), on a dense peak set where every read has dozens of events"""
+@pytest.mark.parametrize("k,e,pairs", [(26, 3, 3_000), (22, 3, 20_000), (24, 2, 6_000), (26, 3, 60_000)])
+def test_dense_vote_bounds(monkeypatch, k, e, pairs):
+    """round 6 (k_vote.hip): the dense vote walks a pair's events only if no bound clears it.  First over groups of whole contigs -- a
+    peak's group follows from its id, so no contig is fetched until one group reaches six, and then only that group's --, then over
+    hashed contigs with the read's own contig counted exactly and taken out.  Same votes with the group bound off
+    (LHGT_VOTE_GROUPS=0) and with every bound off (debug bit 19), on dense peak sets where every read has dozens of events"""
     from localhgt_amd.engine import Engine
     NC, CL = 60, 50_000
     got = {}
-    for dbg in (4, 4 | (1 << 19)):
+    for variant, dbg in (("groups", 4), ("hashed", 4), ("walk", 4 | (1 << 19))):
+        monkeypatch.setenv("LHGT_VOTE_GROUPS", "0" if variant == "hashed" else "1")
         with Engine(k, e) as eng:
             eng.set_debug(dbg)
             eng.rng_seed(1)
@@ -112,6 +114,7 @@ def test_dense_vote_bound_with_the_reads_own_contig_taken_out(k, e, pairs):
             n = eng.ref_scan(0.1, 0.08, 10_000_000)
             eng.vote()
             assert eng.vote_info()["form"] == "dense"
-            got[dbg] = (n, eng.digest(eng.DIGEST_VOTES))
-    assert got[4] == got[4 | (1 << 19)], got
-    assert got[4][0] > 200
+            got[variant] = (n, eng.digest(eng.DIGEST_VOTES))
+    assert got["groups"] == got["walk"] and got["hashed"] == got["walk"], got
+    assert got["walk"][0] > 100
+    print(k, e, pairs, got["walk"])

@@ -754,7 +754,10 @@ int lhgt_vote(lhgt_ctx* ctx) {
         const bool nt = ctx->k >= 28;
         // the dense forms' bound over groups of whole contigs (vote_kernel): the table lhgt_ref_scan left, 4 KiB of LDS per workgroup
         const bool groups_off = getenv("LHGT_VOTE_GROUPS") && !atoi(getenv("LHGT_VOTE_GROUPS"));       // (read per vote: the tests switch it)
-        const uint32_t* vgroups = ctx->vote_groups_ok && !groups_off && !ctx->prefilter_on ? ctx->d_vote_groups : nullptr;
+        // (where most probes hit: with a quarter of the slots registered or more.  On a sparser registry the events are few and their
+        // contigs are better fetched while the probes are still in flight -- 58 -> 65 ms on the batch leg's 1.5 M peaks)
+        const bool groups_pay = (double)ctx->n_selected * (double)ctx->e >= 0.25 * (double)((size_t)1 << ctx->k) || (getenv("LHGT_VOTE_GROUPS") && atoi(getenv("LHGT_VOTE_GROUPS")) == 2);
+        const uint32_t* vgroups = ctx->vote_groups_ok && !groups_off && groups_pay && !ctx->prefilter_on ? ctx->d_vote_groups : nullptr;
         const size_t vg_lds = vgroups ? (size_t)VG_N * 4 : 0;
         // the pairs on a list (the fold form's deferred pairs; a mixed batch's pairs with a long read) in the generic form, sized for
         // the batch's longest read

@@ -102,7 +102,7 @@ def test_dense_vote_bounds(monkeypatch, k, e, pairs):
     NC, CL = 60, 50_000
     got = {}
     for variant, dbg in (("groups", 4), ("hashed", 4), ("walk", 4 | (1 << 19))):
-        monkeypatch.setenv("LHGT_VOTE_GROUPS", "0" if variant == "hashed" else "1")
+        monkeypatch.setenv("LHGT_VOTE_GROUPS", "0" if variant == "hashed" else "2")       # 2: whatever share of the slots is registered
         with Engine(k, e) as eng:
             eng.set_debug(dbg)
             eng.rng_seed(1)

@@ -23,6 +23,8 @@ def test_goldens_with_the_registry_by_partition(case_inputs, tmp_path, monkeypat
         monkeypatch.setenv("LHGT_REGISTER_CHUNKS", "3")
     if variant == "tight":
         monkeypatch.setenv("LHGT_REGISTER_TIGHT", "40")
+    if variant == "no_bitmap":
+        monkeypatch.setenv("LHGT_VOTE_GROUPS", "2")          # ... and the dense vote collects its events without their contigs (k_vote.hip), -t N id ranges included
     for name in ("k24_base", "k24_t4", "k32_base", "k21_e3", "k20_e2", "k24_t10_sample_bases", "k24_nrun_lower"):
         case = cases.CASES[name]
         fa, f1, f2, meta = case_inputs(name)

@@ -282,6 +282,10 @@ int lhgt_counts_histogram(lhgt_ctx* ctx, uint64_t out[4]);            /* cal_tab
 int lhgt_flags_export(lhgt_ctx* ctx, uint64_t first_pos, uint64_t n_pos, uint8_t* out);
 int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci /*[2*n]*/, uint8_t* filter /*[n]*/, long n);
 int lhgt_peak_kmer_export(lhgt_ctx* ctx, uint64_t first_slot, uint64_t n_slots, uint32_t* out);
+/* test handle: the 1024 + 1 group bounds of the dense vote (k_vote.hip: first peak id of runs of whole contigs with about equal shares of
+ * the peaks, [0] = 0, [1024] = all ones), as the last lhgt_ref_scan left them; *valid = 0 if it left none (a vote bitmap is kept, or the
+ * registry was installed from records) */
+int lhgt_vote_groups_export(lhgt_ctx* ctx, uint32_t* out, int n, int* valid);
 
 /* position-sensitive checksum of a whole device table (parity at sizes whose tables cannot travel through the host):
  * out[0] = sum_i mix(i, v[i] & mask) mod 2^64, out[1] = number of i with v[i] & mask != 0.

@@ -70,6 +70,7 @@ SIGNATURES = {
     "lhgt_pairs_batch_info": [_vp, _l, _lp, _u64p, C.POINTER(C.c_int)],
     "lhgt_pairs_store_write": [_vp, _cs, C.c_uint64, _l, _lp, _lp, _u64p],
     "lhgt_pairs_load_packed": [_vp, _cs, C.c_uint64, _l, _l, _l, _d, _i, _lp, _lp, _lp, _lp, _i, _i, _lp, _lp],
+    "lhgt_vote_groups_export": [_vp, _u32p, _i, C.POINTER(C.c_int)],
     "lhgt_registry_info": [_vp, C.POINTER(C.c_int), _u64p, _u64p],
     "lhgt_packed_read_rate": [_cs, C.c_uint64, _l, _l, _i, _i, _i, C.POINTER(C.c_double)],
     "lhgt_set_count_on_load": [_vp, _i],

@@ -897,6 +897,18 @@ int lhgt_filter_buffer(lhgt_ctx* ctx, void** dev_ptr, size_t* bytes) {
     return LHGT_OK;
 }
 
+// test handle: the contig groups of the dense vote's bound as lhgt_ref_scan left them (first peak id of each; VG_N + 1 values), *valid = 0
+// when the registered peaks have none (an installed registry, a vote bitmap in front)
+int lhgt_vote_groups_export(lhgt_ctx* ctx, uint32_t* out, int n, int* valid) {
+    LHGT_DEVICE_ENTRY(ctx);
+    if (!ctx || !out || n != VG_N + 1) LHGT_FAIL(LHGT_E_ARG, "room for %d values, the table has %d", n, VG_N + 1);
+    if (valid) *valid = ctx->vote_groups_ok ? 1 : 0;
+    if (!ctx->vote_groups_ok) return LHGT_OK;
+    LHGT_HIP(hipMemcpyAsync(out, ctx->d_vote_groups, (size_t)(VG_N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LHGT_HIP(hipStreamSynchronize(ctx->stream));
+    return LHGT_OK;
+}
+
 int lhgt_peaks_export(lhgt_ctx* ctx, int32_t* loci, uint8_t* filter, long n) {
     LHGT_DEVICE_ENTRY(ctx);
     if (!ctx) LHGT_FAIL(LHGT_E_ARG, "null context");

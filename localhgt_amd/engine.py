@@ -466,6 +466,13 @@ class Engine:
         _lib.check(self.lib.lhgt_peaks_export(self.h, _ptr(loci, C.c_int32), _ptr(filt, C.c_uint8), n))
         return loci[:2 * n], filt[:n]
 
+    def vote_groups_export(self) -> Optional[np.ndarray]:
+        """the group bounds of the dense vote's bound (include/localhgt_hip.h: lhgt_vote_groups_export), or None if the last scan left none"""
+        out = np.zeros(1025, dtype=np.uint32)
+        ok = C.c_int(0)
+        _lib.check(self.lib.lhgt_vote_groups_export(self.h, _ptr(out, C.c_uint32), 1025, C.byref(ok)))
+        return out if ok.value else None
+
     def peak_kmer_export(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
         n = (1 << self.k) - first if n is None else n
         out = np.zeros(n, dtype=np.uint32)

@@ -120,3 +120,44 @@ def test_dense_vote_bounds(monkeypatch, k, e, pairs):
     assert got["groups"] == got["walk"] and got["hashed"] == got["walk"], got
     assert got["walk"][0] > 100
     print(k, e, pairs, got["walk"])
+
+
+@pytest.mark.parametrize("nc,cl,pairs,threads,ragged", [(60, 50_000, 3_000, 1, 0), (700, 16_384, 12_000, 1, 0), (60, 50_000, 3_000, 1, 2_000), (60, 50_000, 3_000, 4, 0)])
+def test_vote_groups_are_runs_of_whole_contigs(nc, cl, pairs, threads, ragged):
+    """the invariant the dense vote's first bound stands on (k_vote.hip, k_scan.hip: vote_group_bounds): every group bound is the first
+    peak id of a contig -- no contig's peaks lie in two groups --, the bounds ascend, and the groups' shares of the peaks are about
+    equal where contigs allow.  Against the loci of all peaks (contig of every id), with many small contigs, few large ones, and the -t N
+    emulation's id ranges"""
+    from localhgt_amd.engine import Engine
+    with Engine(26, 3) as eng:
+        eng.set_debug(4)
+        eng.rng_seed(1)
+        eng.coder_generate()
+        eng.set_reference_form(True)
+        if ragged:          # the same base stream cut into ~2000 contigs of 30 .. 5000 bases (some no longer than k: they have no tiles)
+            rng = np.random.default_rng(9)
+            cuts = np.unique(np.concatenate([[0, nc * cl], rng.integers(1, nc * cl, ragged)])).astype(np.uint64)
+            eng.synth_reference_cuts(1, nc, cl, cuts)
+        else:
+            eng.synth_reference(1, nc, cl)
+        if threads > 1:
+            eng.set_thread_emulation(threads)
+        eng.synth_pairs(1, 5, nc, cl, 0, pairs)
+        eng.count_kmers()
+        n = eng.ref_scan(0.1, 0.08, 10_000_000)
+        assert n > 300
+        b = eng.vote_groups_export()
+        assert b is not None and b[0] == 0 and b[1024] == 0xffffffff
+        loci, _ = eng.peaks_export(n)
+        chrs = loci[0::2].astype(np.int64)
+        inner = b[1:1024].astype(np.int64)
+        assert (np.diff(inner) >= 0).all()
+        real = inner[inner < len(chrs)]
+        assert len(real) > 0
+        # a bound is where the contig changes (ids below the first real peak belong to nobody: contig 0)
+        assert ((real == 0) | (chrs[real] != chrs[np.maximum(real - 1, 0)])).all()
+        # ... and every contig's ids are one run, so "changes" means "a contig starts"
+        starts = np.flatnonzero(np.diff(chrs) != 0) + 1
+        seen = chrs[np.concatenate([[0], starts])]
+        seen = seen[seen != 0]
+        assert len(seen) == len(set(seen.tolist())), "a contig's peak ids are not one run"

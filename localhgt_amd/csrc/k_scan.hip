@@ -2459,8 +2459,11 @@ static int register_partitioned(lhgt_ctx* ctx, uint32_t first_id, unsigned long 
         LHGT_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t avail = free_b + lhgt::dev_cached_bytes() + ctx->rg_buf_bytes;
         const size_t spare = avail > ((size_t)8 << 30) ? avail - ((size_t)8 << 30) : 0;
-        // (all of a device without a slot list -- one chunk of 130 GB -- made the first scan 4.6 s slower: that much fresh memory is not free to touch)
-        const size_t room = std::min(spare, (size_t)(cap_gb * 1e9));
+        // (all of a device without a slot list -- one chunk of 130 GB -- made the first scan 4.6 s slower: that much fresh memory is not free
+        // to touch.)  Up to 48 GB where that still leaves 40 GB free: three chunks instead of four in the default regime, 5-10 ms
+        const size_t lo_cap = (size_t)(cap_gb * 1e9), hi_cap = std::max(lo_cap, (size_t)48e9);
+        const size_t beyond = spare > (size_t)40e9 ? spare - (size_t)40e9 : 0;
+        const size_t room = std::min(spare, std::max(lo_cap, std::min(hi_cap, beyond)));
         while (nc < 8 && fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) { nc++; plan(nc, &sel_per, &ucap, &b1, &b2); }
         if (fixed + b1 + b2 > std::max(room, ctx->rg_buf_bytes)) {
             if (getenv("LHGT_TRACE")) fprintf(stderr, "[lhgt] registry by partition: %.1f GB wanted for 8 chunks, %.1f GB to spare -- the direct kernel\n", (double)(fixed + b1 + b2) / 1e9, (double)room / 1e9);

@@ -1066,7 +1066,7 @@ __global__ void __launch_bounds__(256) replay_regs(const uint32_t* __restrict__ 
 // region full (repeats) is applied to the table at once -- rg_apply loads its slice behind the scatters, so the table is exact whatever
 // overflows.  The records of the whole reference need 17 bytes each in flight; what the device can spare decides the number of CHUNKS
 // (runs of tile groups with equal shares of the selected positions, from interval_select's per-tile counts), each with its own emit /
-// split / apply and table sweep.  Default regime, 7.68 G records in 4 chunks of 32.7 GB: 81 + 38 + 35 = 154 ms instead of 261
+// split / apply and table sweep.  Default regime, 7.68 G records in 3 chunks of 43.6 GB: 82 + 37 + 29 = 148 ms instead of 261
 // (profiles/r06/kernel_stats_default_sample_registry_by_partition.txt).
 constexpr int RG_TILES = 8, RG_BT = 512;
 constexpr int RG_B1 = 256, RG_B2 = 512, RG_L2 = 17;            // 8 + 9 bits of fan-out

@@ -606,6 +606,7 @@ struct GeomSmall {
     static constexpr int KPT = 20;     // keys per thread and tile of the key scatter: 10 Ki keys, 40 per bucket, 80 for the first (+ 5 sigma = 125)
     static constexpr int GRID = 512;   // workgroups of the read scatter = pieces per level-1 bucket
     static constexpr int HALVES = 2;   // workgroups per level-1 segment in the key scatter, each with its own part of every final region
+    static constexpr int CG = 8;       // keys a final bucket writes at a time (16 bytes): rows of 128 slots have no room for a longer carry
 };
 struct GeomBig {
     static constexpr int T = 1024;
@@ -615,6 +616,7 @@ struct GeomBig {
     static constexpr int KPT = 16;     // 16 Ki keys, 64 per bucket, 128 for the first (+ 5 sigma = 185)
     static constexpr int GRID = 256;
     static constexpr int HALVES = 1;
+    static constexpr int CG = 64;      // whole 128-byte lines (round 6, see part_keys16_direct): mean 64 + carry <= 63 + 5 sigma (40) of 256 slots; first bucket 128 + 63 + 57
 };
 // keys a piece holds: its expected share of the chunk's keys + 1/16 + 512, a multiple of 32 keys (128 B)
 __host__ __device__ inline uint32_t piece_keys(unsigned long long n_keys, int grid) {
@@ -625,10 +627,13 @@ __host__ __device__ inline uint32_t piece_keys(unsigned long long n_keys, int gr
 // side -- the 256 streams a workgroup of the key scatter writes stay within 23 MB -- each sized by the expected load of its top byte
 // (part_region over nb = 256 buckets and 1/256 of the chunk's keys) and split into two half regions, one per workgroup of the segment.
 __host__ __device__ inline PartCap seg_cap(unsigned long long n_keys) { return PartCap{n_keys / NBK + NBK, (uint32_t)NBK}; }
-__host__ __device__ inline uint32_t seg_size(const PartCap& sc) { return part_region(sc, NBK); }
-__host__ __device__ inline uint32_t half_region(const PartCap& sc, uint32_t t, int halves) { return ((part_region(sc, t + 1) - part_region(sc, t)) / (uint32_t)halves) & ~7u; }
+// Every (half) region starts on a 128-byte line (64 keys) and holds a whole number of lines, so that a bucket which only ever writes
+// whole lines (GeomBig::CG) writes every line of its region exactly once.
+__host__ __device__ inline uint32_t seg_region(const PartCap& sc, uint32_t t) { return (part_region(sc, t) + 63u) & ~63u; }
+__host__ __device__ inline uint32_t seg_size(const PartCap& sc) { return seg_region(sc, NBK); }
+__host__ __device__ inline uint32_t half_region(const PartCap& sc, uint32_t t, int halves) { return ((seg_region(sc, t + 1) - seg_region(sc, t)) / (uint32_t)halves) & ~63u; }
 __host__ __device__ inline size_t final_region(const PartCap& sc, uint32_t m, uint32_t t, uint32_t half, int halves) {
-    return (size_t)m * seg_size(sc) + part_region(sc, t) + (size_t)half * half_region(sc, t, halves);
+    return (size_t)m * seg_size(sc) + seg_region(sc, t) + (size_t)half * half_region(sc, t, halves);
 }
 
 // the segments of the chunk's long reads (more than FAST_NK k-mer offsets), in any order: entry = pair (inside the chunk) | mate << 24 |
@@ -912,7 +917,11 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
 
 // level-1 segment m (= the 512 pieces of bucket m, one per workgroup of the read scatter) -> its 256 final buckets (top byte t,
 // middle byte m), as 16-bit keys.  Two workgroups per segment (256 pieces each), each writing its own half of every final region.
-template <class G>
+// CG = keys a bucket writes at a time.  8 (round 4): 16 bytes, a bucket's runs of a tile begin and end anywhere inside a line, and the
+// L2 has long written a half-filled line back when the next tile completes it: WRITE_SIZE 199 GB per 100 M pairs for 143 GB of keys
+// (profiles/r06/pmc_live_uhgg.json).  64 (round 6, GeomBig): a bucket keeps up to 63 keys back and only ever writes whole, aligned
+// 128-byte lines, each exactly once.
+template <class G, int CG>
 __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __restrict__ in, const uint32_t* __restrict__ cnt1, uint32_t piece,
                                                           PartCap pc, uint32_t* __restrict__ cur2 /*[half][final bucket]*/, uint16_t* __restrict__ out,
                                                           uint32_t* __restrict__ counts, int ablate /* 1 no stores, 2 no placement */) {
@@ -1024,16 +1033,17 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
             }
         }
         __syncthreads();
-        // copy-out: a row is LPR lanes x 8 keys (16 bytes); multiples of eight keys leave, the rest is carried
+        // copy-out: a row is LPR lanes x 8 keys (16 bytes); multiples of CG keys leave, the rest is carried
         constexpr int LPR = G::S2 / 8, BPI = 64 / LPR;
+        static_assert(CG % 8 == 0 && CG <= 64 && G::S2 % CG == 0, "a bucket writes whole 16-byte groups, at most a line at a time");
 #pragma unroll
         for (int g = 0; g < NBK / (NW * BPI); g++) {
             const int bq = wib * (NBK / NW) + g * BPI + lane / LPR;
             const uint32_t j = (uint32_t)(lane % LPR) * 8u;
             const uint32_t n_all = cnt[bq] >> 1, c = cur[bq];
             const uint32_t have = n_all < (uint32_t)G::S2 ? n_all : (uint32_t)G::S2;
-            const uint32_t full = have & ~7u;
-            const uint32_t room = rcap[bq] > c ? rcap[bq] - c : 0u;                      // both multiples of 8
+            const uint32_t full = have & ~(uint32_t)(CG - 1);
+            const uint32_t room = rcap[bq] > c ? rcap[bq] - c : 0u;                      // both multiples of 64 (half_region)
             const uint32_t put = full < room ? full : room;
             const uint4 v = *(const uint4*)&tile[bq * RS2 + j];
             if (!(ablate & 1)) {
@@ -1045,7 +1055,9 @@ __global__ void __launch_bounds__(G::T) part_keys16_direct(const uint32_t* __res
                     for (int q = 0; q < 8; q++) part_sat_inc(counts, hi16 | ((w4[q >> 1] >> ((q & 1) * 16)) & 0xffffu));
                 }
             } else if (v.x + v.y == 0x12345u && v.z == v.w) out[c + j] = (uint16_t)v.x;
-            if (j == full && have > full) *(uint4*)&tile[bq * RS2] = v;                  // the carry (its first have - full keys) to slot 0
+            // the carry (have - full keys, fewer than CG) to the head of the row: every lane of the row has read its group above, so a
+            // group may land on one another lane held
+            if (j >= full && j < have) *(uint4*)&tile[bq * RS2 + (j - full)] = v;
             if (lane % LPR == 0) { cur[bq] = c + put; cnt[bq] = (have - full) << 1; }
         }
         __syncthreads();
@@ -1257,8 +1269,14 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
                     hipLaunchKernelGGL((part_reads_direct<G, true>), dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
                                        ctx->d_counts, ablate & 3, (const uint32_t*)d_list);
                 }
-                hipLaunchKernelGGL(part_keys16_direct<G>, dim3(G::HALVES * NBK), dim3(G::T), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, sc, cur2,
-                                   (uint16_t*)ctx->d_part_keys[1], ctx->d_counts, (ablate >> 4) & 3);
+                // LHGT_PART_CG=8: round 4's 16-byte copy-out of the key scatter (A/B; the table is the same)
+                const char* cg_env = getenv("LHGT_PART_CG");
+                if (cg_env && atoi(cg_env) == 8)
+                    hipLaunchKernelGGL((part_keys16_direct<G, 8>), dim3(G::HALVES * NBK), dim3(G::T), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, sc, cur2,
+                                       (uint16_t*)ctx->d_part_keys[1], ctx->d_counts, (ablate >> 4) & 3);
+                else
+                    hipLaunchKernelGGL((part_keys16_direct<G, G::CG>), dim3(G::HALVES * NBK), dim3(G::T), 0, ctx->stream, ctx->d_part_keys[0], cur1, piece, sc, cur2,
+                                       (uint16_t*)ctx->d_part_keys[1], ctx->d_counts, (ablate >> 4) & 3);
                 if (ctx->stats_on && ctx->d_stats)    // keys that reached a final bucket's region (the few sent straight to the table are not in it)
                     hipLaunchKernelGGL(part_sum_cursors, dim3(1), dim3(256), 0, ctx->stream, cur2, G::HALVES * g.nb, ctx->d_stats);
                 hipLaunchKernelGGL(part_apply2<G::HALVES>, dim3(g.nb), dim3(PA), slice_bytes, ctx->stream, (const uint16_t*)ctx->d_part_keys[1], cur2, g, sc,

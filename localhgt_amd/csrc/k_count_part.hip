@@ -613,10 +613,12 @@ struct GeomBig {
     static constexpr int S1 = 128;     // 256 x 128 x 4 B = 128 KiB
     static constexpr int RW = 4;       // 64 reads, <= 22.8 K keys, 89 per bucket: 128 is + 4 sigma
     static constexpr int S2 = 256;     // 256 x 256 x 2 B = 128 KiB
-    static constexpr int KPT = 16;     // 16 Ki keys, 64 per bucket, 128 for the first (+ 5 sigma = 185)
+    static constexpr int KPT = 20;     // 20 Ki keys, 80 per bucket, 160 for the first (+ a carry of <= 63 + 3 sigma: a row that runs over sends keys to the table);
+                                       // 16 until round 6: 214 -> 206 ms per 100 M pairs (fewer barriers and row sweeps per key, a quarter more loads in flight);
+                                       // 24 spills (128 registers), 32-key groups (half lines) lose 2-5 ms to whole lines at either size
     static constexpr int GRID = 256;
     static constexpr int HALVES = 1;
-    static constexpr int CG = 64;      // whole 128-byte lines (round 6, see part_keys16_direct): mean 64 + carry <= 63 + 5 sigma (40) of 256 slots; first bucket 128 + 63 + 57
+    static constexpr int CG = 64;      // whole 128-byte lines (round 6, see part_keys16_direct)
 };
 // keys a piece holds: its expected share of the chunk's keys + 1/16 + 512, a multiple of 32 keys (128 B)
 __host__ __device__ inline uint32_t piece_keys(unsigned long long n_keys, int grid) {

@@ -13,9 +13,14 @@ with Engine(32, 3) as g:
     g.synth_pairs(1, 2, 13000, 1_000_000, 0, pairs, 150)
     ms, dig = {}, {}
     for r in range(rounds + 1):
-        for name, cg in (("16-byte groups (r4)", "8"), ("whole lines (r6)", None)):
-            if cg: os.environ["LHGT_PART_CG"] = cg
-            else: os.environ.pop("LHGT_PART_CG", None)
+        variants = [("16-byte groups (r4)", {"LHGT_PART_CG": "8"}), ("whole lines (r6)", {})]
+        for kv in os.environ.get("PHASE_A_VARIANTS", "").split(";"):      # more variants: "name=ENV:value,ENV:value;..."
+            if kv:
+                nm, envs = kv.split("=", 1)
+                variants.append((nm, dict(e.split(":", 1) for e in envs.split(",") if e)))
+        for name, env in variants:
+            for key in ("LHGT_PART_CG", "LHGT_PART_X"): os.environ.pop(key, None)
+            os.environ.update(env)
             g.counts_clear(); g.count_kmers()
             if r: ms.setdefault(name, []).append(g.phase_ms(0))
             dig[name] = g.digest(g.DIGEST_COUNTS)

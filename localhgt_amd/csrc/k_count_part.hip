@@ -640,17 +640,42 @@ __host__ __device__ inline size_t final_region(const PartCap& sc, uint32_t m, ui
 
 // the segments of the chunk's long reads (more than FAST_NK k-mer offsets), in any order: entry = pair (inside the chunk) | mate << 24 |
 // segment << 25; list[0] counts them
+constexpr int LRS_ROUNDS = 16;            // reads per thread of long_read_segments
 __global__ void __launch_bounds__(256) long_read_segments(ReadBatchDev b, long pair0, long npairs, int k, uint32_t* __restrict__ list, uint32_t cap) {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= 2 * npairs) return;
-    const int m = (int)(r & 1);
-    const long p = r >> 1;
-    const int nk = (int)b.len[m][pair0 + p] - k + 1;
-    if (nk <= FAST_NK) return;
-    const uint32_t n_seg = (uint32_t)((nk + FAST_NK - 1) / FAST_NK);
-    const uint32_t at = atomicAdd(list, n_seg);
-    for (uint32_t sg = 0; sg < n_seg; sg++)
-        if (at + sg < cap) list[1 + at + sg] = (uint32_t)p | ((uint32_t)m << 24) | (sg << 25);
+    // ONE atomic per workgroup of 4096 reads: one per read, or per wave, is a chain of round trips to one address of the L2 -- 1.2 ms per
+    // chunk of 4 Mi pairs of 250-base reads, 36 ms per 100 M pairs, whoever adds (round 6)
+    __shared__ uint32_t wsum[4], wbase;
+    const long r0 = (long)blockIdx.x * (256 * LRS_ROUNDS);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t n_seg[LRS_ROUNDS], mine = 0;
+#pragma unroll
+    for (int i = 0; i < LRS_ROUNDS; i++) {
+        const long r = r0 + (long)i * 256 + threadIdx.x;
+        const int nk = r < 2 * npairs ? (int)((r & 1) ? b.len[1][pair0 + (r >> 1)] : b.len[0][pair0 + (r >> 1)]) - k + 1 : 0;
+        n_seg[i] = nk > FAST_NK ? (uint32_t)((nk + FAST_NK - 1) / FAST_NK) : 0u;
+        mine += n_seg[i];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        wbase = total ? atomicAdd(list, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = wbase + incl - mine;
+    for (int q = 0; q < wv; q++) at += wsum[q];
+#pragma unroll
+    for (int i = 0; i < LRS_ROUNDS; i++) {
+        const long r = r0 + (long)i * 256 + threadIdx.x;
+        for (uint32_t sg = 0; sg < n_seg[i]; sg++, at++)
+            if (at < cap) list[1 + at] = (uint32_t)(r >> 1) | ((uint32_t)(r & 1) << 24) | (sg << 25);
+    }
 }
 
 // LIST (round 5): the reads are SEGMENTS of long reads, listed by long_read_segments -- a read of more than FAST_NK k-mer offsets is
@@ -702,17 +727,25 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
     // arrived in dB, records on their way into recB) and the one after (descriptors on their way into dC) -- two dependent round
     // trips to memory, each given a whole tile's time.
     struct Desc { int len[G::RW]; uint32_t off[G::RW]; uint32_t stride[LIST ? G::RW : 1]; };
-    auto load_descriptors = [&](long t, Desc& d) {        // t >= n_tiles: every length 0
+    // LIST: a tile's list entries are a round trip of their own in front of its descriptors -- requested one tile earlier still (round 6:
+    // taken inside load_descriptors, every tile waited for them: 253 ms per 100 M pairs of 250-base reads where the keys' share is 168)
+    struct Ent { uint32_t e[LIST ? G::RW : 1]; };
+    auto load_entries = [&](long t, Ent& en) {
+        if constexpr (LIST) {
+            const long r0 = t * RPT, r1 = r0 + RPT < n_reads ? r0 + RPT : n_reads;
+#pragma unroll
+            for (int rr = 0; rr < G::RW; rr++) {
+                const long r = r0 + wib + rr * NW;
+                en.e[rr] = list[1 + (r < r1 ? r : (n_reads > 0 ? n_reads - 1 : 0))];
+            }
+        }
+    };
+    auto load_descriptors = [&](long t, Desc& d, const Ent& en) {        // t >= n_tiles: every length 0
         const long r0 = t * RPT, r1 = r0 + RPT < n_reads ? r0 + RPT : n_reads;
         int len[G::RW];
         uint32_t fl[G::RW];
         if constexpr (LIST) {
-            uint32_t ent[G::RW];
-#pragma unroll
-            for (int rr = 0; rr < G::RW; rr++) {
-                const long r = r0 + wib + rr * NW;
-                ent[rr] = list[1 + (r < r1 ? r : (n_reads > 0 ? n_reads - 1 : 0))];
-            }
+            const uint32_t (&ent)[G::RW] = en.e;
 #pragma unroll
             for (int rr = 0; rr < G::RW; rr++) {
                 const long p = pair0 + (long)(ent[rr] & 0xffffffu);
@@ -763,10 +796,14 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         }
     };
     Desc dA, dB, dC;
+    Ent entC, entN;
     uint32_t recA[G::RW], recB[G::RW];
     if (n_reads > 0) {
-        load_descriptors(blockIdx.x, dA);
-        load_descriptors((long)blockIdx.x + gridDim.x, dB);
+        load_entries(blockIdx.x, entC);
+        load_entries((long)blockIdx.x + gridDim.x, entN);
+        load_descriptors(blockIdx.x, dA, entC);
+        load_descriptors((long)blockIdx.x + gridDim.x, dB, entN);
+        load_entries((long)blockIdx.x + 2L * gridDim.x, entC);
         load_records(dA, recA);
     }
     __syncthreads();
@@ -788,7 +825,8 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         }
         __builtin_amdgcn_wave_barrier();
         load_records(dB, recB);
-        load_descriptors(t + 2L * gridDim.x, dC);
+        load_entries(t + 3L * gridDim.x, entN);
+        load_descriptors(t + 2L * gridDim.x, dC, entC);
         // Software pipeline over the wave's reads: the tickets of read r are drawn (six LDS atomics issued back to back), then read
         // r + 1 is HASHED while they are in flight, then the slots of read r are computed and stored.  (Hash, tickets, wait, stores
         // read by read left the vector unit idle during every wait and the LDS idle during every hash: with all sixteen waves of the
@@ -904,6 +942,7 @@ __global__ void __launch_bounds__(G::T) part_reads_direct(ReadBatchDev b, long p
         __syncthreads();
         dA = dB;
         dB = dC;
+        entC = entN;
 #pragma unroll
         for (int rr = 0; rr < G::RW; rr++) recA[rr] = recB[rr];
     }
@@ -1267,7 +1306,7 @@ int lhgt_count_batch_partitioned(lhgt_ctx* ctx, const lhgt::ReadBatch& b) {
                                        ctx->d_counts, ablate & 3, (const uint32_t*)nullptr);
                 if (have_long) {          // the long reads of the chunk, segment by segment, behind the short ones in the same pieces
                     hipMemsetAsync(d_list, 0, 4, ctx->stream);
-                    hipLaunchKernelGGL(long_read_segments, dim3((unsigned)((2 * np + 255) / 256)), dim3(256), 0, ctx->stream, b.d, p0, np, ctx->k, d_list, list_cap);
+                    hipLaunchKernelGGL(long_read_segments, dim3((unsigned)((2 * np + 256 * LRS_ROUNDS - 1) / (256 * LRS_ROUNDS))), dim3(256), 0, ctx->stream, b.d, p0, np, ctx->k, d_list, list_cap);
                     hipLaunchKernelGGL((part_reads_direct<G, true>), dim3(G::GRID), dim3(G::T), 0, ctx->stream, b.d, p0, np, ctx->hp, piece, cur1, ctx->d_part_keys[0],
                                        ctx->d_counts, ablate & 3, (const uint32_t*)d_list);
                 }

@@ -372,12 +372,13 @@ def test_partitioned_count_equals_direct_count(Engine, k):
     assert (tables[0] == tables[1]).all()
 
 
-def test_direct_form_of_the_partition_equals_direct_count(Engine):
+def test_direct_form_of_the_partition_equals_direct_count(Engine, monkeypatch):
     """round 4's scatters (k = 32, e = 3, reads of <= 159 bases: fixed-slot tiles, workgroup-private pieces, no histogram pass)
     against the compare-and-swap kernel and against round 3's sorted-tile scatters (LHGT_DEBUG bit 16): whole-table digest,
     histogram and the first 2^26 slots.  Hot k-mers (poly-A, poly-AC, one read repeated) overflow the 128 slots of a tile bucket,
-    the 192 of the second level and the pieces themselves -- those keys go straight to the table; ragged lengths, N's, reads
-    shorter than k, mates not counted (quirk Q4) and an odd number of reads exercise the tails."""
+    the 256 of the second level and the pieces themselves -- those keys go straight to the table; ragged lengths, N's, reads
+    shorter than k, mates not counted (quirk Q4) and an odd number of reads exercise the tails.  The key scatter copies out whole
+    128-byte lines (round 6: a bucket carries up to 63 keys from tile to tile); LHGT_PART_CG=8 is round 4's 16-byte copy-out."""
     k, e = 32, 3
     rng = np.random.default_rng(7)
     acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
@@ -388,7 +389,9 @@ def test_direct_form_of_the_partition_equals_direct_count(Engine):
     reads2 = rd(20001) + [b"T" * 150, b"GTGT" * 37, hot] * 700 + rd(3000)
     c2 = (rng.random(len(reads1)) < 0.9).astype(np.uint8)
     got = []
-    for mode, dbg in ((0, 0), (1, 0), (1, 65536), (1, 1 << 21)):      # bit 21: the Small geometry of the direct form
+    for mode, dbg, cg in ((0, 0, None), (1, 0, None), (1, 65536, None), (1, 1 << 21, None), (1, 0, "8")):      # bit 21: the Small geometry of the direct form
+        if cg: monkeypatch.setenv("LHGT_PART_CG", cg)
+        else: monkeypatch.delenv("LHGT_PART_CG", raising=False)
         with Engine(k, e) as eng:
             eng.rng_seed(11)
             eng.coder_generate()

@@ -44,16 +44,23 @@ __device__ __forceinline__ int pk_keep(const long* first, const long* count, int
 // the order of the pairs) and its words' place
 __global__ void __launch_bounds__(256) pk_flags(const uint8_t* __restrict__ raw, long stride, long pair0, long n, PackedRule rule,
                                                 const float* __restrict__ random_array, uint8_t* __restrict__ fl_out,
-                                                unsigned long long* __restrict__ totals /* [0] kept pairs, [1] their words, [2] k-mer positions (k below), [3] long reads, [4] longest kept read */,
+                                                unsigned long long* __restrict__ totals /* [0] kept pairs, [1] their words, [2] k-mer positions (k below), [3] long reads, [4] longest kept read,
+                                                                                          [5] records that are none: a length beyond LHGT_MAX_READ_LEN or beyond what the stride holds */,
                                                 int k) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     uint32_t words = 0, nkm = 0, nlong = 0, longest = 0;
     uint8_t fl = 0;
+    bool corrupt = false;
     if (i < n) {
         const long p = pair0 + i, g = 4 * p + 1;
         const uint16_t* hd = reinterpret_cast<const uint16_t*>(raw + i * stride);
         uint32_t la = hd[0], lb = hd[1];
-        if (rule.threads > 1) {
+        // the file is input like any other: a record whose lengths the packer cannot have written (the text loader refuses reads beyond the
+        // reference's buffers, E:1004; pk_gather copies 3 (len / 32 + 1) words per mate from the record) is kept out and fails the load
+        corrupt = la > (uint32_t)LHGT_MAX_READ_LEN || lb > (uint32_t)LHGT_MAX_READ_LEN ||
+                  4 + 4 * (long)(3u * ((la + 31u) / 32u + 1u) + 3u * ((lb + 31u) / 32u + 1u)) > stride;
+        if (corrupt) { /* fl stays 0 */ }
+        else if (rule.threads > 1) {
             fl = (uint8_t)((pk_keep(rule.first1, rule.count1, rule.threads, g, rule.ratio, random_array) == 1 ? PAIR_COUNT1 | PAIR_VOTE : 0) |
                            (pk_keep(rule.first2, rule.count2, rule.threads, g, rule.ratio, random_array) == 1 ? PAIR_COUNT2 : 0));
         } else {
@@ -79,6 +86,8 @@ __global__ void __launch_bounds__(256) pk_flags(const uint8_t* __restrict__ raw,
         const uint32_t o = __shfl_xor(longest, d, 64);
         longest = o > longest ? o : longest;
     }
+    const unsigned long long n_corrupt = (unsigned long long)__popcll(__ballot(corrupt));
+    if ((threadIdx.x & 63) == 0 && n_corrupt) atomicAdd(totals + 5, n_corrupt);
     if ((threadIdx.x & 63) == 0 && kept) {
         atomicAdd(totals, kept); atomicAdd(totals + 1, w); atomicAdd(totals + 2, km); atomicAdd(totals + 3, lg);
         atomicMax(totals + 4, (unsigned long long)longest);
@@ -333,7 +342,7 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
         if (hipMemcpyAsync(d_raw[s], h_raw[s], (size_t)m * (size_t)stride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemsetAsync(d_tot + 16 * s, 0, 128, ctx->stream) != hipSuccess) { set_error("upload of the packed records failed"); return LHGT_E_HIP; }
         hipLaunchKernelGGL(pk_flags, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_raw[s], stride, p0, m, rule, d_random, d_fl[s], d_tot + 16 * s, ctx->k);
-        if (hipMemcpyAsync(h_tot + 16 * s, d_tot + 16 * s, 40, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (hipMemcpyAsync(h_tot + 16 * s, d_tot + 16 * s, 48, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipEventRecord(s ? ctx->ev3 : ctx->ev2, ctx->stream) != hipSuccess) { set_error("copy"); return LHGT_E_HIP; }
         return LHGT_OK;
     };
@@ -361,8 +370,14 @@ int lhgt_pairs_load_packed(lhgt_ctx* ctx, const char* path, unsigned long long d
             }
             t0 = now_s();
             if (hipEventSynchronize(s ? ctx->ev3 : ctx->ev2) != hipSuccess) { set_error("the packed records' flags kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = LHGT_E_HIP; break; }
-            unsigned long long tot[5];
-            memcpy(tot, h_tot + 16 * s, 40);
+            unsigned long long tot[6];
+            memcpy(tot, h_tot + 16 * s, 48);
+            if (tot[5]) {
+                set_error("%s: %llu of the records of pairs %ld .. %ld hold read lengths no packed sample holds (beyond %d bases or beyond the stride of %ld bytes): not a packed sample, or damaged",
+                          path, tot[5], p_at - m, p_at - 1, LHGT_MAX_READ_LEN, stride);
+                rc = LHGT_E_FORMAT;
+                break;
+            }
             if (m_next > 0) { rc = enqueue(c + 1, p_at, m_next); if (rc != LHGT_OK) break; }      // behind this chunk's flags, in front of its gather
             const long nb = (long)tot[0];
             if (nb > 0) {

@@ -134,3 +134,25 @@ def test_the_packer_as_an_executable(case_inputs, tmp_path):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "extract_ref")] + argv, env=env, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
     assert open(tmp_path / "i.txt").read() == open(os.path.join(cases.GOLDEN_DIR, "k24_seed7", "interval.txt")).read()
+
+
+def test_a_damaged_record_fails_the_load(case_inputs, packed, tmp_path):
+    """a packed sample is input like any other: a record whose read lengths the packer cannot have written -- beyond the reference's 500
+    bases (E:1004), or beyond what the stride holds, which the gather would copy from the NEXT records -- is not loaded; the run stops
+    with a format error (round 6, late)"""
+    import struct
+    from localhgt_amd import _lib, extract_ref
+    case = cases.CASES["k24_base"]
+    fa, f1, f2, meta = case_inputs("k24_base")
+    sample, hdr = packed("k24_base")
+    for la in (60000, 501):
+        bad = str(tmp_path / f"bad{la}.lhgp")
+        shutil.copy(sample, bad)
+        with open(bad, "r+b") as f:
+            f.seek(hdr["data_offset"] + 17 * hdr["stride"])
+            f.write(struct.pack("<H", la))
+        fa2 = str(tmp_path / f"ref{la}.fa")
+        shutil.copy(fa, fa2)
+        with pytest.raises(_lib.LocalHGTError) as ei:
+            extract_ref.run(extract_ref.parse_argv(cases.extract_ref_argv(case, bad, "-", fa2, str(tmp_path / "i.txt"))), log=lambda *a: None)
+        assert ei.value.code == 4 and "hold read lengths no packed sample holds" in str(ei.value), str(ei.value)

@@ -203,6 +203,12 @@ int lhgt_pairs_append_flags(lhgt_ctx* ctx, const uint8_t* seq1, const uint64_t* 
  * lhgt_pairs_batches / _batch_info: the resident store as it stands; lhgt_pairs_store_write: its records to `path` from data_offset on
  * (refused unless the store is that of a clean pair of files read whole). */
 int lhgt_pairs_batches(lhgt_ctx* ctx, long* n_batches);
+/* the same file -- the same bytes -- without a GPU in the machine (round 6, late): the loader's own host parse of the two files (every read
+ * kept, no thread emulation: the loops of read_fastq E:1020-1044 / slide_reads E:350-419 as lhgt_pairs_load_fastq restates them), run twice --
+ * for the longest read, which decides the stride (returned), and for the records, 2-bit packed by host threads.  Refuses what
+ * lhgt_pairs_store_write refuses.  threads < 1: the CPUs the process may use. */
+int lhgt_fastq_pack_host(const char* fq1, const char* fq2, const char* out_path, unsigned long long data_offset, int threads, long* stride,
+                         long* n_pairs, long* q4_first_pair, unsigned long long* bases1, int* max_len);
 int lhgt_pairs_batch_info(lhgt_ctx* ctx, long batch, long* n_pairs, unsigned long long* n_words, int* max_len);
 int lhgt_pairs_store_write(lhgt_ctx* ctx, const char* path, unsigned long long data_offset, long stride, long* n_pairs, long* q4_first_pair,
                            unsigned long long* bases1);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "lhgt_pairs_batches": [_vp, _lp],
     "lhgt_pairs_batch_info": [_vp, _l, _lp, _u64p, C.POINTER(C.c_int)],
     "lhgt_pairs_store_write": [_vp, _cs, C.c_uint64, _l, _lp, _lp, _u64p],
+    "lhgt_fastq_pack_host": [_cs, _cs, _cs, C.c_uint64, _i, _lp, _lp, _lp, _u64p, C.POINTER(C.c_int)],
     "lhgt_pairs_load_packed": [_vp, _cs, C.c_uint64, _l, _l, _l, _d, _i, _lp, _lp, _lp, _lp, _i, _i, _lp, _lp],
     "lhgt_vote_groups_export": [_vp, _u32p, _i, C.POINTER(C.c_int)],
     "lhgt_registry_info": [_vp, C.POINTER(C.c_int), _u64p, _u64p],
@@ -167,6 +168,14 @@ def load(require_gpu: bool = True):
         if n.value < 1:
             raise RuntimeError("liblocalhgt_hip: no HIP device visible; localhgt_amd has no CPU fallback")
     return _lib
+
+
+def gpu_available() -> bool:
+    """whether a HIP device is visible (the packer's choice between the GPU and the host's CPUs; the compute path has no such choice)"""
+    lib = load(require_gpu=False)
+    n = C.c_int(0)
+    lib.lhgt_device_count(C.byref(n))
+    return n.value >= 1
 
 
 def check(rc: int):

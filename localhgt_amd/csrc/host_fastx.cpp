@@ -1415,6 +1415,108 @@ int lhgt_fastq_parse_rate(const char* fq1, const char* fq2, double ratio_percent
     return rc;
 }
 
+// Host-only packer (round 6, late): the file `lhgt_pairs_load_fastq` + `lhgt_pairs_store_write` write for a record-aligned pair of files --
+// the same bytes -- without a GPU in the machine: the loader's own parse (every read kept, no thread emulation), twice -- once for the
+// longest read (the stride) and the checks, once to write -- and pack_bases (k_ingest.hip) restated for a host thread: bit 31 - b of word
+// w of a plane = base 32 w + b.  The store's order is the files' order here as there (chunks are handed over in file order).
+namespace {
+struct BaseCodeTable {                                         // lhgt_hash.hpp: base_code (E:1112-1151: upper and lower case ACGT only; 4 = not a base)
+    uint8_t t[256];
+    BaseCodeTable() { memset(t, 4, sizeof t); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; }
+};
+const BaseCodeTable g_base_code;
+inline uint32_t base_code_host(uint8_t c) { return g_base_code.t[c]; }
+void pack_mate_host(uint32_t* dst, const uint8_t* s, size_t len) {
+    const size_t wpr = (len + 31) / 32 + 1;                   // the last word of every plane stays zero
+    for (size_t w = 0; w < wpr; w++) {
+        uint32_t hi = 0, lo = 0, nb = 0;
+        const size_t base = 32 * w, n = len > base ? std::min<size_t>(32, len - base) : 0;
+        for (size_t b = 0; b < n; b++) {
+            const uint32_t c = base_code_host(s[base + b]), bit = 0x80000000u >> b;
+            if (c == 4) nb |= bit;
+            else { if (c & 2) hi |= bit; if (c & 1) lo |= bit; }
+        }
+        dst[w] = hi; dst[wpr + w] = lo; dst[2 * wpr + w] = nb;
+    }
+}
+}  // namespace
+
+int lhgt_fastq_pack_host(const char* fq1, const char* fq2, const char* out_path, unsigned long long data_offset, int threads, long* stride_out,
+                         long* n_pairs_out, long* q4_first_pair, unsigned long long* bases1, int* max_len_out) {
+    if (!fq1 || !fq2 || !out_path) LHGT_FAIL(LHGT_E_ARG, "null argument");
+    if (threads < 1) threads = ingest_default_threads();
+    const long chunk_bytes = lhgt_fastq_plan_chunk_bytes();
+    // pass 1: the longest read, the pairs, the flags a clean pair of files gives (7 everywhere, then 5 -- mate 2 behind size(fq1), quirk Q4 -- to the end)
+    long total = 0, q4 = -1, seen = 0;
+    unsigned long long bases = 0;
+    int max_len = 0, bad_rc = LHGT_OK;
+    int rc = parse_pairs(fq1, fq2, 100.0, nullptr, 0, 1, 1, threads, (size_t)chunk_bytes, 1, &seen, (SlabPool*)nullptr, [&](ParsedChunk& ch) -> int {
+                             const long n = (long)ch.o1.size() - 1;
+                             for (long i = 0; i < n; i++) {
+                                 const uint64_t la = ch.o1[i + 1] - ch.o1[i], lb = ch.o2[i + 1] - ch.o2[i];
+                                 const uint8_t f = ch.flags[i];
+                                 if (f == PAIR_ALL && q4 < 0) { /* counted */ }
+                                 else if (f == (PAIR_COUNT1 | PAIR_VOTE)) { if (q4 < 0) q4 = total + i; }
+                                 else { set_error("pair %ld carries flags %d: not a record-aligned pair of files read whole (the FASTQ loader is the way for those)", total + i, (int)f); bad_rc = LHGT_E_FORMAT; return bad_rc; }
+                                 if ((int)la > max_len) max_len = (int)la;
+                                 if ((int)lb > max_len) max_len = (int)lb;
+                                 bases += la;
+                             }
+                             total += n;
+                             return LHGT_OK;
+                         },
+                         [](bool) {}, nullptr, nullptr, LHGT_MAX_RANDOM,
+                         [&]() -> int { total = 0; q4 = -1; bases = 0; max_len = 0; return LHGT_OK; });
+    if (rc != LHGT_OK) return rc;
+    if (seen != total) LHGT_FAIL(LHGT_E_FORMAT, "the loader kept %ld of %ld pairs: not a clean pair of files; keep them as FASTQ", total, seen);
+    const long stride = 4 + 24 * ((long)(max_len + 31) / 32 + 1);
+    // pass 2: the records
+    const int fd = ::open(out_path, O_WRONLY);
+    if (fd < 0) LHGT_FAIL(LHGT_E_IO, "cannot open %s for writing", out_path);
+    long at = 0;
+    std::vector<uint8_t> buf;
+    rc = parse_pairs(fq1, fq2, 100.0, nullptr, 0, 1, 1, threads, (size_t)chunk_bytes, 1, &seen, (SlabPool*)nullptr, [&](ParsedChunk& ch) -> int {
+                         const long n = (long)ch.o1.size() - 1;
+                         if (n <= 0) return LHGT_OK;
+                         if (buf.size() < (size_t)n * (size_t)stride) buf.resize((size_t)n * (size_t)stride);
+                         std::atomic<int> io_bad{0};
+                         parallel_for((n + 4095) / 4096, threads, [&](long c) {        // a slice of the chunk: packed and written by one thread
+                             const long i0 = c * 4096, i1 = std::min(n, (c + 1) * 4096);
+                             memset(buf.data() + (size_t)i0 * (size_t)stride, 0, (size_t)(i1 - i0) * (size_t)stride);
+                             for (long i = i0; i < i1; i++) {
+                                 const size_t la = ch.o1[i + 1] - ch.o1[i], lb = ch.o2[i + 1] - ch.o2[i];
+                                 uint8_t* r = buf.data() + (size_t)i * (size_t)stride;
+                                 const uint16_t hd[2] = {(uint16_t)la, (uint16_t)lb};
+                                 memcpy(r, hd, 4);
+                                 uint32_t* w = reinterpret_cast<uint32_t*>(r + 4);
+                                 pack_mate_host(w, ch.s1.data() + ch.o1[i], la);
+                                 pack_mate_host(w + 3 * ((la + 31) / 32 + 1), ch.s2.data() + ch.o2[i], lb);
+                             }
+                             const size_t want = (size_t)(i1 - i0) * (size_t)stride;
+                             size_t done = 0;
+                             while (done < want) {
+                                 const ssize_t wr = pwrite(fd, buf.data() + (size_t)i0 * (size_t)stride + done, want - done,
+                                                           (off_t)(data_offset + (unsigned long long)(at + i0) * (unsigned long long)stride + done));
+                                 if (wr <= 0) { io_bad = 1; return; }
+                                 done += (size_t)wr;
+                             }
+                         });
+                         if (io_bad) { set_error("write to %s failed", out_path); return LHGT_E_IO; }
+                         at += n;
+                         return LHGT_OK;
+                     },
+                     [](bool) {}, nullptr, nullptr, LHGT_MAX_RANDOM, [&]() -> int { at = 0; return LHGT_OK; });
+    close(fd);
+    if (rc != LHGT_OK) return rc;
+    if (at != total) LHGT_FAIL(LHGT_E_IO, "%ld records written for %ld pairs", at, total);
+    if (stride_out) *stride_out = stride;
+    if (n_pairs_out) *n_pairs_out = total;
+    if (q4_first_pair) *q4_first_pair = q4 < 0 ? total : q4;
+    if (bases1) *bases1 = bases;
+    if (max_len_out) *max_len_out = max_len;
+    return LHGT_OK;
+}
+
 int lhgt_ingest_last_path(char* why, long cap) {
     if (why && cap > 0) { strncpy(why, lhgt::g_last_path_why.c_str(), (size_t)cap - 1); why[cap - 1] = 0; }
     return lhgt::g_last_path;

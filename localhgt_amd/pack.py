@@ -85,12 +85,40 @@ def _first_id(path: str) -> bytes:
     return line
 
 
-def pack(fq1: str, fq2: str, out: str, max_threads: int = 32, device: int = 0, log=print) -> dict:
+def _lines(lib, path: str) -> int:
+    """the file's lines (lhgt_fastq_plan_part: host only)"""
+    n, tot = C.c_long(0), C.c_long(0)
     from . import _lib
-    from .engine import Engine
-    lib = _lib.load()
+    _lib.check(lib.lhgt_fastq_plan_part(path.encode(), lib.lhgt_fastq_plan_chunk_bytes(), 0, 1, None, None, 0, C.byref(n), C.byref(tot), None))
+    st, cn = np.zeros(max(n.value, 1), dtype=np.uint64), np.zeros(max(n.value, 1), dtype=np.int64)
+    _lib.check(lib.lhgt_fastq_plan_part(path.encode(), lib.lhgt_fastq_plan_chunk_bytes(), 0, 1, st.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        cn.ctypes.data_as(C.POINTER(C.c_long)), n.value, C.byref(n), C.byref(tot), None))
+    return int(cn[:n.value].sum())
+
+
+def pack(fq1: str, fq2: str, out: str, max_threads: int = 32, device: int = 0, log=print, host: Optional[bool] = None) -> dict:
+    """host=True: no GPU is touched -- the loader's host parse and a host restatement of the 2-bit packing write the same bytes
+    (lhgt_fastq_pack_host; round 6, late); host=False: through the resident store on the GPU; None: the GPU if there is one"""
+    from . import _lib
+    lib = _lib.load(require_gpu=False)
     if _first_id(fq1) != _first_id(fq2):
         raise SystemExit(f"{fq1} and {fq2} open with different read IDs: the reference re-synchronises such files by ID (E:368-402); keep them as FASTQ")
+    if host is None:
+        host = os.environ.get("LHGT_PACK_HOST", "") == "1" or not _lib.gpu_available()
+    if host:
+        lines1, lines2 = _lines(lib, fq1), _lines(lib, fq2)
+        if lines1 != lines2 or lines1 % 4:
+            raise SystemExit(f"{fq1} has {lines1} lines, {fq2} {lines2}: only record-aligned pairs of files are packed; keep these as FASTQ")
+        with open(out, "wb") as f:
+            f.truncate(DATA_OFFSET)
+        n, q4, bases, stride_c, ml = C.c_long(0), C.c_long(0), C.c_uint64(0), C.c_long(0), C.c_int(0)
+        _lib.check(lib.lhgt_fastq_pack_host(fq1.encode(), fq2.encode(), out.encode(), DATA_OFFSET, 0, C.byref(stride_c), C.byref(n), C.byref(q4),
+                                            C.byref(bases), C.byref(ml)))
+        if n.value != lines1 // 4:
+            raise SystemExit(f"the loader kept {n.value} pairs of {lines1 // 4} records: not a clean pair of files; keep them as FASTQ")
+        stride, max_len = stride_c.value, ml.value
+        return _finish(lib, fq1, fq2, out, max_threads, n, q4, bases, stride, max_len, lines1, log)
+    from .engine import Engine
     with Engine(32, 3, device) as eng:
         p1, p2 = eng.fastq_plan(fq1, False, other=fq2)
         lines1, lines2 = int(p1[1].sum()), int(p2[1].sum())
@@ -114,6 +142,12 @@ def pack(fq1: str, fq2: str, out: str, max_threads: int = 32, device: int = 0, l
             f.truncate(DATA_OFFSET)
         n, q4, bases = C.c_long(0), C.c_long(0), C.c_uint64(0)
         _lib.check(lib.lhgt_pairs_store_write(eng.h, out.encode(), DATA_OFFSET, stride, C.byref(n), C.byref(q4), C.byref(bases)))
+    return _finish(lib, fq1, fq2, out, max_threads, n, q4, bases, stride, max_len, lines1, log)
+
+
+def _finish(lib, fq1, fq2, out, max_threads, n, q4, bases, stride, max_len, lines1, log) -> dict:
+    """the header: what the loader decides from the text, for every -t N up to max_threads"""
+    from . import _lib
     size1 = os.path.getsize(fq1)
     threads = {}
     for t in range(2, max_threads + 1):
@@ -152,10 +186,12 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("fq2")
     ap.add_argument("out")
     ap.add_argument("--max-threads", type=int, default=32, help="thread chunks of the reference's -t 2 .. N are stored (localhgt bkp passes -t 10)")
+    ap.add_argument("--host", action="store_true", help="pack on the host's CPUs, no GPU touched (the default where there is none; same bytes)")
+    ap.add_argument("--gpu", action="store_true", help="pack through the resident store on the GPU")
     a = ap.parse_args(argv)
     if not 1 <= a.max_threads <= 99:
         raise SystemExit("--max-threads: 1 .. 99 (split_ref holds 100 groups)")
-    pack(a.fq1, a.fq2, a.out, a.max_threads)
+    pack(a.fq1, a.fq2, a.out, a.max_threads, host=True if a.host else (False if a.gpu else None))
     return 0
 
 

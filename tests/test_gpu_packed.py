@@ -156,3 +156,20 @@ def test_a_damaged_record_fails_the_load(case_inputs, packed, tmp_path):
         with pytest.raises(_lib.LocalHGTError) as ei:
             extract_ref.run(extract_ref.parse_argv(cases.extract_ref_argv(case, bad, "-", fa2, str(tmp_path / "i.txt"))), log=lambda *a: None)
         assert ei.value.code == 4 and "hold read lengths no packed sample holds" in str(ei.value), str(ei.value)
+
+
+@pytest.mark.parametrize("name", ["k24_base", "k24_fq2_longer", "k24_nrun_lower", "k21_e3"])
+def test_host_packer_writes_the_bytes_the_gpu_packer_writes(case_inputs, packed, name, tmp_path):
+    """`localhgt_pack --host` (no GPU touched: lhgt_fastq_pack_host) against the packer that goes through the resident store: the same
+    records, byte for byte, and the same header but for the sources' timestamps -- so everything the tests above say of a packed sample
+    holds for one packed on a machine without a GPU"""
+    from localhgt_amd import pack
+    fa, f1, f2, meta = case_inputs(name)
+    gpu_file, gpu_hdr = packed(name)
+    out = str(tmp_path / "host.lhgp")
+    hdr = pack.pack(f1, f2, out, max_threads=12, host=True, log=lambda *a: None)
+    assert {k: v for k, v in hdr.items() if k != "sources"} == {k: v for k, v in gpu_hdr.items() if k != "sources"}
+    with open(out, "rb") as a, open(gpu_file, "rb") as b:
+        a.seek(hdr["data_offset"])
+        b.seek(hdr["data_offset"])
+        assert a.read() == b.read()

@@ -838,3 +838,68 @@ def test_packed_sample_header_on_the_host(lib, tmp_path):
     with open(path, "r+b") as f:
         f.truncate(pack.DATA_OFFSET + (n_pairs - 10) * stride)                 # the records end early: an I/O error, not a short read taken for data
     assert h_lib.lhgt_packed_read_rate(path.encode(), pack.DATA_OFFSET, stride, n_pairs, 2, 3, 2, ctypes.byref(secs)) != 0
+
+
+def test_host_packer_writes_the_store_records(lib, tmp_path):
+    """`localhgt_pack --host` (lhgt_fastq_pack_host; round 6, late): a record-aligned pair of files packed on the host's CPUs, no GPU touched --
+    every record against a literal restatement of the store's layout ([u16 len1][u16 len2][mate 1: hi, lo, not-a-base planes of
+    len / 32 + 1 words, bit 31 - b of word w = base 32 w + b][mate 2 likewise], zero to the stride), ragged lengths 0 .. 259, lower case,
+    N's and other letters; the header's pair count, stride, base count of fq1 (cal_sam_ratio, E:1264-1265) and quirk Q4's first pair
+    (mate 2's record starting behind size(fq1), E:1419-1445); files that are no clean pair are refused"""
+    import struct
+    from localhgt_amd import _lib, pack
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGTNacgtnRy", dtype=np.uint8)
+    n = 3000
+
+    def reads():
+        return [letters[rng.choice(12, size=int(rng.integers(0, 260)), p=[.21, .21, .21, .21, .01, .03, .03, .03, .03, .01, .01, .01])].tobytes() for _ in range(n)]
+
+    r1, r2 = reads(), reads()
+    paths = []
+    for name, rs, tag in (("a.1.fq", r1, b"/1"), ("a.2.fq", r2, b"/2")):
+        paths.append(str(tmp_path / name))
+        with open(paths[-1], "wb") as f:
+            for i, r in enumerate(rs):
+                f.write(b"@read%d%s\n" % (i, tag) + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    out = str(tmp_path / "a.lhgp")
+    hdr = pack.pack(paths[0], paths[1], out, max_threads=4, host=True, log=lambda *a: None)
+    raw = open(out, "rb").read()
+    assert hdr["n_pairs"] == n and hdr["max_len"] == max(map(len, r1 + r2)) and hdr["stride"] == 4 + 24 * ((hdr["max_len"] + 31) // 32 + 1)
+    assert len(raw) == hdr["data_offset"] + n * hdr["stride"] and hdr["fq1_bases"] == sum(map(len, r1))
+    # quirk Q4: the first pair whose mate 2 record starts at or behind size(fq1) in fq2
+    size1, at, q4 = os.path.getsize(paths[0]), 0, n
+    for i, r in enumerate(r2):
+        if at >= size1:
+            q4 = i
+            break
+        at += len(b"@read%d/2\n" % i) + 2 * len(r) + 4
+    assert hdr["q4_first_pair"] == q4
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+
+    def planes(s):
+        wpr = (len(s) + 31) // 32 + 1
+        w = np.zeros(3 * wpr, dtype=np.uint32)
+        for j, c in enumerate(s):
+            q, b = divmod(j, 32)
+            v = code.get(c, 4)
+            if v == 4:
+                w[2 * wpr + q] |= 0x80000000 >> b
+            else:
+                w[q] |= (0x80000000 >> b) if v & 2 else 0
+                w[wpr + q] |= (0x80000000 >> b) if v & 1 else 0
+        return w
+
+    for i in range(n):
+        rec = raw[hdr["data_offset"] + i * hdr["stride"]: hdr["data_offset"] + (i + 1) * hdr["stride"]]
+        assert struct.unpack("<HH", rec[:4]) == (len(r1[i]), len(r2[i]))
+        want = np.concatenate([planes(r1[i]), planes(r2[i])])
+        assert (np.frombuffer(rec[4:4 + 4 * len(want)], dtype=np.uint32) == want).all() and not any(rec[4 + 4 * len(want):]), i
+    assert pack.read_header(out).thread_chunks(2)[0].shape == (2,)
+    # no clean pair: one record fewer in fq2
+    short = str(tmp_path / "b.2.fq")
+    with open(short, "wb") as f:
+        for i, r in enumerate(r2[:-1]):
+            f.write(b"@read%d/2\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    with pytest.raises((SystemExit, _lib.LocalHGTError)):
+        pack.pack(paths[0], short, str(tmp_path / "b.lhgp"), max_threads=2, host=True, log=lambda *a: None)

@@ -413,7 +413,7 @@ int lhgt_slot_list(lhgt_ctx* ctx, int mode, unsigned long long* entries, unsigne
         lhgt::slot_list_drop(ctx);
     }
     if (entries) *entries = ctx->sl_state == 1 ? ctx->sl_entries : 0ull;
-    if (bytes) *bytes = ctx->sl_state == 1 ? (ctx->d_sl_mid ? 10ull : 6ull) * ctx->sl_entries + 8ull * (unsigned long long)(ctx->sl_buckets + 1) : 0ull;
+    if (bytes) *bytes = ctx->sl_state == 1 ? (ctx->d_sl_mid ? 10ull : 6ull) * (ctx->sl_capacity ? ctx->sl_capacity : ctx->sl_entries) + 8ull * (unsigned long long)(ctx->sl_buckets + 1) : 0ull;
     return LHGT_OK;
 }
 

@@ -1460,8 +1460,9 @@ __device__ __forceinline__ uint32_t slot_list_key(const RefSource& rs, const Ref
 // touched, and only the few per cent whose slot does not are followed to their other hashes (ref_single_slots).
 
 __global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
-                                                     int k, int e, int smallest, uint32_t* __restrict__ hist /* [nb], then [nb]: k-mers whose hashes are all 0 */, long nb, long n_blk) {
-    const long blk = block2d();
+                                                     int k, int e, int smallest, uint32_t* __restrict__ hist /* [nb], then [nb]: k-mers whose hashes are all 0 */, long nb, long n_blk,
+                                                     int stride /* > 1: every stride-th tile only -- a SAMPLE of the histogram, slot_list_build */) {
+    const long blk = block2d() * stride;
     if (blk >= n_blk) return;
     const TileDev t = tiles[blk];
     const ContigDev c = contigs[t.contig];
@@ -1476,11 +1477,17 @@ __global__ void __launch_bounds__(BT) slot_list_hist(const TileDev* __restrict__
     }
 }
 // one workgroup: hist -> exclusive offsets (u64), hist cleared to serve as the fill's cursors
-__global__ void __launch_bounds__(1024) slot_list_offsets(uint32_t* __restrict__ hist, long nb, unsigned long long* __restrict__ off) {
+// scale > 1: hist is a sample of every scale-th tile; a bucket's region is its scaled count + six standard deviations of that estimate
+// (the sampled count is Poisson: scale * sqrt(h)) + a pad -- 7.5 % more than the entries at 13 Gbase and scale 8; a bucket that still
+// runs over (repeats that the sample missed) makes the build fall back to the exact histogram
+__device__ __forceinline__ unsigned long long slot_list_cap(uint32_t h, int scale) {
+    return scale > 1 ? (unsigned long long)h * (unsigned)scale + (unsigned long long)(6.0f * (float)scale * sqrtf((float)h + 1.0f)) + 64ull : (unsigned long long)h;
+}
+__global__ void __launch_bounds__(1024) slot_list_offsets(uint32_t* __restrict__ hist, long nb, unsigned long long* __restrict__ off, int scale) {
     __shared__ unsigned long long part[1024];
     const long per = (nb + 1023) / 1024, b0 = (long)threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
     unsigned long long s = 0;
-    for (long b = b0; b < b1; b++) s += hist[b];
+    for (long b = b0; b < b1; b++) s += slot_list_cap(hist[b], scale);
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1490,11 +1497,23 @@ __global__ void __launch_bounds__(1024) slot_list_offsets(uint32_t* __restrict__
     }
     __syncthreads();
     unsigned long long run = part[threadIdx.x];
-    for (long b = b0; b < b1; b++) { off[b] = run; run += hist[b]; hist[b] = 0u; }
+    for (long b = b0; b < b1; b++) { off[b] = run; run += slot_list_cap(hist[b], scale); hist[b] = 0u; }
+}
+// regions sized from a sample: where each bucket's entries end (its cursor), and how many there are in all
+__global__ void __launch_bounds__(256) slot_list_ends(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ cur, long nb,
+                                                      unsigned long long* __restrict__ end, unsigned long long* __restrict__ total) {
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long n = 0;
+    if (b < nb) { n = cur[b]; end[b] = off[b] + n; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
 }
 __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__ tiles, const ContigDev* __restrict__ contigs, const RefSource rs,
                                                      int k, int e, int smallest, const unsigned long long* __restrict__ off, uint32_t* __restrict__ cur,
-                                                     uint32_t* __restrict__ lo, uint16_t* __restrict__ hi, uint32_t* __restrict__ mid /* nullable */, long n_blk) {
+                                                     uint32_t* __restrict__ lo, uint16_t* __restrict__ hi, uint32_t* __restrict__ mid /* nullable */, long n_blk,
+                                                     uint32_t* __restrict__ est /* nullable; regions sized from a sample: [0] set when a bucket runs over its region,
+                                                                                  [1] the k-mers no entry speaks for (the sampled histogram did not see them all) */) {
     const long blk = block2d();
     if (blk >= n_blk) return;
     const TileDev t = tiles[blk];
@@ -1505,9 +1524,14 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
         if (j >= nk) break;
         const RefKmer km = ref_kmer(rs, c, j, k, e);
         const uint32_t h = slot_list_key(rs, km, e, smallest != 0);
-        if (h == 0) continue;
+        if (h == 0) {
+            if (est && !rs.index && km.valid) atomicAdd(est + 1, 1u);
+            continue;
+        }
         const uint32_t b = h >> SL_BITS;
-        const unsigned long long at = off[b] + atomicAdd(&cur[b], 1u);
+        const uint32_t rank = atomicAdd(&cur[b], 1u);
+        if (est && (unsigned long long)rank >= off[b + 1] - off[b]) { est[0] = 1u; continue; }   // (cur[b] keeps counting: the build is done over)
+        const unsigned long long at = off[b] + rank;
         const uint64_t x = c.flat_base + (uint64_t)j;
         lo[at] = (uint32_t)x;
         hi[at] = (uint16_t)((h & (SL_SLOTS - 1u)) | ((uint32_t)(x >> 32) << SL_BITS));
@@ -1527,7 +1551,8 @@ __global__ void __launch_bounds__(BT) slot_list_fill(const TileDev* __restrict__
 // per lane, between two loads of its stream, reached 33 G lines/s of the fabric's 56; waves with rings of their own, no barrier: 38;
 // U = 8 at a time and 512 or 1024 threads: the same time to a tenth of a millisecond -- what is left is not latency).
 template <bool PACKED, int ST, int U, bool MID>
-__global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
+__global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* __restrict__ off, const unsigned long long* __restrict__ end_of /* nullable: off[b + 1] */,
+                                                      const uint32_t* __restrict__ lo,
                                                       const uint16_t* __restrict__ hi, const uint32_t* __restrict__ mid /* MID: every entry's second-largest hash */,
                                                       const RefSource rs, const ContigDev* __restrict__ contigs,
                                                       int n_contigs, const uint32_t* __restrict__ counts, int slice_words, int k, int e,
@@ -1542,7 +1567,7 @@ __global__ void __launch_bounds__(ST) ref_flags_slots(const unsigned long long* 
     __shared__ uint32_t s_tail;
     const long b = block2d();
     if (b >= n_buckets) return;
-    const unsigned long long begin = off[b], end = off[b + 1];
+    const unsigned long long begin = off[b], end = end_of ? end_of[b] : off[b + 1];
     if (begin == end) return;                                   // uniform
     uint32_t any3 = 0;
     for (int i = threadIdx.x; i < slice_words; i += ST) {
@@ -1748,7 +1773,8 @@ __global__ void __launch_bounds__(256) contig_tail_flags(const ContigDev* __rest
     for (long j = from + (threadIdx.x & 31); j < (long)cd.len; j += 32) flags[cd.flat_base + j] = 0x80;
 }
 template <int ST>
-__global__ void __launch_bounds__(ST) ref_single_slots(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ lo,
+__global__ void __launch_bounds__(ST) ref_single_slots(const unsigned long long* __restrict__ off, const unsigned long long* __restrict__ end_of /* nullable: off[b + 1] */,
+                                                       const uint32_t* __restrict__ lo,
                                                        const uint16_t* __restrict__ hi, const RefSource rs, const uint32_t* __restrict__ counts,
                                                        int slice_words, int k, int e, uint8_t* __restrict__ flags,
                                                        unsigned long long* __restrict__ stats /* nullable: [0] probes, [1] positions followed */, long n_buckets) {
@@ -1759,7 +1785,7 @@ __global__ void __launch_bounds__(ST) ref_single_slots(const unsigned long long*
     __shared__ uint32_t s_tail;
     const long b = block2d();
     if (b >= n_buckets) return;
-    const unsigned long long begin = off[b], end = off[b + 1];
+    const unsigned long long begin = off[b], end = end_of ? end_of[b] : off[b + 1];
     if (begin == end) return;                                   // uniform
     uint32_t not3 = 0;
     for (int i = threadIdx.x; i < slice_words; i += ST) {
@@ -1942,8 +1968,9 @@ static RefSource ref_source(const lhgt_ctx* ctx) {
 // it would leave less than LHGT_SLOT_LIST_HEADROOM_GB (default 40) of the device's memory free.
 namespace lhgt {
 void slot_list_drop(lhgt_ctx* ctx) {
-    for (void* p : {(void*)ctx->d_sl_lo, (void*)ctx->d_sl_hi, (void*)ctx->d_sl_off, (void*)ctx->d_sl_mid}) if (p) (void)lhgt::dev_free(p);
-    ctx->d_sl_lo = nullptr; ctx->d_sl_hi = nullptr; ctx->d_sl_off = nullptr; ctx->d_sl_mid = nullptr;
+    for (void* p : {(void*)ctx->d_sl_lo, (void*)ctx->d_sl_hi, (void*)ctx->d_sl_off, (void*)ctx->d_sl_mid, (void*)ctx->d_sl_end}) if (p) (void)lhgt::dev_free(p);
+    ctx->d_sl_lo = nullptr; ctx->d_sl_hi = nullptr; ctx->d_sl_off = nullptr; ctx->d_sl_mid = nullptr; ctx->d_sl_end = nullptr;
+    ctx->sl_capacity = 0;
     ctx->sl_entries = 0; ctx->sl_buckets = 0; ctx->sl_state = 0; ctx->sl_sparse_scans = 0; ctx->sl_need_share = 0.0;
 }
 }  // namespace lhgt
@@ -1970,51 +1997,98 @@ static int slot_list_build(lhgt_ctx* ctx, bool smallest) {
         return LHGT_OK;
     }
     const double t0 = wall_s();
-    uint32_t* d_hist = nullptr;
-    if (lhgt::dev_malloc(&d_hist, (size_t)(nb + 1) * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_off, (size_t)(nb + 1) * 8) != hipSuccess) {
-        if (d_hist) lhgt::dev_free(d_hist);
-        slot_list_drop(ctx); ctx->sl_state = -1;
-        (void)hipGetLastError();
-        return LHGT_OK;
-    }
+    // Round 6 (late): the regions from a SAMPLED histogram -- every 8th tile, a sixteenth of the exact pass's 0.5 s of atomics -- with six
+    // standard deviations of slack (slot_list_cap), then ONE pass over the reference that places the entries and notices a bucket that
+    // runs over its region (repeats the sample missed); only then is the build done over with the exact histogram, as until now.
+    // LHGT_SLOT_LIST_SAMPLE=<n>: every n-th tile (default 8; 0 or 1: the exact histogram at once).
+    static const int sample_env = getenv("LHGT_SLOT_LIST_SAMPLE") ? atoi(getenv("LHGT_SLOT_LIST_SAMPLE")) : 8;
+    const int sample = sample_env >= 2 && sample_env <= 64 && ctx->n_tiles >= 64L * sample_env ? sample_env : 1;
     const dim3 grid = blocks2d(ctx->n_tiles), blk(BT);
-    LHGT_HIP(hipMemsetAsync(d_hist, 0, (size_t)(nb + 1) * 4, ctx->stream));
-    hipLaunchKernelGGL(slot_list_hist, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, smallest ? 1 : 0, d_hist, nb, ctx->n_tiles);
     uint32_t unlisted = 0;
-    LHGT_HIP(hipMemcpyAsync(&unlisted, d_hist + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-    hipLaunchKernelGGL(slot_list_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_hist, nb, ctx->d_sl_off);
-    unsigned long long n_entries = 0;
-    LHGT_HIP(hipMemcpyAsync(&n_entries, ctx->d_sl_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
-    LHGT_HIP(hipStreamSynchronize(ctx->stream));
-    if (lhgt::dev_malloc(&ctx->d_sl_lo, (size_t)(n_entries + 64) * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_hi, (size_t)(n_entries + 64) * 2) != hipSuccess) {
-        lhgt::dev_free(d_hist);
-        slot_list_drop(ctx); ctx->sl_state = -1;
-        (void)hipGetLastError();
-        if (trace) fprintf(stderr, "[lhgt] slot list: no memory for %llu entries -- not built\n", n_entries);
-        return LHGT_OK;
-    }
-    // the sparse-table list (largest hash) takes every entry's second-largest hash along when there is room for it (4 more bytes per
-    // position: 130 GB in all for 13 Gbase; LHGT_SLOT_LIST_MID=0: never): the followed positions then ask the table before the reference
-    static const bool mid_ok = !(getenv("LHGT_SLOT_LIST_MID") && atoi(getenv("LHGT_SLOT_LIST_MID")) == 0);
-    if (!smallest && ctx->e >= 2 && mid_ok) {
-        size_t f2 = 0, t2 = 0;
-        LHGT_HIP(hipMemGetInfo(&f2, &t2));
-        if ((double)f2 - 4.0 * (double)n_entries >= headroom_gb * 1e9) {
-            if (lhgt::dev_malloc(&ctx->d_sl_mid, (size_t)(n_entries + 64) * 4) != hipSuccess) { ctx->d_sl_mid = nullptr; (void)hipGetLastError(); }
+    unsigned long long n_entries = 0, n_cap = 0;
+    bool estimated = false;
+    for (int attempt = sample > 1 ? 0 : 1; attempt < 2; attempt++) {
+        estimated = attempt == 0;
+        const int stride = estimated ? sample : 1;
+        uint32_t* d_hist = nullptr;          // [nb] counts, then cursors; [nb] the unlisted k-mers; [nb + 1], [nb + 2]: the estimated fill's notes
+        unsigned long long* d_total = nullptr;
+        auto give_up = [&]() {
+            if (d_hist) lhgt::dev_free(d_hist);
+            if (d_total) lhgt::dev_free(d_total);
+            slot_list_drop(ctx); ctx->sl_state = -1;
+            (void)hipGetLastError();
+        };
+        if (lhgt::dev_malloc(&d_hist, (size_t)(nb + 4) * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_off, (size_t)(nb + 1) * 8) != hipSuccess ||
+            (estimated && (lhgt::dev_malloc(&ctx->d_sl_end, (size_t)nb * 8) != hipSuccess || lhgt::dev_malloc(&d_total, 8) != hipSuccess))) {
+            give_up();
+            return LHGT_OK;
         }
+        LHGT_HIP(hipMemsetAsync(d_hist, 0, (size_t)(nb + 4) * 4, ctx->stream));
+        hipLaunchKernelGGL(slot_list_hist, blocks2d((ctx->n_tiles + stride - 1) / stride), blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e,
+                           smallest ? 1 : 0, d_hist, nb, ctx->n_tiles, stride);
+        LHGT_HIP(hipMemcpyAsync(&unlisted, d_hist + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+        hipLaunchKernelGGL(slot_list_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_hist, nb, ctx->d_sl_off, stride);
+        LHGT_HIP(hipMemcpyAsync(&n_cap, ctx->d_sl_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        if (estimated) {                     // the sample's slack has to fit like the list itself
+            size_t f1 = 0, t1 = 0;
+            LHGT_HIP(hipMemGetInfo(&f1, &t1));
+            if ((double)f1 - 6.0 * (double)n_cap < headroom_gb * 1e9) {
+                lhgt::dev_free(d_hist); lhgt::dev_free(d_total);
+                slot_list_drop(ctx); ctx->sl_state = -1;
+                continue;                    // the exact histogram's regions are smaller
+            }
+        }
+        if (lhgt::dev_malloc(&ctx->d_sl_lo, (size_t)(n_cap + 64) * 4) != hipSuccess || lhgt::dev_malloc(&ctx->d_sl_hi, (size_t)(n_cap + 64) * 2) != hipSuccess) {
+            give_up();
+            if (trace) fprintf(stderr, "[lhgt] slot list: no memory for %llu entries -- not built\n", n_cap);
+            return LHGT_OK;
+        }
+        // the sparse-table list (largest hash) takes every entry's second-largest hash along when there is room for it (4 more bytes per
+        // position: 130 GB in all for 13 Gbase; LHGT_SLOT_LIST_MID=0: never): the followed positions then ask the table before the reference
+        static const bool mid_ok = !(getenv("LHGT_SLOT_LIST_MID") && atoi(getenv("LHGT_SLOT_LIST_MID")) == 0);
+        if (!smallest && ctx->e >= 2 && mid_ok) {
+            size_t f2 = 0, t2 = 0;
+            LHGT_HIP(hipMemGetInfo(&f2, &t2));
+            if ((double)f2 - 4.0 * (double)n_cap < headroom_gb * 1e9 && lhgt::big_release_all())   // blocks parked by the process count as free here too
+                LHGT_HIP(hipMemGetInfo(&f2, &t2));
+            if ((double)f2 - 4.0 * (double)n_cap >= headroom_gb * 1e9) {
+                if (lhgt::dev_malloc(&ctx->d_sl_mid, (size_t)(n_cap + 64) * 4) != hipSuccess) { ctx->d_sl_mid = nullptr; (void)hipGetLastError(); }
+            }
+        }
+        uint32_t* d_est = estimated ? d_hist + nb + 1 : nullptr;
+        hipLaunchKernelGGL(slot_list_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, smallest ? 1 : 0, ctx->d_sl_off, d_hist,
+                           ctx->d_sl_lo, ctx->d_sl_hi, ctx->d_sl_mid, ctx->n_tiles, d_est);
+        LHGT_HIP(hipGetLastError());
+        n_entries = n_cap;
+        if (estimated) {
+            uint32_t note[2] = {0, 0};
+            LHGT_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(slot_list_ends, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sl_off, d_hist, nb, ctx->d_sl_end, d_total);
+            LHGT_HIP(hipMemcpyAsync(note, d_est, 8, hipMemcpyDeviceToHost, ctx->stream));
+            LHGT_HIP(hipMemcpyAsync(&n_entries, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+            LHGT_HIP(hipStreamSynchronize(ctx->stream));
+            unlisted = note[1];
+            if (note[0]) {                   // a bucket ran over its estimated region: once more, exactly
+                if (trace) fprintf(stderr, "[lhgt] slot list: a bucket ran over the region the sampled histogram gave it -- built again from the exact one\n");
+                lhgt::dev_free(d_hist); lhgt::dev_free(d_total);
+                slot_list_drop(ctx); ctx->sl_state = -1;
+                continue;
+            }
+        }
+        LHGT_HIP(hipStreamSynchronize(ctx->stream));
+        lhgt::dev_free(d_hist);
+        if (d_total) lhgt::dev_free(d_total);
+        break;
     }
-    hipLaunchKernelGGL(slot_list_fill, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->k, ctx->e, smallest ? 1 : 0, ctx->d_sl_off, d_hist,
-                       ctx->d_sl_lo, ctx->d_sl_hi, ctx->d_sl_mid, ctx->n_tiles);
-    LHGT_HIP(hipGetLastError());
-    LHGT_HIP(hipStreamSynchronize(ctx->stream));
-    lhgt::dev_free(d_hist);
+    ctx->sl_capacity = n_cap;
     ctx->sl_entries = n_entries;
     ctx->sl_buckets = nb;
     ctx->sl_state = 1;
     ctx->sl_smallest = smallest;
     ctx->sl_unlisted = unlisted;
     ctx->sl_build_ms = (wall_s() - t0) * 1e3;
-    if (trace) fprintf(stderr, "[lhgt] slot list (by the %s hash%s): %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", smallest ? "smallest" : "largest", ctx->d_sl_mid ? ", with the second-largest" : "", n_entries, nb, (ctx->d_sl_mid ? 10.0 : 6.0) * (double)n_entries / 1e9, wall_s() - t0);
+    if (trace) fprintf(stderr, "[lhgt] slot list (by the %s hash%s; regions from %s): %llu positions in %ld buckets, %.1f GB, built in %.2f s\n", smallest ? "smallest" : "largest", ctx->d_sl_mid ? ", with the second-largest" : "", estimated ? "a sampled histogram" : "the exact histogram", n_entries, nb, (ctx->d_sl_mid ? 10.0 : 6.0) * (double)n_cap / 1e9, wall_s() - t0);
     return LHGT_OK;
 }
 
@@ -2127,7 +2201,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
         const int ablate = (ctx->debug & (1 << 26)) && getenv("LHGT_SLOTS_ABLATE") ? atoi(getenv("LHGT_SLOTS_ABLATE")) : 0;
         auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ctx->d_sl_mid, ref_source(ctx),
+            hipLaunchKernelGGL(kern, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_end, ctx->d_sl_lo, ctx->d_sl_hi, ctx->d_sl_mid, ref_source(ctx),
                                ctx->d_contigs, (int)ctx->contigs.size(), ctx->d_counts, slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets, ablate);
         };
         if (ctx->ref_packed) { if (ctx->d_sl_mid) launch(ref_flags_slots<true, BT, 4, true>); else launch(ref_flags_slots<true, BT, 4, false>); }
@@ -2174,7 +2248,7 @@ static int scan_local(lhgt_ctx* ctx, float hit_ratio, float match_ratio, uint32_
         unsigned long long* st = ctx->stats_on && ctx->d_stats ? ctx->d_stats + 1 : nullptr;
         if (st) LHGT_HIP(hipMemsetAsync(st, 0, 16, ctx->stream));
         const int slice_words = (int)(ctx->counts_words < SL_SLOTS / 16 ? ctx->counts_words : SL_SLOTS / 16);
-        hipLaunchKernelGGL(ref_single_slots<BT>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx), ctx->d_counts,
+        hipLaunchKernelGGL(ref_single_slots<BT>, blocks2d(ctx->sl_buckets), blk, 0, ctx->stream, ctx->d_sl_off, ctx->d_sl_end, ctx->d_sl_lo, ctx->d_sl_hi, ref_source(ctx), ctx->d_counts,
                            slice_words, k, e, ctx->d_flags, st, ctx->sl_buckets);
         hipLaunchKernelGGL(ref_trio_runs, grid, blk, 0, ctx->stream, ctx->d_tiles, ctx->d_contigs, ref_source(ctx), ctx->d_counts, k, e, ctx->d_flags, st, nt);
         LHGT_HIP(hipEventRecord(ctx->ev3, ctx->stream));

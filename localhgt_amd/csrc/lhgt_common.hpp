@@ -164,6 +164,8 @@ struct lhgt_ctx {
     uint32_t* d_sl_lo = nullptr;             // low 32 bits of the flat position
     uint16_t* d_sl_hi = nullptr;             // low 14 bits of the slot | position bits 32-33 << 14
     uint32_t* d_sl_mid = nullptr;            // (list under the largest hash, when there is room) every entry's second-largest hash
+    unsigned long long* d_sl_end = nullptr;  // [sl_buckets], or null: where a bucket's entries end when its region was sized from a sampled histogram (round 6)
+    unsigned long long sl_capacity = 0;      // entries the list's arrays hold (= sl_entries for an exact histogram)
     unsigned long long* d_sl_off = nullptr;  // [sl_buckets + 1]
     unsigned long long sl_entries = 0;
     long sl_buckets = 0;

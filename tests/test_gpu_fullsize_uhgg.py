@@ -216,7 +216,7 @@ def test_packed_reference_equals_index_form(eng, oracle, tmp_path):
         got, sinfo = _scan(eng, 1 << 24)
         assert sinfo["form"] == "slot-first" and got == want[16384], (sinfo, got, want[16384])
         sl = eng.slot_list()
-        assert sl["entries"] == NC * (CL - K + 1) and (77e9 < sl["bytes"] < 79e9 or 129e9 < sl["bytes"] < 131e9), sl   # 6 bytes per position, 10 with the second hash
+        assert sl["entries"] == NC * (CL - K + 1) and (77e9 < sl["bytes"] < 85e9 or 129e9 < sl["bytes"] < 141e9), sl   # 6 bytes per position, 10 with the second hash (+ 7.5 % where the regions come from a sampled histogram)
         got, sinfo = _scan(eng, 0)
         assert got == want[0], sinfo                                 # (by itself: slot-first unless the last sparse scan sent most tiles to the fill -- this sample does)
         got, sinfo = _scan(eng, 16384)                               # bit 14 alone: the trio-first kernel, list or no list

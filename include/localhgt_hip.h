@@ -359,7 +359,9 @@ int lhgt_scan_info(lhgt_ctx* ctx, int* lite, double* frac_slots_at_3, long* n_ti
 int lhgt_registry_info(lhgt_ctx* ctx, int* chunks, unsigned long long* records_bound, unsigned long long* records_direct);
 /* The slot list of the resident reference: every position with a k-mer, grouped by the top bits of the slot its largest hash
  * addresses (6 bytes per position; 10 when the list under the largest hash also carries every position's second-largest hash, which
- * it does when that leaves room on the device).  A context that scans sample after sample against one resident reference answers the first
+ * it does when that leaves room on the device; + 7.5 % where the buckets' regions are sized from a sampled histogram -- every 8th tile,
+ * LHGT_SLOT_LIST_SAMPLE, round 6: one pass of atomics over the reference instead of two, done over exactly if a bucket runs over).
+ * A context that scans sample after sample against one resident reference answers the first
  * question of the sparse-table scan ("does this hash of the position read 3?", E:580) for all positions from a stream over that
  * list and each bucket's counters in LDS instead of one random probe per position; same flags where they are read, same peaks
  * and votes.  mode 0: never build one and drop the one there is; 1 (default; environment LHGT_SLOT_LIST): build it before the

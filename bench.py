@@ -188,7 +188,7 @@ def main():
 
     import torch
     from localhgt_amd.engine import Engine
-    from benchlib.legs import Workload, verify_forms
+    from benchlib.legs import Workload, slot_list_streamed_bytes, verify_forms
     local = local % max(1, torch.cuda.device_count())          # --backend gloo: ranks may share a GPU
     torch.cuda.set_device(local)
 
@@ -239,7 +239,7 @@ def main():
     if world == 1 and not args.debug and not args.force_dist and not args.no_stats:
         stats = wl.stats_step()                              # untimed: the run's own key and probe counts (needed-bytes model)
         if args.ref_form == "packed" and eng.slot_list()["bytes"]:
-            stats["slot_list_bytes"] = eng.slot_list()["bytes"]
+            stats["slot_list_bytes"] = slot_list_streamed_bytes(eng)
         if not args.no_verify:
             verify = verify_forms(eng)
     dt, per_ms, n_peaks, nf = wl.run(args.steps, args.warmup)

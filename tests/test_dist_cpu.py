@@ -299,7 +299,7 @@ def test_bench_needed_bytes_model_and_memory_plan():
     assert abs(p3["reference"] - 4.875e9) < 1e7 and p3["exchange_buffers"] == 2 * (1 << 32) // 4 and 100e9 < p3["total"] < 125e9
     # ... and with the slot list of the packed reference next to it (round 5: what `bench.py --gpus 8` lays out by default): 78 GB more
     p3l = check_fits(memory_plan(125_000_000, 13_000_000_000, 13000, packed=True, world=8, slot_list=True))
-    assert abs(p3l["slot_list"] - 78e9) < 1e8 and p3l["total"] == p3["total"] + p3l["slot_list"] and p3l["total"] < 205e9
+    assert abs(p3l["slot_list"] - 1.075 * 78e9) < 2e8 and p3l["total"] == p3["total"] + p3l["slot_list"] and p3l["total"] < 205e9
     assert memory_plan(25_000_000, 50_000_000_000, 50000, packed=True, slot_list=True)["slot_list"] == 0     # beyond 2^34 positions: no list
     p4 = check_fits(memory_plan(25_000_000, 50_000_000_000, 50000, world=8, shard_index=True))
     assert abs(p4["reference"] - 75e9) < 1e9

@@ -105,6 +105,15 @@ def verify_forms(eng):
             "compared": "peak loci, peak_kmer[2^k], flags of every reference position, votes: picked forms vs exact scan + unfiltered generic vote"}
 
 
+def slot_list_streamed_bytes(engine):
+    """the bytes of the slot list a scan streams: its ENTRIES (6 bytes each, 10 with the second hash) -- the regions they lie in hold
+    7.5 % more since they are sized from a sampled histogram (lhgt_slot_list reports the regions)"""
+    sl = engine.slot_list()
+    if not sl["entries"]:
+        return 0
+    return (10 if sl["bytes"] > 8 * sl["entries"] else 6) * sl["entries"]
+
+
 def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_contigs=0, traffic=None, ref_bases=None, packed=False, recall=True,
         want_stats=True, L=150):
     """one secondary workload on a loaded engine: a stats step, a warm-up step, `steps` timed ones"""
@@ -113,7 +122,7 @@ def leg(engine, out_path, k, e, pairs, n_contigs, contig_len, steps=3, sample_co
     dt, per_ms, n_peaks, nf = w.run(steps, 1)       # (round 5: always a warm-up step -- a context's second scan of a resident reference may build its slot list)
     if want_stats and engine.scan_info()["form"] in ("slot-first", "slot-single"):
         stats = w.stats_step()                      # the counts of the form the timed steps took, not of the first scan's
-        stats["slot_list_bytes"] = engine.slot_list()["bytes"]
+        stats["slot_list_bytes"] = slot_list_streamed_bytes(engine)
     d = {"value": round(pairs * steps / dt / 1e6, 3), "unit": "M paired-reads/s", "ms_per_step": round(dt / steps * 1e3, 2),
          "phase_ms": {"count_A": round(per_ms[0], 2), "scan_B": round(per_ms[1], 2), "vote_C": round(per_ms[2], 2)},
          "scan_B_form": engine.scan_info(), "peak_registry": engine.registry_info(), "vote_form": engine.vote_info(), "raw_peaks": n_peaks, "filtered_peaks": nf, "steps": steps, "pairs": pairs,

@@ -16,7 +16,8 @@ def memory_plan(pairs, ref_bases, n_contigs, k=32, e=3, L=150, packed=False, wor
     nb = 1 << max(0, k - 16)
     plan = {
         "reference": n_pos * 3 / 8 + 64 if packed else (n_pos - n_contigs * share * (k - 1)) * 4 * e + 4 * n_contigs * share,
-        "slot_list": 6 * n_pos + 8 * ((1 << max(0, k - 14)) + 1) if slot_list and packed and n_pos < (1 << 34) else 0,
+        # 6 bytes per position in regions sized from a sampled histogram (+ 7.5 % at 13 Gbase), bucket starts and ends
+        "slot_list": 6 * n_pos * 1.075 + 16 * ((1 << max(0, k - 14)) + 1) if slot_list and packed and n_pos < (1 << 34) else 0,
         "per_position_flags_and_state": 2 * n_pos,
         "tile_tables": (n_pos / 2000 + n_contigs * share) * (8 + 1 + 4 + 4) + n_contigs * share * 24,
         "read_store": pairs * 2 * (3 * wpr * 4 + 4 + 2) + pairs,

@@ -370,8 +370,9 @@ int lhgt_registry_info(lhgt_ctx* ctx, int* chunks, unsigned long long* records_b
  * use it always; -1: leave the mode.  entries / bytes (nullable): the list as it stands (0 = none: not built yet, no memory for
  * it, e > 3, or positions beyond 2^34).  No reference counterpart (the reference walks its index file once per run, E:888-979). */
 int lhgt_slot_list(lhgt_ctx* ctx, int mode, unsigned long long* entries, unsigned long long* bytes);
-/* what the last build of a slot list cost (ms on the host clock: its histogram, offsets and fill kernels and its allocations); 0 if
- * this context has built none.  Measurement only (bench.py: slot_list_build_ms, break_even_samples). */
+/* what the last build of a slot list cost: the time of its kernels (histogram, offsets, placing pass; HIP events, every attempt of the
+ * build), without its allocations -- an 80-140 GB hipMalloc takes 0 or 3 seconds by what the process freed before (LHGT_TRACE prints the
+ * wall time next to it); 0 if this context has built none.  Measurement only (bench.py: slot_list_build_ms, break_even_samples). */
 int lhgt_slot_list_build_ms(lhgt_ctx* ctx, double* ms);
 /* ---- which kernel the last lhgt_vote took (k_vote.hip): *form = 0 the generic kernel probing peak_kmer itself (dense peak sets), 1 the
  *      generic kernel behind the L2-resident bitmap, 2 the queued sparse kernel behind the bitmap, 3 the 128 KiB LDS fold in front of

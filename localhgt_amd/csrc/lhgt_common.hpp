@@ -169,7 +169,7 @@ struct lhgt_ctx {
     unsigned long long* d_sl_off = nullptr;  // [sl_buckets + 1]
     unsigned long long sl_entries = 0;
     long sl_buckets = 0;
-    double sl_build_ms = 0.0;                // wall time of the last slot_list_build that built a list (host clock around its three kernels and allocations)
+    double sl_build_ms = 0.0;                // kernel time of the last slot_list_build that built a list (events around its kernels, without the allocations)
     bool sl_in_use = false;                  // a scan is running on the list: an allocation out of memory must not drop it (cabi.hip: drop_optional)
     int sl_state = 0;                        // 0 not tried for this reference, 1 built, -1 tried and left (no memory, e > 3, positions beyond 2^34)
     int sl_mode = 1;                         // lhgt_slot_list / LHGT_SLOT_LIST: 0 never, 1 before the second sparse scan of a reference, 2 before the first
